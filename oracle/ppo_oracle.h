@@ -1,0 +1,133 @@
+/*
+ * ppo_oracle.h  --  CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the arithmetic of ppo_cpp's rollout-collect + minibatch-update hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call into this file; the
+ * product path (ppo_cpp_amd/csrc, libppo_hip.so) never links or loads it.
+ *
+ * PARITY STATUS: "parity unpinned" at the TensorFlow boundary.  The reference executes a TF-1.14 graph
+ * ("G" = resources/ppo_cl/graphs/ppo_cpp_[4_5]_lr_0.0004_cr_0.1610_ent_0.0007.meta.txt) and TF cannot be
+ * built or imported here; the reference tree holds no TF-produced activation / loss / gradient value.
+ * This restatement is pinned instead against (tests/test_oracle.py):
+ *   - the initial weights embedded in G and the trained checkpoint ...pkl.71 (tests/golden/ npz files),
+ *   - analytic known answers (initial entropy 18*1.4189385, neglogp(a=mu) 18*0.9189385, ...),
+ *   - an independent torch-CPU autograd restatement of the same formulas (oracle/torch_check.py),
+ *   - the checkpoint JSON running statistics (normaliser fixture).
+ *
+ * Accumulation convention: element-wise ops are fp32 exactly as the graph's DT_FLOAT nodes; every
+ * REDUCTION (MatMul k-sum, Sum/Mean over rows, L2Loss, column means) accumulates in double and rounds
+ * to fp32 once.  TF-CPU's Eigen contractions/reductions use an unspecified blocked/threaded order, so
+ * no fp32 order is "the" reference; the double-accumulated value is within 0.5 ulp of the exact sum and
+ * therefore within any fp32 order's own rounding error.
+ *
+ * Layout conventions: all matrices row-major float.  Parameters live in ONE flat vector in TF's
+ * trainable-variable order (G:23738-24074, G:30520-31162):
+ *   pi_fc0/w [O,h0], pi_fc0/b [h0], vf_fc0/w, vf_fc0/b, pi_fc1/w [h0,h1], pi_fc1/b, vf_fc1/w, vf_fc1/b, ...
+ *   vf/w [hL,1], vf/b [1], pi/w [hL,A], pi/b [A], pi/logstd [A]     (q/w,q/b are untrained: not here)
+ */
+#ifndef PPO_ORACLE_H
+#define PPO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LAYERS 8
+
+typedef struct {
+    int obs_dim;                 /* O */
+    int act_dim;                 /* A */
+    int n_hidden;                /* L */
+    int hidden[ORC_MAX_LAYERS];  /* h0..h{L-1} */
+    float ent_coef;              /* G:11323 loss/mul_4/y       */
+    float vf_coef;               /* G:11395 loss/mul_5/y       */
+    float max_grad_norm;         /* G:24370 clip_by_global_norm */
+    float adam_beta1;            /* G:30430 ppo2/_train/beta1   */
+    float adam_beta2;            /* G:30460 ppo2/_train/beta2   */
+    float adam_eps;              /* G:30490 ppo2/_train/epsilon */
+} orc_cfg;
+
+/* ---- flat parameter layout ---------------------------------------------------------------- */
+int orc_num_tensors(const orc_cfg* c);                       /* 4*L + 5 */
+int orc_num_params(const orc_cfg* c);
+/* tensor i: offset into the flat vector, rows, cols (cols==0 => 1-D of length rows); returns name */
+const char* orc_tensor_info(const orc_cfg* c, int i, int* offset, int* rows, int* cols);
+
+/* ---- act model (G:1859-6866; policies.hpp:33-77) ------------------------------------------ */
+/* mu[N,A], v[N] ; either output may be NULL */
+void orc_forward(const orc_cfg* c, const float* theta, const float* obs, int n, float* mu, float* v);
+/* a = mu + exp(logstd)*noise ; neglogp(a) ; value */
+void orc_step(const orc_cfg* c, const float* theta, const float* obs, int n, const float* noise,
+              float* action, float* value, float* neglogp);
+
+/* ---- train model + loss + backward (G:6889-23699) ------------------------------------------ */
+/* losses[5] = pg_loss, vf_loss, entropy, approxkl, clipfrac (ppo2.hpp:71-78); grad[P] = d loss/d theta */
+void orc_loss_grad(const orc_cfg* c, const float* theta, const float* obs, const float* actions,
+                   const float* advs, const float* returns, const float* old_neglogp,
+                   const float* old_values, int n, float cliprange, float losses[5], float* grad);
+/* G:23738-25392 ; scales grad in place, returns the global norm */
+float orc_clip_by_global_norm(const orc_cfg* c, float* grad);
+/* G:25426-25704, 30430-31383 (TF-1.14 ApplyAdam) ; pow[2] = {beta1_power, beta2_power} updated after */
+void orc_adam(const orc_cfg* c, float* theta, float* m, float* v, const float* grad, float lr, float pow[2]);
+/* = PPO2::_train_step's Session::Run (ppo2.hpp:450): loss_grad + clip + adam. returns grad norm */
+float orc_train_step(const orc_cfg* c, float* theta, float* m, float* v, float pow[2], float lr,
+                     float cliprange, const float* obs, const float* actions, const float* advs,
+                     const float* returns, const float* old_neglogp, const float* old_values, int n,
+                     float losses[5], float* grad_scratch);
+
+/* ---- host-side numerics of the path ---------------------------------------------------------- */
+/* ppo2.hpp:401-406 */
+void orc_adv_normalize(const float* returns, const float* values, int n, float* advs);
+/* runner.hpp:159-191 ; all [T,E] time-major; last_dones = dones after the final env step */
+void orc_gae(const float* rewards, const float* values, const float* dones, const float* last_values,
+             const float* last_dones, int T, int E, float gamma, float lam, float* returns);
+
+typedef struct {            /* common/running_statistics.hpp:17-24 */
+    int dim;
+    double count;
+    float* mean;            /* [dim] */
+    float* var;             /* [dim] */
+} orc_rstats;
+void orc_rstats_init(orc_rstats* s, int dim, float* mean_buf, float* var_buf);
+void orc_rstats_update(orc_rstats* s, const float* batch, int rows);           /* :26-54, 88-104 */
+/* env_normalize.hpp:94-109 ; update-then-normalise, clip +-clip */
+void orc_normalize_obs(orc_rstats* s, const float* obs, int rows, int training, float clip, float eps,
+                       float* out);
+/* env_normalize.hpp:64-92 ; ret[E] is the running discounted return state */
+void orc_normalize_reward(orc_rstats* s, float* ret, const float* rew, const float* dones, int rows,
+                          int training, float gamma, float clip, float eps, float* out);
+
+/* ---- seeded synthetic env (same interface shape as env_mock.hpp) ------------------ */
+/* counter-based: obs ~ U(-1,1)^O, reward ~ U(-1,1), done ~ Bernoulli(1/300), keyed by (seed, env, step) */
+uint32_t orc_hash(uint32_t seed, uint32_t env, uint32_t step, uint32_t lane);
+void orc_seeded_env_step(uint32_t seed, int env0, int n_envs, uint32_t step, int obs_dim, float* obs,
+                         float* rew, float* dones);
+
+/* ---- whole-path drivers (runner.hpp:56-157, ppo2.hpp:264-335) -------------------------------- */
+typedef struct {
+    int E, T;
+    float* obs;        /* [T,E,O] normalised observations fed to the policy */
+    float* actions;    /* [T,E,A] */
+    float* values;     /* [T,E]   */
+    float* neglogp;    /* [T,E]   */
+    float* dones;      /* [T,E]   done flag that arrived WITH obs_t (runner.hpp:110) */
+    float* rewards;    /* [T,E]   normalised rewards */
+    float* returns;    /* [T,E]   */
+} orc_rollout;
+
+/* The reference flattens env-major: row r = e*T + t (runner.hpp:136-152). storage index = t*E + e. */
+static inline int orc_row_to_storage(int r, int T, int E) { return (r % T) * E + (r / T); }
+
+/* One full minibatch-update phase on a collected rollout. perms: [epochs, B] int32, perms[ep][i] = the
+ * permuted row position of source row i in epoch ep (out.row(perm[i]) = in.row(i), ppo2.hpp:291-296).
+ * loss_rows [epochs*nminibatches, 5] in execution order ; mean_losses[5] = column means (ppo2.hpp:335). */
+void orc_update(const orc_cfg* c, float* theta, float* m, float* v, float pow[2], const orc_rollout* ro,
+                const int32_t* perms, int epochs, int nminibatches, float lr, float cliprange,
+                float* loss_rows, float mean_losses[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPO_ORACLE_H */

@@ -1,0 +1,46 @@
+"""Shared test helpers: fixture loading and seeded synthetic minibatches."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_npz_named(fname):
+    z = np.load(os.path.join(GOLDEN, fname), allow_pickle=True)
+    return {k.replace("__", "/"): z[k] for k in z.files}
+
+
+def g45_init():
+    d = load_npz_named("g45_init.npz")
+    return {k: v for k, v in d.items() if not k.startswith("const") and k != "adam_order"}
+
+
+def g45_consts():
+    d = load_npz_named("g45_init.npz")
+    return dict(zip([str(x) for x in d["const_names"]], [float(x) for x in d["const_values"]])), \
+        [str(x) for x in d["adam_order"]]
+
+
+def ckpt71():
+    return load_npz_named("ckpt71.npz")
+
+
+def ckpt71_stats():
+    return json.load(open(os.path.join(GOLDEN, "ckpt71_stats.json")))
+
+
+def synth_minibatch(orc, n, seed, adv_normalized=True):
+    """A seeded minibatch that exercises BOTH clip branches: old_neglogp/old_values are perturbed copies of the
+    current model's outputs so that ratio and v - v_old straddle the clip range."""
+    from oracle import oracle as o
+    rng = np.random.RandomState(seed)
+    obs = rng.uniform(-1, 1, (n, orc.O)).astype(np.float32)
+    noise = rng.normal(size=(n, orc.A)).astype(np.float32)
+    act, v, nlp = orc.step(obs, noise)
+    old_nlp = (nlp + rng.normal(scale=0.15, size=n)).astype(np.float32)
+    old_v = (v + rng.normal(scale=0.2, size=n)).astype(np.float32)
+    ret = (v + rng.normal(scale=0.5, size=n)).astype(np.float32)
+    adv = o.adv_normalize(ret, old_v) if adv_normalized else (ret - old_v).astype(np.float32)
+    return dict(obs=obs, actions=act, advs=adv, returns=ret, old_neglogp=old_nlp, old_values=old_v)
