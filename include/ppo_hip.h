@@ -1,0 +1,166 @@
+/*
+ * ppo_hip.h  --  C-ABI of libppo_hip.so: the MI355X (gfx950) replacement for the TensorFlow graph
+ * executor behind ppo_cpp's rollout-collect + minibatch-update hot path.
+ *
+ * The reference has no plugin/FFI layer for this path: the seam is tensorflow::Session::Run addressed by
+ * tensor-name strings (reference ppo2/ppo2.hpp:521-544).  Every entry point below replaces one of those
+ * call sites (cited per function, paths relative to the reference root).  Plain pointers and sizes only;
+ * no torch / Eigen / TF types.
+ *
+ * Conventions
+ *   - all matrices are row-major fp32 (reference env/env.hpp:14 `Mat`), all vectors contiguous fp32
+ *   - every pointer argument is HOST memory unless the name ends in _dev; the caller owns it and it is
+ *     only used for the duration of the call (the reference copies on every call too: ppo2/utils.hpp:42,53)
+ *   - return value: 0 = ok, negative = error; ppo_last_error() gives the message.  The reference prints
+ *     status.ToString() and assert(false)s (ppo2/policies.hpp:39-43, ppo2/ppo2.hpp:452-456)
+ *   - one handle = one caller thread = one HIP device + stream (reference: every Session::Run is issued
+ *     from the single main thread, env worker threads never touch the session: env/vec_env.hpp:247)
+ *   - a non-finite gradient norm poisons the weights with NaN exactly like G:24493-24543; not an error
+ *   - there is NO CPU fallback: every call fails loudly when no gfx950 device is usable
+ */
+#ifndef PPO_HIP_H
+#define PPO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPO_MAX_LAYERS 8
+#define PPO_ABI_VERSION 1
+
+typedef struct ppo_handle ppo_handle;
+
+/* Everything the reference bakes into the graph file at generation time (SURVEY section 5 'config'):
+ * network shape, ent_coef G:11323, vf_coef G:11395, max_grad_norm G:24370, Adam beta1/beta2/eps G:30430-30490. */
+typedef struct ppo_config {
+    int32_t obs_dim;                  /* O */
+    int32_t act_dim;                  /* A */
+    int32_t n_hidden;                 /* L, 1..PPO_MAX_LAYERS */
+    int32_t hidden[PPO_MAX_LAYERS];   /* h0..h{L-1} */
+    float ent_coef;
+    float vf_coef;
+    float max_grad_norm;
+    float adam_beta1;
+    float adam_beta2;
+    float adam_eps;
+    int32_t device;                   /* HIP device ordinal, -1 = current/LOCAL_RANK */
+    int32_t max_rows;                 /* largest row count ever passed to step/value/train_step (0 = 65536) */
+} ppo_config;
+
+/* fills the graph-baked defaults of the reference's shipped graph (ent 0.00071602932, vf 0.5, clip 0.5,
+ * Adam 0.9 / 0.999 / 1e-5) for the given shape */
+void ppo_config_default(ppo_config* cfg, int32_t obs_dim, int32_t act_dim, int32_t n_hidden, const int32_t* hidden);
+
+/* ---- lifecycle: SessionCreator::load_graph + Session::Run("init") (ppo2/session_creator.hpp:23-66) ---- */
+int ppo_create(const ppo_config* cfg, ppo_handle** out);
+void ppo_destroy(ppo_handle* h);
+const char* ppo_last_error(const ppo_handle* h);   /* h may be NULL: error of the last failed ppo_create */
+int ppo_abi_version(void);
+
+/* ---- variables: initializer consts G:2249-5297 / saver G:32312-33437 (ppo2/ppo2.hpp:107-223) ----------
+ * Tensors are addressed by index in TF trainable-variable order
+ *   pi_fc0/w, pi_fc0/b, vf_fc0/w, vf_fc0/b, pi_fc1/w, ... , vf/w, vf/b, pi/w, pi/b, pi/logstd   (4L+5 tensors)
+ * `which`: 0 = weights, 1 = Adam m slot, 2 = Adam v slot. */
+int ppo_num_tensors(const ppo_handle* h);
+int ppo_tensor_info(const ppo_handle* h, int index, char name[32], int32_t* rows, int32_t* cols); /* cols 0 = 1-D */
+int ppo_num_params(const ppo_handle* h);                      /* dense count (146213 for 18/18/[256,256]) */
+int ppo_get_tensor(ppo_handle* h, int which, int index, float* dst, int64_t count);
+int ppo_set_tensor(ppo_handle* h, int which, int index, const float* src, int64_t count);
+/* dense flat vector in the order above (the layout of the oracle's theta / m / v) */
+int ppo_get_flat(ppo_handle* h, int which, float* dst, int64_t count);
+int ppo_set_flat(ppo_handle* h, int which, const float* src, int64_t count);
+int ppo_get_beta_powers(ppo_handle* h, float pw[2]);          /* beta1_power, beta2_power (G:25426,25579) */
+int ppo_set_beta_powers(ppo_handle* h, const float pw[2]);
+/* orthogonal init of the same family as the constants in G (gain sqrt2 hidden, 0.01 pi, 1.0 vf; biases,
+ * logstd, Adam slots zero; beta powers = beta) */
+int ppo_init_orthogonal(ppo_handle* h, uint64_t seed);
+
+/* ---- act model ------------------------------------------------------------------------------------------
+ * MlpPolicy::step (ppo2/policies.hpp:33-46): feeds input/Ob:0, fetches output/_action, _value_flat, _neglogp.
+ * noise [n,A] = the N(0,1) draw of G:5894 made explicit (parity mode); NULL = on-device counter RNG. */
+int ppo_step(ppo_handle* h, const float* obs, int32_t n, const float* noise, float* action, float* value,
+             float* neglogp);
+/* MlpPolicy::value (ppo2/policies.hpp:64-77) */
+int ppo_value(ppo_handle* h, const float* obs, int32_t n, float* value);
+/* MlpPolicy::get_deterministic_action (ppo2/policies.hpp:49-62) */
+int ppo_act_deterministic(ppo_handle* h, const float* obs, int32_t n, float* action);
+
+/* ---- train op: PPO2::_train_step's Session::Run (ppo2/ppo2.hpp:430-468) ---------------------------------
+ * feeds train_model/input/Ob, loss/{action,advs,rewards,old_neglog_pac,old_vpred,learning_rate,clip_range}_ph;
+ * target ppo2/_train; losses = {pg_loss, vf_loss, entropy, approxkl, clipfrac}.  `advs` are ALREADY normalised
+ * (the reference normalises on the host, ppo2/ppo2.hpp:401-406; ppo_adv_normalize does it on the device). */
+int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, const float* actions,
+                   const float* advs, const float* returns, const float* old_neglogp, const float* old_values,
+                   int32_t n, float losses[5]);
+/* gradient of the last ppo_train_step BEFORE clipping (debug/parity), dense flat order */
+int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm);
+
+/* ---- fused host-loop numerics the north star moves onto the device ----------------------------------------
+ * PPO2::_train_step prologue (ppo2/ppo2.hpp:401-406) */
+int ppo_adv_normalize(ppo_handle* h, const float* returns, const float* values, int32_t n, float* advs);
+/* Runner::set_returns (ppo2/runner.hpp:159-191); [T,E] time-major; last_dones = dones after the last step */
+int ppo_gae(ppo_handle* h, const float* rewards, const float* values, const float* dones,
+            const float* last_values, const float* last_dones, int32_t T, int32_t E, float gamma, float lam,
+            float* returns);
+
+/* EnvNormalize (env/env_normalize.hpp:20-116) + RunningStatistics (common/running_statistics.hpp). */
+int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, float clip_rew, float epsilon);
+int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int training, float* out);
+int ppo_norm_reward(ppo_handle* h, const float* raw_rew, const float* dones, int32_t n_envs, int training,
+                    float* out);
+/* which: 0 = obs_rms, 1 = ret_rms; serialise / deserialise of env_normalize.hpp:134-146 */
+int ppo_norm_get_stats(ppo_handle* h, int which, float* mean, float* var, double* count);
+int ppo_norm_set_stats(ppo_handle* h, int which, const float* mean, const float* var, double count);
+
+/* ---- device-resident rollout: Runner::run (ppo2/runner.hpp:56-157) with buffers kept in HBM ---------------
+ * Buffers are time-major [T,E,...]; the reference's env-major row r = e*T + t (runner.hpp:136-152) is mapped
+ * at gather time, nothing is transposed. */
+int ppo_rollout_alloc(ppo_handle* h, int32_t n_envs, int32_t n_steps);
+/* host-Env path (an Env behind env/env.hpp steps on the host):
+ *   reset   : EnvNormalize::reset + Runner ctor (runner.hpp:48-50): normalise raw obs, dones = 0
+ *   act     : policy step on the current obs -> rollout[t]; actions copied back for Env::step (runner.hpp:75-116)
+ *   observe : EnvNormalize::step on the raw step result; stores reward[t]; becomes the current obs/dones */
+int ppo_rollout_reset(ppo_handle* h, const float* raw_obs);
+int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions_out);
+int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const float* raw_rew, const float* dones);
+/* bootstrap value + GAE (runner.hpp:134, 159-191) */
+int ppo_rollout_finish(ppo_handle* h, float gamma, float lam);
+/* device-env path: the whole T-step collect against the on-device seeded synthetic env (obs ~ U(-1,1)^O,
+ * reward ~ U(-1,1), done ~ Bernoulli(1/300), keyed by (seed, global env id, step counter)); env ids start at
+ * env0 (rank sharding).  first != 0 performs the reset (step counter step0), otherwise continues from the carried
+ * obs/dones.  noise [T,E,A] or NULL.  Ends with bootstrap + GAE. */
+int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t step0, int first,
+                          const float* noise, float gamma, float lam);
+/* field: 0 obs[T,E,O] 1 actions[T,E,A] 2 values 3 neglogp 4 dones 5 rewards 6 returns (all [T,E]) */
+int ppo_rollout_download(ppo_handle* h, int field, float* dst, int64_t count);
+int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count);
+
+/* ---- the whole minibatch-update phase of PPO2::learn (ppo2/ppo2.hpp:274-335) on the resident rollout ------
+ * perms [noptepochs, B] int32: perms[ep][i] = destination row of flattened source row i in epoch ep
+ * (out.row(perm[i]) = in.row(i), ppo2.hpp:291-296), or NULL = fresh on-device pseudo-random permutation per
+ * epoch keyed by (seed, epoch).  loss_rows [noptepochs*nminibatches, 5] (may be NULL); mean_losses = their
+ * column means (ppo2.hpp:335).  One HIP launch sequence per minibatch, replayed from a hipGraph. */
+int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t noptepochs, int32_t nminibatches,
+               const int32_t* perms, uint64_t seed, float* loss_rows, float mean_losses[5]);
+
+/* ---- data parallel: one process per GPU, RCCL over xGMI (new work; the reference has no collectives) -------
+ * uid = 128-byte ncclUniqueId made by rank 0 (ppo_dist_unique_id) and broadcast by the launcher.  After init,
+ * ppo_train_step / ppo_update all-reduce (sum) the flat gradient + loss sums across ranks between the backward
+ * and the clip+Adam launches, and ppo_norm_* merge their batch moments across ranks. */
+int ppo_dist_unique_id(char uid[128]);
+int ppo_dist_init(ppo_handle* h, int32_t world_size, int32_t rank, const char uid[128]);
+int ppo_dist_world(const ppo_handle* h);
+
+/* ---- measurement hooks ----------------------------------------------------------------------------------
+ * per-kernel device time (ms) accumulated with hipEvents on the handle's stream since the last reset;
+ * names/values are parallel arrays; returns the number of timed kernel classes */
+int ppo_prof_enable(ppo_handle* h, int on);
+int ppo_prof_read(ppo_handle* h, int max, char names[][32], double* total_ms, int64_t* launches);
+int ppo_sync(ppo_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPO_HIP_H */

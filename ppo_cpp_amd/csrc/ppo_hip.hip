@@ -1,0 +1,1083 @@
+// ppo_hip.hip -- C-ABI (include/ppo_hip.h) of libppo_hip.so: handle, padded parameter layout, HIP launch
+// sequences and hipGraph replay for the PPO rollout-collect + minibatch-update hot path on MI355X (gfx950).
+//
+// There is NO CPU fallback in this library: every entry point needs a HIP device and fails loudly without one.
+#include "../../include/ppo_hip.h"
+#include "ppo_kernels.hpp"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+int ru(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Tensor {
+    char name[32];
+    int rows, cols;          // dense shape (cols 0 = 1-D of length rows)
+    int prow, pcol;          // padded shape as stored ([prow][pcol], pcol = leading dimension)
+    int off_dense, off_pad;  // offsets into the dense flat vector / the padded device vector
+    int count() const { return rows * (cols ? cols : 1); }
+    int dcols() const { return cols ? cols : 1; }
+};
+
+enum ProfClass { PK_STEP = 0, PK_TRAIN_FB, PK_DW, PK_REDUCE, PK_ADAM, PK_EPOCH, PK_STATS, PK_ENV, PK_GAE, PK_COMM, PK_COUNT };
+const char* kProfNames[PK_COUNT] = {"policy_step", "train_fwd_bwd", "weight_grad", "grad_reduce", "adam", "epoch_prepare",
+                                    "running_stats", "seeded_env", "gae", "allreduce"};
+
+// RCCL entry points resolved at run time (the single-GPU path must not depend on librccl being loadable)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, char[128], int) = nullptr;   // ncclUniqueId is a 128-byte struct passed by value
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+}  // namespace
+
+struct ppo_handle {
+    ppo_config cfg{};
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int CT = 1;                       // column tiles per wave in the dense layers (4 for wide nets)
+    NetDev net{};
+    std::vector<Tensor> tensors;
+    int P_dense = 0, P_pad = 0, n_blocks = 0;
+    // parameters + optimiser state (padded layout)
+    float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad = nullptr, *sumsq = nullptr;
+    float* beta_pow = nullptr;        // {cur b1, cur b2, next b1, next b2}
+    float* hyper = nullptr;           // {lr, cliprange}
+    float* norm_out = nullptr;        // [1]
+    GradSrc* grad_src = nullptr;
+    // train workspaces (sized for ws_rows minibatch rows)
+    int ws_rows = 0;
+    float* x0g = nullptr;
+    float* hg[2][PPO_MAX_LAYERS]{};
+    float* dyg[2][PPO_MAX_LAYERS]{};
+    float* dmug = nullptr;
+    float* slots[2]{};
+    float* slabs = nullptr;
+    int max_split = 8;
+    DwTile* dw_tiles = nullptr;
+    int n_dw_tiles = 0;
+    bool dw_has_big = false;
+    // staging for host-pointer calls
+    int st_rows = 0;
+    float *st_obs = nullptr, *st_act = nullptr, *st_noise = nullptr, *st_vec[6]{};
+    float* st_loss = nullptr;         // [8]
+    // normaliser
+    int nz_envs = 0;
+    float nz_gamma = 0.99f, nz_clip_obs = 10.f, nz_clip_rew = 10.f, nz_eps = 1e-8f;
+    NormDev obs_rms{}, ret_rms{};
+    float* nz_ret = nullptr;
+    // rollout
+    int E = 0, T = 0;
+    float *ro_obs = nullptr, *ro_act = nullptr, *ro_val = nullptr, *ro_nlp = nullptr, *ro_done = nullptr, *ro_rew = nullptr,
+          *ro_ret = nullptr;
+    float *cur_obs = nullptr, *cur_done = nullptr, *raw_obs = nullptr, *raw_rew = nullptr, *raw_done = nullptr, *last_val = nullptr;
+    float* ro_noise = nullptr;        // [T,E,A] staging for explicit noise
+    // update
+    int* d_perms = nullptr; int* d_inv = nullptr; int* d_gidx = nullptr; float* d_advstats = nullptr;
+    uint32_t* d_keys = nullptr; float* d_loss_rows = nullptr; float* d_loss_mean = nullptr;
+    int upd_cap_rows = 0, upd_cap_steps = 0;
+    hipGraphExec_t upd_graph = nullptr;
+    int g_epochs = 0, g_nmb = 0, g_E = 0, g_T = 0, g_explicit = -1, g_world = 0;
+    bool use_graph = true;
+    uint32_t rng_calls = 0;
+    // dist
+    Rccl rccl;
+    void* comm = nullptr;
+    int world = 1, rank = 0;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_used;
+    size_t ev_next = 0;
+    double prof_ms[PK_COUNT]{};
+    int64_t prof_n[PK_COUNT]{};
+};
+
+namespace {
+
+int fail(ppo_handle* h, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return -1;
+}
+
+#define HIP_OK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(ppo_handle* h, T** p, size_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIP_OK(h, hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    HIP_OK(h, hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream));
+    return 0;
+}
+
+// ---- profiling (hipEvents on the handle's stream) ---------------------------------------------------------
+struct ProfScope {
+    ppo_handle* h; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ppo_handle* h_, int c) : h(h_), cls(c) {
+        if (!h->prof) return;
+        if (h->ev_next + 2 > h->ev_pool.size()) {
+            for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; h->ev_pool.push_back(e); }
+        }
+        a = h->ev_pool[h->ev_next++]; b = h->ev_pool[h->ev_next++];
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, h->stream);
+        h->ev_used.push_back({cls, {a, b}});
+    }
+};
+
+void prof_collect(ppo_handle* h) {
+    if (h->ev_used.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& u : h->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, u.second.first, u.second.second) == hipSuccess) { h->prof_ms[u.first] += ms; h->prof_n[u.first] += 1; }
+    }
+    h->ev_used.clear();
+    h->ev_next = 0;
+}
+
+// ---- layout -------------------------------------------------------------------------------------------------
+void add_tensor(ppo_handle* h, const char* name, int rows, int cols, int prow, int pcol, int& od, int& op) {
+    Tensor t{};
+    snprintf(t.name, sizeof t.name, "%s", name);
+    t.rows = rows; t.cols = cols; t.prow = prow; t.pcol = pcol;
+    t.off_dense = od; t.off_pad = op;
+    od += t.count();
+    op += ru(prow * pcol, 256);
+    h->tensors.push_back(t);
+}
+
+int build_layout(ppo_handle* h) {
+    const ppo_config& c = h->cfg;
+    NetDev& n = h->net;
+    memset(&n, 0, sizeof n);
+    n.O = c.obs_dim; n.A = c.act_dim; n.L = c.n_hidden;
+    n.Kp0 = ru(c.obs_dim, 16); n.Ap = ru(c.act_dim, 16);
+    int minH = 1 << 30;
+    for (int l = 0; l < n.L; ++l) { n.H[l] = c.hidden[l]; n.Hp[l] = ru(c.hidden[l], 16); minH = std::min(minH, n.Hp[l]); }
+    h->CT = 1;
+    if (minH >= 256) {
+        bool ok = true;
+        for (int l = 0; l < n.L; ++l) ok = ok && (n.Hp[l] % 64 == 0);
+        if (ok) h->CT = 4;
+    }
+    if (h->CT == 4) for (int l = 0; l < n.L; ++l) n.Hp[l] = ru(n.Hp[l], 64);
+    n.ent_coef = c.ent_coef; n.vf_coef = c.vf_coef;
+    int od = 0, op = 0;
+    char nm[32];
+    for (int l = 0; l < n.L; ++l) {
+        const int in = l ? n.H[l - 1] : n.O, inp = l ? n.Hp[l - 1] : n.Kp0;
+        snprintf(nm, sizeof nm, "pi_fc%d/w", l); n.w_off[0][l] = op; add_tensor(h, nm, in, n.H[l], inp, n.Hp[l], od, op);
+        snprintf(nm, sizeof nm, "pi_fc%d/b", l); n.b_off[0][l] = op; add_tensor(h, nm, n.H[l], 0, 1, n.Hp[l], od, op);
+        snprintf(nm, sizeof nm, "vf_fc%d/w", l); n.w_off[1][l] = op; add_tensor(h, nm, in, n.H[l], inp, n.Hp[l], od, op);
+        snprintf(nm, sizeof nm, "vf_fc%d/b", l); n.b_off[1][l] = op; add_tensor(h, nm, n.H[l], 0, 1, n.Hp[l], od, op);
+    }
+    const int HL = n.H[n.L - 1], HpL = n.Hp[n.L - 1];
+    n.wv_off = op;  add_tensor(h, "vf/w", HL, 1, HpL, 1, od, op);
+    n.bv_off = op;  add_tensor(h, "vf/b", 1, 0, 1, 1, od, op);
+    n.wmu_off = op; add_tensor(h, "pi/w", HL, n.A, HpL, n.Ap, od, op);
+    n.bmu_off = op; add_tensor(h, "pi/b", n.A, 0, 1, n.Ap, od, op);
+    n.ls_off = op;  add_tensor(h, "pi/logstd", 1, n.A, 1, n.Ap, od, op);
+    h->P_dense = od; h->P_pad = op; h->n_blocks = op / 256;
+    // LDS carve
+    int o = 0, hmax = n.Ap;
+    n.lds_h[0] = o; o += ROWS_PER_BLOCK * (n.Kp0 + LDS_PAD);
+    for (int l = 0; l < n.L; ++l) { n.lds_h[l + 1] = o; o += ROWS_PER_BLOCK * (n.Hp[l] + LDS_PAD); hmax = std::max(hmax, n.Hp[l]); }
+    n.lds_d[0] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
+    n.lds_d[1] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
+    n.lds_mu = o; o += ROWS_PER_BLOCK * (n.Ap + LDS_PAD);
+    n.lds_misc = o; o += 64 + ROWS_PER_BLOCK * n.Ap + 64;
+    n.lds_total = o;
+    if ((size_t)o * sizeof(float) > 160 * 1024)
+        return fail(h, "network too wide for the LDS-resident 16-row tile (%zu bytes of LDS needed, 163840 available)", (size_t)o * 4);
+    // slot layout
+    int s = 0;
+    for (int l = 0; l < n.L; ++l) { n.slot_db[l] = s; s += n.Hp[l]; }
+    n.slot_head = s; s += std::max(HpL, n.Ap);
+    n.slot_aux = s; s += n.Ap;
+    n.slot_loss = s; s += 8;
+    n.slot_w = ru(s, 4);
+    return 0;
+}
+
+int upload_grad_src(ppo_handle* h) {
+    const NetDev& n = h->net;
+    std::vector<GradSrc> src(h->n_blocks);
+    for (const Tensor& t : h->tensors) {
+        GradSrc g{2, 0, 0, 0, t.off_pad};
+        const std::string nm = t.name;
+        int l = -1;
+        if (nm.find("_fc") != std::string::npos) l = atoi(nm.c_str() + 5);
+        const int tower = nm[0] == 'v' ? 1 : 0;
+        if (nm.size() > 2 && nm.substr(nm.size() - 2) == "/w" && nm != "vf/w") g.kind = 0;
+        else if (l >= 0) { g.kind = 1; g.tower = tower; g.slot_off = n.slot_db[l]; g.count = n.Hp[l]; }
+        else if (nm == "vf/w") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_head; g.count = n.Hp[n.L - 1]; }
+        else if (nm == "vf/b") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_aux; g.count = 1; }
+        else if (nm == "pi/b") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_head; g.count = n.Ap; }
+        else if (nm == "pi/logstd") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_aux; g.count = n.Ap; }
+        const int nb = ru(t.prow * t.pcol, 256) / 256;
+        for (int b = 0; b < nb; ++b) src[t.off_pad / 256 + b] = g;
+    }
+    if (dev_alloc(h, &h->grad_src, src.size())) return -1;
+    HIP_OK(h, hipMemcpyAsync(h->grad_src, src.data(), src.size() * sizeof(GradSrc), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ensure_train_ws(ppo_handle* h, int rows) {
+    rows = ru(rows, 16);
+    if (rows <= h->ws_rows) return 0;
+    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    const NetDev& n = h->net;
+    if (dev_alloc(h, &h->x0g, (size_t)rows * n.Kp0)) return -1;
+    for (int t = 0; t < 2; ++t)
+        for (int l = 0; l < n.L; ++l) {
+            if (dev_alloc(h, &h->hg[t][l], (size_t)rows * n.Hp[l])) return -1;
+            if (dev_alloc(h, &h->dyg[t][l], (size_t)rows * n.Hp[l])) return -1;
+        }
+    if (dev_alloc(h, &h->dmug, (size_t)rows * n.Ap)) return -1;
+    for (int t = 0; t < 2; ++t)
+        if (dev_alloc(h, &h->slots[t], (size_t)(rows / 16) * n.slot_w)) return -1;
+    if (!h->slabs && dev_alloc(h, &h->slabs, (size_t)h->max_split * h->P_pad)) return -1;
+    // weight-gradient tile table
+    std::vector<DwTile> tiles;
+    h->dw_has_big = false;
+    auto add = [&](const float* X, int ldx, const float* dY, int ldy, int Kp, int Np, int out_off) {
+        const bool big = (Kp % 64 == 0) && (Np % 64 == 0);
+        const int ts = big ? 64 : 16;
+        if (big) h->dw_has_big = true;
+        for (int i = 0; i < Kp; i += ts)
+            for (int j = 0; j < Np; j += ts) tiles.push_back(DwTile{X, dY, ldx, ldy, i, j, out_off, Np, big ? 0 : 1});
+    };
+    for (int t = 0; t < 2; ++t)
+        for (int l = 0; l < n.L; ++l) {
+            const float* X = l ? h->hg[t][l - 1] : h->x0g;
+            const int Kp = l ? n.Hp[l - 1] : n.Kp0;
+            add(X, Kp, h->dyg[t][l], n.Hp[l], Kp, n.Hp[l], n.w_off[t][l]);
+        }
+    add(h->hg[0][n.L - 1], n.Hp[n.L - 1], h->dmug, n.Ap, n.Hp[n.L - 1], n.Ap, n.wmu_off);
+    std::stable_sort(tiles.begin(), tiles.end(), [](const DwTile& a, const DwTile& b) { return a.cls < b.cls; });
+    h->n_dw_tiles = (int)tiles.size();
+    if (dev_alloc(h, &h->dw_tiles, tiles.size())) return -1;
+    HIP_OK(h, hipMemcpyAsync(h->dw_tiles, tiles.data(), tiles.size() * sizeof(DwTile), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    h->ws_rows = rows;
+    return 0;
+}
+
+int ensure_staging(ppo_handle* h, int rows) {
+    if (rows <= h->st_rows) return 0;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    const NetDev& n = h->net;
+    if (dev_alloc(h, &h->st_obs, (size_t)rows * n.O)) return -1;
+    if (dev_alloc(h, &h->st_act, (size_t)rows * n.A)) return -1;
+    if (dev_alloc(h, &h->st_noise, (size_t)rows * n.A)) return -1;
+    for (int i = 0; i < 6; ++i) if (dev_alloc(h, &h->st_vec[i], (size_t)rows)) return -1;
+    h->st_rows = rows;
+    return 0;
+}
+
+// ---- launches -------------------------------------------------------------------------------------------------
+template <int CT>
+void launch_step_t(ppo_handle* h, const StepArgs& a) {
+    dim3 grid((a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 2);
+    hipLaunchKernelGGL(policy_step_kernel<CT>, grid, dim3(BLOCK_THREADS), (size_t)h->net.lds_total * sizeof(float), h->stream, h->net, a);
+}
+int launch_step(ppo_handle* h, const StepArgs& a) {
+    ProfScope ps(h, PK_STEP);
+    if (h->CT == 4) launch_step_t<4>(h, a); else launch_step_t<1>(h, a);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int pick_split(ppo_handle* h, int n) {
+    int s = h->max_split;
+    while (s > 1 && (n % (16 * s) != 0)) s >>= 1;
+    return s;
+}
+
+// the per-minibatch launch sequence: fwd+loss+bwd -> weight grads -> reduce [-> all-reduce] -> clip+Adam
+int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
+    const NetDev& n = h->net;
+    const int n_rb = (ta.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    ta.theta = h->theta; ta.hyper = h->hyper;
+    ta.x0g = h->x0g; ta.dmug = h->dmug;
+    for (int t = 0; t < 2; ++t) {
+        ta.slots[t] = h->slots[t];
+        for (int l = 0; l < n.L; ++l) { ta.hg[t][l] = h->hg[t][l]; ta.dyg[t][l] = h->dyg[t][l]; }
+    }
+    {
+        ProfScope ps(h, PK_TRAIN_FB);
+        dim3 grid(n_rb, 2);
+        if (h->CT == 4) hipLaunchKernelGGL(train_fwd_bwd_kernel<4>, grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
+        else hipLaunchKernelGGL(train_fwd_bwd_kernel<1>, grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
+        HIP_OK(h, hipGetLastError());
+    }
+    const int split = pick_split(h, ta.n);
+    {
+        ProfScope ps(h, PK_DW);
+        DwArgs da{h->dw_tiles, ta.n, split, h->slabs, (size_t)h->P_pad};
+        const size_t lds = (h->dw_has_big ? 4 * 64 * 64 : 4 * 16 * 16) * sizeof(float);
+        hipLaunchKernelGGL(weight_grad_kernel, dim3(h->n_dw_tiles, split), dim3(BLOCK_THREADS), lds, h->stream, da);
+        HIP_OK(h, hipGetLastError());
+    }
+    {
+        ProfScope ps(h, PK_REDUCE);
+        ReduceArgs ra{};
+        ra.src = h->grad_src; ra.n_blocks = h->n_blocks; ra.slabs = h->slabs; ra.slab_stride = (size_t)h->P_pad; ra.nsplit = split;
+        ra.slots[0] = h->slots[0]; ra.slots[1] = h->slots[1]; ra.n_rowblocks = n_rb; ra.slot_w = n.slot_w; ra.slot_loss = n.slot_loss;
+        ra.grad = h->grad; ra.sumsq = h->sumsq; ra.n_local = (float)ta.n; ra.beta_pow = h->beta_pow;
+        hipLaunchKernelGGL(grad_reduce_kernel, dim3(h->n_blocks + 1), dim3(256), 0, h->stream, ra);
+        HIP_OK(h, hipGetLastError());
+    }
+    if (h->world > 1) {
+        ProfScope ps(h, PK_COMM);
+        const size_t cnt = (size_t)h->P_pad + 8;
+        const int rc = h->rccl.AllReduce(h->grad, h->grad, cnt, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
+        if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
+        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
+        HIP_OK(h, hipGetLastError());
+    }
+    {
+        ProfScope ps(h, PK_ADAM);
+        AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->hyper, h->beta_pow,
+                    h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out};
+        hipLaunchKernelGGL(adam_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, aa);
+        HIP_OK(h, hipGetLastError());
+    }
+    return 0;
+}
+
+int set_hyper(ppo_handle* h, float lr, float cr) {
+    const float hv[2] = {lr, cr};
+    HIP_OK(h, hipMemcpyAsync(h->hyper, hv, sizeof hv, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+// dense <-> padded copies of one tensor
+int copy_tensor(ppo_handle* h, float* base, const Tensor& t, float* host, bool to_device) {
+    float* d = base + t.off_pad;
+    const size_t w = (size_t)t.dcols() * sizeof(float);
+    const int rows = t.cols ? t.rows : 1;
+    const size_t width = t.cols ? w : (size_t)t.rows * sizeof(float);
+    if (to_device) HIP_OK(h, hipMemcpy2D(d, (size_t)t.pcol * sizeof(float), host, width, width, rows, hipMemcpyHostToDevice));
+    else HIP_OK(h, hipMemcpy2D(host, width, d, (size_t)t.pcol * sizeof(float), width, rows, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+float* which_buf(ppo_handle* h, int which) { return which == 0 ? h->theta : which == 1 ? h->adam_m : which == 2 ? h->adam_v : nullptr; }
+
+ObsNorm no_norm() { return ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}; }
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+int ppo_abi_version(void) { return PPO_ABI_VERSION; }
+
+void ppo_config_default(ppo_config* cfg, int32_t obs_dim, int32_t act_dim, int32_t n_hidden, const int32_t* hidden) {
+    memset(cfg, 0, sizeof *cfg);
+    cfg->obs_dim = obs_dim; cfg->act_dim = act_dim; cfg->n_hidden = n_hidden;
+    for (int i = 0; i < n_hidden && i < PPO_MAX_LAYERS; ++i) cfg->hidden[i] = hidden[i];
+    cfg->ent_coef = 0.0007160293171182275f;   // G:11323
+    cfg->vf_coef = 0.5f;                      // G:11395
+    cfg->max_grad_norm = 0.5f;                // G:24370
+    cfg->adam_beta1 = 0.9f; cfg->adam_beta2 = 0.999f; cfg->adam_eps = 1e-5f;   // G:30430-30490
+    cfg->device = -1; cfg->max_rows = 0;
+}
+
+const char* ppo_last_error(const ppo_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ppo_create(const ppo_config* cfg, ppo_handle** out) {
+    if (!cfg || !out) return fail(nullptr, "ppo_create: null argument");
+    *out = nullptr;
+    if (cfg->n_hidden < 1 || cfg->n_hidden > PPO_MAX_LAYERS) return fail(nullptr, "ppo_create: n_hidden must be 1..%d", PPO_MAX_LAYERS);
+    if (cfg->obs_dim < 1 || cfg->act_dim < 1) return fail(nullptr, "ppo_create: bad obs/act dims");
+    for (int l = 0; l < cfg->n_hidden; ++l) if (cfg->hidden[l] < 1) return fail(nullptr, "ppo_create: bad hidden size");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, "ppo_create: no HIP device available (%s); libppo_hip has no CPU fallback", hipGetErrorString(e));
+    ppo_handle* h = new ppo_handle();
+    h->cfg = *cfg;
+    int dev = cfg->device;
+    if (dev < 0) { const char* lr = getenv("LOCAL_RANK"); dev = lr ? atoi(lr) % ndev : 0; }
+    h->device = dev;
+    auto bail = [&](int) { g_create_error = h->err; ppo_destroy(h); return -1; };
+    if (hipSetDevice(dev) != hipSuccess) { fail(h, "hipSetDevice(%d) failed", dev); return bail(0); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { fail(h, "hipGetDeviceProperties failed"); return bail(0); }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { fail(h, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName); return bail(0); }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { fail(h, "hipStreamCreate failed"); return bail(0); }
+    const char* ng = getenv("PPO_HIP_NO_GRAPH");
+    h->use_graph = !(ng && ng[0] == '1');
+    if (build_layout(h)) return bail(0);
+    // large dynamic LDS needs an explicit opt-in
+    const int lds_bytes = h->net.lds_total * (int)sizeof(float);
+    bool attr_ok = true;
+    if (h->CT == 4) {
+        attr_ok &= hipFuncSetAttribute((const void*)policy_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)train_fwd_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    } else {
+        attr_ok &= hipFuncSetAttribute((const void*)policy_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)train_fwd_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    }
+    attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
+    if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return bail(0); }
+    const size_t P = (size_t)h->P_pad;
+    if (dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||
+        dev_alloc(h, &h->sumsq, (size_t)h->n_blocks) || dev_alloc(h, &h->beta_pow, 4) || dev_alloc(h, &h->hyper, 2) ||
+        dev_alloc(h, &h->norm_out, 1) || dev_alloc(h, &h->st_loss, 8))
+        return bail(0);
+    if (upload_grad_src(h)) return bail(0);
+    const float pw[2] = {cfg->adam_beta1, cfg->adam_beta2};
+    if (ppo_set_beta_powers(h, pw)) return bail(0);
+    *out = h;
+    return 0;
+}
+
+void ppo_destroy(ppo_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->upd_graph) (void)hipGraphExecDestroy(h->upd_graph);
+    if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    void* ptrs[] = {h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
+                    h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
+                    h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->ro_obs, h->ro_act,
+                    h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->cur_obs, h->cur_done, h->raw_obs, h->raw_rew, h->raw_done,
+                    h->last_val, h->ro_noise, h->d_perms, h->d_inv, h->d_gidx, h->d_advstats, h->d_keys, h->d_loss_rows, h->d_loss_mean};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) { if (h->hg[t][l]) (void)hipFree(h->hg[t][l]); if (h->dyg[t][l]) (void)hipFree(h->dyg[t][l]); }
+    for (int i = 0; i < 6; ++i) if (h->st_vec[i]) (void)hipFree(h->st_vec[i]);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ppo_sync(ppo_handle* h) { HIP_OK(h, hipStreamSynchronize(h->stream)); return 0; }
+
+// ---- variables ----------------------------------------------------------------------------------------------------
+int ppo_num_tensors(const ppo_handle* h) { return (int)h->tensors.size(); }
+int ppo_num_params(const ppo_handle* h) { return h->P_dense; }
+
+int ppo_tensor_info(const ppo_handle* h, int index, char name[32], int32_t* rows, int32_t* cols) {
+    if (index < 0 || index >= (int)h->tensors.size()) return -1;
+    const Tensor& t = h->tensors[index];
+    if (name) snprintf(name, 32, "%s", t.name);
+    if (rows) *rows = t.rows;
+    if (cols) *cols = t.cols;
+    return 0;
+}
+
+int ppo_get_tensor(ppo_handle* h, int which, int index, float* dst, int64_t count) {
+    float* base = which_buf(h, which);
+    if (!base || index < 0 || index >= (int)h->tensors.size()) return fail(h, "ppo_get_tensor: bad which/index");
+    const Tensor& t = h->tensors[index];
+    if (count != t.count()) return fail(h, "ppo_get_tensor(%s): count %lld != %d", t.name, (long long)count, t.count());
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return copy_tensor(h, base, t, dst, false);
+}
+
+int ppo_set_tensor(ppo_handle* h, int which, int index, const float* src, int64_t count) {
+    float* base = which_buf(h, which);
+    if (!base || index < 0 || index >= (int)h->tensors.size()) return fail(h, "ppo_set_tensor: bad which/index");
+    const Tensor& t = h->tensors[index];
+    if (count != t.count()) return fail(h, "ppo_set_tensor(%s): count %lld != %d", t.name, (long long)count, t.count());
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return copy_tensor(h, base, t, const_cast<float*>(src), true);
+}
+
+int ppo_get_flat(ppo_handle* h, int which, float* dst, int64_t count) {
+    if (count != h->P_dense) return fail(h, "ppo_get_flat: count %lld != %d", (long long)count, h->P_dense);
+    for (size_t i = 0; i < h->tensors.size(); ++i)
+        if (ppo_get_tensor(h, which, (int)i, dst + h->tensors[i].off_dense, h->tensors[i].count())) return -1;
+    return 0;
+}
+
+int ppo_set_flat(ppo_handle* h, int which, const float* src, int64_t count) {
+    if (count != h->P_dense) return fail(h, "ppo_set_flat: count %lld != %d", (long long)count, h->P_dense);
+    for (size_t i = 0; i < h->tensors.size(); ++i)
+        if (ppo_set_tensor(h, which, (int)i, src + h->tensors[i].off_dense, h->tensors[i].count())) return -1;
+    return 0;
+}
+
+int ppo_get_beta_powers(ppo_handle* h, float pw[2]) {
+    float v[4];
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(v, h->beta_pow, sizeof v, hipMemcpyDeviceToHost));
+    pw[0] = v[2]; pw[1] = v[3];          // "next" = the value the following train step will use
+    return 0;
+}
+
+int ppo_set_beta_powers(ppo_handle* h, const float pw[2]) {
+    const float v[4] = {pw[0], pw[1], pw[0], pw[1]};
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(h->beta_pow, v, sizeof v, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ppo_init_orthogonal(ppo_handle* h, uint64_t seed) {
+    // orthogonal initialiser of the same family as the constants in G (a16): rows or columns orthonormal, scaled by gain
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    auto next_u = [&]() { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    auto next_n = [&]() { const double u1 = ((next_u() >> 11) + 1.0) / 9007199254740993.0, u2 = (next_u() >> 11) / 9007199254740992.0; return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2); };
+    std::vector<float> flat(h->P_dense, 0.f);
+    for (const Tensor& t : h->tensors) {
+        const std::string nm = t.name;
+        if (nm.size() < 2 || nm.substr(nm.size() - 2) != "/w") continue;
+        const double gain = nm == "pi/w" ? 0.01 : nm == "vf/w" ? 1.0 : sqrt(2.0);
+        const int R = t.rows, C = t.dcols();
+        const bool tall = R >= C;
+        const int nv = tall ? C : R, len = tall ? R : C;            // nv orthonormal vectors of length len
+        std::vector<double> q((size_t)nv * len);
+        for (int v = 0; v < nv; ++v) {
+            double* qv = &q[(size_t)v * len];
+            for (int i = 0; i < len; ++i) qv[i] = next_n();
+            for (int pass = 0; pass < 2; ++pass)                      // modified Gram-Schmidt, twice for orthogonality
+                for (int u = 0; u < v; ++u) {
+                    const double* qu = &q[(size_t)u * len];
+                    double d = 0; for (int i = 0; i < len; ++i) d += qv[i] * qu[i];
+                    for (int i = 0; i < len; ++i) qv[i] -= d * qu[i];
+                }
+            double nn = 0; for (int i = 0; i < len; ++i) nn += qv[i] * qv[i];
+            nn = 1.0 / sqrt(nn);
+            for (int i = 0; i < len; ++i) qv[i] *= nn;
+        }
+        float* w = &flat[t.off_dense];
+        for (int r = 0; r < R; ++r)
+            for (int c = 0; c < C; ++c) w[(size_t)r * C + c] = (float)(gain * (tall ? q[(size_t)c * len + r] : q[(size_t)r * len + c]));
+    }
+    if (ppo_set_flat(h, 0, flat.data(), h->P_dense)) return -1;
+    std::vector<float> zero(h->P_dense, 0.f);
+    if (ppo_set_flat(h, 1, zero.data(), h->P_dense) || ppo_set_flat(h, 2, zero.data(), h->P_dense)) return -1;
+    const float pw[2] = {h->cfg.adam_beta1, h->cfg.adam_beta2};
+    return ppo_set_beta_powers(h, pw);
+}
+
+// ---- act model ----------------------------------------------------------------------------------------------------
+static int step_common(ppo_handle* h, const float* obs, int n, const float* noise, bool sample, float* action, float* det_action,
+                       float* value, float* neglogp) {
+    if (n < 1) return fail(h, "step: n must be positive");
+    if (ensure_staging(h, n)) return -1;
+    const NetDev& net = h->net;
+    HIP_OK(h, hipMemcpyAsync(h->st_obs, obs, (size_t)n * net.O * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (noise) HIP_OK(h, hipMemcpyAsync(h->st_noise, noise, (size_t)n * net.A * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    StepArgs a{};
+    a.theta = h->theta; a.obs = h->st_obs; a.noise = noise ? h->st_noise : nullptr;
+    a.action = (sample && action) ? h->st_act : nullptr;
+    a.det_action = det_action ? h->st_act : nullptr;
+    a.value = value ? h->st_vec[0] : nullptr;
+    a.neglogp = neglogp ? h->st_vec[1] : nullptr;
+    a.obs_out = nullptr; a.nz = no_norm(); a.n = n;
+    a.seed = 0x5EEDu; a.rng_step = h->rng_calls++; a.row_base = 0;
+    if (launch_step(h, a)) return -1;
+    if (action || det_action) HIP_OK(h, hipMemcpyAsync(action ? action : det_action, h->st_act, (size_t)n * net.A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (value) HIP_OK(h, hipMemcpyAsync(value, h->st_vec[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (neglogp) HIP_OK(h, hipMemcpyAsync(neglogp, h->st_vec[1], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_step(ppo_handle* h, const float* obs, int32_t n, const float* noise, float* action, float* value, float* neglogp) {
+    return step_common(h, obs, n, noise, true, action, nullptr, value, neglogp);
+}
+int ppo_value(ppo_handle* h, const float* obs, int32_t n, float* value) {
+    return step_common(h, obs, n, nullptr, false, nullptr, nullptr, value, nullptr);
+}
+int ppo_act_deterministic(ppo_handle* h, const float* obs, int32_t n, float* action) {
+    return step_common(h, obs, n, nullptr, false, nullptr, action, nullptr, nullptr);
+}
+
+// ---- train op -------------------------------------------------------------------------------------------------------
+int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, const float* actions, const float* advs,
+                   const float* returns, const float* old_neglogp, const float* old_values, int32_t n, float losses[5]) {
+    if (n < 16 || n % 16) return fail(h, "ppo_train_step: n=%d must be a positive multiple of 16", n);
+    if (ensure_staging(h, n) || ensure_train_ws(h, n)) return -1;
+    const NetDev& net = h->net;
+    const size_t fb = sizeof(float);
+    HIP_OK(h, hipMemcpyAsync(h->st_obs, obs, (size_t)n * net.O * fb, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->st_act, actions, (size_t)n * net.A * fb, hipMemcpyHostToDevice, h->stream));
+    const float* vecs[4] = {advs, returns, old_neglogp, old_values};
+    for (int i = 0; i < 4; ++i) HIP_OK(h, hipMemcpyAsync(h->st_vec[2 + i], vecs[i], (size_t)n * fb, hipMemcpyHostToDevice, h->stream));
+    if (set_hyper(h, lr, cliprange)) return -1;
+    TrainArgs ta{};
+    ta.obs = h->st_obs; ta.actions = h->st_act; ta.advs = h->st_vec[2]; ta.returns = h->st_vec[3]; ta.old_neglogp = h->st_vec[4];
+    ta.old_values = h->st_vec[5]; ta.adv_stats = nullptr; ta.rowidx = nullptr; ta.n = n;
+    ta.inv_n = 1.0f / (float)((int64_t)n * h->world);
+    if (enqueue_train(h, ta, h->st_loss)) return -1;
+    HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    prof_collect(h);
+    return 0;
+}
+
+int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm) {
+    if (count != h->P_dense) return fail(h, "ppo_get_last_grad: count %lld != %d", (long long)count, h->P_dense);
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    for (const Tensor& t : h->tensors) if (copy_tensor(h, h->grad, t, dst + t.off_dense, false)) return -1;
+    if (global_norm) HIP_OK(h, hipMemcpy(global_norm, h->norm_out, sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- host-loop numerics on the device -------------------------------------------------------------------------------
+int ppo_adv_normalize(ppo_handle* h, const float* returns, const float* values, int32_t n, float* advs) {
+    if (n < 1) return fail(h, "ppo_adv_normalize: n must be positive");
+    if (ensure_staging(h, n)) return -1;
+    HIP_OK(h, hipMemcpyAsync(h->st_vec[0], returns, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->st_vec[1], values, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(adv_normalize_kernel, dim3(1), dim3(1024), 0, h->stream, h->st_vec[0], h->st_vec[1], n, h->st_vec[2]);
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipMemcpyAsync(advs, h->st_vec[2], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_gae(ppo_handle* h, const float* rewards, const float* values, const float* dones, const float* last_values,
+            const float* last_dones, int32_t T, int32_t E, float gamma, float lam, float* returns) {
+    if (T < 1 || E < 1) return fail(h, "ppo_gae: bad shape");
+    const size_t n = (size_t)T * E;
+    if (n > (size_t)1 << 30) return fail(h, "ppo_gae: too large");
+    if (ensure_staging(h, (int)n)) return -1;
+    const float* src[5] = {rewards, values, dones, last_values, last_dones};
+    const size_t cnt[5] = {n, n, n, (size_t)E, (size_t)E};
+    for (int i = 0; i < 5; ++i) HIP_OK(h, hipMemcpyAsync(h->st_vec[i], src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    {
+        ProfScope ps(h, PK_GAE);
+        hipLaunchKernelGGL(gae_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, h->st_vec[0], h->st_vec[1], h->st_vec[2], h->st_vec[3],
+                           h->st_vec[4], T, E, gamma, lam, h->st_vec[5]);
+        HIP_OK(h, hipGetLastError());
+    }
+    HIP_OK(h, hipMemcpyAsync(returns, h->st_vec[5], n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int norm_alloc_stats(ppo_handle* h, NormDev& s, int dim) {
+    if (dev_alloc(h, &s.mean, dim) || dev_alloc(h, &s.var, dim) || dev_alloc(h, &s.count, 1)) return -1;
+    std::vector<float> ones(dim, 1.0f);
+    const double c0 = 1e-6;                                    // running_statistics.hpp:17-21
+    HIP_OK(h, hipMemcpyAsync(s.var, ones.data(), dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(s.count, &c0, sizeof c0, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, float clip_rew, float epsilon) {
+    if (n_envs < 1) return fail(h, "ppo_norm_init: n_envs must be positive");
+    if (h->net.O > STATS_THREADS) return fail(h, "ppo_norm_init: obs_dim > %d unsupported", STATS_THREADS);
+    h->nz_envs = n_envs; h->nz_gamma = gamma; h->nz_clip_obs = clip_obs; h->nz_clip_rew = clip_rew; h->nz_eps = epsilon;
+    if (norm_alloc_stats(h, h->obs_rms, h->net.O) || norm_alloc_stats(h, h->ret_rms, 1)) return -1;
+    if (dev_alloc(h, &h->nz_ret, n_envs)) return -1;
+    if (dev_alloc(h, &h->raw_obs, (size_t)n_envs * h->net.O) || dev_alloc(h, &h->raw_rew, n_envs) || dev_alloc(h, &h->raw_done, n_envs)) return -1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// device-side pieces shared by the host-pointer API and the rollout loop
+static int enqueue_obs_stats(ppo_handle* h, const float* raw_dev, int rows) {
+    ProfScope ps(h, PK_STATS);
+    hipLaunchKernelGGL(running_stats_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, raw_dev, rows, h->net.O, h->obs_rms);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+static int enqueue_reward_norm(ppo_handle* h, const float* rew_dev, const float* done_dev, int rows, int training, float* out_dev) {
+    ProfScope ps(h, PK_STATS);
+    hipLaunchKernelGGL(reward_norm_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, rew_dev, done_dev, rows, training, h->nz_gamma,
+                       h->nz_clip_rew, h->nz_eps, h->nz_ret, h->ret_rms, out_dev);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int training, float* out) {
+    if (!h->nz_envs) return fail(h, "ppo_norm_obs: call ppo_norm_init first");
+    if (n_envs != h->nz_envs) return fail(h, "ppo_norm_obs: n_envs %d != %d", n_envs, h->nz_envs);
+    if (h->world > 1) return fail(h, "ppo_norm_obs: host-pointer normaliser is single-rank; use the rollout API under ppo_dist_init");
+    const size_t cnt = (size_t)n_envs * h->net.O;
+    if (ensure_staging(h, n_envs)) return -1;
+    HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (training && enqueue_obs_stats(h, h->raw_obs, n_envs)) return -1;
+    hipLaunchKernelGGL(obs_normalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->raw_obs, n_envs, h->net.O, h->obs_rms,
+                       h->nz_eps, h->nz_clip_obs, h->st_obs);
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipMemcpyAsync(out, h->st_obs, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_norm_reward(ppo_handle* h, const float* raw_rew, const float* dones, int32_t n_envs, int training, float* out) {
+    if (!h->nz_envs) return fail(h, "ppo_norm_reward: call ppo_norm_init first");
+    if (n_envs != h->nz_envs) return fail(h, "ppo_norm_reward: n_envs %d != %d", n_envs, h->nz_envs);
+    if (ensure_staging(h, n_envs)) return -1;
+    HIP_OK(h, hipMemcpyAsync(h->raw_rew, raw_rew, (size_t)n_envs * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->raw_done, dones, (size_t)n_envs * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (enqueue_reward_norm(h, h->raw_rew, h->raw_done, n_envs, training, h->st_vec[0])) return -1;
+    HIP_OK(h, hipMemcpyAsync(out, h->st_vec[0], (size_t)n_envs * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_norm_get_stats(ppo_handle* h, int which, float* mean, float* var, double* count) {
+    if (!h->nz_envs) return fail(h, "ppo_norm_get_stats: call ppo_norm_init first");
+    NormDev& s = which == 0 ? h->obs_rms : h->ret_rms;
+    const int dim = which == 0 ? h->net.O : 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(mean, s.mean, dim * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(h, hipMemcpy(var, s.var, dim * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(h, hipMemcpy(count, s.count, sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ppo_norm_set_stats(ppo_handle* h, int which, const float* mean, const float* var, double count) {
+    if (!h->nz_envs) return fail(h, "ppo_norm_set_stats: call ppo_norm_init first");
+    NormDev& s = which == 0 ? h->obs_rms : h->ret_rms;
+    const int dim = which == 0 ? h->net.O : 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(s.mean, mean, dim * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(h, hipMemcpy(s.var, var, dim * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(h, hipMemcpy(s.count, &count, sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ---- rollout ----------------------------------------------------------------------------------------------------------
+int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
+    if (E < 1 || T < 1) return fail(h, "ppo_rollout_alloc: bad shape");
+    if (!h->nz_envs && ppo_norm_init(h, E, 0.99f, 10.f, 10.f, 1e-8f)) return -1;
+    if (h->nz_envs != E) return fail(h, "ppo_rollout_alloc: n_envs %d != normaliser's %d", E, h->nz_envs);
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    const NetDev& n = h->net;
+    const size_t B = (size_t)E * T;
+    if (dev_alloc(h, &h->ro_obs, B * n.O) || dev_alloc(h, &h->ro_act, B * n.A) || dev_alloc(h, &h->ro_val, B) || dev_alloc(h, &h->ro_nlp, B) ||
+        dev_alloc(h, &h->ro_done, B) || dev_alloc(h, &h->ro_rew, B) || dev_alloc(h, &h->ro_ret, B) || dev_alloc(h, &h->cur_obs, (size_t)E * n.O) ||
+        dev_alloc(h, &h->cur_done, E) || dev_alloc(h, &h->last_val, E) || dev_alloc(h, &h->ro_noise, B * n.A))
+        return -1;
+    h->E = E; h->T = T;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// normalise raw obs (update-then-normalise, env_normalize.hpp:94-105) into cur_obs
+static int enqueue_obs_normalize(ppo_handle* h, int training) {
+    const size_t cnt = (size_t)h->E * h->net.O;
+    if (training && enqueue_obs_stats(h, h->raw_obs, h->E)) return -1;
+    hipLaunchKernelGGL(obs_normalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->raw_obs, h->E, h->net.O, h->obs_rms,
+                       h->nz_eps, h->nz_clip_obs, h->cur_obs);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+// policy step on cur_obs -> rollout[t]
+static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uint32_t seed, uint32_t rng_step, uint32_t row_base) {
+    const NetDev& n = h->net;
+    const size_t E = h->E;
+    HIP_OK(h, hipMemcpyAsync(h->ro_obs + t * E * n.O, h->cur_obs, E * n.O * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->ro_done + t * E, h->cur_done, E * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    StepArgs a{};
+    a.theta = h->theta; a.obs = h->cur_obs; a.noise = noise_dev; a.action = h->ro_act + t * E * n.A; a.det_action = nullptr;
+    a.value = h->ro_val + t * E; a.neglogp = h->ro_nlp + t * E; a.obs_out = nullptr; a.nz = no_norm(); a.n = (int)E;
+    a.seed = seed; a.rng_step = rng_step; a.row_base = row_base;
+    return launch_step(h, a);
+}
+
+static int enqueue_finish(ppo_handle* h, float gamma, float lam) {
+    StepArgs a{};
+    a.theta = h->theta; a.obs = h->cur_obs; a.value = h->last_val; a.nz = no_norm(); a.n = h->E;
+    if (launch_step(h, a)) return -1;
+    ProfScope ps(h, PK_GAE);
+    hipLaunchKernelGGL(gae_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, h->ro_rew, h->ro_val, h->ro_done, h->last_val, h->cur_done,
+                       h->T, h->E, gamma, lam, h->ro_ret);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int ppo_rollout_reset(ppo_handle* h, const float* raw_obs) {
+    if (!h->E) return fail(h, "ppo_rollout_reset: call ppo_rollout_alloc first");
+    HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, (size_t)h->E * h->net.O * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)h->E * sizeof(float), h->stream));          // env_normalize.hpp:114
+    HIP_OK(h, hipMemsetAsync(h->cur_done, 0, (size_t)h->E * sizeof(float), h->stream));        // runner.hpp:50
+    if (enqueue_obs_normalize(h, 1)) return -1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions_out) {
+    if (!h->E || t < 0 || t >= h->T) return fail(h, "ppo_rollout_act: bad step %d", t);
+    const NetDev& n = h->net;
+    const size_t cnt = (size_t)h->E * n.A;
+    float* nd = nullptr;
+    if (noise) { nd = h->ro_noise; HIP_OK(h, hipMemcpyAsync(nd, noise, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream)); }
+    if (enqueue_rollout_act(h, t, nd, 0x5EEDu, h->rng_calls++, 0)) return -1;
+    HIP_OK(h, hipMemcpyAsync(actions_out, h->ro_act + (size_t)t * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const float* raw_rew, const float* dones) {
+    if (!h->E || t < 0 || t >= h->T) return fail(h, "ppo_rollout_observe: bad step %d", t);
+    const size_t E = h->E;
+    HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, E * h->net.O * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->raw_rew, raw_rew, E * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->cur_done, dones, E * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (enqueue_obs_normalize(h, 1)) return -1;
+    if (enqueue_reward_norm(h, h->raw_rew, h->cur_done, (int)E, 1, h->ro_rew + (size_t)t * E)) return -1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
+    if (!h->E) return fail(h, "ppo_rollout_finish: call ppo_rollout_alloc first");
+    if (enqueue_finish(h, gamma, lam)) return -1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    prof_collect(h);
+    return 0;
+}
+
+int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t step0, int first, const float* noise, float gamma, float lam) {
+    if (!h->E) return fail(h, "ppo_collect_synthetic: call ppo_rollout_alloc first");
+    const NetDev& n = h->net;
+    const int E = h->E, T = h->T;
+    const int envW = E * (n.O + 2);
+    if (noise) HIP_OK(h, hipMemcpyAsync(h->ro_noise, noise, (size_t)E * T * n.A * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (first) {
+        { ProfScope ps(h, PK_ENV);
+          hipLaunchKernelGGL(seeded_env_kernel, dim3((envW + 255) / 256), dim3(256), 0, h->stream, seed, env0, E, step0, n.O, h->raw_obs, (float*)nullptr, (float*)nullptr);
+          HIP_OK(h, hipGetLastError()); }
+        HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)E * sizeof(float), h->stream));
+        HIP_OK(h, hipMemsetAsync(h->cur_done, 0, (size_t)E * sizeof(float), h->stream));
+        if (enqueue_obs_normalize(h, 1)) return -1;
+    }
+    for (int t = 0; t < T; ++t) {
+        if (enqueue_rollout_act(h, t, noise ? h->ro_noise + (size_t)t * E * n.A : nullptr, seed, step0 + t, (uint32_t)env0)) return -1;
+        { ProfScope ps(h, PK_ENV);
+          hipLaunchKernelGGL(seeded_env_kernel, dim3((envW + 255) / 256), dim3(256), 0, h->stream, seed, env0, E, step0 + (uint32_t)t + 1u, n.O, h->raw_obs, h->raw_rew, h->cur_done);
+          HIP_OK(h, hipGetLastError()); }
+        if (enqueue_obs_normalize(h, 1)) return -1;
+        if (enqueue_reward_norm(h, h->raw_rew, h->cur_done, E, 1, h->ro_rew + (size_t)t * E)) return -1;
+    }
+    if (enqueue_finish(h, gamma, lam)) return -1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    prof_collect(h);
+    return 0;
+}
+
+static float* rollout_field(ppo_handle* h, int field, size_t* count) {
+    const size_t B = (size_t)h->E * h->T;
+    switch (field) {
+        case 0: *count = B * h->net.O; return h->ro_obs;
+        case 1: *count = B * h->net.A; return h->ro_act;
+        case 2: *count = B; return h->ro_val;
+        case 3: *count = B; return h->ro_nlp;
+        case 4: *count = B; return h->ro_done;
+        case 5: *count = B; return h->ro_rew;
+        case 6: *count = B; return h->ro_ret;
+    }
+    return nullptr;
+}
+
+int ppo_rollout_download(ppo_handle* h, int field, float* dst, int64_t count) {
+    size_t c = 0;
+    float* p = h->E ? rollout_field(h, field, &c) : nullptr;
+    if (!p || (size_t)count != c) return fail(h, "ppo_rollout_download: bad field/count");
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(dst, p, c * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count) {
+    size_t c = 0;
+    float* p = h->E ? rollout_field(h, field, &c) : nullptr;
+    if (!p || (size_t)count != c) return fail(h, "ppo_rollout_upload: bad field/count");
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(p, src, c * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ---- update -----------------------------------------------------------------------------------------------------------
+static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perms) {
+    const int B = h->E * h->T, M = B / nmb;
+    uint32_t bits = 1;
+    while ((1u << bits) < (uint32_t)B) ++bits;
+    for (int ep = 0; ep < epochs; ++ep) {
+        if (explicit_perms) {
+            hipLaunchKernelGGL(invert_perm_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->d_perms + (size_t)ep * B, h->d_inv, B);
+            HIP_OK(h, hipGetLastError());
+        }
+        {
+            ProfScope ps(h, PK_EPOCH);
+            EpochArgs ea{};
+            ea.inv_perm = explicit_perms ? h->d_inv : nullptr; ea.keys = h->d_keys + 2 * ep; ea.bits = bits;
+            ea.B = B; ea.M = M; ea.T = h->T; ea.E = h->E; ea.returns = h->ro_ret; ea.values = h->ro_val; ea.gidx = h->d_gidx; ea.stats = h->d_advstats;
+            hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(256), 0, h->stream, ea);
+            HIP_OK(h, hipGetLastError());
+        }
+        for (int k = 0; k < nmb; ++k) {
+            TrainArgs ta{};
+            ta.obs = h->ro_obs; ta.actions = h->ro_act; ta.returns = h->ro_ret; ta.old_values = h->ro_val; ta.old_neglogp = h->ro_nlp;
+            ta.advs = nullptr; ta.adv_stats = h->d_advstats + 2 * k; ta.rowidx = h->d_gidx + (size_t)k * M; ta.n = M;
+            ta.inv_n = 1.0f / (float)((int64_t)M * h->world);
+            if (enqueue_train(h, ta, h->d_loss_rows + (size_t)(ep * nmb + k) * 5)) return -1;
+        }
+    }
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, h->stream, h->d_loss_rows, epochs * nmb, h->d_loss_mean);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t nmb, const int32_t* perms, uint64_t seed, float* loss_rows,
+               float mean_losses[5]) {
+    if (!h->E) return fail(h, "ppo_update: no rollout (ppo_rollout_alloc + collect first)");
+    const int B = h->E * h->T;
+    if (epochs < 1 || nmb < 1 || B % nmb) return fail(h, "ppo_update: n_batch %d not divisible by nminibatches %d", B, nmb);
+    const int M = B / nmb;
+    if (M % 16) return fail(h, "ppo_update: minibatch rows %d must be a multiple of 16", M);
+    if (h->world > 1 && perms == nullptr && false) return fail(h, "unreachable");
+    if (ensure_train_ws(h, M)) return -1;
+    const int steps = epochs * nmb;
+    if (B > h->upd_cap_rows || steps > h->upd_cap_steps || !h->d_keys) {
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        const int cr = std::max(B, h->upd_cap_rows), cs = std::max(steps, h->upd_cap_steps);
+        if (dev_alloc(h, &h->d_perms, (size_t)cs * cr) || dev_alloc(h, &h->d_inv, cr) || dev_alloc(h, &h->d_gidx, cr) ||
+            dev_alloc(h, &h->d_advstats, (size_t)2 * cs) || dev_alloc(h, &h->d_keys, (size_t)2 * cs) || dev_alloc(h, &h->d_loss_rows, (size_t)5 * cs) ||
+            dev_alloc(h, &h->d_loss_mean, 8))
+            return -1;
+        h->upd_cap_rows = cr; h->upd_cap_steps = cs;
+    }
+    if (set_hyper(h, lr, cliprange)) return -1;
+    const bool explicit_perms = perms != nullptr;
+    if (explicit_perms) HIP_OK(h, hipMemcpyAsync(h->d_perms, perms, (size_t)epochs * B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    std::vector<uint32_t> keys(2 * (size_t)epochs);
+    for (int ep = 0; ep < epochs; ++ep) {
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(ep + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        keys[2 * ep] = (uint32_t)z; keys[2 * ep + 1] = (uint32_t)(z >> 32);
+    }
+    HIP_OK(h, hipMemcpyAsync(h->d_keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    // hipGraph replay of the whole update; RCCL calls and event-bracketed profiling run eagerly
+    const bool graph_ok = h->use_graph && !h->prof && h->world == 1;
+    if (graph_ok) {
+        const bool same = h->upd_graph && h->g_epochs == epochs && h->g_nmb == nmb && h->g_E == h->E && h->g_T == h->T &&
+                          h->g_explicit == (int)explicit_perms && h->g_world == h->world;
+        if (!same) {
+            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            HIP_OK(h, hipStreamSynchronize(h->stream));
+            hipGraph_t graph = nullptr;
+            HIP_OK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_update(h, epochs, nmb, explicit_perms);
+            const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return -1; }
+            HIP_OK(h, ce);
+            HIP_OK(h, hipGraphInstantiate(&h->upd_graph, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            h->g_epochs = epochs; h->g_nmb = nmb; h->g_E = h->E; h->g_T = h->T; h->g_explicit = (int)explicit_perms; h->g_world = h->world;
+        }
+        HIP_OK(h, hipGraphLaunch(h->upd_graph, h->stream));
+    } else if (enqueue_update(h, epochs, nmb, explicit_perms)) return -1;
+    if (loss_rows) HIP_OK(h, hipMemcpyAsync(loss_rows, h->d_loss_rows, (size_t)steps * 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    prof_collect(h);
+    return 0;
+}
+
+// ---- data parallel -------------------------------------------------------------------------------------------------------
+static int load_rccl(Rccl& r, std::string& err) {
+    if (r.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break; }   // prefer a copy torch already mapped
+    if (!r.lib) for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
+    if (!r.lib) { err = std::string("cannot load librccl: ") + dlerror(); return -1; }
+    r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void**, int, char[128], int))dlsym(r.lib, "ncclCommInitRank");
+    r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclAllReduce");
+    r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(r.lib, "ncclAllGather");
+    r.CommDestroy = (int (*)(void*))dlsym(r.lib, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) { err = "librccl lacks the expected nccl* symbols"; return -1; }
+    return 0;
+}
+
+int ppo_dist_unique_id(char uid[128]) {
+    static Rccl r;
+    std::string err;
+    if (load_rccl(r, err)) { g_create_error = err; return -1; }
+    const int rc = r.GetUniqueId(uid);
+    if (rc) { g_create_error = "ncclGetUniqueId failed"; return -1; }
+    return 0;
+}
+
+struct UidByValue { char b[128]; };
+
+int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128]) {
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, "ppo_dist_init: bad world/rank");
+    if (load_rccl(h->rccl, h->err)) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    UidByValue u;
+    memcpy(u.b, uid, 128);
+    typedef int (*init_fn)(void**, int, UidByValue, int);
+    init_fn init = (init_fn)dlsym(h->rccl.lib, "ncclCommInitRank");
+    const int rc = init(&h->comm, world, u, rank);
+    if (rc) return fail(h, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
+    h->world = world; h->rank = rank;
+    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    return 0;
+}
+
+int ppo_dist_world(const ppo_handle* h) { return h->world; }
+
+// ---- measurement ----------------------------------------------------------------------------------------------------------
+int ppo_prof_enable(ppo_handle* h, int on) {
+    prof_collect(h);
+    h->prof = on != 0;
+    for (int i = 0; i < PK_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+    return 0;
+}
+
+int ppo_prof_read(ppo_handle* h, int max, char names[][32], double* total_ms, int64_t* launches) {
+    prof_collect(h);
+    int n = 0;
+    for (int i = 0; i < PK_COUNT && n < max; ++i) {
+        snprintf(names[n], 32, "%s", kProfNames[i]);
+        total_ms[n] = h->prof_ms[i];
+        launches[n] = h->prof_n[i];
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

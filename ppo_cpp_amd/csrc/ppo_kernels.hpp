@@ -1,0 +1,1001 @@
+// ppo_kernels.hpp -- gfx950 (MI355X, CDNA4) device code of libppo_hip.so.
+//
+// Hand-written HIP for the PPO rollout-collect + minibatch-update hot path of ppo_cpp.  All dense layers run on
+// the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain, bit-for-bit fp32) with the
+// activation tile of a 16-row block resident in LDS and the weights streamed straight from L2 into VGPRs
+// (each weight element is used by exactly one wave of a block, so an LDS round trip would be pure overhead).
+//
+// Kernel inventory (reference arithmetic each one replaces, paths relative to the reference root; "G" is the
+// TF graph resources/ppo_cl/graphs/ppo_cpp_[4_5]_lr_0.0004_cr_0.1610_ent_0.0007.meta.txt):
+//   policy_step_kernel   act model forward + sampling + neglogp        G:1859-6866, ppo2/policies.hpp:33-77
+//   train_fwd_bwd_kernel train model forward, loss, dLoss/dactivations G:6889-23699 (all but the weight grads)
+//   weight_grad_kernel   dW = X^T dY for every layer (split-K slabs)    G: .../MatMul_grad/MatMul_1 nodes
+//   grad_reduce_kernel   slab/slot reduction, bias/logstd grads, losses G: .../Add_grad/Sum_1, loss/* Mean nodes
+//   adam_kernel          global-norm clip + TF-1.14 ApplyAdam           G:23738-25392, 25426-25704, 30430-31383
+//   epoch_prepare_kernel shuffle -> gather index, advantage statistics  ppo2/ppo2.hpp:274-307, 401-406
+//   gae_kernel           GAE(lambda) / returns scan                     ppo2/runner.hpp:159-191
+//   running_stats_kernel / reward_norm_kernel  VecNormalize numerics    env/env_normalize.hpp:64-116,
+//                                                                       common/running_statistics.hpp:26-104
+//   seeded_env_kernel    on-device synthetic env (bench / parity data)  stands in for env/env_mock.hpp
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PPO_MAX_LAYERS 8
+#define ROWS_PER_BLOCK 16          // one 16x16x4 MFMA row tile per workgroup
+#define BLOCK_THREADS 256          // 4 waves, one per SIMD
+#define LDS_PAD 4                  // row padding (floats): keeps float4 alignment, spreads rows over banks
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------
+// Device-visible network description (padded internal layout).
+// ------------------------------------------------------------------------------------------------------------
+struct NetDev {
+    int O, A, L;
+    int Kp0;                        // obs dim padded to 16
+    int Ap;                         // act dim padded to 16
+    int H[PPO_MAX_LAYERS];
+    int Hp[PPO_MAX_LAYERS];         // hidden dims padded to 16
+    int w_off[2][PPO_MAX_LAYERS];   // [tower][layer] offsets into the padded parameter vector (tower 0 = pi, 1 = vf)
+    int b_off[2][PPO_MAX_LAYERS];
+    int wv_off, bv_off, wmu_off, bmu_off, ls_off;
+    // LDS carve (floats)
+    int lds_h[PPO_MAX_LAYERS + 1];  // [0] = input tile, [l+1] = h_{l+1}
+    int lds_d[2];                   // ping-pong gradient tiles
+    int lds_mu;                     // head tile [16][Ap+PAD]
+    int lds_misc;                   // 512 floats scratch
+    int lds_total;
+    // per-workgroup slot layout (floats) -- partial sums a row block contributes to non-matrix gradients
+    int slot_db[PPO_MAX_LAYERS];    // bias grads of layer l        [Hp[l]]
+    int slot_head;                  // pi: db_mu [Ap] ; vf: dW_v [Hp[L-1]]
+    int slot_aux;                   // pi: dlogstd [Ap] ; vf: db_v [1]
+    int slot_loss;                  // pi: pg, entropy, kl, clipfrac ; vf: vf_loss
+    int slot_w;                     // slot width
+    float ent_coef, vf_coef;
+};
+
+struct NormDev {                    // EnvNormalize state for one statistics object
+    float* mean;                    // [D]
+    float* var;                     // [D]
+    double* count;                  // [1]
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tf_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float tf_max(float a, float b) { return a > b ? a : b; }
+
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// counter-based hash shared with the oracle's seeded env (oracle/ppo_oracle.c orc_hash)
+__device__ __forceinline__ uint32_t ctr_hash(uint32_t seed, uint32_t env, uint32_t step, uint32_t lane) {
+    const uint64_t a = ((uint64_t)seed << 32) | (uint64_t)env;
+    const uint64_t b = ((uint64_t)step << 32) | (uint64_t)lane;
+    return (uint32_t)(splitmix64_dev(splitmix64_dev(a) ^ b) >> 32);
+}
+__device__ __forceinline__ float u32_to_sym_unit(uint32_t h) { return (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f; }
+
+// N(0,1) from two counter hashes (Box-Muller); used only when the caller passes no explicit noise
+__device__ __forceinline__ float ctr_normal(uint32_t seed, uint32_t row, uint32_t step, uint32_t j) {
+    const uint32_t h1 = ctr_hash(seed ^ 0xA5A5A5A5u, row, step, 2u * j);
+    const uint32_t h2 = ctr_hash(seed ^ 0xA5A5A5A5u, row, step, 2u * j + 1u);
+    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0,1]
+    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);              // [0,1)
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+}
+
+// reduce over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Dense layer on one 16-row tile.   Y[16,Np] = act( X[16,K] * W[K,Np] + b )
+//   X  : LDS, row-major, leading dimension ldx (multiple of 4)
+//   W  : global, row-major [K][ldw]  (K multiple of 16, ldw = Np multiple of 16*CT)
+//   Y  : LDS (ldy) and optionally global (gy, row stride ldg, rows row0.. , only rows < nrows are written)
+// Each wave owns 16*CT output columns at a time; MFMA j of a wave covers columns n0 + CT*c + j (c = lane & 15) so
+// that one 16-byte load per lane feeds CT matrix instructions and the epilogue writes 16-byte vectors.
+// Reduction index of instruction s for lane group g = lane >> 4 is k = kb + 4g + s: A comes from ONE 16-byte
+// LDS read per 16 k values.
+// ------------------------------------------------------------------------------------------------------------
+template <int CT>
+struct WFrag { float v[4][CT]; };
+
+template <int CT>
+__device__ __forceinline__ void load_w_rows(WFrag<CT>& w, const float* __restrict__ W, int ldw, int krow, int col) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float* p = W + (size_t)(krow + s) * ldw + col;
+        if constexpr (CT == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            w.v[s][0] = t.x; w.v[s][1] = t.y; w.v[s][2] = t.z; w.v[s][3] = t.w;
+        } else if constexpr (CT == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(p);
+            w.v[s][0] = t.x; w.v[s][1] = t.y;
+        } else {
+            w.v[s][0] = *p;
+        }
+    }
+}
+
+template <int CT, bool TANH>
+__device__ __forceinline__ void layer_forward(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                              const float* Xs, int ldx, int K, float* Ys, int ldy, int Np,
+                                              float* __restrict__ gy, int ldg, int row0, int nrows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    constexpr int CW = 16 * CT;
+    for (int n0 = wave * CW; n0 < Np; n0 += (BLOCK_THREADS / 64) * CW) {
+        f32x4 acc[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int col = n0 + CT * c;
+        WFrag<CT> wcur, wnext;
+        load_w_rows<CT>(wcur, W, ldw, 4 * g, col);
+        for (int kb = 0; kb < K; kb += 16) {
+            if (kb + 16 < K) load_w_rows<CT>(wnext, W, ldw, kb + 16 + 4 * g, col);
+            const float4 a = *reinterpret_cast<const float4*>(Xs + c * ldx + kb + 4 * g);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wcur.v[s][j], acc[j], 0, 0, 0);
+            }
+            if (kb + 16 < K) wcur = wnext;
+        }
+        // epilogue: accumulator register r of MFMA j holds Y[row 4g + r][col n0 + CT*c + j]
+        float bv[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) bv[j] = bias[col + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            float y[CT];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const float z = acc[j][r] + bv[j];
+                y[j] = TANH ? tanhf(z) : z;
+            }
+            float* ys = Ys + row * ldy + col;
+            float* yg = gy ? gy + (size_t)(row0 + row) * ldg + col : nullptr;
+            const bool wr = gy && (row0 + row) < nrows;
+            if constexpr (CT == 4) {
+                *reinterpret_cast<float4*>(ys) = make_float4(y[0], y[1], y[2], y[3]);
+                if (wr) *reinterpret_cast<float4*>(yg) = make_float4(y[0], y[1], y[2], y[3]);
+            } else if constexpr (CT == 2) {
+                *reinterpret_cast<float2*>(ys) = make_float2(y[0], y[1]);
+                if (wr) *reinterpret_cast<float2*>(yg) = make_float2(y[0], y[1]);
+            } else {
+                *ys = y[0];
+                if (wr) *yg = y[0];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward through one dense layer for a 16-row tile:  dXs[16,Kp] = (dYs[16,Np] * W^T) .* (1 - Hs .* Hs)
+//   W global [Kp][ldw=Np] (the forward layout; read "transposed": lane (g,c), MFMA j loads W[k0+CT*c+j][nb+4g..+3])
+//   Hs = the tanh outputs this gradient flows into (TanhGrad, G:21272,...); HS == false => no activation factor
+// Result goes to LDS (dXs) and to global gd (it is the dY operand of the previous layer's weight gradient).
+// ------------------------------------------------------------------------------------------------------------
+template <int CT, bool HS>
+__device__ __forceinline__ void layer_backward(const float* __restrict__ W, int ldw, const float* dYs, int ldy, int Np,
+                                               const float* Hs, int ldh, float* dXs, int ldd, int Kp,
+                                               float* __restrict__ gd, int ldg, int row0, int nrows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    constexpr int CW = 16 * CT;
+    for (int k0 = wave * CW; k0 < Kp; k0 += (BLOCK_THREADS / 64) * CW) {
+        f32x4 acc[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int orow = k0 + CT * c;                       // this lane's first output column = row of W
+        float4 wcur[CT], wnext[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) wcur[j] = *reinterpret_cast<const float4*>(W + (size_t)(orow + j) * ldw + 4 * g);
+        for (int nb = 0; nb < Np; nb += 16) {
+            if (nb + 16 < Np) {
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    wnext[j] = *reinterpret_cast<const float4*>(W + (size_t)(orow + j) * ldw + nb + 16 + 4 * g);
+            }
+            const float4 a = *reinterpret_cast<const float4*>(dYs + c * ldy + nb + 4 * g);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const float wv[4] = {wcur[j].x, wcur[j].y, wcur[j].z, wcur[j].w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wv[s], acc[j], 0, 0, 0);
+            }
+            if (nb + 16 < Np) {
+#pragma unroll
+                for (int j = 0; j < CT; ++j) wcur[j] = wnext[j];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            float d[CT];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                float v = acc[j][r];
+                if (HS) { const float h = Hs[row * ldh + orow + j]; v = v * (1.0f - h * h); }
+                d[j] = v;
+            }
+            float* ds = dXs + row * ldd + orow;
+            float* dg = gd + (size_t)(row0 + row) * ldg + orow;
+            const bool wr = (row0 + row) < nrows;
+            if constexpr (CT == 4) {
+                *reinterpret_cast<float4*>(ds) = make_float4(d[0], d[1], d[2], d[3]);
+                if (wr) *reinterpret_cast<float4*>(dg) = make_float4(d[0], d[1], d[2], d[3]);
+            } else if constexpr (CT == 2) {
+                *reinterpret_cast<float2*>(ds) = make_float2(d[0], d[1]);
+                if (wr) *reinterpret_cast<float2*>(dg) = make_float2(d[0], d[1]);
+            } else {
+                *ds = d[0];
+                if (wr) *dg = d[0];
+            }
+        }
+    }
+}
+
+// value head: v[row] = h[row,:] . w + b    (N = 1: VALU dot products, 16 lanes per row)
+__device__ __forceinline__ float value_head(const float* Hs, int ldh, int Kp, const float* __restrict__ wv, float bv) {
+    const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
+    float s = 0.f;
+    for (int k = part; k < Kp; k += 16) s = fmaf(Hs[row * ldh + k], wv[k], s);
+    s = group16_sum(s);
+    return s + bv;
+}
+
+// stage a 16-row input tile (gathered rows, optional running-stat normalisation) into LDS, zero padded
+struct ObsNorm { const float* mean; const float* var; float eps; float clip; int enabled; };
+
+__device__ __forceinline__ void stage_obs_tile(float* Xs, int ldx, int Kp0, int O, const float* __restrict__ obs,
+                                               const int* __restrict__ rowidx, int row0, int nrows, ObsNorm nz,
+                                               float* __restrict__ obs_out, float* __restrict__ x0g, int ldxg) {
+    for (int i = threadIdx.x; i < ROWS_PER_BLOCK * Kp0; i += BLOCK_THREADS) {
+        const int r = i / Kp0, j = i - r * Kp0;
+        const int row = row0 + r;
+        float x = 0.f;
+        if (row < nrows && j < O) {
+            const int src = rowidx ? rowidx[row] : row;
+            x = obs[(size_t)src * O + j];
+            if (nz.enabled) {
+                // env_normalize.hpp:99-104: (x - mean) * 1/sqrt(var + eps), then clamp
+                x = (x - nz.mean[j]) * (1.0f / sqrtf(nz.var[j] + nz.eps));
+                x = tf_min(tf_max(x, -nz.clip), nz.clip);
+            }
+            if (obs_out) obs_out[(size_t)row * O + j] = x;
+        }
+        Xs[r * ldx + j] = x;
+        if (x0g && row < nrows) x0g[(size_t)row * ldxg + j] = x;
+    }
+}
+
+#define HALF_LOG_2PI 0.9189385175704956f   /* G:6531 */
+#define HALF_LOG_2PIE 1.4189385175704956f  /* G:10021-10180 */
+
+// ------------------------------------------------------------------------------------------------------------
+// Act model: blockIdx.y = 0 policy tower (mu, sample, neglogp), = 1 value tower.
+// ------------------------------------------------------------------------------------------------------------
+struct StepArgs {
+    const float* theta;
+    const float* obs;        // [n,O] raw or already normalised
+    const float* noise;      // [n,A] or null -> counter RNG (seed, rng_step)
+    float* action;           // [n,A] (null: skip)   -- sampled action
+    float* det_action;       // [n,A] (null: skip)   -- mu
+    float* value;            // [n]   (null: value tower blocks exit)
+    float* neglogp;          // [n]
+    float* obs_out;          // [n,O] normalised obs copy (rollout buffer) or null
+    ObsNorm nz;
+    int n;
+    uint32_t seed, rng_step, row_base;
+};
+
+template <int CT>
+__global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tower = blockIdx.y;
+    if (tower == 1 && !a.value) return;
+    if (tower == 0 && !a.action && !a.det_action && !a.neglogp && !a.obs_out) return;
+    const int row0 = blockIdx.x * ROWS_PER_BLOCK;
+    const int ld0 = net.Kp0 + LDS_PAD;
+    stage_obs_tile(lds + net.lds_h[0], ld0, net.Kp0, net.O, a.obs, nullptr, row0, a.n, a.nz,
+                   tower == 0 ? a.obs_out : nullptr, nullptr, 0);
+    __syncthreads();
+    int K = net.Kp0, ldx = ld0;
+    for (int l = 0; l < net.L; ++l) {
+        const int Np = net.Hp[l], ldy = Np + LDS_PAD;
+        layer_forward<CT, true>(a.theta + net.w_off[tower][l], Np, a.theta + net.b_off[tower][l], lds + net.lds_h[l], ldx, K,
+                                lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, row0, a.n);
+        __syncthreads();
+        K = Np; ldx = ldy;
+    }
+    const float* hL = lds + net.lds_h[net.L];
+    if (tower == 1) {
+        const float v = value_head(hL, ldx, K, a.theta + net.wv_off, a.theta[net.bv_off]);
+        const int row = row0 + (threadIdx.x >> 4);
+        if ((threadIdx.x & 15) == 0 && row < a.n) a.value[row] = v;
+        return;
+    }
+    float* mus = lds + net.lds_mu;
+    const int ldm = net.Ap + LDS_PAD;
+    layer_forward<1, false>(a.theta + net.wmu_off, net.Ap, a.theta + net.bmu_off, hL, ldx, K, mus, ldm, net.Ap, nullptr, 0,
+                            row0, a.n);
+    __syncthreads();
+    // sampling + neglogp (G:5894-6672): 16 lanes per row, each lane owns actions j = part, part+16, ...
+    const int r = threadIdx.x >> 4, part = threadIdx.x & 15;
+    const int row = row0 + r;
+    float ssq = 0.f, slog = 0.f;
+    for (int j = part; j < net.A; j += 16) {
+        const float mu = mus[r * ldm + j];
+        const float logstd = mu * 0.0f + a.theta[net.ls_off + j];
+        const float sigma = expf(logstd);
+        float eps = 0.f;
+        if (row < a.n) eps = a.noise ? a.noise[(size_t)row * net.A + j] : ctr_normal(a.seed, a.row_base + row, a.rng_step, j);
+        const float act = mu + sigma * eps;
+        const float z = (act - mu) / sigma;
+        ssq += z * z;
+        slog += logstd;
+        if (row < a.n) {
+            if (a.action) a.action[(size_t)row * net.A + j] = act;
+            if (a.det_action) a.det_action[(size_t)row * net.A + j] = mu;
+        }
+    }
+    ssq = group16_sum(ssq);
+    slog = group16_sum(slog);
+    if (part == 0 && row < a.n && a.neglogp) a.neglogp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Train model forward + loss + backward down to the pre-activation gradients of every layer, for one 16-row
+// tile of the minibatch and one tower.  Everything a row needs stays in LDS; what the weight-gradient kernel
+// needs (layer inputs X_l and pre-activation gradients dY_l) is written to HBM/L2 once.
+// ------------------------------------------------------------------------------------------------------------
+struct TrainArgs {
+    const float* theta;
+    // minibatch sources; rowidx (null = identity) maps minibatch row -> source row
+    const float* obs; const float* actions; const float* returns; const float* old_values; const float* old_neglogp;
+    const float* advs;           // explicit normalised advantages (indexed like the others) or null
+    const float* adv_stats;      // {mean, denom} of this minibatch when advs == null (ppo2.hpp:401-406)
+    const int* rowidx;
+    const float* hyper;          // {lr, cliprange}
+    int n;                       // rows in this minibatch on this rank
+    float inv_n;                 // 1 / (global minibatch rows): gradient of the Mean nodes
+    // workspaces, row-major with padded leading dimensions
+    float* x0g;                  // [n][Kp0]
+    float* hg[2][PPO_MAX_LAYERS];   // [tower][l] = h_{l+1} [n][Hp[l]]   (input of layer l+1 / of the head)
+    float* dyg[2][PPO_MAX_LAYERS];  // [tower][l] = dLoss/d(pre-activation of layer l) [n][Hp[l]]
+    float* dmug;                 // [n][Ap]
+    float* slots[2];             // [tower][n_blocks][slot_w]
+};
+
+template <int CT>
+__global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net, TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tower = blockIdx.y;
+    const int row0 = blockIdx.x * ROWS_PER_BLOCK;
+    const int tid = threadIdx.x;
+    const int ld0 = net.Kp0 + LDS_PAD;
+    float* misc = lds + net.lds_misc;
+    float* slot = a.slots[tower] + (size_t)blockIdx.x * net.slot_w;
+    ObsNorm nz = {nullptr, nullptr, 0.f, 0.f, 0};
+    stage_obs_tile(lds + net.lds_h[0], ld0, net.Kp0, net.O, a.obs, a.rowidx, row0, a.n, nz, nullptr,
+                   tower == 0 ? a.x0g : nullptr, net.Kp0);
+    __syncthreads();
+    // ---- forward (G:6889-9187) -------------------------------------------------------------------------------
+    int K = net.Kp0, ldx = ld0;
+    for (int l = 0; l < net.L; ++l) {
+        const int Np = net.Hp[l], ldy = Np + LDS_PAD;
+        layer_forward<CT, true>(a.theta + net.w_off[tower][l], Np, a.theta + net.b_off[tower][l], lds + net.lds_h[l], ldx, K,
+                                lds + net.lds_h[l + 1], ldy, Np, a.hg[tower][l], Np, row0, a.n);
+        __syncthreads();
+        K = Np; ldx = ldy;
+    }
+    const float* hL = lds + net.lds_h[net.L];
+    const int HpL = K, ldhL = ldx;
+    const float cr = a.hyper[1];
+    const int r = tid >> 4, part = tid & 15;
+    const int row = row0 + r;
+    const bool live = row < a.n;
+    const int src = live ? (a.rowidx ? a.rowidx[row] : row) : 0;
+    float* dcur = lds + net.lds_d[0];
+    float* dnext = lds + net.lds_d[1];
+
+    if (tower == 0) {
+        // ---- policy head + surrogate loss (G:9428-11290) and its gradient (G:12609-22656) -------------------
+        float* mus = lds + net.lds_mu;
+        const int ldm = net.Ap + LDS_PAD;
+        layer_forward<1, false>(a.theta + net.wmu_off, net.Ap, a.theta + net.bmu_off, hL, ldhL, HpL, mus, ldm, net.Ap, nullptr, 0,
+                                row0, a.n);
+        __syncthreads();
+        float ssq = 0.f, slog = 0.f, sent = 0.f;
+        for (int j = part; j < net.A; j += 16) {
+            const float mu = mus[r * ldm + j];
+            const float logstd = mu * 0.0f + a.theta[net.ls_off + j];
+            const float act = live ? a.actions[(size_t)src * net.A + j] : mu;
+            const float z = (act - mu) / expf(logstd);
+            ssq += z * z;
+            slog += logstd;
+            sent += logstd + HALF_LOG_2PIE;
+        }
+        ssq = group16_sum(ssq); slog = group16_sum(slog); sent = group16_sum(sent);
+        const float nlp = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
+        float adv = 0.f, old_nlp = nlp;
+        if (live) {
+            old_nlp = a.old_neglogp[src];
+            if (a.advs) adv = a.advs[src];
+            else adv = ((a.returns[src] - a.old_values[src]) - a.adv_stats[0]) / a.adv_stats[1];
+        }
+        const float lo = 1.0f - cr, hi = 1.0f + cr;
+        const float ratio = expf(old_nlp - nlp);
+        const float rmin = tf_min(ratio, hi);
+        const float rclip = tf_max(rmin, lo);
+        const float m1 = -adv * ratio, m2 = -adv * rclip;
+        const float g = a.inv_n;
+        const float sel = (m1 >= m2) ? 1.0f : 0.0f;                                   // Maximum tie rule G:12609
+        const float pass = ((rmin >= lo) ? 1.0f : 0.0f) * ((ratio <= hi) ? 1.0f : 0.0f); // G:15357, 16113
+        float d_ratio = (-adv) * g * sel;
+        d_ratio += (-adv) * g * (1.0f - sel) * pass;
+        const float d_nlp = live ? -(d_ratio * ratio) : 0.0f;
+        if (part == 0) {
+            const float dk = nlp - old_nlp;
+            misc[r * 4 + 0] = live ? tf_max(m1, m2) : 0.f;
+            misc[r * 4 + 1] = live ? sent : 0.f;
+            misc[r * 4 + 2] = live ? dk * dk : 0.f;
+            misc[r * 4 + 3] = (live && fabsf(ratio - 1.0f) > cr) ? 1.0f : 0.f;
+        }
+        // d mu (-> dcur tile, also the dY operand of the head weight gradient) and d logstd rows (-> misc)
+        float* dls = misc + 64;                       // [16][Ap]
+        for (int j = part; j < net.Ap; j += 16) {
+            float dmu = 0.f, dl = 0.f;
+            if (j < net.A && live) {
+                const float mu = mus[r * ldm + j];
+                const float sigma = expf(mu * 0.0f + a.theta[net.ls_off + j]);
+                const float z = (a.actions[(size_t)src * net.A + j] - mu) / sigma;
+                dl = d_nlp * (1.0f - z * z) - net.ent_coef * g;                    // AddN_2 G:21299
+                dmu = d_nlp * (-(z / sigma)) + dl * 0.0f;                          // AddN_3 G:22656
+            }
+            dcur[r * ldm + j] = dmu;
+            dls[r * net.Ap + j] = dl;
+            if (live) a.dmug[(size_t)row * net.Ap + j] = dmu;
+        }
+        __syncthreads();
+        // per-block partial sums: db_mu, dlogstd (over the 16 rows, fixed order), loss terms
+        for (int j = tid; j < net.Ap; j += BLOCK_THREADS) {
+            float sb = 0.f, sl = 0.f;
+            for (int q = 0; q < ROWS_PER_BLOCK; ++q) { sb += dcur[q * ldm + j]; sl += dls[q * net.Ap + j]; }
+            slot[net.slot_head + j] = sb;
+            slot[net.slot_aux + j] = sl;
+        }
+        if (tid < 4) {
+            float s = 0.f;
+            for (int q = 0; q < ROWS_PER_BLOCK; ++q) s += misc[q * 4 + tid];
+            slot[net.slot_loss + tid] = s;
+        }
+        // dh_L = (dmu * W_mu^T) .* (1 - h_L^2)
+        layer_backward<CT, true>(a.theta + net.wmu_off, net.Ap, dcur, ldm, net.Ap, hL, ldhL, dnext, HpL + LDS_PAD, HpL,
+                                 a.dyg[0][net.L - 1], HpL, row0, a.n);
+        __syncthreads();
+    } else {
+        // ---- value head + clipped value loss (G:10213-10837) and its gradient (G:14975-19571) ---------------
+        const float* wv = a.theta + net.wv_off;
+        const float v = value_head(hL, ldhL, HpL, wv, a.theta[net.bv_off]);
+        float dv = 0.f, lossv = 0.f;
+        if (live) {
+            const float R = a.returns[src], vo = a.old_values[src];
+            const float dvo = v - vo;
+            const float vmin = tf_min(dvo, cr);
+            const float vclip = vo + tf_max(vmin, -cr);
+            const float e1 = v - R, e2 = vclip - R;
+            const float s1 = e1 * e1, s2 = e2 * e2;
+            lossv = tf_max(s1, s2);
+            const float gv = net.vf_coef * 0.5f * a.inv_n;
+            const float selv = (s1 >= s2) ? 1.0f : 0.0f;                                       // G:14975
+            const float passv = ((vmin >= -cr) ? 1.0f : 0.0f) * ((dvo <= cr) ? 1.0f : 0.0f);   // G:17477, 18071
+            dv = gv * selv * (2.0f * e1) + gv * (1.0f - selv) * (2.0f * e2) * passv;           // AddN_1 G:19571
+        }
+        if (part == 0) { misc[r] = dv; misc[16 + r] = lossv; }
+        __syncthreads();
+        if (tid == 0) {
+            float sb = 0.f, sl = 0.f;
+            for (int q = 0; q < ROWS_PER_BLOCK; ++q) { sb += misc[q]; sl += misc[16 + q]; }
+            slot[net.slot_aux] = sb;            // db_v
+            slot[net.slot_loss] = sl;           // sum of max((v-R)^2, (vclip-R)^2)
+        }
+        // dW_v[k] = sum_rows h_L[row,k] * dv[row] ; dh_L = dv (x) w_v .* (1 - h_L^2)
+        const int ldd = HpL + LDS_PAD;
+        for (int k = tid; k < HpL; k += BLOCK_THREADS) {
+            float s = 0.f;
+            for (int q = 0; q < ROWS_PER_BLOCK; ++q) s = fmaf(hL[q * ldhL + k], misc[q], s);
+            slot[net.slot_head + k] = s;
+            const float w = wv[k];
+            for (int q = 0; q < ROWS_PER_BLOCK; ++q) {
+                const float h = hL[q * ldhL + k];
+                const float d = (misc[q] * w) * (1.0f - h * h);
+                dnext[q * ldd + k] = d;
+                if (row0 + q < a.n) a.dyg[1][net.L - 1][(size_t)(row0 + q) * HpL + k] = d;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- hidden layers, top down: dnext holds dLoss/d(pre-activation of layer l) -------------------------------
+    for (int l = net.L - 1; l >= 0; --l) {
+        float* t = dcur; dcur = dnext; dnext = t;            // dcur = dY_l
+        const int Np = net.Hp[l], ldd = Np + LDS_PAD;
+        for (int j = tid; j < Np; j += BLOCK_THREADS) {      // db_l = sum_rows dY_l  (…/Add_grad/Sum_1)
+            float s = 0.f;
+            for (int q = 0; q < ROWS_PER_BLOCK; ++q) s += dcur[q * ldd + j];
+            slot[net.slot_db[l] + j] = s;
+        }
+        if (l > 0) {                                         // first-layer dX is never needed
+            const int Kp = net.Hp[l - 1];
+            layer_backward<CT, true>(a.theta + net.w_off[tower][l], Np, dcur, ldd, Np, lds + net.lds_h[l], Kp + LDS_PAD,
+                                     dnext, Kp + LDS_PAD, Kp, a.dyg[tower][l - 1], Kp, row0, a.n);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradients dW = X^T dY (reduction over the minibatch rows), all layers of both towers in one launch.
+// One workgroup = one (TI*16 x TJ*16) output tile x one K-split; its 4 waves take quarter row-slices and are
+// summed through LDS.  Operands stream L2 -> VGPR as 16-byte vectors: lane (g, c) of MFMA (a, b) covers output
+// row i0 + TI*c' ... see the index algebra in the body.
+// ------------------------------------------------------------------------------------------------------------
+struct DwTile {
+    const float* X; const float* dY;   // [n][ldx], [n][ldy]
+    int ldx, ldy;
+    int i0, j0;                        // tile origin in the [Kp x Np] gradient
+    int out_off;                       // offset of the tensor inside the padded parameter vector
+    int ldo;                           // = Np
+    int cls;                           // 0: 64x64 tile (TI=TJ=4) ; 1: 16x16 tile
+};
+
+template <int TI, int TJ>
+__device__ __forceinline__ void dw_tile_body(const DwTile& t, int n, int nsplit, float* __restrict__ slabs, size_t slab_stride,
+                                             float* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int split = blockIdx.y;
+    const int rows_per_split = n / nsplit;
+    const int rows_per_wave = rows_per_split / 4;
+    const int rbeg = split * rows_per_split + wave * rows_per_wave;
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // MFMA (a,b): A[i][k] = X[row k][i0 + TI*i + a], B[k][j] = dY[row k][j0 + TJ*j + b], k = lane group g
+    const float* xp = t.X + (size_t)(rbeg + g) * t.ldx + t.i0 + TI * c;
+    const float* yp = t.dY + (size_t)(rbeg + g) * t.ldy + t.j0 + TJ * c;
+    float xa[TI], yb[TJ], xn[TI], yn[TJ];
+    auto ld = [&](float* xo, float* yo, int koff) {
+        const float* x = xp + (size_t)koff * t.ldx;
+        const float* y = yp + (size_t)koff * t.ldy;
+        if constexpr (TI == 4) { const float4 v = *reinterpret_cast<const float4*>(x); xo[0] = v.x; xo[1] = v.y; xo[2] = v.z; xo[3] = v.w; }
+        else { xo[0] = *x; }
+        if constexpr (TJ == 4) { const float4 v = *reinterpret_cast<const float4*>(y); yo[0] = v.x; yo[1] = v.y; yo[2] = v.z; yo[3] = v.w; }
+        else { yo[0] = *y; }
+    };
+    if (rows_per_wave > 0) ld(xa, yb, 0);
+    for (int k = 0; k < rows_per_wave; k += 4) {
+        if (k + 4 < rows_per_wave) ld(xn, yn, k + 4);
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[a], yb[b], acc[a][b], 0, 0, 0);
+        if (k + 4 < rows_per_wave) {
+#pragma unroll
+            for (int a = 0; a < TI; ++a) xa[a] = xn[a];
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) yb[b] = yn[b];
+        }
+    }
+    // in-workgroup split-K: every wave parks its tile in LDS, then all threads add the 4 copies in wave order
+    constexpr int TW = 16 * TJ, TH = 16 * TI;
+    float* mine = lds + wave * (TH * TW);
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int orow = TI * (4 * g + r) + a;          // accumulator row 4g+r of MFMA (a,*) = output row i0 + orow
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) mine[orow * TW + TJ * c + b] = acc[a][b][r];
+        }
+    __syncthreads();
+    float* out = slabs + (size_t)split * slab_stride + t.out_off;
+    for (int i = threadIdx.x; i < TH * TW; i += BLOCK_THREADS) {
+        const float s = ((lds[i] + lds[TH * TW + i]) + lds[2 * TH * TW + i]) + lds[3 * TH * TW + i];
+        const int orow = i / TW, ocol = i - orow * TW;
+        out[(size_t)(t.i0 + orow) * t.ldo + t.j0 + ocol] = s;
+    }
+}
+
+struct DwArgs {
+    const DwTile* tiles;
+    int n;                 // minibatch rows
+    int nsplit;            // gridDim.y
+    float* slabs;          // [nsplit][P_pad]
+    size_t slab_stride;
+};
+
+__global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DwTile t = a.tiles[blockIdx.x];
+    if (t.cls == 0) dw_tile_body<4, 4>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+    else dw_tile_body<1, 1>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Gradient assembly.  One 256-thread block covers 256 consecutive elements of the padded parameter vector; the
+// host table says where the block's elements come from (block-uniform):
+//   kind 0: matrix -> sum of the split-K slabs (fixed order)
+//   kind 1: slot   -> sum over the row blocks' slots (fixed order), `count` valid elements, rest are padding
+//   kind 2: padding / untrained -> 0
+// Also emits the block's sum of squares for the global norm, and (last block) the five loss scalars.
+// ------------------------------------------------------------------------------------------------------------
+struct GradSrc { int kind; int tower; int slot_off; int count; int base; };   // base = first element of the tensor
+
+struct ReduceArgs {
+    const GradSrc* src;          // [n_blocks]
+    int n_blocks;                // blocks covering P_pad ; block n_blocks = loss block
+    const float* slabs; size_t slab_stride; int nsplit;
+    const float* slots[2]; int n_rowblocks; int slot_w;
+    int slot_loss;
+    float* grad;                 // [P_pad]  (+ 8 tail floats: 5 loss sums, row count)
+    float* sumsq;                // [n_blocks]
+    float n_local;               // rows summed on this rank
+    float* beta_pow;             // {cur b1, cur b2, next b1, next b2}: cur <- next here (adam writes next)
+};
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
+    __shared__ float red[4];
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk == a.n_blocks) {
+        // loss partial sums (fixed order over row blocks): tail = {pg, vf, ent, kl, cf, rows}
+        if (tid < 5) {
+            const int tower = (tid == 1) ? 1 : 0;
+            const int off = a.slot_loss + (tid == 0 ? 0 : tid == 1 ? 0 : tid - 1);
+            float s = 0.f;
+            for (int b = 0; b < a.n_rowblocks; ++b) s += a.slots[tower][(size_t)b * a.slot_w + off];
+            a.grad[(size_t)a.n_blocks * 256 + tid] = s;
+        }
+        if (tid == 5) a.grad[(size_t)a.n_blocks * 256 + 5] = a.n_local;
+        if (tid == 6) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }
+        return;
+    }
+    const GradSrc s = a.src[blk];
+    const size_t idx = (size_t)blk * 256 + tid;
+    float gsum = 0.f;
+    if (s.kind == 0) {
+        for (int k = 0; k < a.nsplit; ++k) gsum += a.slabs[(size_t)k * a.slab_stride + idx];
+    } else if (s.kind == 1) {
+        const int e = (int)(idx - (size_t)s.base);
+        if (e < s.count) {
+            const float* p = a.slots[s.tower] + s.slot_off + e;
+            for (int b = 0; b < a.n_rowblocks; ++b) gsum += p[(size_t)b * a.slot_w];
+        }
+    }
+    a.grad[idx] = gsum;
+    float q = gsum * gsum;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) a.sumsq[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// after a cross-rank all-reduce of grad the per-block sums of squares must be recomputed
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* grad, float* sumsq) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const float gv = grad[(size_t)blockIdx.x * 256 + tid];
+    float q = gv * gv;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// clip_by_global_norm (G:23738-25392) + ApplyAdam (TF 1.14; G:30430-31383) on the padded flat vector.
+// Every block re-derives the norm from the per-block partials in the same fixed order -> identical on all
+// blocks (and on all ranks after the all-reduce).  Block 0 also writes the loss row and the next beta powers.
+// ------------------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float* theta; float* m; float* v; const float* grad; const float* sumsq; int n_blocks;
+    const float* hyper;          // {lr, cliprange}
+    float* beta_pow;             // {cur b1, cur b2, next b1, next b2}
+    float beta1, beta2, eps, max_norm;
+    float* loss_row;             // [5] destination for this train step (may be null)
+    float* norm_out;             // [1] (may be null)
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    __shared__ float s_norm2;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        float s = 0.f;
+        for (int i = tid; i < a.n_blocks; i += 64) s += a.sumsq[i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (tid == 0) s_norm2 = s;
+    }
+    __syncthreads();
+    const float norm = sqrtf(s_norm2);
+    float scale = a.max_norm * tf_min(1.0f / norm, 1.0f / a.max_norm);          // G:24289-24472
+    if (!isfinite(norm)) scale = __builtin_nanf("");                            // G:24493-24543
+    const float b1p = a.beta_pow[0], b2p = a.beta_pow[1];
+    const float alpha = a.hyper[0] * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    const size_t idx = (size_t)blockIdx.x * 256 + tid;
+    const float g = a.grad[idx] * scale;
+    const float m = a.m[idx] + (g - a.m[idx]) * (1.0f - a.beta1);
+    const float v = a.v[idx] + (g * g - a.v[idx]) * (1.0f - a.beta2);
+    a.m[idx] = m;
+    a.v[idx] = v;
+    a.theta[idx] = a.theta[idx] - (m * alpha) / (sqrtf(v) + a.eps);
+    if (blockIdx.x == 0) {
+        if (tid == 0) {
+            a.beta_pow[2] = b1p * a.beta1;                                      // G:31217-31342 (after the applies)
+            a.beta_pow[3] = b2p * a.beta2;
+            if (a.norm_out) *a.norm_out = norm;
+        }
+        if (a.loss_row && tid < 5) {
+            const float* tail = a.grad + (size_t)a.n_blocks * 256;
+            const float n = tail[5];
+            const float sum = tail[tid];
+            float r = sum / n;
+            if (tid == 1 || tid == 3) r = 0.5f * r;                             // vf_loss, approxkl carry the 0.5
+            a.loss_row[tid] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Epoch preparation (ppo2.hpp:274-307 + 401-406).  Block k handles minibatch k of the epoch:
+//   r    = flattened env-major source row that lands at permuted position k*M + i   (inverse permutation)
+//   gidx = its time-major storage row (runner.hpp:136-152: r = e*T + t  ->  t*E + e)
+//   stats[k] = { mean(adv), sqrt(mean((adv-mean)^2)) + 1e-8 }  with adv = returns - values
+// inv_perm == null: a keyed bijection on [0,B) (multiply-xorshift rounds + cycle walking) plays the shuffle.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t keyed_bijection(uint32_t x, uint32_t bits, uint32_t mask, uint32_t k0, uint32_t k1) {
+    const uint32_t sh = bits > 1 ? bits / 2 : 1;
+    x = (x * (k0 | 1u) + k1) & mask;  x ^= x >> sh;
+    x = (x * 0x9E3779B1u + (k0 >> 7)) & mask;  x ^= x >> sh;
+    x = (x * (k1 | 1u) + 0x85EBCA6Bu) & mask;  x ^= x >> sh;
+    x = (x * 0xC2B2AE35u + k0) & mask;  x ^= x >> sh;
+    return x;
+}
+
+struct EpochArgs {
+    const int* inv_perm;     // [B] or null
+    const uint32_t* keys;    // {k0, k1} of this epoch (device memory: a replayed graph must see fresh keys)
+    uint32_t bits;
+    int B, M, T, E;
+    const float* returns; const float* values;   // [T*E] storage order
+    int* gidx;               // [B]
+    float* stats;            // [B/M][2]
+};
+
+__global__ __launch_bounds__(256) void epoch_prepare_kernel(EpochArgs a) {
+    __shared__ float red[4];
+    __shared__ float s_mean;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const uint32_t mask = (a.bits >= 32) ? 0xFFFFFFFFu : ((1u << a.bits) - 1u);
+    float sum = 0.f;
+    for (int i = tid; i < a.M; i += 256) {
+        const int pos = k * a.M + i;
+        int r;
+        if (a.inv_perm) r = a.inv_perm[pos];
+        else {
+            uint32_t x = (uint32_t)pos;
+            do { x = keyed_bijection(x, a.bits, mask, a.keys[0], a.keys[1]); } while (x >= (uint32_t)a.B);
+            r = (int)x;
+        }
+        const int s = (r % a.T) * a.E + (r / a.T);
+        a.gidx[pos] = s;
+        sum += a.returns[s] - a.values[s];
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) s_mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.M;
+    __syncthreads();
+    const float mean = s_mean;
+    float sq = 0.f;
+    for (int i = tid; i < a.M; i += 256) {
+        const int s = a.gidx[k * a.M + i];
+        const float d = (a.returns[s] - a.values[s]) - mean;
+        sq += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.M;
+        a.stats[2 * k] = mean;
+        a.stats[2 * k + 1] = (float)((double)sqrtf(var) + 1e-8);
+    }
+}
+
+// inv[perm[i]] = i   (out.row(perm[i]) = in.row(i), ppo2.hpp:291-296)
+__global__ void invert_perm_kernel(const int* perm, int* inv, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) inv[perm[i]] = i;
+}
+
+// standalone advantage normalisation of an explicit minibatch (ppo2.hpp:401-406), single block
+__global__ __launch_bounds__(1024) void adv_normalize_kernel(const float* returns, const float* values, int n, float* advs) {
+    __shared__ float red[16];
+    __shared__ float s_val;
+    const int tid = threadIdx.x;
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 1024) sum += returns[i] - values[i];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) { float s = 0.f; for (int w = 0; w < 16; ++w) s += red[w]; s_val = s / (float)n; }
+    __syncthreads();
+    const float mean = s_val;
+    float sq = 0.f;
+    for (int i = tid; i < n; i += 1024) { const float d = (returns[i] - values[i]) - mean; sq += d * d; }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) { float s = 0.f; for (int w = 0; w < 16; ++w) s += red[w]; s_val = (float)((double)sqrtf(s / (float)n) + 1e-8); }
+    __syncthreads();
+    const float denom = s_val;
+    for (int i = tid; i < n; i += 1024) advs[i] = ((returns[i] - values[i]) - mean) / denom;
+}
+
+// column means of the loss rows (ppo2.hpp:335)
+__global__ void loss_mean_kernel(const float* rows, int n, float* mean) {
+    const int j = threadIdx.x;
+    if (j < 5) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += rows[i * 5 + j];
+        mean[j] = s / (float)n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GAE(lambda) (runner.hpp:159-191): one thread per env, serial in t, coalesced across envs (time-major buffers)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void gae_kernel(const float* rewards, const float* values, const float* dones, const float* last_values,
+                           const float* last_dones, int T, int E, float gamma, float lam, float* returns) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float last = 0.f;
+    float nv = last_values[e];
+    float nnt = 1.0f - last_dones[e];
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t i = (size_t)t * E + e;
+        const float v = values[i];
+        const float delta = rewards[i] + gamma * (nv * nnt) - v;
+        last = delta + (gamma * lam) * (nnt * last);
+        returns[i] = last + v;
+        nv = v;
+        nnt = 1.0f - dones[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// RunningStatistics::update (common/running_statistics.hpp:26-54, 88-104) over a [rows, D] batch, one block.
+// Thread t owns column t % D and rows t / D + i * (threads / D): consecutive threads read consecutive addresses.
+// Two passes exactly like the reference (mean, then sum of squared deviations), then the Chan merge with the
+// reference's float/double mixing (count is double, every matrix op is fp32).
+// ------------------------------------------------------------------------------------------------------------
+#define STATS_THREADS 576   /* = 32 * 18: whole rows for the 18-wide case; any D <= 576 works */
+
+__device__ __forceinline__ void running_stats_update_block(const float* __restrict__ batch, int rows, int D, NormDev st,
+                                                           float* sh /* >= STATS_THREADS + 2*D floats */) {
+    const int tid = threadIdx.x;
+    const int rpp = STATS_THREADS / D;             // rows per pass
+    const int col = tid % D, rsub = tid / D;
+    const bool act = rsub < rpp;
+    float* part = sh;                              // [rpp][D]
+    float* bmean = sh + STATS_THREADS;             // [D]
+    float s = 0.f;
+    if (act) for (int r = rsub; r < rows; r += rpp) s += batch[(size_t)r * D + col];
+    if (act) part[rsub * D + col] = s;
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+        for (int q = 0; q < rpp; ++q) t += part[q * D + tid];
+        bmean[tid] = t / (float)rows;              // colwise().mean()
+    }
+    __syncthreads();
+    float m2 = 0.f;
+    if (act) {
+        const float bm = bmean[col];
+        for (int r = rsub; r < rows; r += rpp) { const float d = batch[(size_t)r * D + col] - bm; m2 += d * d; }
+        part[rsub * D + col] = m2;
+    }
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+        for (int q = 0; q < rpp; ++q) t += part[q * D + tid];
+        const double cnt = *st.count;
+        const double nb = (double)rows;
+        const double tot = cnt + nb;
+        const float bvar = t / (float)nb;                                        // :51-54
+        const float delta = bmean[tid] - st.mean[tid];                           // :90
+        const float new_mean = st.mean[tid] + (delta * (float)nb) / (float)tot;  // :94
+        const float m_a = st.var[tid] * (float)cnt;                              // :97
+        const float m_b = bvar * (float)nb;                                      // :98
+        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;  // :100
+        st.mean[tid] = new_mean;
+        st.var[tid] = M2 / (float)tot;                                           // :101
+    }
+    __syncthreads();
+    if (tid == 0) *st.count = (double)rows + *st.count;                          // :103
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(STATS_THREADS) void running_stats_kernel(const float* batch, int rows, int D, NormDev st) {
+    __shared__ float sh[STATS_THREADS + 2 * 576];
+    running_stats_update_block(batch, rows, D, st, sh);
+}
+
+// normalise + clip an [rows, D] batch with frozen statistics (env_normalize.hpp:99-104)
+__global__ void obs_normalize_kernel(const float* in, int rows, int D, NormDev st, float eps, float clip, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const int j = i % D;
+    float x = (in[i] - st.mean[j]) * (1.0f / sqrtf(st.var[j] + eps));
+    x = tf_min(tf_max(x, -clip), clip);
+    out[i] = x;
+}
+
+// EnvNormalize::step reward branch (env_normalize.hpp:64-92), one block:
+//   ret = ret*gamma + r ; ret_rms.update(ret) if training ; out = clip(r / sqrt(var + eps)) ; ret *= (1 - done)
+__global__ __launch_bounds__(STATS_THREADS) void reward_norm_kernel(const float* rew, const float* dones, int rows, int training,
+                                                                    float gamma, float clip, float eps, float* ret, NormDev st,
+                                                                    float* out) {
+    __shared__ float sh[STATS_THREADS + 2 * 576];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < rows; i += STATS_THREADS) ret[i] = ret[i] * gamma + rew[i];
+    __syncthreads();
+    if (training) running_stats_update_block(ret, rows, 1, st, sh);
+    const float inv = 1.0f / sqrtf(st.var[0] + eps);
+    for (int i = tid; i < rows; i += STATS_THREADS) {
+        float y = rew[i] * inv;
+        y = tf_min(tf_max(y, -clip), clip);
+        out[i] = y;
+        ret[i] = ret[i] * (1.0f - dones[i]);
+    }
+}
+
+// on-device seeded synthetic env (oracle/ppo_oracle.c orc_seeded_env_step): thread per (env, lane)
+__global__ void seeded_env_kernel(uint32_t seed, int env0, int n_envs, uint32_t step, int O, float* obs, float* rew, float* dones) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = O + 2;
+    if (i >= n_envs * W) return;
+    const int e = i / W, j = i - e * W;
+    const uint32_t h = ctr_hash(seed, (uint32_t)(env0 + e), step, (uint32_t)j);
+    if (j < O) obs[(size_t)e * O + j] = u32_to_sym_unit(h);
+    else if (j == O) { if (rew) rew[e] = u32_to_sym_unit(h); }
+    else if (dones) dones[e] = (h % 300u == 0u) ? 1.0f : 0.0f;
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}

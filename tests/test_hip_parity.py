@@ -1,0 +1,262 @@
+"""GPU parity tests: the HIP path (through the C-ABI, ctypes) against the CPU oracle on the same seeded inputs.
+fp32 tolerances (north star: losses within 1e-4 rel; BASELINE.md section 4: 1e-5 abs / 1e-4 rel)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CR = 0.16102319955825806
+LR = 0.000393141177482903
+GAMMA, LAM = 0.99, 0.95
+
+
+def hip(hidden, O=18, A=18):
+    import ppo_cpp_amd
+    return ppo_cpp_amd.PPOHip(O, A, list(hidden))
+
+
+def pair(hidden, src="orth", O=18, A=18, seed=3):
+    orc = o.Oracle(O, A, list(hidden))
+    if src == "ginit":
+        orc.set_tensors(H.g45_init())
+    elif src == "ckpt":
+        orc.set_tensors(H.ckpt71())
+    else:
+        orc.init_orthogonal(seed)
+        orc.tensor("pi/logstd")[:] = np.random.RandomState(seed + 1).uniform(-1.0, 0.2, (1, A))
+    g = hip(hidden, O, A)
+    g.set_flat(orc.theta)
+    return orc, g
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, msg=""):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+def test_parameter_roundtrip_and_layout_order():
+    orc, g = pair((4, 5), "ginit")
+    assert g.P == orc.P == 334
+    assert [n for n, _ in g.tensors] == [n for n, _, _ in orc.tensors]
+    np.testing.assert_array_equal(g.get_flat(), orc.theta)
+    np.testing.assert_array_equal(g.get_tensor("pi_fc0/w"), H.g45_init()["pi_fc0/w"])
+    np.testing.assert_array_equal(g.beta_powers(), np.float32([0.9, 0.999]))
+    g2 = hip((256, 256))
+    assert g2.P == 146213
+    g2.init_orthogonal(0)
+    w = g2.get_tensor("pi_fc1/w").astype(np.float64)
+    close(w.T @ w, 2 * np.eye(256), atol=1e-5)
+    w = g2.get_tensor("pi/w").astype(np.float64)
+    close(w.T @ w, 1e-4 * np.eye(18), atol=1e-9)
+    assert not g2.get_tensor("pi/logstd").any()
+
+
+@pytest.mark.parametrize("hidden,n,src", [((4, 5), 1, "ginit"), ((4, 5), 37, "ckpt"), ((64, 64), 100, "orth"),
+                                          ((256, 256), 4096, "orth"), ((32,), 16, "orth"), ((16, 8, 8), 33, "orth")])
+def test_policy_step_value_neglogp(hidden, n, src):
+    orc, g = pair(hidden, src)
+    rng = np.random.RandomState(5)
+    obs = rng.uniform(-2, 2, (n, 18)).astype(np.float32)
+    noise = rng.normal(size=(n, 18)).astype(np.float32)
+    a, v, nlp = g.step(obs, noise)
+    ra, rv, rnlp = orc.step(obs, noise)
+    close(a, ra, msg="action"); close(v, rv, msg="value"); close(nlp, rnlp, msg="neglogp")
+    close(g.value(obs), rv)
+    mu, _ = orc.forward(obs)
+    close(g.act_deterministic(obs), mu)
+
+
+def test_on_device_noise_is_standard_normal():
+    _, g = pair((64, 64))
+    obs = np.zeros((4096, 18), np.float32)
+    a, _, nlp = g.step(obs)                         # no explicit noise -> counter RNG
+    mu = g.act_deterministic(obs)
+    sigma = np.exp(g.get_tensor("pi/logstd"))
+    z = (a - mu) / sigma
+    assert abs(float(z.mean())) < 0.02 and float(z.std()) == pytest.approx(1.0, abs=0.02)
+    close(nlp, 0.5 * (z.astype(np.float64) ** 2).sum(1) + 18 * 0.9189385175704956 + np.log(sigma).sum(), rtol=2e-4)
+    a2, _, _ = g.step(obs)
+    assert np.abs(a2 - a).max() > 0.1               # fresh draw per call
+
+
+@pytest.mark.parametrize("hidden,n,src", [((4, 5), 64, "ginit"), ((4, 5), 2048, "ckpt"), ((64, 64), 64, "orth"),
+                                          ((64, 64), 256, "orth"), ((256, 256), 2048, "orth"), ((16, 8, 8), 48, "orth")])
+def test_train_step_losses_gradient_and_weights(hidden, n, src):
+    orc, g = pair(hidden, src)
+    for it in range(3):
+        mb = H.synth_minibatch(orc, n, seed=50 + it)
+        args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+        ref_losses, ref_grad = orc.loss_grad(*args, CR)
+        _, ref_norm = orc.clip(ref_grad)
+        losses = g.train_step(LR, CR, *args)
+        orc.train_step(LR, CR, *args)
+        grad, norm = g.last_grad()
+        assert 0.02 < ref_losses[4] < 0.98
+        close(losses, ref_losses, rtol=1e-4, atol=1e-6, msg="losses it=%d" % it)
+        gs = float(np.abs(ref_grad).max())
+        close(grad, ref_grad, rtol=2e-4, atol=2e-6 * gs, msg="grad it=%d" % it)
+        assert norm == pytest.approx(ref_norm, rel=1e-4)
+        close(g.get_flat(0), orc.theta, rtol=1e-4, atol=2e-6, msg="theta it=%d" % it)
+        close(g.get_flat(1), orc.m, rtol=2e-4, atol=1e-7 * max(1.0, gs), msg="adam m")
+        close(g.get_flat(2), orc.v, rtol=4e-4, atol=1e-10, msg="adam v")
+    close(g.beta_powers(), orc.pow, rtol=1e-6)
+
+
+def test_nonfinite_gradient_poisons_weights_like_the_graph():
+    orc, g = pair((4, 5), "ginit")
+    mb = H.synth_minibatch(orc, 64, seed=1)
+    bad = mb["returns"].copy(); bad[3] = np.inf
+    g.train_step(LR, CR, mb["obs"], mb["actions"], mb["advs"], bad, mb["old_neglogp"], mb["old_values"])
+    assert np.isnan(g.get_flat()).all()              # G:24493-24543: NaN scale, not an error
+
+
+def test_gae_and_advantage_normalisation_kernels():
+    _, g = pair((4, 5), "ginit")
+    rng = np.random.RandomState(4)
+    T, E = 16, 4096
+    rew, val = rng.normal(size=(T, E)).astype(np.float32), rng.normal(size=(T, E)).astype(np.float32)
+    dones = (rng.uniform(size=(T, E)) < 0.05).astype(np.float32)
+    lv, ld = rng.normal(size=E).astype(np.float32), (rng.uniform(size=E) < 0.3).astype(np.float32)
+    np.testing.assert_array_equal(g.gae(rew, val, dones, lv, ld, GAMMA, LAM), o.gae(rew, val, dones, lv, ld, GAMMA, LAM))
+    got = g.gae(rew[:5, :3], val[:5, :3], dones[:5, :3], lv[:3], ld[:3], 0.9, 1.0)      # ragged small case
+    np.testing.assert_array_equal(got, o.gae(rew[:5, :3], val[:5, :3], dones[:5, :3], lv[:3], ld[:3], 0.9, 1.0))
+    for n in (16, 2048, 1000):
+        r, v = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+        close(g.adv_normalize(r, v), o.adv_normalize(r, v), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("E", [1, 7, 64, 4096])
+def test_running_statistics_and_normalisation(E):
+    _, g = pair((4, 5), "ginit")
+    g.norm_init(E)
+    nz = o.Normalizer(E, 18)
+    rng = np.random.RandomState(7)
+    for it in range(6):
+        raw = rng.normal(loc=0.5, scale=2.0, size=(E, 18)).astype(np.float32)
+        if it == 3:
+            raw[0, 0] = 1e4                                       # clip exercised
+        rew = rng.normal(size=E).astype(np.float32)
+        dn = (rng.uniform(size=E) < 0.2).astype(np.float32)
+        training = it != 4                                        # one frozen step (env_normalize.hpp:76,96)
+        nz.training = training
+        close(g.norm_obs(raw, training), nz.obs(raw), rtol=2e-5, atol=2e-6, msg="obs it=%d" % it)
+        close(g.norm_reward(rew, dn, training), nz.reward(rew, dn), rtol=2e-5, atol=2e-6, msg="rew it=%d" % it)
+    m, v, c = g.norm_stats(0)
+    close(m, nz.obs_rms.mean, rtol=1e-5, atol=1e-6); close(v, nz.obs_rms.var, rtol=1e-5); assert c == nz.obs_rms.count
+    m, v, c = g.norm_stats(1)
+    close(m, nz.ret_rms.mean, rtol=1e-5, atol=1e-6); close(v, nz.ret_rms.var, rtol=1e-5); assert c == nz.ret_rms.count
+    st = H.ckpt71_stats()                                         # serialise / deserialise round trip with the fixture
+    g.set_norm_stats(0, st["obs_rms"]["mean"], st["obs_rms"]["var"], st["obs_rms"]["count"])
+    m, v, c = g.norm_stats(0)
+    np.testing.assert_array_equal(m, np.float32(st["obs_rms"]["mean"])); assert c == st["obs_rms"]["count"]
+
+
+def _rollout_pair(hidden, E, T, seed, src="orth"):
+    orc, g = pair(hidden, src)
+    rng = np.random.RandomState(seed)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    nz = o.Normalizer(E, 18)
+    ro, state, last_v = o.collect(orc, nz, 1234, T, noise, GAMMA, LAM)
+    g.norm_init(E)
+    g.rollout_alloc(E, T)
+    return orc, g, nz, ro, noise
+
+
+@pytest.mark.parametrize("hidden,E,T", [((4, 5), 1, 64), ((64, 64), 32, 8), ((256, 256), 512, 4)])
+def test_collect_on_device_env_matches_oracle_rollout(hidden, E, T):
+    orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 21)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+        close(g.rollout_get(f), ro[f], rtol=2e-4, atol=2e-5, msg=f)
+    np.testing.assert_array_equal(g.rollout_get("dones"), ro["dones"])
+    m, v, c = g.norm_stats(0)
+    close(m, nz.obs_rms.mean, rtol=1e-5, atol=1e-6); assert c == nz.obs_rms.count
+
+
+def test_host_env_rollout_api_matches_device_env_path():
+    """The Env-on-host path (reset / act / observe / finish) and the fused device-env path are the same arithmetic."""
+    E, T = 8, 6
+    orc, g, nz, ro, noise = _rollout_pair((64, 64), E, T, 22)
+    raw, _, _ = o.seeded_env_step(1234, 0, E, 0, 18)
+    g.rollout_reset(raw)
+    for t in range(T):
+        acts = g.rollout_act(t, noise[t])
+        close(acts, ro["actions"][t], msg="actions t=%d" % t)
+        raw, rew, dn = o.seeded_env_step(1234, 0, E, t + 1, 18)
+        g.rollout_observe(t, raw, rew, dn)
+    g.rollout_finish(GAMMA, LAM)
+    for f in ("obs", "values", "neglogp", "rewards", "returns", "dones"):
+        close(g.rollout_get(f), ro[f], rtol=2e-4, atol=2e-5, msg=f)
+
+
+@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((4, 5), 1, 256, 4, 2), ((64, 64), 16, 16, 4, 3), ((256, 256), 64, 16, 4, 2)])
+def test_update_phase_matches_oracle(hidden, E, T, nmb, epochs):
+    orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 23)
+    for f in ("obs", "actions", "values", "neglogp", "returns"):
+        g.rollout_set(f, ro[f])                      # identical inputs: isolate the update arithmetic
+    B = E * T
+    rng = np.random.RandomState(99)
+    perm = np.arange(B, dtype=np.int32); perms = []
+    for _ in range(epochs):
+        rng.shuffle(perm); perms.append(perm.copy())
+    perms = np.stack(perms)
+    ref_rows, ref_mean = orc.update(ro, perms, nmb, LR, CR)
+    rows, mean = g.update(LR, CR, epochs, nmb, perms)
+    close(rows, ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows")
+    close(mean, ref_mean, rtol=2e-4, atol=2e-6, msg="mean losses")
+    close(g.get_flat(0), orc.theta, rtol=2e-4, atol=5e-6, msg="theta")
+    close(g.beta_powers(), orc.pow, rtol=1e-5)
+    # replaying the captured graph on the same rollout continues the optimisation identically
+    ref_rows2, _ = orc.update(ro, perms, nmb, LR, CR)
+    rows2, _ = g.update(LR, CR, epochs, nmb, perms)
+    close(rows2, ref_rows2, rtol=3e-4, atol=3e-6, msg="second update")
+
+
+def test_update_with_device_permutation_is_a_valid_shuffle():
+    """perms=NULL: the keyed bijection must visit every row exactly once per epoch (sum of per-minibatch means of a
+    permutation-invariant quantity) and runs must be reproducible for a fixed seed."""
+    orc, g, nz, ro, noise = _rollout_pair((64, 64), 16, 16, 24)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    theta0 = g.get_flat()
+    rows_a, mean_a = g.update(LR, CR, 2, 4, None, seed=7)
+    th_a = g.get_flat()
+    assert np.isfinite(rows_a).all() and np.abs(th_a - theta0).max() > 0
+    close(rows_a[:, 2], 18 * 1.4189385175704956 + np.zeros(8), rtol=0.05)      # entropy stays near its analytic value
+    g.set_flat(theta0); g.set_flat(np.zeros_like(theta0), 1); g.set_flat(np.zeros_like(theta0), 2)
+    g.set_beta_powers([0.9, 0.999])
+    rows_b, _ = g.update(LR, CR, 2, 4, None, seed=7)
+    np.testing.assert_array_equal(rows_a, rows_b)                                # bitwise reproducible
+    np.testing.assert_array_equal(th_a, g.get_flat())
+    g.set_flat(theta0); g.set_flat(np.zeros_like(theta0), 1); g.set_flat(np.zeros_like(theta0), 2)
+    g.set_beta_powers([0.9, 0.999])
+    rows_c, _ = g.update(LR, CR, 2, 4, None, seed=8)
+    assert np.abs(rows_c - rows_a).max() > 0                                     # a different shuffle
+
+
+def test_full_size_config3_properties():
+    """BASELINE config 3 at full size (4096 envs x 16 steps, [256,256], 32 minibatches): size-independent properties.
+    approxkl/clipfrac are exactly 0 on the first minibatch (old == current), entropy is analytic, the update is
+    deterministic, and returns obey the GAE identity R_t - V_t = delta_t + gamma*lam*nnt*(R_{t+1} - V_{t+1})."""
+    import ppo_cpp_amd
+    g = ppo_cpp_amd.PPOHip(18, 18, [256, 256])
+    g.init_orthogonal(0)
+    E, T = 4096, 16
+    g.norm_init(E); g.rollout_alloc(E, T)
+    g.collect_synthetic(1234, GAMMA, LAM)
+    val, ret, rew, dn = (g.rollout_get(f) for f in ("values", "returns", "rewards", "dones"))
+    adv = ret - val
+    gam, lam = np.float32(GAMMA), np.float32(LAM)
+    for t in range(T - 1):
+        nnt = 1 - dn[t + 1]
+        lhs = adv[t]
+        rhs = rew[t] + gam * val[t + 1] * nnt - val[t] + gam * lam * nnt * adv[t + 1]
+        close(lhs, rhs, rtol=1e-4, atol=1e-5)
+    obs = g.rollout_get("obs")
+    assert np.abs(obs).max() <= 10.0 and abs(float(obs.mean())) < 0.05 and float(obs.std()) == pytest.approx(1.0, abs=0.05)
+    rows, mean = g.update(LR, CR, 1, 32, None, seed=3)
+    assert rows.shape == (32, 5) and np.isfinite(rows).all()
+    assert rows[0, 3] == pytest.approx(0.0, abs=1e-9) and rows[0, 4] == 0.0
+    close(rows[:, 2], np.full(32, 18 * 1.4189385175704956), rtol=1e-3)
+    assert (rows[1:, 3] > 0).all()
