@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- PPO env-steps/s of the rollout-collect + minibatch-update hot path on N MI355X.
+
+One "step" = one full PPO update of BASELINE.json configs[2] per rank: collect B = n_envs*n_steps transitions with the
+18-obs/18-act MLP [256,256] policy (on-device seeded synthetic env of the env_mock shape, inputs resident in HBM),
+then noptepochs x nminibatches clipped-surrogate train steps (fwd + loss + backward + global-norm clip + Adam).
+`value` = total env-steps of all ranks / wall time (the reference's own `fps`, ppo2/ppo2.hpp:337-343).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n_envs, n_steps, hidden, obs, act, nminibatches, noptepochs)   -- SURVEY section 8 table
+    "cfg3": dict(n_envs=4096, n_steps=16, hidden=[256, 256], obs=18, act=18, nminibatches=32, noptepochs=10,
+                 desc="env_mock-shaped synthetic env, 4096 envs x 16 steps (B=65536), MLP [256,256], 32 minibatches x 10 epochs"),
+    "cfg2": dict(n_envs=1, n_steps=2048, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
+                 desc="1 env x 2048 steps, MLP [64,64] (launch-latency bound)"),
+    "cfg4": dict(n_envs=1024, n_steps=64, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
+                 desc="1024 envs x 64 steps, MLP [64,64]"),
+}
+LR, CR, GAMMA, LAM = 3.93141e-4, 0.161023, 0.99, 0.95      # README.md:70-81, ppo2.cpp:215-217
+PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_row(O, A, hidden):
+    """(forward, dX backward, dW backward) FLOP per row, both towers (SURVEY section 8 table footnote)."""
+    dims = [O] + list(hidden)
+    tower = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+    fwd = 2 * tower + hidden[-1] * A + hidden[-1]
+    first = 2 * O * hidden[0]
+    dx = fwd - first
+    return 2 * fwd, 2 * dx, 2 * fwd
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The oracle's C restatement (a scalar port, 1 thread) timed on a bounded sample of the same workload."""
+    from oracle import oracle as o
+    E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
+    B = E * T; M = B // nmb
+    orc = o.Oracle(cfg["obs"], cfg["act"], cfg["hidden"])
+    orc.init_orthogonal(0)
+    rng = np.random.RandomState(0)
+    obs = rng.uniform(-1, 1, (E, cfg["obs"])).astype(np.float32)
+    noise = rng.normal(size=(E, cfg["act"])).astype(np.float32)
+    t0 = time.perf_counter(); n_step = 0
+    while n_step < 1 or (time.perf_counter() - t0 < 0.15 * budget_s and n_step < 8):
+        a, v, nlp = orc.step(obs, noise); n_step += 1
+    t_step = (time.perf_counter() - t0) / n_step
+    mobs = rng.uniform(-1, 1, (M, cfg["obs"])).astype(np.float32)
+    act, v, nlp = orc.step(mobs, rng.normal(size=(M, cfg["act"])).astype(np.float32))
+    ret = (v + rng.normal(size=M)).astype(np.float32)
+    adv = o.adv_normalize(ret, v)
+    t0 = time.perf_counter(); n_tr = 0
+    while n_tr < 1 or (time.perf_counter() - t0 < 0.85 * budget_s and n_tr < 64):
+        orc.train_step(LR, CR, mobs, act, adv, ret, nlp, v); n_tr += 1
+    t_train = (time.perf_counter() - t0) / n_tr
+    t_update = T * t_step + ep * nmb * t_train
+    return {"value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d policy steps at %d rows + %d train steps at %d rows of the oracle's C restatement, extrapolated to "
+                      "%d steps + %d train steps per update" % (n_step, E, n_tr, M, T, ep * nmb),
+            "update_samples_per_s": ep * B / (ep * nmb * t_train)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-env", action="store_true", help="also time the Env-on-host path (PCIe inclusive)")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import ppo_cpp_amd
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only; data path = RCCL in libppo_hip
+
+    E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
+    B = E * T; M = B // nmb
+    g = ppo_cpp_amd.PPOHip(cfg["obs"], cfg["act"], cfg["hidden"], device=local_rank)
+    g.init_orthogonal(0)                                                   # same seed on every rank: replicated weights
+    if world > 1:
+        import torch
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(ppo_cpp_amd.PPOHip.dist_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, 0)
+        g.dist_init(world, rank, bytes(uid.numpy().tobytes()))
+    g.norm_init(E, GAMMA)
+    g.rollout_alloc(E, T)
+    env0 = rank * E                                                        # weak scaling: every rank owns E more envs
+
+    def one_step(i, first=False):
+        g.collect_synthetic(1234, GAMMA, LAM, None, env0=env0, step0=i * T, first=first)
+        return g.update(LR, CR, ep, nmb, None, seed=1000 + i, want_rows=False)[1]
+
+    def barrier():
+        g.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(max(args.warmup, 1)):
+        losses = one_step(i, first=(i == 0))
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = one_step(args.warmup + i)
+    g.sync()
+    dt = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    # per-kernel device time of the same workload, HIP events on the handle's stream, right after the timed region
+    g.prof_enable(True)
+    t_c0 = time.perf_counter()
+    g.collect_synthetic(1234, GAMMA, LAM, None, env0=env0, step0=(args.warmup + args.steps) * T, first=False)
+    t_collect = time.perf_counter() - t_c0
+    g.update(LR, CR, ep, nmb, None, seed=999, want_rows=False)
+    prof = g.prof_read()
+    g.prof_enable(False)
+
+    # phase split of one un-profiled step
+    t_a = time.perf_counter()
+    g.collect_synthetic(1234, GAMMA, LAM, None, env0=env0, step0=(args.warmup + args.steps + 1) * T, first=False)
+    t_b = time.perf_counter()
+    g.update(LR, CR, ep, nmb, None, seed=998, want_rows=False)
+    t_c = time.perf_counter()
+
+    if rank != 0:
+        return
+    f_fwd, f_dx, f_dw = flops_per_row(cfg["obs"], cfg["act"], cfg["hidden"])
+    kflops = {"train_fwd_bwd": (f_fwd + f_dx) * M, "weight_grad": f_dw * M, "policy_step": f_fwd * E}
+    kern = {k: {"avg_us": 1e3 * ms / n, "launches": n} for k, (ms, n) in prof.items() if n}
+    dom = max((k for k in kern if k in kflops), key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
+    ach = kflops[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e12
+    step_flops = (f_fwd + f_dx + f_dw) * M
+    step_us = sum(kern[k]["avg_us"] for k in ("train_fwd_bwd", "weight_grad", "grad_reduce", "adam") if k in kern)
+    out = {
+        "metric": "PPO env-steps/s", "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2] (%s): %s" % (args.config, cfg["desc"]), "n_envs_per_gpu": E, "n_steps": T,
+                   "n_batch_per_gpu": B, "minibatch_rows_per_gpu": M, "parallelism": "dp%d" % world,
+                   "env": "on-device seeded synthetic env (env_mock shape), rollout buffers resident in HBM"},
+        "update_samples_per_s": world * ep * B / (t_c - t_b),
+        "phase_ms": {"collect": 1e3 * (t_b - t_a), "update": 1e3 * (t_c - t_b)},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "flop_per_launch": kflops[dom], "avg_us": kern[dom]["avg_us"],
+                     "train_step": {"flop": step_flops, "kernel_us_sum": step_us,
+                                    "achieved": step_flops / (step_us * 1e-6) / 1e12 if step_us else None}},
+        "kernels": kern,
+        "losses": [float(x) for x in losses],
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -31,7 +31,7 @@ def build_hip(force=False, verbose=False):
     csrc = os.path.join(PKG, "csrc")
     deps = _sources(csrc, (".hip", ".hpp", ".h")) + [os.path.join(ROOT, "include", "ppo_hip.h")]
     if force or _newer(HIP_SO, deps):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                "-o", HIP_SO, os.path.join(csrc, "ppo_hip.hip"), "-ldl"]
         if verbose:
             print(" ".join(cmd))
