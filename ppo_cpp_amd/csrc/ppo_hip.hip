@@ -19,6 +19,9 @@
 namespace {
 
 std::string g_create_error;
+#ifdef PPO_STAMPS
+unsigned long long* g_stamps = nullptr;
+#endif
 
 int ru(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -309,14 +312,14 @@ int ensure_staging(ppo_handle* h, int rows) {
 }
 
 // ---- launches -------------------------------------------------------------------------------------------------
-template <int CT>
+template <int CT, int KS>
 void launch_step_t(ppo_handle* h, const StepArgs& a) {
     dim3 grid((a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 2);
-    hipLaunchKernelGGL(policy_step_kernel<CT>, grid, dim3(BLOCK_THREADS), (size_t)h->net.lds_total * sizeof(float), h->stream, h->net, a);
+    hipLaunchKernelGGL((policy_step_kernel<CT, KS>), grid, dim3(BLOCK_THREADS), (size_t)h->net.lds_total * sizeof(float), h->stream, h->net, a);
 }
 int launch_step(ppo_handle* h, const StepArgs& a) {
     ProfScope ps(h, PK_STEP);
-    if (h->CT == 4) launch_step_t<4>(h, a); else launch_step_t<1>(h, a);
+    if (h->CT == 4) launch_step_t<4, 2>(h, a); else launch_step_t<1, 1>(h, a);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -333,6 +336,10 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     const int n_rb = (ta.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     ta.theta = h->theta; ta.hyper = h->hyper;
     ta.x0g = h->x0g; ta.dmug = h->dmug;
+#ifdef PPO_STAMPS
+    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 16 * sizeof(unsigned long long));
+    ta.stamps = g_stamps;
+#endif
     for (int t = 0; t < 2; ++t) {
         ta.slots[t] = h->slots[t];
         for (int l = 0; l < n.L; ++l) { ta.hg[t][l] = h->hg[t][l]; ta.dyg[t][l] = h->dyg[t][l]; }
@@ -340,8 +347,8 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     {
         ProfScope ps(h, PK_TRAIN_FB);
         dim3 grid(n_rb, 2);
-        if (h->CT == 4) hipLaunchKernelGGL(train_fwd_bwd_kernel<4>, grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
-        else hipLaunchKernelGGL(train_fwd_bwd_kernel<1>, grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
+        if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
+        else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
         HIP_OK(h, hipGetLastError());
     }
     const int split = pick_split(h, ta.n);
@@ -349,7 +356,9 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
         ProfScope ps(h, PK_DW);
         DwArgs da{h->dw_tiles, ta.n, split, h->slabs, (size_t)h->P_pad};
         const size_t lds = (h->dw_has_big ? 4 * 64 * 64 : 4 * 16 * 16) * sizeof(float);
-        hipLaunchKernelGGL(weight_grad_kernel, dim3(h->n_dw_tiles, split), dim3(BLOCK_THREADS), lds, h->stream, da);
+        const int rows_per_wave = ta.n / split / 4;
+        if (rows_per_wave % 16 == 0) hipLaunchKernelGGL(weight_grad_kernel<4>, dim3(h->n_dw_tiles, split), dim3(BLOCK_THREADS), lds, h->stream, da);
+        else hipLaunchKernelGGL(weight_grad_kernel<1>, dim3(h->n_dw_tiles, split), dim3(BLOCK_THREADS), lds, h->stream, da);
         HIP_OK(h, hipGetLastError());
     }
     {
@@ -450,13 +459,14 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     const int lds_bytes = h->net.lds_total * (int)sizeof(float);
     bool attr_ok = true;
     if (h->CT == 4) {
-        attr_ok &= hipFuncSetAttribute((const void*)policy_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)train_fwd_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)policy_step_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)train_fwd_bwd_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
     } else {
-        attr_ok &= hipFuncSetAttribute((const void*)policy_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)train_fwd_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)policy_step_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)train_fwd_bwd_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
     }
-    attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
+    attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
+    attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
     if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return bail(0); }
     const size_t P = (size_t)h->P_pad;
     if (dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||
@@ -953,7 +963,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             if (enqueue_train(h, ta, h->d_loss_rows + (size_t)(ep * nmb + k) * 5)) return -1;
         }
     }
-    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, h->stream, h->d_loss_rows, epochs * nmb, h->d_loss_mean);
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(320), 0, h->stream, h->d_loss_rows, epochs * nmb, h->d_loss_mean);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -1079,5 +1089,13 @@ int ppo_prof_read(ppo_handle* h, int max, char names[][32], double* total_ms, in
     }
     return n;
 }
+
+#ifdef PPO_STAMPS
+int ppo_debug_read_stamps(ppo_handle* h, unsigned long long* dst, int n) {
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(dst, g_stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 
 }  // extern "C"

@@ -91,6 +91,21 @@ __device__ __forceinline__ float ctr_normal(uint32_t seed, uint32_t row, uint32_
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
 }
 
+// tanh with ~3 ulp error and ~14 instructions: odd Taylor polynomial near 0 (no cancellation), 1 - 2/(e^{2|x|}+1)
+// elsewhere on the hardware exp2 / rcp units.  (ocml tanhf costs ~100 instructions per element.)
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    float p = fmaf(x2, 0.021869488536155203f, -0.053968253968253971f);     // 62/2835, -17/315
+    p = fmaf(x2, p, 0.13333333333333333f);                                   // 2/15
+    p = fmaf(x2, p, -0.33333333333333333f);
+    p = fmaf(x2 * x, p, x);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);        // e^{2|x|}
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float big = copysignf(t, x);
+    return ax < 0.2f ? p : big;
+}
+
 // reduce over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float group16_sum(float v) {
     v += __shfl_xor(v, 8);
@@ -110,51 +125,72 @@ __device__ __forceinline__ float group16_sum(float v) {
 // Reduction index of instruction s for lane group g = lane >> 4 is k = kb + 4g + s: A comes from ONE 16-byte
 // LDS read per 16 k values.
 // ------------------------------------------------------------------------------------------------------------
-template <int CT>
-struct WFrag { float v[4][CT]; };
+template <int CT, int KS>
+struct WFrag { float v[4 * KS][CT]; };
 
-template <int CT>
-__device__ __forceinline__ void load_w_rows(WFrag<CT>& w, const float* __restrict__ W, int ldw, int krow, int col) {
+// rows kb + 16q + 4g + s (q < KS, s < 4) of W, CT consecutive columns starting at col
+template <int CT, int KS>
+__device__ __forceinline__ void load_w_rows(WFrag<CT, KS>& w, const float* __restrict__ W, int ldw, int krow, int col) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const float* p = W + (size_t)(krow + s) * ldw + col;
-        if constexpr (CT == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            w.v[s][0] = t.x; w.v[s][1] = t.y; w.v[s][2] = t.z; w.v[s][3] = t.w;
-        } else if constexpr (CT == 2) {
-            const float2 t = *reinterpret_cast<const float2*>(p);
-            w.v[s][0] = t.x; w.v[s][1] = t.y;
-        } else {
-            w.v[s][0] = *p;
+    for (int q = 0; q < KS; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* p = W + (size_t)(krow + 16 * q + s) * ldw + col;
+            if constexpr (CT == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                w.v[4 * q + s][0] = t.x; w.v[4 * q + s][1] = t.y; w.v[4 * q + s][2] = t.z; w.v[4 * q + s][3] = t.w;
+            } else if constexpr (CT == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(p);
+                w.v[4 * q + s][0] = t.x; w.v[4 * q + s][1] = t.y;
+            } else {
+                w.v[4 * q + s][0] = *p;
+            }
         }
-    }
 }
 
-template <int CT, bool TANH>
+// KS = 16-deep k blocks per pipeline stage: the weights of stage i+1 (KS*4 16-byte loads per lane) are issued and
+// pinned above the 16*KS*CT/4 MFMAs of stage i, which is what hides the L2 latency (with KS = 2: ~1000 cycles).
+template <int CT, bool TANH, int KS>
 __device__ __forceinline__ void layer_forward(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
                                               const float* Xs, int ldx, int K, float* Ys, int ldy, int Np,
                                               float* __restrict__ gy, int ldg, int row0, int nrows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     constexpr int CW = 16 * CT;
+    constexpr int KB = 16 * KS;
     for (int n0 = wave * CW; n0 < Np; n0 += (BLOCK_THREADS / 64) * CW) {
         f32x4 acc[CT];
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int col = n0 + CT * c;
-        WFrag<CT> wcur, wnext;
-        load_w_rows<CT>(wcur, W, ldw, 4 * g, col);
-        for (int kb = 0; kb < K; kb += 16) {
-            if (kb + 16 < K) load_w_rows<CT>(wnext, W, ldw, kb + 16 + 4 * g, col);
-            const float4 a = *reinterpret_cast<const float4*>(Xs + c * ldx + kb + 4 * g);
-            const float av[4] = {a.x, a.y, a.z, a.w};
+        // two named register stages (ping-pong, no copies: a copy would make the compiler wait for the loads it
+        // has just issued); the loads of stage i+1 are pinned above the MFMAs of stage i by sched_barrier
+        WFrag<CT, KS> w0, w1;
+        auto compute = [&](const WFrag<CT, KS>& w, int kb) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int q = 0; q < KS; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(Xs + c * ldx + kb + 16 * q + 4 * g);
+                const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                for (int j = 0; j < CT; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wcur.v[s][j], acc[j], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], w.v[4 * q + s][j], acc[j], 0, 0, 0);
+                }
             }
-            if (kb + 16 < K) wcur = wnext;
+        };
+        load_w_rows<CT, KS>(w0, W, ldw, 4 * g, col);
+        for (int kb = 0; kb < K; kb += 2 * KB) {
+            const int k1 = (kb + KB < K) ? kb + KB : kb;            // clamped: unconditional loads, counted vmcnt
+            load_w_rows<CT, KS>(w1, W, ldw, k1 + 4 * g, col);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(w0, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            const int k2 = (kb + 2 * KB < K) ? kb + 2 * KB : kb;
+            load_w_rows<CT, KS>(w0, W, ldw, k2 + 4 * g, col);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + KB < K) compute(w1, kb + KB);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue: accumulator register r of MFMA j holds Y[row 4g + r][col n0 + CT*c + j]
         float bv[CT];
@@ -167,7 +203,7 @@ __device__ __forceinline__ void layer_forward(const float* __restrict__ W, int l
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
                 const float z = acc[j][r] + bv[j];
-                y[j] = TANH ? tanhf(z) : z;
+                y[j] = TANH ? fast_tanh(z) : z;
             }
             float* ys = Ys + row * ldy + col;
             float* yg = gy ? gy + (size_t)(row0 + row) * ldg + col : nullptr;
@@ -192,40 +228,52 @@ __device__ __forceinline__ void layer_forward(const float* __restrict__ W, int l
 //   Hs = the tanh outputs this gradient flows into (TanhGrad, G:21272,...); HS == false => no activation factor
 // Result goes to LDS (dXs) and to global gd (it is the dY operand of the previous layer's weight gradient).
 // ------------------------------------------------------------------------------------------------------------
-template <int CT, bool HS>
+template <int CT, bool HS, int KS>
 __device__ __forceinline__ void layer_backward(const float* __restrict__ W, int ldw, const float* dYs, int ldy, int Np,
                                                const float* Hs, int ldh, float* dXs, int ldd, int Kp,
                                                float* __restrict__ gd, int ldg, int row0, int nrows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     constexpr int CW = 16 * CT;
+    constexpr int NB = 16 * KS;
     for (int k0 = wave * CW; k0 < Kp; k0 += (BLOCK_THREADS / 64) * CW) {
         f32x4 acc[CT];
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int orow = k0 + CT * c;                       // this lane's first output column = row of W
-        float4 wcur[CT], wnext[CT];
+        float4 w0[KS][CT], w1[KS][CT];
+        auto load = [&](float4 (*w)[CT], int nb) {
 #pragma unroll
-        for (int j = 0; j < CT; ++j) wcur[j] = *reinterpret_cast<const float4*>(W + (size_t)(orow + j) * ldw + 4 * g);
-        for (int nb = 0; nb < Np; nb += 16) {
-            if (nb + 16 < Np) {
+            for (int q = 0; q < KS; ++q)
 #pragma unroll
                 for (int j = 0; j < CT; ++j)
-                    wnext[j] = *reinterpret_cast<const float4*>(W + (size_t)(orow + j) * ldw + nb + 16 + 4 * g);
-            }
-            const float4 a = *reinterpret_cast<const float4*>(dYs + c * ldy + nb + 4 * g);
-            const float av[4] = {a.x, a.y, a.z, a.w};
+                    w[q][j] = *reinterpret_cast<const float4*>(W + (size_t)(orow + j) * ldw + nb + 16 * q + 4 * g);
+        };
+        auto compute = [&](const float4 (*w)[CT], int nb) {
 #pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                const float wv[4] = {wcur[j].x, wcur[j].y, wcur[j].z, wcur[j].w};
+            for (int q = 0; q < KS; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(dYs + c * ldy + nb + 16 * q + 4 * g);
+                const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wv[s], acc[j], 0, 0, 0);
-            }
-            if (nb + 16 < Np) {
+                for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int j = 0; j < CT; ++j) wcur[j] = wnext[j];
+                    for (int j = 0; j < CT; ++j) {
+                        const float wv = s == 0 ? w[q][j].x : s == 1 ? w[q][j].y : s == 2 ? w[q][j].z : w[q][j].w;
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wv, acc[j], 0, 0, 0);
+                    }
+                }
             }
+        };
+        load(w0, 0);
+        for (int nb = 0; nb < Np; nb += 2 * NB) {
+            load(w1, (nb + NB < Np) ? nb + NB : nb);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(w0, nb);
+            __builtin_amdgcn_sched_barrier(0);
+            load(w0, (nb + 2 * NB < Np) ? nb + 2 * NB : nb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (nb + NB < Np) compute(w1, nb + NB);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -288,6 +336,13 @@ __device__ __forceinline__ void stage_obs_tile(float* Xs, int ldx, int Kp0, int 
     }
 }
 
+#ifdef PPO_STAMPS
+#define STAMP(i)                                                                                        \
+    do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 #define HALF_LOG_2PI 0.9189385175704956f   /* G:6531 */
 #define HALF_LOG_2PIE 1.4189385175704956f  /* G:10021-10180 */
 
@@ -308,7 +363,7 @@ struct StepArgs {
     uint32_t seed, rng_step, row_base;
 };
 
-template <int CT>
+template <int CT, int KS>
 __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tower = blockIdx.y;
@@ -322,7 +377,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
     int K = net.Kp0, ldx = ld0;
     for (int l = 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
-        layer_forward<CT, true>(a.theta + net.w_off[tower][l], Np, a.theta + net.b_off[tower][l], lds + net.lds_h[l], ldx, K,
+        layer_forward<CT, true, KS>(a.theta + net.w_off[tower][l], Np, a.theta + net.b_off[tower][l], lds + net.lds_h[l], ldx, K,
                                 lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, row0, a.n);
         __syncthreads();
         K = Np; ldx = ldy;
@@ -336,7 +391,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
     }
     float* mus = lds + net.lds_mu;
     const int ldm = net.Ap + LDS_PAD;
-    layer_forward<1, false>(a.theta + net.wmu_off, net.Ap, a.theta + net.bmu_off, hL, ldx, K, mus, ldm, net.Ap, nullptr, 0,
+    layer_forward<1, false, 1>(a.theta + net.wmu_off, net.Ap, a.theta + net.bmu_off, hL, ldx, K, mus, ldm, net.Ap, nullptr, 0,
                             row0, a.n);
     __syncthreads();
     // sampling + neglogp (G:5894-6672): 16 lanes per row, each lane owns actions j = part, part+16, ...
@@ -384,9 +439,10 @@ struct TrainArgs {
     float* dyg[2][PPO_MAX_LAYERS];  // [tower][l] = dLoss/d(pre-activation of layer l) [n][Hp[l]]
     float* dmug;                 // [n][Ap]
     float* slots[2];             // [tower][n_blocks][slot_w]
+    unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS): [blocks][16] s_memtime stamps
 };
 
-template <int CT>
+template <int CT, int KS>
 __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tower = blockIdx.y;
@@ -395,17 +451,20 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     const int ld0 = net.Kp0 + LDS_PAD;
     float* misc = lds + net.lds_misc;
     float* slot = a.slots[tower] + (size_t)blockIdx.x * net.slot_w;
+    STAMP(0);
     ObsNorm nz = {nullptr, nullptr, 0.f, 0.f, 0};
     stage_obs_tile(lds + net.lds_h[0], ld0, net.Kp0, net.O, a.obs, a.rowidx, row0, a.n, nz, nullptr,
                    tower == 0 ? a.x0g : nullptr, net.Kp0);
     __syncthreads();
+    STAMP(1);
     // ---- forward (G:6889-9187) -------------------------------------------------------------------------------
     int K = net.Kp0, ldx = ld0;
     for (int l = 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
-        layer_forward<CT, true>(a.theta + net.w_off[tower][l], Np, a.theta + net.b_off[tower][l], lds + net.lds_h[l], ldx, K,
+        layer_forward<CT, true, KS>(a.theta + net.w_off[tower][l], Np, a.theta + net.b_off[tower][l], lds + net.lds_h[l], ldx, K,
                                 lds + net.lds_h[l + 1], ldy, Np, a.hg[tower][l], Np, row0, a.n);
         __syncthreads();
+        STAMP(2 + l);
         K = Np; ldx = ldy;
     }
     const float* hL = lds + net.lds_h[net.L];
@@ -422,9 +481,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
         // ---- policy head + surrogate loss (G:9428-11290) and its gradient (G:12609-22656) -------------------
         float* mus = lds + net.lds_mu;
         const int ldm = net.Ap + LDS_PAD;
-        layer_forward<1, false>(a.theta + net.wmu_off, net.Ap, a.theta + net.bmu_off, hL, ldhL, HpL, mus, ldm, net.Ap, nullptr, 0,
+        layer_forward<1, false, 1>(a.theta + net.wmu_off, net.Ap, a.theta + net.bmu_off, hL, ldhL, HpL, mus, ldm, net.Ap, nullptr, 0,
                                 row0, a.n);
         __syncthreads();
+        STAMP(6);
         float ssq = 0.f, slog = 0.f, sent = 0.f;
         for (int j = part; j < net.A; j += 16) {
             const float mu = mus[r * ldm + j];
@@ -489,8 +549,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
             for (int q = 0; q < ROWS_PER_BLOCK; ++q) s += misc[q * 4 + tid];
             slot[net.slot_loss + tid] = s;
         }
+        STAMP(7);
         // dh_L = (dmu * W_mu^T) .* (1 - h_L^2)
-        layer_backward<CT, true>(a.theta + net.wmu_off, net.Ap, dcur, ldm, net.Ap, hL, ldhL, dnext, HpL + LDS_PAD, HpL,
+        layer_backward<CT, true, 1>(a.theta + net.wmu_off, net.Ap, dcur, ldm, net.Ap, hL, ldhL, dnext, HpL + LDS_PAD, HpL,
                                  a.dyg[0][net.L - 1], HpL, row0, a.n);
         __syncthreads();
     } else {
@@ -535,6 +596,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
         }
         __syncthreads();
     }
+    STAMP(8);
     // ---- hidden layers, top down: dnext holds dLoss/d(pre-activation of layer l) -------------------------------
     for (int l = net.L - 1; l >= 0; --l) {
         float* t = dcur; dcur = dnext; dnext = t;            // dcur = dY_l
@@ -546,10 +608,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
         }
         if (l > 0) {                                         // first-layer dX is never needed
             const int Kp = net.Hp[l - 1];
-            layer_backward<CT, true>(a.theta + net.w_off[tower][l], Np, dcur, ldd, Np, lds + net.lds_h[l], Kp + LDS_PAD,
+            layer_backward<CT, true, KS>(a.theta + net.w_off[tower][l], Np, dcur, ldd, Np, lds + net.lds_h[l], Kp + LDS_PAD,
                                      dnext, Kp + LDS_PAD, Kp, a.dyg[tower][l - 1], Kp, row0, a.n);
         }
         __syncthreads();
+        STAMP(9 + (net.L - 1 - l));
     }
 }
 
@@ -568,7 +631,7 @@ struct DwTile {
     int cls;                           // 0: 64x64 tile (TI=TJ=4) ; 1: 16x16 tile
 };
 
-template <int TI, int TJ>
+template <int TI, int TJ, int KQ>
 __device__ __forceinline__ void dw_tile_body(const DwTile& t, int n, int nsplit, float* __restrict__ slabs, size_t slab_stride,
                                              float* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -582,31 +645,41 @@ __device__ __forceinline__ void dw_tile_body(const DwTile& t, int n, int nsplit,
     for (int a = 0; a < TI; ++a)
 #pragma unroll
         for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // MFMA (a,b): A[i][k] = X[row k][i0 + TI*i + a], B[k][j] = dY[row k][j0 + TJ*j + b], k = lane group g
+    // MFMA (a,b): A[i][k] = X[row k][i0 + TI*i + a], B[k][j] = dY[row k][j0 + TJ*j + b], k = lane group g.
+    // One pipeline stage = KQ k-steps (4*KQ minibatch rows): 2*KQ 16-byte loads per lane feed TI*TJ*KQ MFMAs.
     const float* xp = t.X + (size_t)(rbeg + g) * t.ldx + t.i0 + TI * c;
     const float* yp = t.dY + (size_t)(rbeg + g) * t.ldy + t.j0 + TJ * c;
-    float xa[TI], yb[TJ], xn[TI], yn[TJ];
-    auto ld = [&](float* xo, float* yo, int koff) {
-        const float* x = xp + (size_t)koff * t.ldx;
-        const float* y = yp + (size_t)koff * t.ldy;
-        if constexpr (TI == 4) { const float4 v = *reinterpret_cast<const float4*>(x); xo[0] = v.x; xo[1] = v.y; xo[2] = v.z; xo[3] = v.w; }
-        else { xo[0] = *x; }
-        if constexpr (TJ == 4) { const float4 v = *reinterpret_cast<const float4*>(y); yo[0] = v.x; yo[1] = v.y; yo[2] = v.z; yo[3] = v.w; }
-        else { yo[0] = *y; }
-    };
-    if (rows_per_wave > 0) ld(xa, yb, 0);
-    for (int k = 0; k < rows_per_wave; k += 4) {
-        if (k + 4 < rows_per_wave) ld(xn, yn, k + 4);
+    float x0[KQ][TI], y0[KQ][TJ], x1[KQ][TI], y1[KQ][TJ];
+    auto ld = [&](float (*xo)[TI], float (*yo)[TJ], int koff) {
 #pragma unroll
-        for (int a = 0; a < TI; ++a)
-#pragma unroll
-            for (int b = 0; b < TJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[a], yb[b], acc[a][b], 0, 0, 0);
-        if (k + 4 < rows_per_wave) {
-#pragma unroll
-            for (int a = 0; a < TI; ++a) xa[a] = xn[a];
-#pragma unroll
-            for (int b = 0; b < TJ; ++b) yb[b] = yn[b];
+        for (int q = 0; q < KQ; ++q) {
+            const float* x = xp + (size_t)(koff + 4 * q) * t.ldx;
+            const float* y = yp + (size_t)(koff + 4 * q) * t.ldy;
+            if constexpr (TI == 4) { const float4 v = *reinterpret_cast<const float4*>(x); xo[q][0] = v.x; xo[q][1] = v.y; xo[q][2] = v.z; xo[q][3] = v.w; }
+            else { xo[q][0] = *x; }
+            if constexpr (TJ == 4) { const float4 v = *reinterpret_cast<const float4*>(y); yo[q][0] = v.x; yo[q][1] = v.y; yo[q][2] = v.z; yo[q][3] = v.w; }
+            else { yo[q][0] = *y; }
         }
+    };
+    auto compute = [&](const float (*xi)[TI], const float (*yi)[TJ]) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int b = 0; b < TJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xi[q][a], yi[q][b], acc[a][b], 0, 0, 0);
+    };
+    constexpr int RS = 4 * KQ;                                      // minibatch rows per pipeline stage
+    ld(x0, y0, 0);
+    for (int k = 0; k < rows_per_wave; k += 2 * RS) {               // ping-pong stages, unconditional clamped loads
+        ld(x1, y1, (k + RS < rows_per_wave) ? k + RS : k);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(x0, y0);
+        __builtin_amdgcn_sched_barrier(0);
+        ld(x0, y0, (k + 2 * RS < rows_per_wave) ? k + 2 * RS : k);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + RS < rows_per_wave) compute(x1, y1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // in-workgroup split-K: every wave parks its tile in LDS, then all threads add the 4 copies in wave order
     constexpr int TW = 16 * TJ, TH = 16 * TI;
@@ -636,11 +709,12 @@ struct DwArgs {
     size_t slab_stride;
 };
 
+template <int KQ>
 __global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const DwTile t = a.tiles[blockIdx.x];
-    if (t.cls == 0) dw_tile_body<4, 4>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
-    else dw_tile_body<1, 1>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+    if (t.cls == 0) dw_tile_body<4, 4, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+    else dw_tile_body<1, 1, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -669,16 +743,18 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
     __shared__ float red[4];
     const int blk = blockIdx.x, tid = threadIdx.x;
     if (blk == a.n_blocks) {
-        // loss partial sums (fixed order over row blocks): tail = {pg, vf, ent, kl, cf, rows}
-        if (tid < 5) {
-            const int tower = (tid == 1) ? 1 : 0;
-            const int off = a.slot_loss + (tid == 0 ? 0 : tid == 1 ? 0 : tid - 1);
+        // loss partial sums over the row blocks: tail = {pg, vf, ent, kl, cf, rows}; 32 lanes per quantity
+        if (tid < 160) {
+            const int q = tid >> 5, ln = tid & 31;
+            const int tower = (q == 1) ? 1 : 0;
+            const int off = a.slot_loss + (q <= 1 ? 0 : q - 1);
             float s = 0.f;
-            for (int b = 0; b < a.n_rowblocks; ++b) s += a.slots[tower][(size_t)b * a.slot_w + off];
-            a.grad[(size_t)a.n_blocks * 256 + tid] = s;
+            for (int b = ln; b < a.n_rowblocks; b += 32) s += a.slots[tower][(size_t)b * a.slot_w + off];
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (ln == 0) a.grad[(size_t)a.n_blocks * 256 + q] = s;
         }
-        if (tid == 5) a.grad[(size_t)a.n_blocks * 256 + 5] = a.n_local;
-        if (tid == 6) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }
+        if (tid == 160) a.grad[(size_t)a.n_blocks * 256 + 5] = a.n_local;
+        if (tid == 161) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }
         return;
     }
     const GradSrc s = a.src[blk];
@@ -689,8 +765,20 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
     } else if (s.kind == 1) {
         const int e = (int)(idx - (size_t)s.base);
         if (e < s.count) {
+            // 4 independent chains x unroll 8 = 32 loads in flight (a serial chain of n_rowblocks L2 round trips
+            // costs ~30 us); the summation order is fixed, so the result is reproducible
             const float* p = a.slots[s.tower] + s.slot_off + e;
-            for (int b = 0; b < a.n_rowblocks; ++b) gsum += p[(size_t)b * a.slot_w];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int b = 0;
+#pragma unroll 8
+            for (; b + 4 <= a.n_rowblocks; b += 4) {
+                s0 += p[(size_t)b * a.slot_w];
+                s1 += p[(size_t)(b + 1) * a.slot_w];
+                s2 += p[(size_t)(b + 2) * a.slot_w];
+                s3 += p[(size_t)(b + 3) * a.slot_w];
+            }
+            for (; b < a.n_rowblocks; ++b) s0 += p[(size_t)b * a.slot_w];
+            gsum = (s0 + s1) + (s2 + s3);
         }
     }
     a.grad[idx] = gsum;
@@ -866,13 +954,12 @@ __global__ __launch_bounds__(1024) void adv_normalize_kernel(const float* return
 }
 
 // column means of the loss rows (ppo2.hpp:335)
-__global__ void loss_mean_kernel(const float* rows, int n, float* mean) {
-    const int j = threadIdx.x;
-    if (j < 5) {
-        float s = 0.f;
-        for (int i = 0; i < n; ++i) s += rows[i * 5 + j];
-        mean[j] = s / (float)n;
-    }
+__global__ void loss_mean_kernel(const float* rows, int n, float* mean) {      // launch with 5 * 64 threads
+    const int j = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    float s = 0.f;
+    for (int i = ln; i < n; i += 64) s += rows[i * 5 + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (ln == 0) mean[j] = s / (float)n;
 }
 
 // ------------------------------------------------------------------------------------------------------------

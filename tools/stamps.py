@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Diagnostic: builds libppo_hip with -DPPO_STAMPS, runs train steps at cfg3 shape, prints per-phase cycles."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+so = os.path.join(ROOT, "ppo_cpp_amd", "libppo_hip.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                       "-DPPO_STAMPS", "-o", so, os.path.join(ROOT, "ppo_cpp_amd/csrc/ppo_hip.hip"), "-ldl"])
+import ppo_cpp_amd
+g = ppo_cpp_amd.PPOHip(18, 18, [256, 256]); g.init_orthogonal(0)
+n = 2048; rng = np.random.RandomState(0)
+obs = rng.uniform(-1, 1, (n, 18)).astype(np.float32); a, v, nlp = g.step(obs, rng.normal(size=(n, 18)).astype(np.float32))
+ret = (v + rng.normal(size=n)).astype(np.float32); adv = g.adv_normalize(ret, v)
+for _ in range(5): g.train_step(3e-4, 0.16, obs, a, adv, ret, nlp, v)
+buf = np.zeros(256 * 16, np.uint64)
+g.lib.ppo_debug_read_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size)
+st = buf.reshape(256, 16).astype(np.int64)
+names = ["stage", "L0", "L1", "-", "-", "head_fwd", "loss", "head_bwd/vf", "bwd_L1", "bwd_L0"]
+for tower in (0, 1):
+    blk = st[tower * 128:(tower + 1) * 128]
+    print("tower", tower, "total cycles median", np.median(blk[:, 10] - blk[:, 0]), "min start", (blk[:, 0] - st[:, 0].min()).min(), "max end", (blk[:, 10] - st[:, 0].min()).max())
+    for i in range(10):
+        d = blk[:, i + 1] - blk[:, i]
+        if (blk[:, i + 1] > 0).all() and (blk[:, i] > 0).all(): print("   %-12s median %8.0f  max %8.0f" % (names[i], np.median(d), d.max()))
