@@ -57,9 +57,11 @@ struct ppo_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     int CT = 1;                       // column tiles per wave in the dense layers (4 for wide nets)
+    int CTH = 0;                      // split-K policy head column tiles (2 when Ap == 32 on the wide path), 0 = generic
     NetDev net{};
     std::vector<Tensor> tensors;
-    int P_dense = 0, P_pad = 0, n_blocks = 0;
+    int P_dense = 0, P_pad = 0, n_blocks = 0, PT = 0;
+    float* thetaT = nullptr;          // transposed copies (layout: NetDev::wT_off / wmuT_off)
     // parameters + optimiser state (padded layout)
     float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad = nullptr, *sumsq = nullptr;
     float* beta_pow = nullptr;        // {cur b1, cur b2, next b1, next b2}
@@ -95,6 +97,7 @@ struct ppo_handle {
     float* ro_noise = nullptr;        // [T,E,A] staging for explicit noise
     // update
     int* d_perms = nullptr; int* d_inv = nullptr; int* d_gidx = nullptr; float* d_advstats = nullptr;
+    float *mb_obs = nullptr, *mb_act = nullptr, *mb_adv = nullptr, *mb_ret = nullptr, *mb_val = nullptr, *mb_nlp = nullptr;
     uint32_t* d_keys = nullptr; float* d_loss_rows = nullptr; float* d_loss_mean = nullptr;
     int upd_cap_rows = 0, upd_cap_steps = 0;
     hipGraphExec_t upd_graph = nullptr;
@@ -185,7 +188,6 @@ int build_layout(ppo_handle* h) {
     NetDev& n = h->net;
     memset(&n, 0, sizeof n);
     n.O = c.obs_dim; n.A = c.act_dim; n.L = c.n_hidden;
-    n.Kp0 = ru(c.obs_dim, 16); n.Ap = ru(c.act_dim, 16);
     int minH = 1 << 30;
     for (int l = 0; l < n.L; ++l) { n.H[l] = c.hidden[l]; n.Hp[l] = ru(c.hidden[l], 16); minH = std::min(minH, n.Hp[l]); }
     h->CT = 1;
@@ -195,6 +197,9 @@ int build_layout(ppo_handle* h) {
         if (ok) h->CT = 4;
     }
     if (h->CT == 4) for (int l = 0; l < n.L; ++l) n.Hp[l] = ru(n.Hp[l], 64);
+    const int kq = h->CT == 4 ? 32 : 16;                  // reduction dims must be whole pipeline stages (16*KS)
+    n.Kp0 = ru(c.obs_dim, kq); n.Ap = ru(c.act_dim, kq);
+    h->CTH = (h->CT == 4 && n.Ap == 32) ? 2 : 0;
     n.ent_coef = c.ent_coef; n.vf_coef = c.vf_coef;
     int od = 0, op = 0;
     char nm[32];
@@ -212,6 +217,13 @@ int build_layout(ppo_handle* h) {
     n.bmu_off = op; add_tensor(h, "pi/b", n.A, 0, 1, n.Ap, od, op);
     n.ls_off = op;  add_tensor(h, "pi/logstd", 1, n.A, 1, n.Ap, od, op);
     h->P_dense = od; h->P_pad = op; h->n_blocks = op / 256;
+    // transposed copies streamed by the backward pass
+    int ot = 0;
+    for (int tw = 0; tw < 2; ++tw)
+        for (int l = 1; l < n.L; ++l) { n.wT_off[tw][l] = ot; ot += n.Hp[l] * n.Hp[l - 1]; }
+    n.wmuT_off = ot; ot += n.Ap * n.Hp[n.L - 1];
+    h->PT = ot;
+    n.n_theta = op; n.n_thetaT = ot;
     // LDS carve
     int o = 0, hmax = n.Ap;
     n.lds_h[0] = o; o += ROWS_PER_BLOCK * (n.Kp0 + LDS_PAD);
@@ -219,7 +231,18 @@ int build_layout(ppo_handle* h) {
     n.lds_d[0] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
     n.lds_d[1] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
     n.lds_mu = o; o += ROWS_PER_BLOCK * (n.Ap + LDS_PAD);
-    n.lds_misc = o; o += 64 + ROWS_PER_BLOCK * n.Ap + 64;
+    n.lds_head = o; o += 4 * ROWS_PER_BLOCK * n.Ap;
+    n.lds_misc = o; o += 64 + 2 * ROWS_PER_BLOCK * n.Ap + 64;
+    n.lds_par = o;
+    {
+        int po = 0;
+        for (int l = 0; l < n.L; ++l) { n.par_b[l] = po; po += n.Hp[l]; }
+        n.par_bmu = po; po += n.Ap;
+        n.par_ls = po; po += n.Ap;
+        n.par_wv = po; po += n.Hp[n.L - 1];
+        n.par_bv = po; po += 4;
+        n.par_total = po; o += po;
+    }
     n.lds_total = o;
     if ((size_t)o * sizeof(float) > 160 * 1024)
         return fail(h, "network too wide for the LDS-resident 16-row tile (%zu bytes of LDS needed, 163840 available)", (size_t)o * 4);
@@ -237,12 +260,16 @@ int upload_grad_src(ppo_handle* h) {
     const NetDev& n = h->net;
     std::vector<GradSrc> src(h->n_blocks);
     for (const Tensor& t : h->tensors) {
-        GradSrc g{2, 0, 0, 0, t.off_pad};
+        GradSrc g{2, 0, 0, 0, t.off_pad, -1, t.prow, t.pcol};
         const std::string nm = t.name;
         int l = -1;
         if (nm.find("_fc") != std::string::npos) l = atoi(nm.c_str() + 5);
         const int tower = nm[0] == 'v' ? 1 : 0;
-        if (nm.size() > 2 && nm.substr(nm.size() - 2) == "/w" && nm != "vf/w") g.kind = 0;
+        if (nm.size() > 2 && nm.substr(nm.size() - 2) == "/w" && nm != "vf/w") {
+            g.kind = 0;
+            if (nm == "pi/w") g.t_off = n.wmuT_off;
+            else if (l >= 1) g.t_off = n.wT_off[tower][l];
+        }
         else if (l >= 0) { g.kind = 1; g.tower = tower; g.slot_off = n.slot_db[l]; g.count = n.Hp[l]; }
         else if (nm == "vf/w") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_head; g.count = n.Hp[n.L - 1]; }
         else if (nm == "vf/b") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_aux; g.count = 1; }
@@ -312,14 +339,14 @@ int ensure_staging(ppo_handle* h, int rows) {
 }
 
 // ---- launches -------------------------------------------------------------------------------------------------
-template <int CT, int KS>
+template <int CT, int KS, int CTH>
 void launch_step_t(ppo_handle* h, const StepArgs& a) {
     dim3 grid((a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 2);
-    hipLaunchKernelGGL((policy_step_kernel<CT, KS>), grid, dim3(BLOCK_THREADS), (size_t)h->net.lds_total * sizeof(float), h->stream, h->net, a);
+    hipLaunchKernelGGL((policy_step_kernel<CT, KS, CTH>), grid, dim3(BLOCK_THREADS), (size_t)h->net.lds_total * sizeof(float), h->stream, h->net, a);
 }
 int launch_step(ppo_handle* h, const StepArgs& a) {
     ProfScope ps(h, PK_STEP);
-    if (h->CT == 4) launch_step_t<4, 2>(h, a); else launch_step_t<1, 1>(h, a);
+    if (h->CT == 4 && h->CTH == 2) launch_step_t<4, 2, 2>(h, a); else if (h->CT == 4) launch_step_t<4, 2, 0>(h, a); else launch_step_t<1, 1, 0>(h, a);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -334,10 +361,10 @@ int pick_split(ppo_handle* h, int n) {
 int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     const NetDev& n = h->net;
     const int n_rb = (ta.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    ta.theta = h->theta; ta.hyper = h->hyper;
+    ta.theta = h->theta; ta.thetaT = h->thetaT; ta.hyper = h->hyper;
     ta.x0g = h->x0g; ta.dmug = h->dmug;
 #ifdef PPO_STAMPS
-    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 16 * sizeof(unsigned long long));
+    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 32 * sizeof(unsigned long long));
     ta.stamps = g_stamps;
 #endif
     for (int t = 0; t < 2; ++t) {
@@ -347,8 +374,9 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     {
         ProfScope ps(h, PK_TRAIN_FB);
         dim3 grid(n_rb, 2);
-        if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
-        else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
+        if (h->CT == 4 && h->CTH == 2) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
+        else if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
+        else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
         HIP_OK(h, hipGetLastError());
     }
     const int split = pick_split(h, ta.n);
@@ -380,7 +408,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     }
     {
         ProfScope ps(h, PK_ADAM);
-        AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->hyper, h->beta_pow,
+        AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->grad_src, h->hyper, h->beta_pow,
                     h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out};
         hipLaunchKernelGGL(adam_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, aa);
         HIP_OK(h, hipGetLastError());
@@ -458,18 +486,15 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     // large dynamic LDS needs an explicit opt-in
     const int lds_bytes = h->net.lds_total * (int)sizeof(float);
     bool attr_ok = true;
-    if (h->CT == 4) {
-        attr_ok &= hipFuncSetAttribute((const void*)policy_step_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)train_fwd_bwd_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-    } else {
-        attr_ok &= hipFuncSetAttribute((const void*)policy_step_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)train_fwd_bwd_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-    }
+    auto set_lds = [&](const void* f) { attr_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess; };
+    set_lds((const void*)policy_step_kernel<4, 2, 2>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2>);
+    set_lds((const void*)policy_step_kernel<4, 2, 0>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0>);
+    set_lds((const void*)policy_step_kernel<1, 1, 0>); set_lds((const void*)train_fwd_bwd_kernel<1, 1, 0>);
     attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
     attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
     if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return bail(0); }
     const size_t P = (size_t)h->P_pad;
-    if (dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||
+    if (dev_alloc(h, &h->thetaT, (size_t)h->PT) || dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||
         dev_alloc(h, &h->sumsq, (size_t)h->n_blocks) || dev_alloc(h, &h->beta_pow, 4) || dev_alloc(h, &h->hyper, 2) ||
         dev_alloc(h, &h->norm_out, 1) || dev_alloc(h, &h->st_loss, 8))
         return bail(0);
@@ -486,11 +511,11 @@ void ppo_destroy(ppo_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->upd_graph) (void)hipGraphExecDestroy(h->upd_graph);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
-    void* ptrs[] = {h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
+    void* ptrs[] = {h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
                     h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->ro_obs, h->ro_act,
                     h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->cur_obs, h->cur_done, h->raw_obs, h->raw_rew, h->raw_done,
-                    h->last_val, h->ro_noise, h->d_perms, h->d_inv, h->d_gidx, h->d_advstats, h->d_keys, h->d_loss_rows, h->d_loss_mean};
+                    h->last_val, h->ro_noise, h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp, h->d_perms, h->d_inv, h->d_gidx, h->d_advstats, h->d_keys, h->d_loss_rows, h->d_loss_mean};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) { if (h->hg[t][l]) (void)hipFree(h->hg[t][l]); if (h->dyg[t][l]) (void)hipFree(h->dyg[t][l]); }
     for (int i = 0; i < 6; ++i) if (h->st_vec[i]) (void)hipFree(h->st_vec[i]);
@@ -529,7 +554,12 @@ int ppo_set_tensor(ppo_handle* h, int which, int index, const float* src, int64_
     const Tensor& t = h->tensors[index];
     if (count != t.count()) return fail(h, "ppo_set_tensor(%s): count %lld != %d", t.name, (long long)count, t.count());
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    return copy_tensor(h, base, t, const_cast<float*>(src), true);
+    if (copy_tensor(h, base, t, const_cast<float*>(src), true)) return -1;
+    if (which == 0) {
+        hipLaunchKernelGGL(transpose_refresh_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->theta, h->thetaT, h->grad_src);
+        HIP_OK(h, hipGetLastError());
+    }
+    return 0;
 }
 
 int ppo_get_flat(ppo_handle* h, int which, float* dst, int64_t count) {
@@ -955,10 +985,18 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(256), 0, h->stream, ea);
             HIP_OK(h, hipGetLastError());
         }
+        {
+            ProfScope ps(h, PK_EPOCH);
+            GatherArgs ga{h->d_gidx, h->d_advstats, B, M, h->net.O, h->net.A, h->ro_obs, h->ro_act, h->ro_ret, h->ro_val, h->ro_nlp,
+                          h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};
+            hipLaunchKernelGGL(epoch_gather_kernel, dim3((B + 15) / 16), dim3(256), 0, h->stream, ga);
+            HIP_OK(h, hipGetLastError());
+        }
         for (int k = 0; k < nmb; ++k) {
             TrainArgs ta{};
-            ta.obs = h->ro_obs; ta.actions = h->ro_act; ta.returns = h->ro_ret; ta.old_values = h->ro_val; ta.old_neglogp = h->ro_nlp;
-            ta.advs = nullptr; ta.adv_stats = h->d_advstats + 2 * k; ta.rowidx = h->d_gidx + (size_t)k * M; ta.n = M;
+            const size_t r0 = (size_t)k * M;
+            ta.obs = h->mb_obs + r0 * h->net.O; ta.actions = h->mb_act + r0 * h->net.A; ta.returns = h->mb_ret + r0; ta.old_values = h->mb_val + r0;
+            ta.old_neglogp = h->mb_nlp + r0; ta.advs = h->mb_adv + r0; ta.adv_stats = nullptr; ta.rowidx = nullptr; ta.n = M;
             ta.inv_n = 1.0f / (float)((int64_t)M * h->world);
             if (enqueue_train(h, ta, h->d_loss_rows + (size_t)(ep * nmb + k) * 5)) return -1;
         }
@@ -982,6 +1020,8 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
         HIP_OK(h, hipStreamSynchronize(h->stream));
         if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
         const int cr = std::max(B, h->upd_cap_rows), cs = std::max(steps, h->upd_cap_steps);
+        if (dev_alloc(h, &h->mb_obs, (size_t)cr * h->net.O) || dev_alloc(h, &h->mb_act, (size_t)cr * h->net.A) || dev_alloc(h, &h->mb_adv, cr) ||
+            dev_alloc(h, &h->mb_ret, cr) || dev_alloc(h, &h->mb_val, cr) || dev_alloc(h, &h->mb_nlp, cr)) return -1;
         if (dev_alloc(h, &h->d_perms, (size_t)cs * cr) || dev_alloc(h, &h->d_inv, cr) || dev_alloc(h, &h->d_gidx, cr) ||
             dev_alloc(h, &h->d_advstats, (size_t)2 * cs) || dev_alloc(h, &h->d_keys, (size_t)2 * cs) || dev_alloc(h, &h->d_loss_rows, (size_t)5 * cs) ||
             dev_alloc(h, &h->d_loss_mean, 8))

@@ -41,11 +41,17 @@ struct NetDev {
     int w_off[2][PPO_MAX_LAYERS];   // [tower][layer] offsets into the padded parameter vector (tower 0 = pi, 1 = vf)
     int b_off[2][PPO_MAX_LAYERS];
     int wv_off, bv_off, wmu_off, bmu_off, ls_off;
+    int wT_off[2][PPO_MAX_LAYERS];  // offsets into the transposed-copy buffer: W_l^T [Hp_l][Hp_{l-1}] for l >= 1
+    int wmuT_off;                   // W_mu^T [Ap][Hp_{L-1}]
+    int n_theta, n_thetaT;          // float counts of the padded parameter vector / the transposed-copy buffer
     // LDS carve (floats)
     int lds_h[PPO_MAX_LAYERS + 1];  // [0] = input tile, [l+1] = h_{l+1}
     int lds_d[2];                   // ping-pong gradient tiles
     int lds_mu;                     // head tile [16][Ap+PAD]
-    int lds_misc;                   // 512 floats scratch
+    int lds_head;                   // split-K scratch of the policy head [4][16][Ap]
+    int lds_par;                    // small parameters staged once per block: biases | b_mu | logstd | w_v | b_v
+    int par_b[PPO_MAX_LAYERS], par_bmu, par_ls, par_wv, par_bv, par_total;
+    int lds_misc;                   // loss scratch: 64 + 16*Ap (dlogstd) + 16*Ap (actions) + 64
     int lds_total;
     // per-workgroup slot layout (floats) -- partial sums a row block contributes to non-matrix gradients
     int slot_db[PPO_MAX_LAYERS];    // bias grads of layer l        [Hp[l]]
@@ -116,19 +122,73 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Dense layer on one 16-row tile.   Y[16,Np] = act( X[16,K] * W[K,Np] + b )
+// Dense product on one 16-row tile:   Y[16,Np] = epilogue( X[16,K] * W[K,Np] )
 //   X  : LDS, row-major, leading dimension ldx (multiple of 4)
-//   W  : global, row-major [K][ldw]  (K multiple of 16, ldw = Np multiple of 16*CT)
-//   Y  : LDS (ldy) and optionally global (gy, row stride ldg, rows row0.. , only rows < nrows are written)
-// Each wave owns 16*CT output columns at a time; MFMA j of a wave covers columns n0 + CT*c + j (c = lane & 15) so
-// that one 16-byte load per lane feeds CT matrix instructions and the epilogue writes 16-byte vectors.
-// Reduction index of instruction s for lane group g = lane >> 4 is k = kb + 4g + s: A comes from ONE 16-byte
-// LDS read per 16 k values.
+//   W  : global, row-major [K][ldw]   (K multiple of 16*KS, Np multiple of 16*CT)
+//   Y  : LDS (ldy) and optionally global (gy, row stride ldg; only rows < nrows are written)
+// The forward layers use W = the layer's weights (epilogue bias + tanh); the backward pass uses W = the
+// TRANSPOSED copy the Adam kernel keeps (epilogue TanhGrad), so both directions stream weights identically:
+// each wave owns 16*CT output columns; MFMA j covers columns n0 + CT*c + j (c = lane & 15), so ONE 16-byte load per
+// lane feeds CT matrix instructions and the epilogue writes 16-byte vectors.  The reduction index of instruction s
+// for lane group g = lane >> 4 is k = kb + 4g + s: the A operand is ONE 16-byte LDS read per 16 k values.
+// Weights are pipelined through two named register stages (ping-pong; a copy would make the compiler wait for the
+// loads it has just issued); stage i+1's loads are pinned above stage i's MFMAs by sched_barrier.  The first stage
+// of a layer is loaded by dense_prefetch() BEFORE the previous layer's epilogue and barrier (weights do not depend
+// on activations), which takes one L2 round trip per layer off the critical path.
 // ------------------------------------------------------------------------------------------------------------
 template <int CT, int KS>
-struct WFrag { float v[4 * KS][CT]; };
+struct WFrag { float v[4 * KS][CT]; float4 a[KS]; };   // one pipeline stage: weights + the matching A-operand vectors
 
-// rows kb + 16q + 4g + s (q < KS, s < 4) of W, CT consecutive columns starting at col
+// Addressing: a stage's weights are rows kb + 16q + 4g + s of W.  The per-lane part (4g + 16q + s)*ldw + col is a 32-bit
+// element offset computed ONCE per column chunk (WOff); the per-stage part kb*ldw is wave-uniform and lives in scalar
+// registers, so a stage's loads are `global_load_dwordx4 v, voff, s[base]` with no vector address arithmetic between the
+// matrix instructions (64-bit per-lane multiplies there cost ~700 cycles per stage, un-overlapped with the MFMAs).
+template <int KS>
+struct WOff { unsigned e[4 * KS]; };          // BYTE offsets
+
+// make a value / pointer provably wave-uniform for the compiler (it then lives in SGPRs)
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ const float* uni(const float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int KS>
+__device__ __forceinline__ WOff<KS> make_woff(int ldw, int g, int col) {
+    WOff<KS> o;
+#pragma unroll
+    for (int q = 0; q < KS; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o.e[4 * q + s] = (unsigned)(((4 * g + 16 * q + s) * ldw + col) * 4);
+    return o;
+}
+
+// Wk = W + kb*ldw (wave-uniform)
+template <int CT, int KS>
+__device__ __forceinline__ void load_w_stage(WFrag<CT, KS>& w, const float* __restrict__ Wk, const WOff<KS>& off) {
+#pragma unroll
+    for (int i = 0; i < 4 * KS; ++i) {
+        // global address space + uniform base + 32-bit lane offset -> `global_load_dwordx4 v, voff, s[base:base+1]`
+        typedef const __attribute__((address_space(1))) char* gchar;
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef const __attribute__((address_space(1))) f32x4* gfloat4;
+        typedef const __attribute__((address_space(1))) f32x2_t* gfloat2;
+        typedef const __attribute__((address_space(1))) float* gfloat;
+        gchar p = (gchar)(reinterpret_cast<unsigned long long>(Wk)) + off.e[i];
+        if constexpr (CT == 4) {
+            const f32x4 t = *(gfloat4)p;
+            w.v[i][0] = t.x; w.v[i][1] = t.y; w.v[i][2] = t.z; w.v[i][3] = t.w;
+        } else if constexpr (CT == 2) {
+            const f32x2_t t = *(gfloat2)p;
+            w.v[i][0] = t.x; w.v[i][1] = t.y;
+        } else {
+            w.v[i][0] = *(gfloat)p;
+        }
+    }
+}
+
+// rows krow + 16q + s (q < KS, s < 4) of W, CT consecutive columns starting at col  (head / one-off loads)
 template <int CT, int KS>
 __device__ __forceinline__ void load_w_rows(WFrag<CT, KS>& w, const float* __restrict__ W, int ldw, int krow, int col) {
 #pragma unroll
@@ -148,62 +208,111 @@ __device__ __forceinline__ void load_w_rows(WFrag<CT, KS>& w, const float* __res
         }
 }
 
-// KS = 16-deep k blocks per pipeline stage: the weights of stage i+1 (KS*4 16-byte loads per lane) are issued and
-// pinned above the 16*KS*CT/4 MFMAs of stage i, which is what hides the L2 latency (with KS = 2: ~1000 cycles).
-template <int CT, bool TANH, int KS>
-__device__ __forceinline__ void layer_forward(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
-                                              const float* Xs, int ldx, int K, float* Ys, int ldy, int Np,
-                                              float* __restrict__ gy, int ldg, int row0, int nrows) {
+#ifndef PPO_RING
+#define PPO_RING 3                  // register stages in flight per wave: PPO_RING-1 stages (each 16*KS k deep) ahead
+#endif
+template <int CT, int KS>
+struct WRing { WFrag<CT, KS> s[PPO_RING]; };
+
+// the first PPO_RING-1 k stages of this wave's first column chunk (a wave without a chunk loads chunk 0: harmless);
+// K = reduction depth of the layer (addresses clamped to the last stage)
+template <int CT, int KS>
+__device__ __forceinline__ void dense_prefetch(WRing<CT, KS>& w, const float* W, int ldw, int Np, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    W = uni(W); ldw = uni(ldw); K = uni(K);
+    int n0 = wave * 16 * CT;
+    if (n0 >= Np) n0 = 0;
+    const WOff<KS> off = make_woff<KS>(ldw, lane >> 4, n0 + CT * (lane & 15));
+#pragma unroll
+    for (int i = 0; i < PPO_RING - 1; ++i) {
+        const int kb = (i * 16 * KS < K) ? i * 16 * KS : K - 16 * KS;
+        load_w_stage<CT, KS>(w.s[i], W + (size_t)kb * ldw, off);
+    }
+}
+
+enum { EP_BIAS_TANH = 0, EP_TANHGRAD = 1 };
+
+template <int CT, int KS, int EP, class Between>
+__device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int ldw, const float* __restrict__ bias,
+                                           const float* Xs, int ldx, int K, float* Ys, int ldy, int Np, const float* Hs, int ldh,
+                                           float* __restrict__ gy, int ldg, int row0, int nrows, Between&& between,
+                                           unsigned long long* dbg = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     constexpr int CW = 16 * CT;
     constexpr int KB = 16 * KS;
-    for (int n0 = wave * CW; n0 < Np; n0 += (BLOCK_THREADS / 64) * CW) {
+    constexpr int NSTRIDE = (BLOCK_THREADS / 64) * CW;
+    W = uni(W); ldw = uni(ldw); K = uni(K); Np = uni(Np);
+    bool first = true;
+    bool called = false;
+#ifdef PPO_STAMPS
+#define DSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
+    DSTAMP(0);
+    for (int n0 = wave * CW; n0 < Np; n0 += NSTRIDE) {
         f32x4 acc[CT];
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int col = n0 + CT * c;
-        // two named register stages (ping-pong, no copies: a copy would make the compiler wait for the loads it
-        // has just issued); the loads of stage i+1 are pinned above the MFMAs of stage i by sched_barrier
-        WFrag<CT, KS> w0, w1;
-        auto compute = [&](const WFrag<CT, KS>& w, int kb) {
+        auto compute = [&](const WFrag<CT, KS>& wf) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < KS; ++q) {
-                const float4 a = *reinterpret_cast<const float4*>(Xs + c * ldx + kb + 16 * q + 4 * g);
-                const float av[4] = {a.x, a.y, a.z, a.w};
+                const float av[4] = {wf.a[q].x, wf.a[q].y, wf.a[q].z, wf.a[q].w};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
 #pragma unroll
                     for (int j = 0; j < CT; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], w.v[4 * q + s][j], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wf.v[4 * q + s][j], acc[j], 0, 0, 0);
                 }
             }
         };
-        load_w_rows<CT, KS>(w0, W, ldw, 4 * g, col);
-        for (int kb = 0; kb < K; kb += 2 * KB) {
-            const int k1 = (kb + KB < K) ? kb + KB : kb;            // clamped: unconditional loads, counted vmcnt
-            load_w_rows<CT, KS>(w1, W, ldw, k1 + 4 * g, col);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(w0, kb);
-            __builtin_amdgcn_sched_barrier(0);
-            const int k2 = (kb + 2 * KB < K) ? kb + 2 * KB : kb;
-            load_w_rows<CT, KS>(w0, W, ldw, k2 + 4 * g, col);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb + KB < K) compute(w1, kb + KB);
-            __builtin_amdgcn_sched_barrier(0);
+        auto clampk = [&](int kb) __attribute__((always_inline)) { return kb < K ? kb : K - KB; };
+        // the A operand (this tile's activations, LDS) travels in the same ring as the weights: read PPO_RING-1 stages
+        // ahead of its MFMAs, so no LDS latency sits between matrix instructions
+        auto load_a = [&](WFrag<CT, KS>& wf, int kb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < KS; ++q) wf.a[q] = *reinterpret_cast<const float4*>(Xs + c * ldx + kb + 16 * q + 4 * g);
+        };
+        const WOff<KS> off = make_woff<KS>(ldw, g, col);
+        if (!first) {
+#pragma unroll
+            for (int i = 0; i < PPO_RING - 1; ++i) load_w_stage<CT, KS>(w.s[i], W + (size_t)clampk(i * KB) * ldw, off);
         }
+#pragma unroll
+        for (int i = 0; i < PPO_RING - 1; ++i) load_a(w.s[i], clampk(i * KB));
+        first = false;
+        // ring of PPO_RING named register stages (compile-time indices, no copies); every load is unconditional with a
+        // clamped address so the compiler waits with counted vmcnt; sched_barrier pins the loads above the MFMAs
+        for (int kb = 0; kb < K; kb += PPO_RING * KB) {
+#pragma unroll
+            for (int i = 0; i < PPO_RING; ++i) {
+                DSTAMP(4 + (kb / KB + i < 11 ? kb / KB + i : 11));
+                const int kn = clampk(kb + (i + PPO_RING - 1) * KB);                  // wave-uniform
+                load_a(w.s[(i + PPO_RING - 1) % PPO_RING], kn);
+                load_w_stage<CT, KS>(w.s[(i + PPO_RING - 1) % PPO_RING], W + (size_t)kn * ldw, off);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + i * KB < K) compute(w.s[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        DSTAMP(1);
+        if (n0 + NSTRIDE >= Np) { between(); called = true; }       // next layer's first stage goes out before this epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        DSTAMP(2);
         // epilogue: accumulator register r of MFMA j holds Y[row 4g + r][col n0 + CT*c + j]
         float bv[CT];
 #pragma unroll
-        for (int j = 0; j < CT; ++j) bv[j] = bias[col + j];
+        for (int j = 0; j < CT; ++j) bv[j] = (EP == EP_BIAS_TANH) ? bias[col + j] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * g + r;
             float y[CT];
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
-                const float z = acc[j][r] + bv[j];
-                y[j] = TANH ? fast_tanh(z) : z;
+                if constexpr (EP == EP_BIAS_TANH) y[j] = fast_tanh(acc[j][r] + bv[j]);
+                else { const float h = Hs[row * ldh + col + j]; y[j] = acc[j][r] * (1.0f - h * h); }   // TanhGrad
             }
             float* ys = Ys + row * ldy + col;
             float* yg = gy ? gy + (size_t)(row0 + row) * ldg + col : nullptr;
@@ -220,85 +329,72 @@ __device__ __forceinline__ void layer_forward(const float* __restrict__ W, int l
             }
         }
     }
+    DSTAMP(3);
+    if (!called) between();                                          // waves without a column chunk
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Backward through one dense layer for a 16-row tile:  dXs[16,Kp] = (dYs[16,Np] * W^T) .* (1 - Hs .* Hs)
-//   W global [Kp][ldw=Np] (the forward layout; read "transposed": lane (g,c), MFMA j loads W[k0+CT*c+j][nb+4g..+3])
-//   Hs = the tanh outputs this gradient flows into (TanhGrad, G:21272,...); HS == false => no activation factor
-// Result goes to LDS (dXs) and to global gd (it is the dY operand of the previous layer's weight gradient).
+// Policy head  mu[16,Ap] = h[16,K] * Wmu[K,Ap] + b  with Ap = 16*CTH: too narrow to split over waves by columns, so
+// the 4 waves split K instead (each K/4 deep, ALL its weights prefetched in one go), partial tiles meet in LDS.
 // ------------------------------------------------------------------------------------------------------------
-template <int CT, bool HS, int KS>
-__device__ __forceinline__ void layer_backward(const float* __restrict__ W, int ldw, const float* dYs, int ldy, int Np,
-                                               const float* Hs, int ldh, float* dXs, int ldd, int Kp,
-                                               float* __restrict__ gd, int ldg, int row0, int nrows) {
+#define HEAD_KS 4          // 64 k values per wave and stage
+
+template <int CTH>
+__device__ __forceinline__ void head_prefetch(WFrag<CTH, HEAD_KS>& w, const float* __restrict__ Wmu, int Ap, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    load_w_rows<CTH, HEAD_KS>(w, Wmu, Ap, wave * (K / 4) + 4 * (lane >> 4), CTH * (lane & 15));
+}
+
+template <int CTH>
+__device__ __forceinline__ void head_splitk(WFrag<CTH, HEAD_KS>& w, const float* __restrict__ Wmu, const float* __restrict__ bmu,
+                                            const float* Hs, int ldh, int K, int Ap, float* scratch /* [4][16][Ap] */,
+                                            float* mus, int ldm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
-    constexpr int CW = 16 * CT;
-    constexpr int NB = 16 * KS;
-    for (int k0 = wave * CW; k0 < Kp; k0 += (BLOCK_THREADS / 64) * CW) {
-        f32x4 acc[CT];
+    const int kq = K / 4, kbeg = wave * kq;
+    f32x4 acc[CTH];
 #pragma unroll
-        for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int orow = k0 + CT * c;                       // this lane's first output column = row of W
-        float4 w0[KS][CT], w1[KS][CT];
-        auto load = [&](float4 (*w)[CT], int nb) {
+    for (int j = 0; j < CTH; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < kq; kb += 16 * HEAD_KS) {
+        if (kb > 0) load_w_rows<CTH, HEAD_KS>(w, Wmu, Ap, kbeg + kb + 4 * g, CTH * c);
 #pragma unroll
-            for (int q = 0; q < KS; ++q)
+        for (int q = 0; q < HEAD_KS; ++q) {
+            const float4 av4 = *reinterpret_cast<const float4*>(Hs + c * ldh + kbeg + kb + 16 * q + 4 * g);
+            const float av[4] = {av4.x, av4.y, av4.z, av4.w};
 #pragma unroll
-                for (int j = 0; j < CT; ++j)
-                    w[q][j] = *reinterpret_cast<const float4*>(W + (size_t)(orow + j) * ldw + nb + 16 * q + 4 * g);
-        };
-        auto compute = [&](const float4 (*w)[CT], int nb) {
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int q = 0; q < KS; ++q) {
-                const float4 a = *reinterpret_cast<const float4*>(dYs + c * ldy + nb + 16 * q + 4 * g);
-                const float av[4] = {a.x, a.y, a.z, a.w};
+                for (int j = 0; j < CTH; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], w.v[4 * q + s][j], acc[j], 0, 0, 0);
+        }
+    }
+    float* mine = scratch + wave * (ROWS_PER_BLOCK * Ap);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int j = 0; j < CT; ++j) {
-                        const float wv = s == 0 ? w[q][j].x : s == 1 ? w[q][j].y : s == 2 ? w[q][j].z : w[q][j].w;
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wv, acc[j], 0, 0, 0);
-                    }
-                }
-            }
-        };
-        load(w0, 0);
-        for (int nb = 0; nb < Np; nb += 2 * NB) {
-            load(w1, (nb + NB < Np) ? nb + NB : nb);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(w0, nb);
-            __builtin_amdgcn_sched_barrier(0);
-            load(w0, (nb + 2 * NB < Np) ? nb + 2 * NB : nb);
-            __builtin_amdgcn_sched_barrier(0);
-            if (nb + NB < Np) compute(w1, nb + NB);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < CTH; ++j) mine[(4 * g + r) * Ap + CTH * c + j] = acc[j][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < ROWS_PER_BLOCK * Ap; i += BLOCK_THREADS) {
+        const int row = i / Ap, col = i - row * Ap;
+        const float sum = ((scratch[i] + scratch[ROWS_PER_BLOCK * Ap + i]) + scratch[2 * ROWS_PER_BLOCK * Ap + i]) + scratch[3 * ROWS_PER_BLOCK * Ap + i];
+        mus[row * ldm + col] = sum + bmu[col];
+    }
+}
+
+// generic (narrow-net) head: one 16-column chunk per wave, K serial
+__device__ __forceinline__ void head_generic(const float* __restrict__ Wmu, const float* __restrict__ bmu, const float* Hs, int ldh, int K,
+                                             int Ap, float* mus, int ldm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    for (int n0 = wave * 16; n0 < Ap; n0 += 64) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < K; kb += 16) {
+            const float4 av4 = *reinterpret_cast<const float4*>(Hs + c * ldh + kb + 4 * g);
+            const float av[4] = {av4.x, av4.y, av4.z, av4.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Wmu[(size_t)(kb + 4 * g + s) * Ap + n0 + c], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * g + r;
-            float d[CT];
-#pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                float v = acc[j][r];
-                if (HS) { const float h = Hs[row * ldh + orow + j]; v = v * (1.0f - h * h); }
-                d[j] = v;
-            }
-            float* ds = dXs + row * ldd + orow;
-            float* dg = gd + (size_t)(row0 + row) * ldg + orow;
-            const bool wr = (row0 + row) < nrows;
-            if constexpr (CT == 4) {
-                *reinterpret_cast<float4*>(ds) = make_float4(d[0], d[1], d[2], d[3]);
-                if (wr) *reinterpret_cast<float4*>(dg) = make_float4(d[0], d[1], d[2], d[3]);
-            } else if constexpr (CT == 2) {
-                *reinterpret_cast<float2*>(ds) = make_float2(d[0], d[1]);
-                if (wr) *reinterpret_cast<float2*>(dg) = make_float2(d[0], d[1]);
-            } else {
-                *ds = d[0];
-                if (wr) *dg = d[0];
-            }
-        }
+        for (int r = 0; r < 4; ++r) mus[(4 * g + r) * ldm + n0 + c] = acc[r] + bmu[n0 + c];
     }
 }
 
@@ -336,15 +432,45 @@ __device__ __forceinline__ void stage_obs_tile(float* Xs, int ldx, int Kp0, int 
     }
 }
 
+// biases, logstd and the value head are read in epilogues / loss code: staging them in LDS at kernel start keeps
+// dependent L2 round trips (which would also drain the in-order vmcnt queue of weight prefetches) off those paths
+__device__ __forceinline__ void stage_small_params(const NetDev& net, const float* __restrict__ theta, int tower, float* par) {
+    for (int l = 0; l < net.L; ++l)
+        for (int i = threadIdx.x; i < net.Hp[l]; i += BLOCK_THREADS) par[net.par_b[l] + i] = theta[net.b_off[tower][l] + i];
+    if (tower == 0) {
+        for (int i = threadIdx.x; i < net.Ap; i += BLOCK_THREADS) {
+            par[net.par_bmu + i] = theta[net.bmu_off + i];
+            par[net.par_ls + i] = theta[net.ls_off + i];
+        }
+    } else {
+        for (int i = threadIdx.x; i < net.Hp[net.L - 1]; i += BLOCK_THREADS) par[net.par_wv + i] = theta[net.wv_off + i];
+        if (threadIdx.x == 0) par[net.par_bv] = theta[net.bv_off];
+    }
+}
+
 #ifdef PPO_STAMPS
 #define STAMP(i)                                                                                        \
-    do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+    do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
 
 #define HALF_LOG_2PI 0.9189385175704956f   /* G:6531 */
 #define HALF_LOG_2PIE 1.4189385175704956f  /* G:10021-10180 */
+
+// policy head dispatch shared by the act and train kernels (CTH = Ap/16 for the split-K form, 0 = generic):
+// fills mus[16][Ap+PAD]; ends with a barrier
+template <int CTH> struct HeadFrag { WFrag<(CTH > 0 ? CTH : 1), HEAD_KS> w; };
+
+template <int CTH>
+__device__ __forceinline__ void policy_head(const NetDev& net, const float* __restrict__ theta, HeadFrag<CTH>& hpre, const float* hL, int ldh,
+                                            int K, float* lds) {
+    float* mus = lds + net.lds_mu;
+    const int ldm = net.Ap + LDS_PAD;
+    if constexpr (CTH > 0) head_splitk<CTH>(hpre.w, theta + net.wmu_off, lds + net.lds_par + net.par_bmu, hL, ldh, K, net.Ap, lds + net.lds_head, mus, ldm);
+    else head_generic(theta + net.wmu_off, lds + net.lds_par + net.par_bmu, hL, ldh, K, net.Ap, mus, ldm);
+    __syncthreads();
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // Act model: blockIdx.y = 0 policy tower (mu, sample, neglogp), = 1 value tower.
@@ -363,7 +489,7 @@ struct StepArgs {
     uint32_t seed, rng_step, row_base;
 };
 
-template <int CT, int KS>
+template <int CT, int KS, int CTH>
 __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tower = blockIdx.y;
@@ -371,36 +497,42 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
     if (tower == 0 && !a.action && !a.det_action && !a.neglogp && !a.obs_out) return;
     const int row0 = blockIdx.x * ROWS_PER_BLOCK;
     const int ld0 = net.Kp0 + LDS_PAD;
+    WRing<CT, KS> wpre;
+    HeadFrag<CTH> hpre;
+    dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
+    float* par = lds + net.lds_par;
+    stage_small_params(net, a.theta, tower, par);
     stage_obs_tile(lds + net.lds_h[0], ld0, net.Kp0, net.O, a.obs, nullptr, row0, a.n, a.nz,
                    tower == 0 ? a.obs_out : nullptr, nullptr, 0);
     __syncthreads();
     int K = net.Kp0, ldx = ld0;
     for (int l = 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
-        layer_forward<CT, true, KS>(a.theta + net.w_off[tower][l], Np, a.theta + net.b_off[tower][l], lds + net.lds_h[l], ldx, K,
-                                lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, row0, a.n);
+        dense_tile<CT, KS, EP_BIAS_TANH>(wpre, a.theta + net.w_off[tower][l], Np, par + net.par_b[l], lds + net.lds_h[l], ldx, K,
+                                         lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, nullptr, 0, row0, a.n, [&]() __attribute__((always_inline)) {
+                                             if (l + 1 < net.L) dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][l + 1], net.Hp[l + 1], net.Hp[l + 1], Np);
+                                             else if constexpr (CTH > 0) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, Np);   // (both towers: uniform code)
+                                         });
         __syncthreads();
         K = Np; ldx = ldy;
     }
     const float* hL = lds + net.lds_h[net.L];
     if (tower == 1) {
-        const float v = value_head(hL, ldx, K, a.theta + net.wv_off, a.theta[net.bv_off]);
+        const float v = value_head(hL, ldx, K, par + net.par_wv, par[net.par_bv]);
         const int row = row0 + (threadIdx.x >> 4);
         if ((threadIdx.x & 15) == 0 && row < a.n) a.value[row] = v;
         return;
     }
-    float* mus = lds + net.lds_mu;
+    policy_head<CTH>(net, a.theta, hpre, hL, ldx, K, lds);
+    const float* mus = lds + net.lds_mu;
     const int ldm = net.Ap + LDS_PAD;
-    layer_forward<1, false, 1>(a.theta + net.wmu_off, net.Ap, a.theta + net.bmu_off, hL, ldx, K, mus, ldm, net.Ap, nullptr, 0,
-                            row0, a.n);
-    __syncthreads();
     // sampling + neglogp (G:5894-6672): 16 lanes per row, each lane owns actions j = part, part+16, ...
     const int r = threadIdx.x >> 4, part = threadIdx.x & 15;
     const int row = row0 + r;
     float ssq = 0.f, slog = 0.f;
     for (int j = part; j < net.A; j += 16) {
         const float mu = mus[r * ldm + j];
-        const float logstd = mu * 0.0f + a.theta[net.ls_off + j];
+        const float logstd = mu * 0.0f + par[net.par_ls + j];
         const float sigma = expf(logstd);
         float eps = 0.f;
         if (row < a.n) eps = a.noise ? a.noise[(size_t)row * net.A + j] : ctr_normal(a.seed, a.row_base + row, a.rng_step, j);
@@ -425,6 +557,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
 // ------------------------------------------------------------------------------------------------------------
 struct TrainArgs {
     const float* theta;
+    const float* thetaT;         // transposed copies of the matrices the backward pass streams (kept by adam_kernel)
     // minibatch sources; rowidx (null = identity) maps minibatch row -> source row
     const float* obs; const float* actions; const float* returns; const float* old_values; const float* old_neglogp;
     const float* advs;           // explicit normalised advantages (indexed like the others) or null
@@ -442,27 +575,68 @@ struct TrainArgs {
     unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS): [blocks][16] s_memtime stamps
 };
 
-template <int CT, int KS>
+template <int CT, int KS, int CTH>
 __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tower = blockIdx.y;
     const int row0 = blockIdx.x * ROWS_PER_BLOCK;
     const int tid = threadIdx.x;
     const int ld0 = net.Kp0 + LDS_PAD;
-    float* misc = lds + net.lds_misc;
+    float* misc = lds + net.lds_misc;          // [0,64) per-row loss terms | [64, 64+16Ap) dlogstd rows | then actions | row scalars
+    float* dls = misc + 64;
+    float* acts = dls + ROWS_PER_BLOCK * net.Ap;
+    float* rowv = acts + ROWS_PER_BLOCK * net.Ap;   // [16][2]: pi {adv, old_neglogp} ; vf {return, old_value}
     float* slot = a.slots[tower] + (size_t)blockIdx.x * net.slot_w;
     STAMP(0);
+    WRing<CT, KS> wpre;
+    HeadFrag<CTH> hpre;
+    dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
+    float* par = lds + net.lds_par;
+    stage_small_params(net, a.theta, tower, par);
     ObsNorm nz = {nullptr, nullptr, 0.f, 0.f, 0};
     stage_obs_tile(lds + net.lds_h[0], ld0, net.Kp0, net.O, a.obs, a.rowidx, row0, a.n, nz, nullptr,
                    tower == 0 ? a.x0g : nullptr, net.Kp0);
+    // everything else a row needs is fetched now, under the first layer, instead of at the loss
+    if (tower == 0) {
+        for (int i = tid; i < ROWS_PER_BLOCK * net.Ap; i += BLOCK_THREADS) {
+            const int r = i / net.Ap, j = i - r * net.Ap;
+            const int row = row0 + r;
+            float x = 0.f;
+            if (row < a.n && j < net.A) x = a.actions[(size_t)(a.rowidx ? a.rowidx[row] : row) * net.A + j];
+            acts[i] = x;
+        }
+    }
+    if (tid < ROWS_PER_BLOCK) {
+        const int row = row0 + tid;
+        float v0 = 0.f, v1 = 0.f;
+        if (row < a.n) {
+            const int src = a.rowidx ? a.rowidx[row] : row;
+            if (tower == 0) {
+                v1 = a.old_neglogp[src];
+                if (a.advs) v0 = a.advs[src];
+                else v0 = ((a.returns[src] - a.old_values[src]) - a.adv_stats[0]) / a.adv_stats[1];
+            } else { v0 = a.returns[src]; v1 = a.old_values[src]; }
+        }
+        rowv[2 * tid] = v0; rowv[2 * tid + 1] = v1;
+    }
     __syncthreads();
     STAMP(1);
     // ---- forward (G:6889-9187) -------------------------------------------------------------------------------
     int K = net.Kp0, ldx = ld0;
     for (int l = 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
-        layer_forward<CT, true, KS>(a.theta + net.w_off[tower][l], Np, a.theta + net.b_off[tower][l], lds + net.lds_h[l], ldx, K,
-                                lds + net.lds_h[l + 1], ldy, Np, a.hg[tower][l], Np, row0, a.n);
+        dense_tile<CT, KS, EP_BIAS_TANH>(wpre, a.theta + net.w_off[tower][l], Np, par + net.par_b[l], lds + net.lds_h[l], ldx, K,
+                                         lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, a.hg[tower][l], Np, row0, a.n, [&]() __attribute__((always_inline)) {
+                                             if (l + 1 < net.L) dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][l + 1], net.Hp[l + 1], net.Hp[l + 1], Np);
+                                             else {
+                                                 if constexpr (CTH > 0) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, Np);
+                                                 if (tower == 1 && net.L > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[1][net.L - 1], net.Hp[net.L - 2], net.Hp[net.L - 2], Np);
+                                             }
+                                         }
+#ifdef PPO_STAMPS
+                                         , a.stamps ? (l == 1 ? a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 : nullptr) : nullptr
+#endif
+                                         );
         __syncthreads();
         STAMP(2 + l);
         K = Np; ldx = ldy;
@@ -473,23 +647,22 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     const int r = tid >> 4, part = tid & 15;
     const int row = row0 + r;
     const bool live = row < a.n;
-    const int src = live ? (a.rowidx ? a.rowidx[row] : row) : 0;
     float* dcur = lds + net.lds_d[0];
     float* dnext = lds + net.lds_d[1];
 
     if (tower == 0) {
         // ---- policy head + surrogate loss (G:9428-11290) and its gradient (G:12609-22656) -------------------
-        float* mus = lds + net.lds_mu;
-        const int ldm = net.Ap + LDS_PAD;
-        layer_forward<1, false, 1>(a.theta + net.wmu_off, net.Ap, a.theta + net.bmu_off, hL, ldhL, HpL, mus, ldm, net.Ap, nullptr, 0,
-                                row0, a.n);
-        __syncthreads();
+        policy_head<CTH>(net, a.theta, hpre, hL, ldhL, HpL, lds);
+        // the head's backward weights (transposed copy) stream in under the loss arithmetic
+        dense_prefetch<CT, KS>(wpre, a.thetaT + net.wmuT_off, HpL, HpL, net.Ap);
         STAMP(6);
+        const float* mus = lds + net.lds_mu;
+        const int ldm = net.Ap + LDS_PAD;
         float ssq = 0.f, slog = 0.f, sent = 0.f;
         for (int j = part; j < net.A; j += 16) {
             const float mu = mus[r * ldm + j];
-            const float logstd = mu * 0.0f + a.theta[net.ls_off + j];
-            const float act = live ? a.actions[(size_t)src * net.A + j] : mu;
+            const float logstd = mu * 0.0f + par[net.par_ls + j];
+            const float act = live ? acts[r * net.Ap + j] : mu;
             const float z = (act - mu) / expf(logstd);
             ssq += z * z;
             slog += logstd;
@@ -497,12 +670,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
         }
         ssq = group16_sum(ssq); slog = group16_sum(slog); sent = group16_sum(sent);
         const float nlp = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
-        float adv = 0.f, old_nlp = nlp;
-        if (live) {
-            old_nlp = a.old_neglogp[src];
-            if (a.advs) adv = a.advs[src];
-            else adv = ((a.returns[src] - a.old_values[src]) - a.adv_stats[0]) / a.adv_stats[1];
-        }
+        const float adv = live ? rowv[2 * r] : 0.f;
+        const float old_nlp = live ? rowv[2 * r + 1] : nlp;
         const float lo = 1.0f - cr, hi = 1.0f + cr;
         const float ratio = expf(old_nlp - nlp);
         const float rmin = tf_min(ratio, hi);
@@ -521,14 +690,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
             misc[r * 4 + 2] = live ? dk * dk : 0.f;
             misc[r * 4 + 3] = (live && fabsf(ratio - 1.0f) > cr) ? 1.0f : 0.f;
         }
-        // d mu (-> dcur tile, also the dY operand of the head weight gradient) and d logstd rows (-> misc)
-        float* dls = misc + 64;                       // [16][Ap]
+        // d mu (-> dcur tile, also the dY operand of the head weight gradient) and d logstd rows
         for (int j = part; j < net.Ap; j += 16) {
             float dmu = 0.f, dl = 0.f;
             if (j < net.A && live) {
                 const float mu = mus[r * ldm + j];
-                const float sigma = expf(mu * 0.0f + a.theta[net.ls_off + j]);
-                const float z = (a.actions[(size_t)src * net.A + j] - mu) / sigma;
+                const float sigma = expf(mu * 0.0f + par[net.par_ls + j]);
+                const float z = (acts[r * net.Ap + j] - mu) / sigma;
                 dl = d_nlp * (1.0f - z * z) - net.ent_coef * g;                    // AddN_2 G:21299
                 dmu = d_nlp * (-(z / sigma)) + dl * 0.0f;                          // AddN_3 G:22656
             }
@@ -550,17 +718,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
             slot[net.slot_loss + tid] = s;
         }
         STAMP(7);
-        // dh_L = (dmu * W_mu^T) .* (1 - h_L^2)
-        layer_backward<CT, true, 1>(a.theta + net.wmu_off, net.Ap, dcur, ldm, net.Ap, hL, ldhL, dnext, HpL + LDS_PAD, HpL,
-                                 a.dyg[0][net.L - 1], HpL, row0, a.n);
+        // dh_L = (dmu * W_mu^T) .* (1 - h_L^2): a dense product against the transposed head weights [Ap][HpL]
+        dense_tile<CT, KS, EP_TANHGRAD>(wpre, a.thetaT + net.wmuT_off, HpL, nullptr, dcur, ldm, net.Ap, dnext, HpL + LDS_PAD, HpL, hL, ldhL,
+                                        a.dyg[0][net.L - 1], HpL, row0, a.n, [&]() __attribute__((always_inline)) {
+                                            if (net.L > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[0][net.L - 1], net.Hp[net.L - 2], net.Hp[net.L - 2], HpL);
+                                        });
         __syncthreads();
     } else {
         // ---- value head + clipped value loss (G:10213-10837) and its gradient (G:14975-19571) ---------------
-        const float* wv = a.theta + net.wv_off;
-        const float v = value_head(hL, ldhL, HpL, wv, a.theta[net.bv_off]);
+        const float* wv = par + net.par_wv;
+        const float v = value_head(hL, ldhL, HpL, wv, par[net.par_bv]);
         float dv = 0.f, lossv = 0.f;
         if (live) {
-            const float R = a.returns[src], vo = a.old_values[src];
+            const float R = rowv[2 * r], vo = rowv[2 * r + 1];
             const float dvo = v - vo;
             const float vmin = tf_min(dvo, cr);
             const float vclip = vo + tf_max(vmin, -cr);
@@ -574,6 +744,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
         }
         if (part == 0) { misc[r] = dv; misc[16 + r] = lossv; }
         __syncthreads();
+        STAMP(7);
         if (tid == 0) {
             float sb = 0.f, sl = 0.f;
             for (int q = 0; q < ROWS_PER_BLOCK; ++q) { sb += misc[q]; sl += misc[16 + q]; }
@@ -606,10 +777,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
             for (int q = 0; q < ROWS_PER_BLOCK; ++q) s += dcur[q * ldd + j];
             slot[net.slot_db[l] + j] = s;
         }
-        if (l > 0) {                                         // first-layer dX is never needed
+        if (l > 0) {                                         // first-layer dX is never needed (obs is a placeholder)
             const int Kp = net.Hp[l - 1];
-            layer_backward<CT, true, KS>(a.theta + net.w_off[tower][l], Np, dcur, ldd, Np, lds + net.lds_h[l], Kp + LDS_PAD,
-                                     dnext, Kp + LDS_PAD, Kp, a.dyg[tower][l - 1], Kp, row0, a.n);
+            // dY_{l-1} = (dY_l * W_l^T) .* (1 - h_l^2), W_l^T = transposed copy [Hp_l][Hp_{l-1}]
+            dense_tile<CT, KS, EP_TANHGRAD>(wpre, a.thetaT + net.wT_off[tower][l], Kp, nullptr, dcur, ldd, Np, dnext, Kp + LDS_PAD, Kp,
+                                            lds + net.lds_h[l], Kp + LDS_PAD, a.dyg[tower][l - 1], Kp, row0, a.n, [&]() __attribute__((always_inline)) {
+                                                if (l > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[tower][l - 1], net.Hp[l - 2], net.Hp[l - 2], Kp);
+                                            });
         }
         __syncthreads();
         STAMP(9 + (net.L - 1 - l));
@@ -725,7 +899,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
 //   kind 2: padding / untrained -> 0
 // Also emits the block's sum of squares for the global norm, and (last block) the five loss scalars.
 // ------------------------------------------------------------------------------------------------------------
-struct GradSrc { int kind; int tower; int slot_off; int count; int base; };   // base = first element of the tensor
+struct GradSrc { int kind; int tower; int slot_off; int count; int base;   // base = first element of the tensor
+                 int t_off, prow, pcol; };                                   // transposed copy: thetaT[t_off + c*prow + r], t_off < 0: none
 
 struct ReduceArgs {
     const GradSrc* src;          // [n_blocks]
@@ -789,6 +964,15 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
     if (tid == 0) a.sumsq[blk] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// rebuild every transposed copy from theta (after parameters were written from the host)
+__global__ __launch_bounds__(256) void transpose_refresh_kernel(const float* theta, float* thetaT, const GradSrc* src) {
+    const GradSrc gs = src[blockIdx.x];
+    if (gs.t_off < 0) return;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int e = (int)(idx - (size_t)gs.base);
+    if (e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; thetaT[gs.t_off + c * gs.prow + r] = theta[idx]; }
+}
+
 // after a cross-rank all-reduce of grad the per-block sums of squares must be recomputed
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* grad, float* sumsq) {
     __shared__ float red[4];
@@ -808,6 +992,7 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* grad, floa
 // ------------------------------------------------------------------------------------------------------------
 struct AdamArgs {
     float* theta; float* m; float* v; const float* grad; const float* sumsq; int n_blocks;
+    float* thetaT; const GradSrc* src;
     const float* hyper;          // {lr, cliprange}
     float* beta_pow;             // {cur b1, cur b2, next b1, next b2}
     float beta1, beta2, eps, max_norm;
@@ -836,7 +1021,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     const float v = a.v[idx] + (g * g - a.v[idx]) * (1.0f - a.beta2);
     a.m[idx] = m;
     a.v[idx] = v;
-    a.theta[idx] = a.theta[idx] - (m * alpha) / (sqrtf(v) + a.eps);
+    const float th = a.theta[idx] - (m * alpha) / (sqrtf(v) + a.eps);
+    a.theta[idx] = th;
+    const GradSrc gs = a.src[blockIdx.x];
+    if (gs.t_off >= 0) {                                   // keep the backward pass's transposed copy current
+        const int e = (int)(idx - (size_t)gs.base);
+        if (e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; a.thetaT[gs.t_off + c * gs.prow + r] = th; }
+    }
     if (blockIdx.x == 0) {
         if (tid == 0) {
             a.beta_pow[2] = b1p * a.beta1;                                      // G:31217-31342 (after the applies)
@@ -919,6 +1110,35 @@ __global__ __launch_bounds__(256) void epoch_prepare_kernel(EpochArgs a) {
         const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.M;
         a.stats[2 * k] = mean;
         a.stats[2 * k + 1] = (float)((double)sqrtf(var) + 1e-8);
+    }
+}
+
+// Materialise the permuted epoch (the reference's `perm * v` copies, ppo2.hpp:291-296) in minibatch order so that the
+// train kernel reads contiguous rows with no index indirection: 16 rows per block; advantages are normalised here
+// with the minibatch statistics of epoch_prepare_kernel.
+struct GatherArgs {
+    const int* gidx; const float* stats; int B, M, O, A;
+    const float* obs; const float* act; const float* ret; const float* val; const float* nlp;
+    float* mb_obs; float* mb_act; float* mb_adv; float* mb_ret; float* mb_val; float* mb_nlp;
+};
+
+__global__ __launch_bounds__(256) void epoch_gather_kernel(GatherArgs a) {
+    __shared__ int src[16];
+    const int pos0 = blockIdx.x * 16, tid = threadIdx.x;
+    if (tid < 16 && pos0 + tid < a.B) src[tid] = a.gidx[pos0 + tid];
+    __syncthreads();
+    const int W = a.O + a.A;
+    for (int i = tid; i < 16 * W; i += 256) {
+        const int r = i / W, j = i - r * W;
+        if (pos0 + r >= a.B) continue;
+        if (j < a.O) a.mb_obs[(size_t)(pos0 + r) * a.O + j] = a.obs[(size_t)src[r] * a.O + j];
+        else a.mb_act[(size_t)(pos0 + r) * a.A + (j - a.O)] = a.act[(size_t)src[r] * a.A + (j - a.O)];
+    }
+    if (tid < 16 && pos0 + tid < a.B) {
+        const int p = pos0 + tid, s = src[tid], k = p / a.M;
+        const float R = a.ret[s], V = a.val[s];
+        a.mb_ret[p] = R; a.mb_val[p] = V; a.mb_nlp[p] = a.nlp[s];
+        a.mb_adv[p] = ((R - V) - a.stats[2 * k]) / a.stats[2 * k + 1];          // ppo2.hpp:401-406
     }
 }
 

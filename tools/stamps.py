@@ -12,13 +12,17 @@ n = 2048; rng = np.random.RandomState(0)
 obs = rng.uniform(-1, 1, (n, 18)).astype(np.float32); a, v, nlp = g.step(obs, rng.normal(size=(n, 18)).astype(np.float32))
 ret = (v + rng.normal(size=n)).astype(np.float32); adv = g.adv_normalize(ret, v)
 for _ in range(5): g.train_step(3e-4, 0.16, obs, a, adv, ret, nlp, v)
-buf = np.zeros(256 * 16, np.uint64)
+buf = np.zeros(256 * 32, np.uint64)
 g.lib.ppo_debug_read_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size)
-st = buf.reshape(256, 16).astype(np.int64)
-names = ["stage", "L0", "L1", "-", "-", "head_fwd", "loss", "head_bwd/vf", "bwd_L1", "bwd_L0"]
+st = buf.reshape(256, 32).astype(np.int64)
+t0 = st[:, 0].min()
 for tower in (0, 1):
     blk = st[tower * 128:(tower + 1) * 128]
-    print("tower", tower, "total cycles median", np.median(blk[:, 10] - blk[:, 0]), "min start", (blk[:, 0] - st[:, 0].min()).min(), "max end", (blk[:, 10] - st[:, 0].min()).max())
-    for i in range(10):
-        d = blk[:, i + 1] - blk[:, i]
-        if (blk[:, i + 1] > 0).all() and (blk[:, i] > 0).all(): print("   %-12s median %8.0f  max %8.0f" % (names[i], np.median(d), d.max()))
+    print("tower", tower, "kernel cycles median", np.median(blk[:, 10] - blk[:, 0]))
+    seq = [16, 20, 21, 22, 23, 24, 25, 26, 27, 28, 17, 18, 19]
+    names = ["entry", "st0", "st1", "st2", "st3", "st4", "st5", "st6", "st7", "st8(tail)", "loop end", "between done", "epilogue done"]
+    prev = None
+    for idx, nm in zip(seq, names):
+        if (blk[:, idx] > 0).all():
+            if prev is not None: print("   %-14s +%6.0f (max %6.0f)" % (nm, np.median(blk[:, idx] - blk[:, prev]), (blk[:, idx] - blk[:, prev]).max()))
+            prev = idx
