@@ -1,0 +1,10 @@
+// ISerializable: the (de)serialisation half of the reference's Env interface (common/serializable.hpp:11-15).
+#pragma once
+#include "../json_min.hpp"
+
+class ISerializable {
+public:
+    virtual ~ISerializable() {}
+    virtual void serialize(nlohmann::json& json) = 0;
+    virtual void deserialize(nlohmann::json& json) = 0;
+};

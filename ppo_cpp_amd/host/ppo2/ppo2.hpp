@@ -1,0 +1,168 @@
+// ppo2.hpp -- the PPO2 host algorithm with the reference's surface (ppo2/ppo2.hpp:31-547): constructor arguments,
+// learn(), eval(), _train_step() and the "fps,pg_loss,vf_loss,entropy,approxkl,clipfrac," line per update.
+//
+// Differences that follow from replacing the TensorFlow graph executor:
+//   * the first constructor argument is the libppo_hip handle (network shape + graph-baked constants live in its
+//     ppo_config) instead of a graph file name;
+//   * learn() keeps the rollout and the whole minibatch-update phase in HBM when the environment is an EnvNormalize
+//     (the reference's stack, ppo2.cpp:188-207): ppo_rollout_* per env step, one ppo_update per update;
+//     any other Env goes through the literal reference loop (Runner::run, host shuffle, _train_step per minibatch);
+//   * the epoch shuffle is a seeded on-device permutation (the reference uses std::random_shuffle over rand() seeded
+//     from the clock, ppo2.hpp:288 / ppo2.cpp:159-162, i.e. it is not reproducible either way).
+#pragma once
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <numeric>
+#include <random>
+
+#include "../env/env_normalize.hpp"
+#include "runner.hpp"
+#include "utils.hpp"
+
+class PPO2 {
+public:
+    PPO2(ppo_handle* handle, Env& env, float gamma = 0.99f, int n_steps = 128, float ent_coef = 0.01f, float learning_rate = 2.5e-4f,
+         float vf_coef = 0.5f, float max_grad_norm = 0.5f, float lam = 0.95f, int nminibatches = 4, int noptepochs = 4, float cliprange = 0.2f,
+         float cliprange_vf = -1.f, std::string tensorboard_log = "")
+        : h_(handle), env_(env), gamma_(gamma), n_steps_(n_steps), ent_coef_(ent_coef), learning_rate_(learning_rate), vf_coef_(vf_coef),
+          max_grad_norm_(max_grad_norm), lam_(lam), nminibatches_(nminibatches), noptepochs_(noptepochs), cliprange_(cliprange),
+          cliprange_vf_(cliprange_vf), tensorboard_log_(std::move(tensorboard_log)), n_envs_(env.get_num_envs()), num_timesteps_(0),
+          act_model_(handle, env.get_action_space_size()), episode_reward_(Mat::Zero(n_envs_, 1)) {
+        n_batch_ = n_envs_ * n_steps_;
+    }
+
+    struct UpdateLog { int fps; float losses[5]; double collect_ms, update_ms; };
+    const std::vector<UpdateLog>& history() const { return history_; }
+    std::vector<std::pair<int, float>>& episode_rewards() { return episodes_; }
+    bool quiet = false;
+    unsigned long long seed = 0;
+
+    // deterministic action for one observation row (ppo2.hpp:225-237)
+    Mat eval(const Mat& obs) { return act_model_.get_deterministic_action(obs); }
+
+    void learn(int total_timesteps) {
+        num_timesteps_ = 0;
+        const int n_updates = total_timesteps / n_batch_;
+        if (n_batch_ % nminibatches_ != 0) throw std::runtime_error("PPO2: n_batch must be divisible by nminibatches");
+        EnvNormalize* nz = dynamic_cast<EnvNormalize*>(&env_);
+        if (nz && nz->training()) learn_resident(*nz, n_updates);
+        else learn_reference_loop(n_updates);
+    }
+
+    // PPO2::_train_step (ppo2.hpp:380-471): advantage normalisation over the minibatch, then the train op
+    Mat _train_step(float lr, float cliprange, const Mat& obs, const Mat& returns, const Mat& /*masks*/, const Mat& actions, const Mat& values,
+                    const Mat& neglogpacs) {
+        const int n = static_cast<int>(obs.rows());
+        Mat advs(n, 1), losses(1, 5);
+        check(ppo_adv_normalize(h_, returns.data(), values.data(), n, advs.data()));
+        check(ppo_train_step(h_, lr, cliprange, obs.data(), actions.data(), advs.data(), returns.data(), neglogpacs.data(), values.data(), n,
+                             losses.data()));
+        return losses;
+    }
+
+private:
+    using clk = std::chrono::steady_clock;
+    static double ms(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+    void learn_resident(EnvNormalize& nz, int n_updates) {
+        Env& raw = nz.inner();
+        const int E = n_envs_, T = n_steps_;
+        check(ppo_rollout_alloc(h_, E, T));
+        check(ppo_rollout_reset(h_, raw.reset().data()));                  // EnvNormalize::reset + Runner ctor
+        Mat actions(E, raw.get_action_space_size()), rew_view(E, T), done_view(E, T), dones = Mat::Zero(E, 1);
+        for (int update = 1; update <= n_updates; ++update) {
+            const auto t0 = clk::now();
+            for (int t = 0; t < T; ++t) {
+                for (int e = 0; e < E; ++e) done_view(e, t) = dones(e, 0);
+                check(ppo_rollout_act(h_, t, nullptr, actions.data()));
+                const std::vector<Mat> r = raw.step(actions);
+                check(ppo_rollout_observe(h_, t, r[0].data(), r[1].data(), r[2].data()));
+                dones = r[2];
+                const Mat orig = raw.get_original_rew();
+                for (int e = 0; e < E; ++e) rew_view(e, t) = orig(e, 0);
+            }
+            check(ppo_rollout_finish(h_, gamma_, lam_));
+            const auto t1 = clk::now();
+            num_timesteps_ += n_batch_;
+            UpdateLog log{};
+            check(ppo_update(h_, learning_rate_, cliprange_, noptepochs_, nminibatches_, nullptr, seed + (unsigned long long)update, nullptr,
+                             log.losses));
+            const auto t2 = clk::now();
+            finish_update(log, t0, t1, t2, rew_view, done_view);
+        }
+    }
+
+    void learn_reference_loop(int n_updates) {
+        Runner runner{env_, act_model_, n_steps_, gamma_, lam_};
+        std::mt19937 rng((unsigned)seed);
+        const int batch_size = n_batch_ / nminibatches_;
+        for (int update = 1; update <= n_updates; ++update) {
+            const auto t0 = clk::now();
+            const MiniBatch mb = runner.run();
+            const auto t1 = clk::now();
+            const auto all = mb.get_train_input();
+            std::vector<int> perm(n_batch_);
+            std::iota(perm.begin(), perm.end(), 0);
+            num_timesteps_ += n_batch_;
+            double acc[5] = {0, 0, 0, 0, 0};
+            for (int epoch = 0; epoch < noptepochs_; ++epoch) {
+                std::shuffle(perm.begin(), perm.end(), rng);                 // cumulative, like ppo2.hpp:288
+                std::vector<Mat> shuffled;
+                for (const auto& v : all) {                                  // out.row(perm[i]) = in.row(i)  (ppo2.hpp:291-296)
+                    Mat o(v->rows(), v->cols());
+                    for (int i = 0; i < n_batch_; ++i) mat_set_row(o, perm[i], mat_row_ptr(*v, i));
+                    shuffled.push_back(o);
+                }
+                for (int start = 0; start < n_batch_; start += batch_size) {
+                    std::vector<Mat> sl;
+                    for (const Mat& v : shuffled) {
+                        Mat s(batch_size, v.cols());
+                        std::memcpy(s.data(), mat_row_ptr(v, start), sizeof(float) * (size_t)batch_size * v.cols());
+                        sl.push_back(s);
+                    }
+                    const Mat l = _train_step(learning_rate_, cliprange_, sl[0], sl[1], sl[2], sl[3], sl[4], sl[5]);
+                    for (int j = 0; j < 5; ++j) acc[j] += l(0, j);
+                }
+            }
+            const auto t2 = clk::now();
+            UpdateLog log{};
+            for (int j = 0; j < 5; ++j) log.losses[j] = (float)(acc[j] / (noptepochs_ * nminibatches_));   // colwise().mean() (ppo2.hpp:335)
+            Mat rew_view(n_envs_, n_steps_), done_view(n_envs_, n_steps_);
+            std::memcpy(rew_view.data(), mb.unnormalized_rewards->data(), sizeof(float) * (size_t)n_batch_);
+            std::memcpy(done_view.data(), mb.dones->data(), sizeof(float) * (size_t)n_batch_);
+            finish_update(log, t0, t1, t2, rew_view, done_view);
+        }
+    }
+
+    void finish_update(UpdateLog& log, clk::time_point t0, clk::time_point t1, clk::time_point t2, const Mat& rew_view, const Mat& done_view) {
+        log.collect_ms = ms(t0, t1);
+        log.update_ms = ms(t1, t2);
+        const double total = std::max(ms(t0, t2), 1e-3);
+        log.fps = static_cast<int>(n_batch_ * 1000.0 / total);            // ppo2.hpp:337-341
+        if (!quiet) {
+            std::printf("%d,", log.fps);
+            for (int i = 0; i < 5; ++i) std::printf("%g,", log.losses[i]);
+            std::printf("\n");
+        }
+        episode_reward_ = Utils::total_episode_reward_logger(
+            episode_reward_, rew_view, done_view, [this](int step, const char*, float v) { episodes_.push_back({step, v}); }, num_timesteps_ - n_batch_);
+        history_.push_back(log);
+    }
+
+    void check(int rc) { if (rc != 0) throw std::runtime_error(std::string("PPO2: ") + ppo_last_error(h_)); }
+
+    ppo_handle* h_;
+    Env& env_;
+    float gamma_;
+    int n_steps_;
+    float ent_coef_, learning_rate_, vf_coef_, max_grad_norm_, lam_;
+    int nminibatches_, noptepochs_;
+    float cliprange_, cliprange_vf_;
+    std::string tensorboard_log_;
+    int n_envs_, n_batch_, num_timesteps_;
+    MlpPolicy act_model_;
+    Mat episode_reward_;
+    std::vector<UpdateLog> history_;
+    std::vector<std::pair<int, float>> episodes_;
+};

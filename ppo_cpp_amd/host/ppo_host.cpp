@@ -1,0 +1,169 @@
+// ppo_host.cpp -- C entry points over the C++ host layer (env stack, Runner, PPO2) so that tests and bench.py can
+// drive it with ctypes.  The wiring of ppo_host_learn mirrors the reference's main() (ppo2.cpp:188-250):
+//   N x Env -> VecEnv -> EnvNormalize{training} -> PPO2{gamma .99, lam .95, vf .5, max_grad_norm .5, 32 minibatches}.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "env/env_mock.hpp"
+#include "env/env_normalize.hpp"
+#include "env/vec_env.hpp"
+#include "ppo2/ppo2.hpp"
+
+extern "C" {
+
+// Port of the reference's only test (test/vecenv_test.cpp:13-49): N x EnvMock(i+1) behind a VecEnv, `steps` steps of
+// zero actions; every observation column and the reward column must equal [1..N]^T.  Returns 0 or the failing check.
+int ppo_host_vecenv_check(int num_envs, int steps, int max_workers) {
+    std::vector<std::shared_ptr<Env>> envs;
+    Mat expect = Mat::Zero(num_envs, 1);
+    for (int i = 0; i < num_envs; ++i) { envs.push_back(std::make_shared<EnvMock>(i + 1)); expect(i, 0) = (float)(i + 1); }
+    VecEnv ve{envs, max_workers};
+    for (int s = 0; s < steps; ++s) {
+        const Mat actions = Mat::Zero(ve.get_num_envs(), ve.get_action_space_size());
+        const std::vector<Mat> result = ve.step(actions);
+        const Mat& obs = result[0];
+        const Mat& rew = result[1];
+        if (obs.rows() != ve.get_num_envs()) return 1;
+        if (rew.rows() != ve.get_num_envs()) return 2;
+        if (obs.cols() != ve.get_observation_space_size()) return 3;
+        if (rew.cols() != 1) return 4;
+        if ((rew - expect).squaredNorm() > 1e-2f) return 5;
+        for (int j = 0; j < ve.get_observation_space_size(); ++j)
+            if ((obs.col(j) - expect).squaredNorm() > 1e-2f) return 6;
+        const Mat dones = result[2];
+        for (int i = 0; i < num_envs; ++i) if (dones(i, 0) != ((s + 1) % 300 == 0 ? 1.f : 0.f)) return 7;
+        if ((ve.get_original_rew() - expect).squaredNorm() > 1e-2f) return 8;
+    }
+    const Mat r = ve.reset();                         // gathers get_original_obs(), does not reset sub-envs
+    if (r.rows() != num_envs || r.cols() != 18) return 9;
+    for (int i = 0; i < num_envs; ++i) if (r(i, 0) != (float)(i + 1)) return 10;
+    return 0;
+}
+
+// pure host checks of the small utilities (no GPU): Mat shim, JSON, episode logger, env-major flatten
+int ppo_host_selftest() {
+    {   // flatten: [T,E,W] -> row e*T+t
+        const int T = 3, E = 2, W = 2;
+        float src[T * E * W];
+        for (int i = 0; i < T * E * W; ++i) src[i] = (float)i;
+        auto m = Runner::flatten(src, T, E, W);
+        for (int e = 0; e < E; ++e) for (int t = 0; t < T; ++t) for (int w = 0; w < W; ++w)
+            if ((*m)(e * T + t, w) != src[(t * E + e) * W + w]) return 1;
+    }
+    {   // episode logger: env 0 has a done at k=2 -> episode reward = acc + r0 + r1, new accumulator r2 + r3
+        Mat acc = Mat::Zero(2, 1), rew(2, 4), dn = Mat::Zero(2, 4);
+        acc(0, 0) = 10.f;
+        for (int e = 0; e < 2; ++e) for (int k = 0; k < 4; ++k) rew(e, k) = (float)(k + 1);
+        dn(0, 2) = 1.f;
+        std::vector<std::pair<int, float>> got;
+        acc = Utils::total_episode_reward_logger(acc, rew, dn, [&](int s, const char*, float v) { got.push_back({s, v}); }, 100);
+        if (got.size() != 1 || got[0].first != 102 || got[0].second != 13.f) return 2;
+        if (acc(0, 0) != 7.f || acc(1, 0) != 10.f) return 3;
+    }
+    {   // JSON round trip in the reference's running-statistics format
+        nlohmann::json j;
+        j["obs_rms"]["mean"] = std::vector<float>{0.5f, -1.25f};
+        j["obs_rms"]["count"] = 72001473.000001;
+        const std::string text = j.dump();
+#ifndef PPO_HAVE_NLOHMANN
+        nlohmann::json k = nlohmann::json::parse(text);
+        if (k["obs_rms"]["mean"].get<std::vector<float>>()[1] != -1.25f) return 4;
+        if (std::fabs(k["obs_rms"]["count"].get<double>() - 72001473.000001) > 1e-6) return 5;
+#endif
+    }
+    {   // seeded mock: deterministic, bounded
+        SeededEnvMock a(1234, 7), b(1234, 7);
+        const Mat o1 = a.reset(), o2 = b.reset();
+        for (int j = 0; j < 18; ++j) if (o1(0, j) != o2(0, j) || o1(0, j) < -1.f || o1(0, j) >= 1.f) return 6;
+    }
+    return 0;
+}
+
+struct ppo_host_args {
+    int n_envs, n_steps, n_hidden, hidden[8];
+    int nminibatches, noptepochs, n_updates;
+    float lr, cliprange, gamma, lam;
+    int seeded_env;          // 0: EnvMock(i+1) (degenerate constant data, the reference's stub) ; 1: SeededEnvMock
+    int device;
+    int max_workers;
+    int reference_loop;      // 1: force the literal reference loop (Runner::run + host shuffle + _train_step)
+};
+struct ppo_host_result {
+    double env_steps_per_s, collect_ms, update_ms;
+    float losses[5];
+    int fps_last;
+    char error[256];
+};
+
+int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
+    std::memset(out, 0, sizeof *out);
+    ppo_handle* h = nullptr;
+    try {
+        ppo_config cfg;
+        ppo_config_default(&cfg, 18, 18, a->n_hidden, a->hidden);
+        cfg.device = a->device;
+        if (ppo_create(&cfg, &h) != 0) throw std::runtime_error(ppo_last_error(nullptr));
+        if (ppo_init_orthogonal(h, 0) != 0) throw std::runtime_error(ppo_last_error(h));
+        std::vector<std::shared_ptr<Env>> envs;
+        for (int i = 0; i < a->n_envs; ++i) {
+            if (a->seeded_env) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i));
+            else envs.push_back(std::make_shared<EnvMock>(i + 1));
+        }
+        std::unique_ptr<Env> inner;
+        if (a->n_envs > 1) inner.reset(new VecEnv(envs, a->max_workers));
+        else inner.reset(a->seeded_env ? static_cast<Env*>(new SeededEnvMock(1234u, 0)) : static_cast<Env*>(new EnvMock(1)));
+        {
+            EnvNormalize env{std::move(inner), h, /*training=*/true, true, true, 10.f, 10.f, a->gamma};
+            PPO2 algorithm{h, env, a->gamma, a->n_steps, cfg.ent_coef, a->lr, 0.5f, 0.5f, a->lam, a->nminibatches, a->noptepochs, a->cliprange};
+            algorithm.quiet = true;
+            struct Plain : Env {       // hides the EnvNormalize type to force the reference loop
+                Env& e; explicit Plain(Env& x) : e(x) {}
+                std::string get_action_space() override { return e.get_action_space(); }
+                std::string get_observation_space() override { return e.get_observation_space(); }
+                int get_action_space_size() override { return e.get_action_space_size(); }
+                int get_observation_space_size() override { return e.get_observation_space_size(); }
+                int get_num_envs() override { return e.get_num_envs(); }
+                Mat reset() override { return e.reset(); }
+                std::vector<Mat> step(const Mat& x) override { return e.step(x); }
+                void render() override {}
+                float get_time() override { return 0; }
+                Mat get_original_obs() override { return e.get_original_obs(); }
+                Mat get_original_rew() override { return e.get_original_rew(); }
+                void serialize(nlohmann::json& j) override { e.serialize(j); }
+                void deserialize(nlohmann::json& j) override { e.deserialize(j); }
+            } plain{env};
+            PPO2 literal{h, plain, a->gamma, a->n_steps, cfg.ent_coef, a->lr, 0.5f, 0.5f, a->lam, a->nminibatches, a->noptepochs, a->cliprange};
+            literal.quiet = true;
+            PPO2& algo = a->reference_loop ? literal : algorithm;
+            const auto t0 = std::chrono::steady_clock::now();
+            algo.learn(a->n_updates * a->n_envs * a->n_steps);
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const auto& hist = algo.history();
+            if (hist.empty()) throw std::runtime_error("no update ran");
+            // the first update pays allocation + graph capture: report the steady state when there is one
+            size_t from = hist.size() > 1 ? 1 : 0;
+            double c = 0, u = 0;
+            for (size_t i = from; i < hist.size(); ++i) { c += hist[i].collect_ms; u += hist[i].update_ms; }
+            const double n = (double)(hist.size() - from);
+            out->collect_ms = c / n; out->update_ms = u / n;
+            out->env_steps_per_s = (double)a->n_envs * a->n_steps / ((c + u) / n / 1e3);
+            std::memcpy(out->losses, hist.back().losses, sizeof out->losses);
+            out->fps_last = hist.back().fps;
+            (void)sec;
+            nlohmann::json j;                                   // serialise round trip of the normaliser
+            env.serialize(j);
+            env.deserialize(j);
+        }
+        ppo_destroy(h);
+        return 0;
+    } catch (const std::exception& e) {
+        std::snprintf(out->error, sizeof out->error, "%s", e.what());
+        if (h) ppo_destroy(h);
+        return -1;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+"""ctypes binding of libppo_host.so: the C++ host layer (Env stack, Runner, PPO2) above the libppo_hip C-ABI."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class HostArgs(C.Structure):
+    _fields_ = [("n_envs", C.c_int), ("n_steps", C.c_int), ("n_hidden", C.c_int), ("hidden", C.c_int * 8),
+                ("nminibatches", C.c_int), ("noptepochs", C.c_int), ("n_updates", C.c_int),
+                ("lr", C.c_float), ("cliprange", C.c_float), ("gamma", C.c_float), ("lam", C.c_float),
+                ("seeded_env", C.c_int), ("device", C.c_int), ("max_workers", C.c_int), ("reference_loop", C.c_int)]
+
+
+class HostResult(C.Structure):
+    _fields_ = [("env_steps_per_s", C.c_double), ("collect_ms", C.c_double), ("update_ms", C.c_double),
+                ("losses", C.c_float * 5), ("fps_last", C.c_int), ("error", C.c_char * 256)]
+
+
+def load_host_library(build=True):
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_PKG, "libppo_host.so")
+        if build and os.path.exists("/opt/rocm/bin/hipcc"):
+            from . import build as _b
+            _b.build_hip()
+            so = _b.build_host()
+        C.CDLL(os.path.join(_PKG, "libppo_hip.so"), mode=C.RTLD_GLOBAL)
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def learn(n_envs, n_steps, hidden, n_updates, nminibatches=32, noptepochs=10, lr=3.93141e-4, cliprange=0.161023, gamma=0.99,
+          lam=0.95, seeded_env=True, device=-1, max_workers=0, reference_loop=False):
+    lib = load_host_library()
+    a = HostArgs()
+    a.n_envs, a.n_steps, a.n_hidden = n_envs, n_steps, len(hidden)
+    for i, h in enumerate(hidden):
+        a.hidden[i] = h
+    a.nminibatches, a.noptepochs, a.n_updates = nminibatches, noptepochs, n_updates
+    a.lr, a.cliprange, a.gamma, a.lam = lr, cliprange, gamma, lam
+    a.seeded_env, a.device, a.max_workers, a.reference_loop = int(seeded_env), device, max_workers, int(reference_loop)
+    r = HostResult()
+    if lib.ppo_host_learn(C.byref(a), C.byref(r)) != 0:
+        raise RuntimeError(r.error.decode())
+    return {"env_steps_per_s": r.env_steps_per_s, "collect_ms": r.collect_ms, "update_ms": r.update_ms,
+            "losses": [float(x) for x in r.losses], "fps_last": r.fps_last}
