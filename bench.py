@@ -83,8 +83,8 @@ def main():
     ap.add_argument("--host-env", action="store_true", help="also time the Env-on-host path (PCIe inclusive)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from ppo_cpp_amd import dist as ppodist
+    rank, world, local_rank = ppodist.env_rank_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -103,15 +103,10 @@ def main():
     g = ppo_cpp_amd.PPOHip(cfg["obs"], cfg["act"], cfg["hidden"], device=local_rank)
     g.init_orthogonal(0)                                                   # same seed on every rank: replicated weights
     if world > 1:
-        import torch
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(ppo_cpp_amd.PPOHip.dist_unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(uid, 0)
-        g.dist_init(world, rank, bytes(uid.numpy().tobytes()))
+        g.dist_init(world, rank, ppodist.broadcast_unique_id(dist, rank, ppo_cpp_amd.PPOHip.dist_unique_id))
     g.norm_init(E, GAMMA)
     g.rollout_alloc(E, T)
-    env0 = rank * E                                                        # weak scaling: every rank owns E more envs
+    env0 = ppodist.env_offset(E, rank)                                     # weak scaling: every rank owns E more envs
 
     def one_step(i, first=False):
         g.collect_synthetic(1234, GAMMA, LAM, None, env0=env0, step0=i * T, first=first)
@@ -132,10 +127,7 @@ def main():
     dt = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+        dt = ppodist.allreduce_max(dist, dt)
 
     # per-kernel device time of the same workload, HIP events on the handle's stream, right after the timed region
     g.prof_enable(True)
@@ -181,6 +173,14 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg)
+    if args.host_env and world == 1:
+        # PCIe-inclusive: the reference's own stack (N x mock Env -> VecEnv -> EnvNormalize -> PPO2::learn) on the host,
+        # actions D2H / observations H2D every env step.  Reported beside `value`, never as `value`.
+        from ppo_cpp_amd import hostapi
+        g.close()
+        r = hostapi.learn(E, T, cfg["hidden"], n_updates=4, nminibatches=nmb, noptepochs=ep, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM)
+        out["host_env"] = {"env_steps_per_s": r["env_steps_per_s"], "collect_ms": r["collect_ms"], "update_ms": r["update_ms"],
+                           "note": "SeededEnvMock x %d behind the pooled VecEnv on the host cores, PCIe round trip per env step" % E}
     print(json.dumps(out))
 
 

@@ -398,7 +398,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(h->n_blocks + 1), dim3(256), 0, h->stream, ra);
         HIP_OK(h, hipGetLastError());
     }
-    if (h->world > 1) {
+    if (h->comm) {                                       // also with a 1-rank communicator: same code path as N ranks
         ProfScope ps(h, PK_COMM);
         const size_t cnt = (size_t)h->P_pad + 8;
         const int rc = h->rccl.AllReduce(h->grad, h->grad, cnt, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
@@ -1039,7 +1039,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     }
     HIP_OK(h, hipMemcpyAsync(h->d_keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     // hipGraph replay of the whole update; RCCL calls and event-bracketed profiling run eagerly
-    const bool graph_ok = h->use_graph && !h->prof && h->world == 1;
+    const bool graph_ok = h->use_graph && !h->prof && !h->comm;
     if (graph_ok) {
         const bool same = h->upd_graph && h->g_epochs == epochs && h->g_nmb == nmb && h->g_E == h->E && h->g_T == h->T &&
                           h->g_explicit == (int)explicit_perms && h->g_world == h->world;

@@ -261,3 +261,22 @@ def test_full_size_config3_properties():
     assert rows[0, 3] == pytest.approx(0.0, abs=1e-9) and rows[0, 4] == 0.0
     close(rows[:, 2], np.full(32, 18 * 1.4189385175704956), rtol=1e-3)
     assert (rows[1:, 3] > 0).all()
+
+
+def test_rccl_plumbing_single_rank_communicator():
+    """ppo_dist_init with world_size 1 exercises the run-time RCCL loading, the communicator and the in-stream
+    ncclAllReduce of the gradient buffer (the N-rank code path); results must still match the oracle."""
+    import ppo_cpp_amd
+    orc, g = pair((64, 64))
+    g.dist_init(1, 0, ppo_cpp_amd.PPOHip.dist_unique_id())
+    for it in range(2):
+        mb = H.synth_minibatch(orc, 128, seed=70 + it)
+        args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+        ref_losses, _, _ = orc.train_step(LR, CR, *args)
+        close(g.train_step(LR, CR, *args), ref_losses, rtol=1e-4, atol=1e-6)
+    close(g.get_flat(0), orc.theta, rtol=1e-4, atol=2e-6)
+    orc2, g2, nz, ro, noise = _rollout_pair((64, 64), 16, 16, 31)
+    g2.dist_init(1, 0, ppo_cpp_amd.PPOHip.dist_unique_id())
+    g2.collect_synthetic(1234, GAMMA, LAM, noise)
+    rows, mean = g2.update(LR, CR, 1, 4, None, seed=1)            # eager launch sequence with the collective in it
+    assert np.isfinite(rows).all()
