@@ -77,7 +77,7 @@ struct ppo_handle {
     float* slots[2]{};
     float* slabs = nullptr;
     int max_split = 8;
-    DwTile* dw_tiles = nullptr;
+    DwWork* dw_tiles = nullptr;
     int n_dw_tiles = 0;
     bool dw_has_big = false;
     // staging for host-pointer calls
@@ -300,15 +300,19 @@ int ensure_train_ws(ppo_handle* h, int rows) {
     for (int t = 0; t < 2; ++t)
         if (dev_alloc(h, &h->slots[t], (size_t)(rows / 16) * n.slot_w)) return -1;
     if (!h->slabs && dev_alloc(h, &h->slabs, (size_t)h->max_split * h->P_pad)) return -1;
-    // weight-gradient tile table
-    std::vector<DwTile> tiles;
+    // weight-gradient work table
+    std::vector<DwTile> big, rest, strips;
     h->dw_has_big = false;
     auto add = [&](const float* X, int ldx, const float* dY, int ldy, int Kp, int Np, int out_off) {
-        const bool big = (Kp % 64 == 0) && (Np % 64 == 0);
-        const int ts = big ? 64 : 16;
-        if (big) h->dw_has_big = true;
-        for (int i = 0; i < Kp; i += ts)
-            for (int j = 0; j < Np; j += ts) tiles.push_back(DwTile{X, dY, ldx, ldy, i, j, out_off, Np, big ? 0 : 1});
+        if (Kp % 64 == 0 && Np % 64 == 0) {                       // 64x64 tiles
+            for (int i = 0; i < Kp; i += 64) for (int j = 0; j < Np; j += 64) big.push_back(DwTile{X, dY, ldx, ldy, i, j, out_off, Np, 0});
+        } else if (Kp == 32 && Np % 16 == 0) {                    // narrow first layer: [32 x 16] strips
+            for (int j = 0; j < Np; j += 16) strips.push_back(DwTile{X, dY, ldx, ldy, 0, j, out_off, Np, 4});
+        } else if (Np == 32 && Kp % 16 == 0) {                    // narrow head: [16 x 32] strips
+            for (int i = 0; i < Kp; i += 16) strips.push_back(DwTile{X, dY, ldx, ldy, i, 0, out_off, Np, 5});
+        } else {
+            for (int i = 0; i < Kp; i += 16) for (int j = 0; j < Np; j += 16) rest.push_back(DwTile{X, dY, ldx, ldy, i, j, out_off, Np, 1});
+        }
     };
     for (int t = 0; t < 2; ++t)
         for (int l = 0; l < n.L; ++l) {
@@ -317,10 +321,18 @@ int ensure_train_ws(ppo_handle* h, int rows) {
             add(X, Kp, h->dyg[t][l], n.Hp[l], Kp, n.Hp[l], n.w_off[t][l]);
         }
     add(h->hg[0][n.L - 1], n.Hp[n.L - 1], h->dmug, n.Ap, n.Hp[n.L - 1], n.Ap, n.wmu_off);
-    std::stable_sort(tiles.begin(), tiles.end(), [](const DwTile& a, const DwTile& b) { return a.cls < b.cls; });
-    h->n_dw_tiles = (int)tiles.size();
-    if (dev_alloc(h, &h->dw_tiles, tiles.size())) return -1;
-    HIP_OK(h, hipMemcpyAsync(h->dw_tiles, tiles.data(), tiles.size() * sizeof(DwTile), hipMemcpyHostToDevice, h->stream));
+    std::vector<DwWork> work;
+    for (const DwTile& b : big) { DwWork w{}; w.main = b; w.n_extra = 0; work.push_back(w); }
+    h->dw_has_big = !big.empty();
+    if (!big.empty() && strips.size() <= 2 * big.size()) {        // fold the strips into the big workgroups, round robin
+        for (size_t i = 0; i < strips.size(); ++i) { DwWork& w = work[i % big.size()]; w.extra[w.n_extra++] = strips[i]; }
+    } else {
+        for (const DwTile& s : strips) { DwWork w{}; w.main = s; work.push_back(w); }
+    }
+    for (const DwTile& r : rest) { DwWork w{}; w.main = r; work.push_back(w); }
+    h->n_dw_tiles = (int)work.size();
+    if (dev_alloc(h, &h->dw_tiles, work.size())) return -1;
+    HIP_OK(h, hipMemcpyAsync(h->dw_tiles, work.data(), work.size() * sizeof(DwWork), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     h->ws_rows = rows;
     return 0;
@@ -364,7 +376,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     ta.theta = h->theta; ta.thetaT = h->thetaT; ta.hyper = h->hyper;
     ta.x0g = h->x0g; ta.dmug = h->dmug;
 #ifdef PPO_STAMPS
-    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 32 * sizeof(unsigned long long));
+    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
     ta.stamps = g_stamps;
 #endif
     for (int t = 0; t < 2; ++t) {
@@ -382,11 +394,14 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     const int split = pick_split(h, ta.n);
     {
         ProfScope ps(h, PK_DW);
-        DwArgs da{h->dw_tiles, ta.n, split, h->slabs, (size_t)h->P_pad};
-        const size_t lds = (h->dw_has_big ? 4 * 64 * 64 : 4 * 16 * 16) * sizeof(float);
+        DwArgs da{h->dw_tiles, ta.n, split, h->slabs, (size_t)h->P_pad, nullptr};
+#ifdef PPO_STAMPS
+        da.stamps = g_stamps + 4096 * 16;
+#endif
+        const size_t lds = (h->dw_has_big ? 4 * 64 * 64 : 4 * 32 * 32) * sizeof(float);     // 4 waves x largest tile
         const int rows_per_wave = ta.n / split / 4;
-        if (rows_per_wave % 16 == 0) hipLaunchKernelGGL(weight_grad_kernel<4>, dim3(h->n_dw_tiles, split), dim3(BLOCK_THREADS), lds, h->stream, da);
-        else hipLaunchKernelGGL(weight_grad_kernel<1>, dim3(h->n_dw_tiles, split), dim3(BLOCK_THREADS), lds, h->stream, da);
+        if (rows_per_wave % 16 == 0) hipLaunchKernelGGL(weight_grad_kernel<4>, dim3(h->n_dw_tiles * split), dim3(BLOCK_THREADS), lds, h->stream, da);
+        else hipLaunchKernelGGL(weight_grad_kernel<1>, dim3(h->n_dw_tiles * split), dim3(BLOCK_THREADS), lds, h->stream, da);
         HIP_OK(h, hipGetLastError());
     }
     {
@@ -1133,7 +1148,7 @@ int ppo_prof_read(ppo_handle* h, int max, char names[][32], double* total_ms, in
 #ifdef PPO_STAMPS
 int ppo_debug_read_stamps(ppo_handle* h, unsigned long long* dst, int n) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    HIP_OK(h, hipMemcpy(dst, g_stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_OK(h, hipMemcpy(dst, g_stamps + (n < 0 ? 4096 * 16 : 0), (size_t)(n < 0 ? -n : n) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -136,6 +136,12 @@ __device__ __forceinline__ float group16_sum(float v) {
 // of a layer is loaded by dense_prefetch() BEFORE the previous layer's epilogue and barrier (weights do not depend
 // on activations), which takes one L2 round trip per layer off the critical path.
 // ------------------------------------------------------------------------------------------------------------
+#ifdef PPO_STAMPS
+#define DSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
+
 template <int CT, int KS>
 struct WFrag { float v[4 * KS][CT]; float4 a[KS]; };   // one pipeline stage: weights + the matching A-operand vectors
 
@@ -245,11 +251,6 @@ __device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int
     W = uni(W); ldw = uni(ldw); K = uni(K); Np = uni(Np);
     bool first = true;
     bool called = false;
-#ifdef PPO_STAMPS
-#define DSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define DSTAMP(i) do { } while (0)
-#endif
     DSTAMP(0);
     for (int n0 = wave * CW; n0 < Np; n0 += NSTRIDE) {
         f32x4 acc[CT];
@@ -802,59 +803,90 @@ struct DwTile {
     int i0, j0;                        // tile origin in the [Kp x Np] gradient
     int out_off;                       // offset of the tensor inside the padded parameter vector
     int ldo;                           // = Np
-    int cls;                           // 0: 64x64 tile (TI=TJ=4) ; 1: 16x16 tile
+    int cls;                           // 0: 64x64 tile (TI=TJ=4) ; 1: 16x16 ; 2: 32x64 (TI=2,TJ=4) ; 3: 64x32 (TI=4,TJ=2)
+                                       // 4: 32x16 strip (TI=2,TJ=1) ; 5: 16x32 strip (TI=1,TJ=2)
 };
+
+// One workgroup's work: a main tile plus up to two thin strips of the narrow matrices (first layer, policy head).
+// Folding the strips into the 64x64 workgroups keeps the launch at one balanced workgroup per CU (extra workgroups
+// would double up on some CUs and set the kernel's critical path).
+struct DwWork { DwTile main; int n_extra; DwTile extra[2]; };
+
+#ifndef PPO_DW_RING
+#define PPO_DW_RING 3              // register stages per wave in the weight-gradient kernel (operands come from the
+#endif                             // Infinity Cache / HBM: the producer kernel ran on other XCDs)
+
+template <int N>
+__device__ __forceinline__ void gload_vec(float (&dst)[N], const float* base, unsigned byte_off) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) char* gchar;
+    gchar p = (gchar)(reinterpret_cast<unsigned long long>(base)) + byte_off;
+    if constexpr (N == 4) { const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)p; dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+    else if constexpr (N == 2) { const f32x2_t v = *(const __attribute__((address_space(1))) f32x2_t*)p; dst[0] = v[0]; dst[1] = v[1]; }
+    else { dst[0] = *(const __attribute__((address_space(1))) float*)p; }
+}
 
 template <int TI, int TJ, int KQ>
 __device__ __forceinline__ void dw_tile_body(const DwTile& t, int n, int nsplit, float* __restrict__ slabs, size_t slab_stride,
-                                             float* lds) {
+                                             float* lds, unsigned long long* dbg = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const int split = blockIdx.y;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so id % nsplit puts every tile of one row
+    // split on one XCD (nsplit = 8): the X / dY slabs of that split are fetched from the fabric once per XCD and
+    // shared through its L2 by the tiles that need them (speed only, never correctness)
+    const int split = blockIdx.x % nsplit;
+    DSTAMP(0);
     const int rows_per_split = n / nsplit;
     const int rows_per_wave = rows_per_split / 4;
-    const int rbeg = split * rows_per_split + wave * rows_per_wave;
+    const int rbeg = uni(split * rows_per_split + wave * rows_per_wave);
+    const int ldx = uni(t.ldx), ldy = uni(t.ldy);
     f32x4 acc[TI][TJ];
 #pragma unroll
     for (int a = 0; a < TI; ++a)
 #pragma unroll
         for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // MFMA (a,b): A[i][k] = X[row k][i0 + TI*i + a], B[k][j] = dY[row k][j0 + TJ*j + b], k = lane group g.
-    // One pipeline stage = KQ k-steps (4*KQ minibatch rows): 2*KQ 16-byte loads per lane feed TI*TJ*KQ MFMAs.
-    const float* xp = t.X + (size_t)(rbeg + g) * t.ldx + t.i0 + TI * c;
-    const float* yp = t.dY + (size_t)(rbeg + g) * t.ldy + t.j0 + TJ * c;
-    float x0[KQ][TI], y0[KQ][TJ], x1[KQ][TI], y1[KQ][TJ];
-    auto ld = [&](float (*xo)[TI], float (*yo)[TJ], int koff) {
+    // One pipeline stage = KQ k-steps (4*KQ minibatch rows): 2*KQ vector loads per lane feed TI*TJ*KQ MFMAs.
+    // Addresses = wave-uniform stage base (scalar registers) + per-lane 32-bit byte offsets computed once.
+    const float* Xb = uni(t.X) + (size_t)rbeg * ldx;
+    const float* Yb = uni(t.dY) + (size_t)rbeg * ldy;
+    unsigned xo[KQ], yo[KQ];
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const float* x = xp + (size_t)(koff + 4 * q) * t.ldx;
-            const float* y = yp + (size_t)(koff + 4 * q) * t.ldy;
-            if constexpr (TI == 4) { const float4 v = *reinterpret_cast<const float4*>(x); xo[q][0] = v.x; xo[q][1] = v.y; xo[q][2] = v.z; xo[q][3] = v.w; }
-            else { xo[q][0] = *x; }
-            if constexpr (TJ == 4) { const float4 v = *reinterpret_cast<const float4*>(y); yo[q][0] = v.x; yo[q][1] = v.y; yo[q][2] = v.z; yo[q][3] = v.w; }
-            else { yo[q][0] = *y; }
-        }
+    for (int q = 0; q < KQ; ++q) {
+        xo[q] = (unsigned)(((g + 4 * q) * ldx + t.i0 + TI * c) * 4);
+        yo[q] = (unsigned)(((g + 4 * q) * ldy + t.j0 + TJ * c) * 4);
+    }
+    struct Stage { float x[KQ][TI]; float y[KQ][TJ]; };
+    Stage st[PPO_DW_RING];
+    constexpr int RS = 4 * KQ;                                      // minibatch rows per pipeline stage
+    auto ld = [&](Stage& s_, int koff) __attribute__((always_inline)) {
+        koff = koff < rows_per_wave ? koff : rows_per_wave - RS;   // clamped: unconditional loads, counted vmcnt
+        const float* xs = Xb + (size_t)koff * ldx;
+        const float* ys = Yb + (size_t)koff * ldy;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) { gload_vec<TI>(s_.x[q], xs, xo[q]); gload_vec<TJ>(s_.y[q], ys, yo[q]); }
     };
-    auto compute = [&](const float (*xi)[TI], const float (*yi)[TJ]) {
+    auto compute = [&](const Stage& s_) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
             for (int a = 0; a < TI; ++a)
 #pragma unroll
-                for (int b = 0; b < TJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xi[q][a], yi[q][b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_.x[q][a], s_.y[q][b], acc[a][b], 0, 0, 0);
     };
-    constexpr int RS = 4 * KQ;                                      // minibatch rows per pipeline stage
-    ld(x0, y0, 0);
-    for (int k = 0; k < rows_per_wave; k += 2 * RS) {               // ping-pong stages, unconditional clamped loads
-        ld(x1, y1, (k + RS < rows_per_wave) ? k + RS : k);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(x0, y0);
-        __builtin_amdgcn_sched_barrier(0);
-        ld(x0, y0, (k + 2 * RS < rows_per_wave) ? k + 2 * RS : k);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + RS < rows_per_wave) compute(x1, y1);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < PPO_DW_RING - 1; ++i) ld(st[i], i * RS);
+    DSTAMP(1);
+    for (int k = 0; k < rows_per_wave; k += PPO_DW_RING * RS) {
+#pragma unroll
+        for (int i = 0; i < PPO_DW_RING; ++i) {
+            ld(st[(i + PPO_DW_RING - 1) % PPO_DW_RING], k + (i + PPO_DW_RING - 1) * RS);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + i * RS < rows_per_wave) compute(st[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    DSTAMP(2);
     // in-workgroup split-K: every wave parks its tile in LDS, then all threads add the 4 copies in wave order
     constexpr int TW = 16 * TJ, TH = 16 * TI;
     float* mine = lds + wave * (TH * TW);
@@ -867,28 +899,45 @@ __device__ __forceinline__ void dw_tile_body(const DwTile& t, int n, int nsplit,
             for (int b = 0; b < TJ; ++b) mine[orow * TW + TJ * c + b] = acc[a][b][r];
         }
     __syncthreads();
+    DSTAMP(3);
     float* out = slabs + (size_t)split * slab_stride + t.out_off;
     for (int i = threadIdx.x; i < TH * TW; i += BLOCK_THREADS) {
         const float s = ((lds[i] + lds[TH * TW + i]) + lds[2 * TH * TW + i]) + lds[3 * TH * TW + i];
         const int orow = i / TW, ocol = i - orow * TW;
         out[(size_t)(t.i0 + orow) * t.ldo + t.j0 + ocol] = s;
     }
+    DSTAMP(4);
 }
 
 struct DwArgs {
-    const DwTile* tiles;
+    const DwWork* tiles;
     int n;                 // minibatch rows
-    int nsplit;            // gridDim.y
+    int nsplit;            // row splits; grid = n_tiles * nsplit workgroups, split = id % nsplit
     float* slabs;          // [nsplit][P_pad]
     size_t slab_stride;
+    unsigned long long* stamps;   // diagnostic builds only
 };
 
 template <int KQ>
 __global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const DwTile t = a.tiles[blockIdx.x];
-    if (t.cls == 0) dw_tile_body<4, 4, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
-    else dw_tile_body<1, 1, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+    const DwWork& w = a.tiles[blockIdx.x / a.nsplit];
+    const int n_sub = 1 + uni(w.n_extra);
+    for (int e = 0; e < n_sub; ++e) {
+        const DwTile t = e == 0 ? w.main : w.extra[e - 1];
+        const int cls = uni(t.cls);
+        if (e) __syncthreads();                        // LDS of the previous tile's split-K reduction is reused
+        if (cls == 0) dw_tile_body<4, 4, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds
+#ifdef PPO_STAMPS
+            , a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr
+#endif
+            );
+        else if (cls == 2) dw_tile_body<2, 4, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+        else if (cls == 3) dw_tile_body<4, 2, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+        else if (cls == 4) dw_tile_body<2, 1, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+        else if (cls == 5) dw_tile_body<1, 2, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+        else dw_tile_body<1, 1, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -26,3 +26,13 @@ for tower in (0, 1):
         if (blk[:, idx] > 0).all():
             if prev is not None: print("   %-14s +%6.0f (max %6.0f)" % (nm, np.median(blk[:, idx] - blk[:, prev]), (blk[:, idx] - blk[:, prev]).max()))
             prev = idx
+
+buf = np.zeros(352 * 8 * 8, np.uint64)
+g.lib.ppo_debug_read_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), -buf.size)
+sb = buf.reshape(-1, 8).astype(np.int64)
+big = sb[(sb[:, 4] > 0)]
+t0 = big[:, 0].min()
+print("weight_grad 64x64 tiles: %d blocks; start spread %d, last end %d cycles after first start" % (len(big), (big[:, 0] - t0).max(), (big[:, 4] - t0).max()))
+for i, nm in enumerate(["issue prologue loads", "main loop", "lds park + barrier", "sum + slab store"]):
+    d = big[:, i + 1] - big[:, i]
+    print("   %-22s median %7.0f max %7.0f" % (nm, np.median(d), d.max()))
