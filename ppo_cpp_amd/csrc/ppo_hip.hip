@@ -62,6 +62,7 @@ struct ppo_handle {
     std::vector<Tensor> tensors;
     int P_dense = 0, P_pad = 0, n_blocks = 0, PT = 0;
     float* thetaT = nullptr;          // transposed copies (layout: NetDev::wT_off / wmuT_off)
+    float* par = nullptr;             // small-parameter mirror [2][par_total] (layout: NetDev::par_*)
     // parameters + optimiser state (padded layout)
     float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad = nullptr, *sumsq = nullptr;
     float* beta_pow = nullptr;        // {cur b1, cur b2, next b1, next b2}
@@ -260,7 +261,7 @@ int upload_grad_src(ppo_handle* h) {
     const NetDev& n = h->net;
     std::vector<GradSrc> src(h->n_blocks);
     for (const Tensor& t : h->tensors) {
-        GradSrc g{2, 0, 0, 0, t.off_pad, -1, t.prow, t.pcol};
+        GradSrc g{2, 0, 0, 0, t.off_pad, -1, t.prow, t.pcol, -1, 0};
         const std::string nm = t.name;
         int l = -1;
         if (nm.find("_fc") != std::string::npos) l = atoi(nm.c_str() + 5);
@@ -270,11 +271,11 @@ int upload_grad_src(ppo_handle* h) {
             if (nm == "pi/w") g.t_off = n.wmuT_off;
             else if (l >= 1) g.t_off = n.wT_off[tower][l];
         }
-        else if (l >= 0) { g.kind = 1; g.tower = tower; g.slot_off = n.slot_db[l]; g.count = n.Hp[l]; }
-        else if (nm == "vf/w") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_head; g.count = n.Hp[n.L - 1]; }
-        else if (nm == "vf/b") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_aux; g.count = 1; }
-        else if (nm == "pi/b") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_head; g.count = n.Ap; }
-        else if (nm == "pi/logstd") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_aux; g.count = n.Ap; }
+        else if (l >= 0) { g.kind = 1; g.tower = tower; g.slot_off = n.slot_db[l]; g.count = n.Hp[l]; g.p_off = tower * n.par_total + n.par_b[l]; g.p_count = n.Hp[l]; }
+        else if (nm == "vf/w") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_head; g.count = n.Hp[n.L - 1]; g.p_off = n.par_total + n.par_wv; g.p_count = n.Hp[n.L - 1]; }
+        else if (nm == "vf/b") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_aux; g.count = 1; g.p_off = n.par_total + n.par_bv; g.p_count = 1; }
+        else if (nm == "pi/b") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_head; g.count = n.Ap; g.p_off = n.par_bmu; g.p_count = n.Ap; }
+        else if (nm == "pi/logstd") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_aux; g.count = n.Ap; g.p_off = n.par_ls; g.p_count = n.Ap; }
         const int nb = ru(t.prow * t.pcol, 256) / 256;
         for (int b = 0; b < nb; ++b) src[t.off_pad / 256 + b] = g;
     }
@@ -373,7 +374,7 @@ int pick_split(ppo_handle* h, int n) {
 int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     const NetDev& n = h->net;
     const int n_rb = (ta.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    ta.theta = h->theta; ta.thetaT = h->thetaT; ta.hyper = h->hyper;
+    ta.theta = h->theta; ta.thetaT = h->thetaT; ta.par = h->par; ta.hyper = h->hyper;
     ta.x0g = h->x0g; ta.dmug = h->dmug;
 #ifdef PPO_STAMPS
     if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
@@ -423,7 +424,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     }
     {
         ProfScope ps(h, PK_ADAM);
-        AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->grad_src, h->hyper, h->beta_pow,
+        AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
                     h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out};
         hipLaunchKernelGGL(adam_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, aa);
         HIP_OK(h, hipGetLastError());
@@ -509,7 +510,7 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
     if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return bail(0); }
     const size_t P = (size_t)h->P_pad;
-    if (dev_alloc(h, &h->thetaT, (size_t)h->PT) || dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||
+    if (dev_alloc(h, &h->par, (size_t)2 * h->net.par_total) || dev_alloc(h, &h->thetaT, (size_t)h->PT) || dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||
         dev_alloc(h, &h->sumsq, (size_t)h->n_blocks) || dev_alloc(h, &h->beta_pow, 4) || dev_alloc(h, &h->hyper, 2) ||
         dev_alloc(h, &h->norm_out, 1) || dev_alloc(h, &h->st_loss, 8))
         return bail(0);
@@ -526,7 +527,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->upd_graph) (void)hipGraphExecDestroy(h->upd_graph);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
-    void* ptrs[] = {h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
+    void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
                     h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->ro_obs, h->ro_act,
                     h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->cur_obs, h->cur_done, h->raw_obs, h->raw_rew, h->raw_done,
@@ -571,7 +572,7 @@ int ppo_set_tensor(ppo_handle* h, int which, int index, const float* src, int64_
     HIP_OK(h, hipStreamSynchronize(h->stream));
     if (copy_tensor(h, base, t, const_cast<float*>(src), true)) return -1;
     if (which == 0) {
-        hipLaunchKernelGGL(transpose_refresh_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->theta, h->thetaT, h->grad_src);
+        hipLaunchKernelGGL(transpose_refresh_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->theta, h->thetaT, h->par, h->grad_src);
         HIP_OK(h, hipGetLastError());
     }
     return 0;
@@ -653,7 +654,7 @@ static int step_common(ppo_handle* h, const float* obs, int n, const float* nois
     HIP_OK(h, hipMemcpyAsync(h->st_obs, obs, (size_t)n * net.O * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (noise) HIP_OK(h, hipMemcpyAsync(h->st_noise, noise, (size_t)n * net.A * sizeof(float), hipMemcpyHostToDevice, h->stream));
     StepArgs a{};
-    a.theta = h->theta; a.obs = h->st_obs; a.noise = noise ? h->st_noise : nullptr;
+    a.theta = h->theta; a.par = h->par; a.obs = h->st_obs; a.noise = noise ? h->st_noise : nullptr;
     a.action = (sample && action) ? h->st_act : nullptr;
     a.det_action = det_action ? h->st_act : nullptr;
     a.value = value ? h->st_vec[0] : nullptr;
@@ -863,7 +864,7 @@ static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uin
     HIP_OK(h, hipMemcpyAsync(h->ro_obs + t * E * n.O, h->cur_obs, E * n.O * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     HIP_OK(h, hipMemcpyAsync(h->ro_done + t * E, h->cur_done, E * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     StepArgs a{};
-    a.theta = h->theta; a.obs = h->cur_obs; a.noise = noise_dev; a.action = h->ro_act + t * E * n.A; a.det_action = nullptr;
+    a.theta = h->theta; a.par = h->par; a.obs = h->cur_obs; a.noise = noise_dev; a.action = h->ro_act + t * E * n.A; a.det_action = nullptr;
     a.value = h->ro_val + t * E; a.neglogp = h->ro_nlp + t * E; a.obs_out = nullptr; a.nz = no_norm(); a.n = (int)E;
     a.seed = seed; a.rng_step = rng_step; a.row_base = row_base;
     return launch_step(h, a);
@@ -871,7 +872,7 @@ static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uin
 
 static int enqueue_finish(ppo_handle* h, float gamma, float lam) {
     StepArgs a{};
-    a.theta = h->theta; a.obs = h->cur_obs; a.value = h->last_val; a.nz = no_norm(); a.n = h->E;
+    a.theta = h->theta; a.par = h->par; a.obs = h->cur_obs; a.value = h->last_val; a.nz = no_norm(); a.n = h->E;
     if (launch_step(h, a)) return -1;
     ProfScope ps(h, PK_GAE);
     hipLaunchKernelGGL(gae_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, h->ro_rew, h->ro_val, h->ro_done, h->last_val, h->cur_done,

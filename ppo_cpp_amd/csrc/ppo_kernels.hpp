@@ -97,20 +97,22 @@ __device__ __forceinline__ float ctr_normal(uint32_t seed, uint32_t row, uint32_
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
 }
 
-// tanh with ~3 ulp error and ~14 instructions: odd Taylor polynomial near 0 (no cancellation), 1 - 2/(e^{2|x|}+1)
-// elsewhere on the hardware exp2 / rcp units.  (ocml tanhf costs ~100 instructions per element.)
+// tanh on the hardware exp2 / rcp units: 1 - 2/(e^{2|x|}+1) with the sign restored, and the odd Taylor polynomial for
+// |x| < 1/16 where that form would cancel.  Absolute error <= 2 ulp of 1.0 (~1.2e-7) everywhere, ~10 instructions
+// (ocml tanhf costs ~100 per element; a 256-wide layer epilogue has 16 per lane).
 __device__ __forceinline__ float fast_tanh(float x) {
     const float ax = fabsf(x);
     const float x2 = x * x;
-    float p = fmaf(x2, 0.021869488536155203f, -0.053968253968253971f);     // 62/2835, -17/315
-    p = fmaf(x2, p, 0.13333333333333333f);                                   // 2/15
-    p = fmaf(x2, p, -0.33333333333333333f);
-    p = fmaf(x2 * x, p, x);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);        // e^{2|x|}
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    const float big = copysignf(t, x);
-    return ax < 0.2f ? p : big;
+    const float p = fmaf(x2 * x, fmaf(x2, 0.13333333333333333f, -0.33333333333333333f), x);   // x - x^3/3 + 2x^5/15
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);                          // e^{2|x|}
+    const float t = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f), x);
+    return ax < 0.0625f ? p : t;
 }
+
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also fences global memory, i.e. emits s_waitcnt vmcnt(0):
+// it would drain the weight prefetch that was just issued for the NEXT layer and wait for this layer's activation
+// stores (which only the next kernel reads).  LDS traffic is ordered by lgkmcnt alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // reduce over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float group16_sum(float v) {
@@ -136,6 +138,9 @@ __device__ __forceinline__ float group16_sum(float v) {
 // of a layer is loaded by dense_prefetch() BEFORE the previous layer's epilogue and barrier (weights do not depend
 // on activations), which takes one L2 round trip per layer off the critical path.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef PPO_STAMP_LAYER
+#define PPO_STAMP_LAYER 1
+#endif
 #ifdef PPO_STAMPS
 #define DSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -214,6 +219,9 @@ __device__ __forceinline__ void load_w_rows(WFrag<CT, KS>& w, const float* __res
         }
 }
 
+#ifndef PPO_INTERLEAVE
+#define PPO_INTERLEAVE 1
+#endif
 #ifndef PPO_RING
 #define PPO_RING 3                  // register stages in flight per wave: PPO_RING-1 stages (each 16*KS k deep) ahead
 #endif
@@ -230,10 +238,8 @@ __device__ __forceinline__ void dense_prefetch(WRing<CT, KS>& w, const float* W,
     if (n0 >= Np) n0 = 0;
     const WOff<KS> off = make_woff<KS>(ldw, lane >> 4, n0 + CT * (lane & 15));
 #pragma unroll
-    for (int i = 0; i < PPO_RING - 1; ++i) {
-        const int kb = (i * 16 * KS < K) ? i * 16 * KS : K - 16 * KS;
-        load_w_stage<CT, KS>(w.s[i], W + (size_t)kb * ldw, off);
-    }
+    for (int i = 0; i < PPO_RING - 1; ++i)
+        if (i * 16 * KS < K) load_w_stage<CT, KS>(w.s[i], W + (size_t)(i * 16 * KS) * ldw, off);
 }
 
 enum { EP_BIAS_TANH = 0, EP_TANHGRAD = 1 };
@@ -269,7 +275,6 @@ __device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int
                 }
             }
         };
-        auto clampk = [&](int kb) __attribute__((always_inline)) { return kb < K ? kb : K - KB; };
         // the A operand (this tile's activations, LDS) travels in the same ring as the weights: read PPO_RING-1 stages
         // ahead of its MFMAs, so no LDS latency sits between matrix instructions
         auto load_a = [&](WFrag<CT, KS>& wf, int kb) __attribute__((always_inline)) {
@@ -279,22 +284,53 @@ __device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int
         const WOff<KS> off = make_woff<KS>(ldw, g, col);
         if (!first) {
 #pragma unroll
-            for (int i = 0; i < PPO_RING - 1; ++i) load_w_stage<CT, KS>(w.s[i], W + (size_t)clampk(i * KB) * ldw, off);
+            for (int i = 0; i < PPO_RING - 1; ++i)
+                if (i * KB < K) load_w_stage<CT, KS>(w.s[i], W + (size_t)(i * KB) * ldw, off);
         }
 #pragma unroll
-        for (int i = 0; i < PPO_RING - 1; ++i) load_a(w.s[i], clampk(i * KB));
+        for (int i = 0; i < PPO_RING - 1; ++i)
+            if (i * KB < K) load_a(w.s[i], i * KB);
         first = false;
-        // ring of PPO_RING named register stages (compile-time indices, no copies); every load is unconditional with a
-        // clamped address so the compiler waits with counted vmcnt; sched_barrier pins the loads above the MFMAs
-        for (int kb = 0; kb < K; kb += PPO_RING * KB) {
+        // ring of PPO_RING named register stages (compile-time indices, no copies).  Steady state: whole rounds of
+        // PPO_RING steps whose loads are all in range and UNCONDITIONAL, so the compiler waits with counted vmcnt;
+        // sched_barrier pins each step's loads above its MFMAs.  The tail (at most 2*PPO_RING-2 steps) is straight-
+        // line code that issues only the loads that exist: no stage is fetched twice.
+        int kb = 0;
+        for (; kb + (2 * PPO_RING - 1) * KB <= K; kb += PPO_RING * KB) {
 #pragma unroll
             for (int i = 0; i < PPO_RING; ++i) {
                 DSTAMP(4 + (kb / KB + i < 11 ? kb / KB + i : 11));
-                const int kn = clampk(kb + (i + PPO_RING - 1) * KB);                  // wave-uniform
+                const int kn = kb + (i + PPO_RING - 1) * KB;                          // wave-uniform, < K
+                __builtin_amdgcn_sched_barrier(0);
                 load_a(w.s[(i + PPO_RING - 1) % PPO_RING], kn);
                 load_w_stage<CT, KS>(w.s[(i + PPO_RING - 1) % PPO_RING], W + (size_t)kn * ldw, off);
+#if PPO_INTERLEAVE
+                compute(w.s[i]);
+                // one weight load after every CT matrix instructions: the wave never sits in a burst of VMEM issue
+                // while its MFMA pipe runs dry (the loads are for stage i+RING-1, independent of these MFMAs)
+                __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
+#pragma unroll
+                for (int t = 0; t < 4 * KS; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#else
                 __builtin_amdgcn_sched_barrier(0);
-                if (kb + i * KB < K) compute(w.s[i]);
+                compute(w.s[i]);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * PPO_RING - 2; ++i) {
+            if (kb + i * KB < K) {
+                const int kn = kb + (i + PPO_RING - 1) * KB;
+                if (kn < K) {
+                    load_a(w.s[(i + PPO_RING - 1) % PPO_RING], kn);
+                    load_w_stage<CT, KS>(w.s[(i + PPO_RING - 1) % PPO_RING], W + (size_t)kn * ldw, off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                compute(w.s[i % PPO_RING]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -373,7 +409,7 @@ __device__ __forceinline__ void head_splitk(WFrag<CTH, HEAD_KS>& w, const float*
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int j = 0; j < CTH; ++j) mine[(4 * g + r) * Ap + CTH * c + j] = acc[j][r];
-    __syncthreads();
+    lds_barrier();
     for (int i = threadIdx.x; i < ROWS_PER_BLOCK * Ap; i += BLOCK_THREADS) {
         const int row = i / Ap, col = i - row * Ap;
         const float sum = ((scratch[i] + scratch[ROWS_PER_BLOCK * Ap + i]) + scratch[2 * ROWS_PER_BLOCK * Ap + i]) + scratch[3 * ROWS_PER_BLOCK * Ap + i];
@@ -408,44 +444,89 @@ __device__ __forceinline__ float value_head(const float* Hs, int ldh, int Kp, co
     return s + bv;
 }
 
-// stage a 16-row input tile (gathered rows, optional running-stat normalisation) into LDS, zero padded
 struct ObsNorm { const float* mean; const float* var; float eps; float clip; int enabled; };
 
-__device__ __forceinline__ void stage_obs_tile(float* Xs, int ldx, int Kp0, int O, const float* __restrict__ obs,
-                                               const int* __restrict__ rowidx, int row0, int nrows, ObsNorm nz,
-                                               float* __restrict__ obs_out, float* __restrict__ x0g, int ldxg) {
-    for (int i = threadIdx.x; i < ROWS_PER_BLOCK * Kp0; i += BLOCK_THREADS) {
-        const int r = i / Kp0, j = i - r * Kp0;
-        const int row = row0 + r;
-        float x = 0.f;
+// Block prologue: everything a 16-row block reads that is not a weight matrix -- its input rows, the small parameters
+// (biases, logstd, value head; a contiguous per-tower mirror `par_src` kept current by the Adam kernel) and, for the
+// train kernel, the rows' actions and scalars -- is fetched with ALL loads issued before the first LDS store, i.e. in
+// ONE memory round trip (separate load->store loops cost one dependent round trip each, ~1 us apiece, and each wait
+// also drains the in-order queue behind the weight prefetch).
+struct RowScalars { const float* actions; const float* v0a; const float* v0b; const float* v1; const float* stats; int mode; };
+// mode 0: none ; 1 (policy): v0 = advs[src] (v0b null) or ((v0a - v0b) - stats[0]) / stats[1], v1 = old_neglogp
+// mode 2 (value) : v0 = returns, v1 = old_values
+
+__device__ __forceinline__ void stage_block_inputs(const NetDev& net, const float* __restrict__ par_src, float* par, float* Xs, int ldx,
+                                                   const float* __restrict__ obs, const int* __restrict__ rowidx, int row0, int nrows,
+                                                   ObsNorm nz, float* __restrict__ obs_out, float* __restrict__ x0g, RowScalars rs,
+                                                   float* acts, float* rowv) {
+    const int tid = threadIdx.x;
+    const int Kp0 = net.Kp0, O = net.O, A = net.A, Ap = net.Ap;
+    constexpr int PK = 4, OK = 2, AK = 2;
+    float pv[PK], ov[OK], av[AK], r0 = 0.f, r1 = 0.f, r2 = 0.f, s0 = 0.f, s1 = 1.f;
+    // ---- issue every load -----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < PK; ++k) { const int i = tid + BLOCK_THREADS * k; pv[k] = i < net.par_total ? par_src[i] : 0.f; }
+#pragma unroll
+    for (int k = 0; k < OK; ++k) {
+        const int i = tid + BLOCK_THREADS * k;
+        const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
+        ov[k] = 0.f;
+        if (i < ROWS_PER_BLOCK * Kp0 && row < nrows && j < O) ov[k] = obs[(size_t)(rowidx ? rowidx[row] : row) * O + j];
+    }
+    if (rs.mode == 1) {
+#pragma unroll
+        for (int k = 0; k < AK; ++k) {
+            const int i = tid + BLOCK_THREADS * k;
+            const int r = i / Ap, j = i - r * Ap, row = row0 + r;
+            av[k] = 0.f;
+            if (i < ROWS_PER_BLOCK * Ap && row < nrows && j < A) av[k] = rs.actions[(size_t)(rowidx ? rowidx[row] : row) * A + j];
+        }
+    }
+    if (rs.mode && tid < ROWS_PER_BLOCK && row0 + tid < nrows) {
+        const int src = rowidx ? rowidx[row0 + tid] : row0 + tid;
+        r0 = rs.v0a[src]; r2 = rs.v1[src];
+        if (rs.v0b) { r1 = rs.v0b[src]; s0 = rs.stats[0]; s1 = rs.stats[1]; }
+    }
+    // ---- consume ---------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < PK; ++k) { const int i = tid + BLOCK_THREADS * k; if (i < net.par_total) par[i] = pv[k]; }
+    for (int i = tid + BLOCK_THREADS * PK; i < net.par_total; i += BLOCK_THREADS) par[i] = par_src[i];
+    auto put_obs = [&](int i, float x) __attribute__((always_inline)) {
+        const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
         if (row < nrows && j < O) {
-            const int src = rowidx ? rowidx[row] : row;
-            x = obs[(size_t)src * O + j];
-            if (nz.enabled) {
-                // env_normalize.hpp:99-104: (x - mean) * 1/sqrt(var + eps), then clamp
+            if (nz.enabled) {        // env_normalize.hpp:99-104: (x - mean) * 1/sqrt(var + eps), then clamp
                 x = (x - nz.mean[j]) * (1.0f / sqrtf(nz.var[j] + nz.eps));
                 x = tf_min(tf_max(x, -nz.clip), nz.clip);
             }
             if (obs_out) obs_out[(size_t)row * O + j] = x;
         }
         Xs[r * ldx + j] = x;
-        if (x0g && row < nrows) x0g[(size_t)row * ldxg + j] = x;
+        if (x0g && row < nrows) x0g[(size_t)row * Kp0 + j] = x;
+    };
+#pragma unroll
+    for (int k = 0; k < OK; ++k) { const int i = tid + BLOCK_THREADS * k; if (i < ROWS_PER_BLOCK * Kp0) put_obs(i, ov[k]); }
+    for (int i = tid + BLOCK_THREADS * OK; i < ROWS_PER_BLOCK * Kp0; i += BLOCK_THREADS) {
+        const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
+        float x = 0.f;
+        if (row < nrows && j < O) x = obs[(size_t)(rowidx ? rowidx[row] : row) * O + j];
+        put_obs(i, x);
     }
-}
-
-// biases, logstd and the value head are read in epilogues / loss code: staging them in LDS at kernel start keeps
-// dependent L2 round trips (which would also drain the in-order vmcnt queue of weight prefetches) off those paths
-__device__ __forceinline__ void stage_small_params(const NetDev& net, const float* __restrict__ theta, int tower, float* par) {
-    for (int l = 0; l < net.L; ++l)
-        for (int i = threadIdx.x; i < net.Hp[l]; i += BLOCK_THREADS) par[net.par_b[l] + i] = theta[net.b_off[tower][l] + i];
-    if (tower == 0) {
-        for (int i = threadIdx.x; i < net.Ap; i += BLOCK_THREADS) {
-            par[net.par_bmu + i] = theta[net.bmu_off + i];
-            par[net.par_ls + i] = theta[net.ls_off + i];
+    if (rs.mode == 1) {
+#pragma unroll
+        for (int k = 0; k < AK; ++k) { const int i = tid + BLOCK_THREADS * k; if (i < ROWS_PER_BLOCK * Ap) acts[i] = av[k]; }
+        for (int i = tid + BLOCK_THREADS * AK; i < ROWS_PER_BLOCK * Ap; i += BLOCK_THREADS) {
+            const int r = i / Ap, j = i - r * Ap, row = row0 + r;
+            float x = 0.f;
+            if (row < nrows && j < A) x = rs.actions[(size_t)(rowidx ? rowidx[row] : row) * A + j];
+            acts[i] = x;
         }
-    } else {
-        for (int i = threadIdx.x; i < net.Hp[net.L - 1]; i += BLOCK_THREADS) par[net.par_wv + i] = theta[net.wv_off + i];
-        if (threadIdx.x == 0) par[net.par_bv] = theta[net.bv_off];
+    }
+    if (rs.mode && tid < ROWS_PER_BLOCK) {
+        float v0 = r0;
+        if (rs.v0b) v0 = ((r0 - r1) - s0) / s1;                                  // ppo2.hpp:401-406
+        const bool live = row0 + tid < nrows;
+        rowv[2 * tid] = live ? v0 : 0.f;
+        rowv[2 * tid + 1] = live ? r2 : 0.f;
     }
 }
 
@@ -470,7 +551,7 @@ __device__ __forceinline__ void policy_head(const NetDev& net, const float* __re
     const int ldm = net.Ap + LDS_PAD;
     if constexpr (CTH > 0) head_splitk<CTH>(hpre.w, theta + net.wmu_off, lds + net.lds_par + net.par_bmu, hL, ldh, K, net.Ap, lds + net.lds_head, mus, ldm);
     else head_generic(theta + net.wmu_off, lds + net.lds_par + net.par_bmu, hL, ldh, K, net.Ap, mus, ldm);
-    __syncthreads();
+    lds_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -478,6 +559,7 @@ __device__ __forceinline__ void policy_head(const NetDev& net, const float* __re
 // ------------------------------------------------------------------------------------------------------------
 struct StepArgs {
     const float* theta;
+    const float* par;        // small-parameter mirror [2][par_total]
     const float* obs;        // [n,O] raw or already normalised
     const float* noise;      // [n,A] or null -> counter RNG (seed, rng_step)
     float* action;           // [n,A] (null: skip)   -- sampled action
@@ -502,10 +584,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
     HeadFrag<CTH> hpre;
     dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
     float* par = lds + net.lds_par;
-    stage_small_params(net, a.theta, tower, par);
-    stage_obs_tile(lds + net.lds_h[0], ld0, net.Kp0, net.O, a.obs, nullptr, row0, a.n, a.nz,
-                   tower == 0 ? a.obs_out : nullptr, nullptr, 0);
-    __syncthreads();
+    stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, nullptr, row0, a.n, a.nz,
+                       tower == 0 ? a.obs_out : nullptr, nullptr, RowScalars{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, nullptr);
+    lds_barrier();
     int K = net.Kp0, ldx = ld0;
     for (int l = 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
@@ -514,7 +595,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
                                              if (l + 1 < net.L) dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][l + 1], net.Hp[l + 1], net.Hp[l + 1], Np);
                                              else if constexpr (CTH > 0) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, Np);   // (both towers: uniform code)
                                          });
-        __syncthreads();
+        lds_barrier();
         K = Np; ldx = ldy;
     }
     const float* hL = lds + net.lds_h[net.L];
@@ -559,6 +640,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
 struct TrainArgs {
     const float* theta;
     const float* thetaT;         // transposed copies of the matrices the backward pass streams (kept by adam_kernel)
+    const float* par;            // small-parameter mirror [2][par_total] (kept by adam_kernel)
     // minibatch sources; rowidx (null = identity) maps minibatch row -> source row
     const float* obs; const float* actions; const float* returns; const float* old_values; const float* old_neglogp;
     const float* advs;           // explicit normalised advantages (indexed like the others) or null
@@ -593,34 +675,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     HeadFrag<CTH> hpre;
     dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
     float* par = lds + net.lds_par;
-    stage_small_params(net, a.theta, tower, par);
     ObsNorm nz = {nullptr, nullptr, 0.f, 0.f, 0};
-    stage_obs_tile(lds + net.lds_h[0], ld0, net.Kp0, net.O, a.obs, a.rowidx, row0, a.n, nz, nullptr,
-                   tower == 0 ? a.x0g : nullptr, net.Kp0);
-    // everything else a row needs is fetched now, under the first layer, instead of at the loss
-    if (tower == 0) {
-        for (int i = tid; i < ROWS_PER_BLOCK * net.Ap; i += BLOCK_THREADS) {
-            const int r = i / net.Ap, j = i - r * net.Ap;
-            const int row = row0 + r;
-            float x = 0.f;
-            if (row < a.n && j < net.A) x = a.actions[(size_t)(a.rowidx ? a.rowidx[row] : row) * net.A + j];
-            acts[i] = x;
-        }
-    }
-    if (tid < ROWS_PER_BLOCK) {
-        const int row = row0 + tid;
-        float v0 = 0.f, v1 = 0.f;
-        if (row < a.n) {
-            const int src = a.rowidx ? a.rowidx[row] : row;
-            if (tower == 0) {
-                v1 = a.old_neglogp[src];
-                if (a.advs) v0 = a.advs[src];
-                else v0 = ((a.returns[src] - a.old_values[src]) - a.adv_stats[0]) / a.adv_stats[1];
-            } else { v0 = a.returns[src]; v1 = a.old_values[src]; }
-        }
-        rowv[2 * tid] = v0; rowv[2 * tid + 1] = v1;
-    }
-    __syncthreads();
+    RowScalars rs;
+    if (tower == 0) rs = RowScalars{a.actions, a.advs ? a.advs : a.returns, a.advs ? nullptr : a.old_values, a.old_neglogp, a.adv_stats, 1};
+    else rs = RowScalars{nullptr, a.returns, nullptr, a.old_values, nullptr, 2};
+    stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, a.rowidx, row0, a.n, nz, nullptr,
+                       tower == 0 ? a.x0g : nullptr, rs, acts, rowv);
+    lds_barrier();
     STAMP(1);
     // ---- forward (G:6889-9187) -------------------------------------------------------------------------------
     int K = net.Kp0, ldx = ld0;
@@ -635,10 +696,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
                                              }
                                          }
 #ifdef PPO_STAMPS
-                                         , a.stamps ? (l == 1 ? a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 : nullptr) : nullptr
+                                         , a.stamps ? (l == PPO_STAMP_LAYER ? a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 : nullptr) : nullptr
 #endif
                                          );
-        __syncthreads();
+        lds_barrier();
         STAMP(2 + l);
         K = Np; ldx = ldy;
     }
@@ -705,7 +766,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
             dls[r * net.Ap + j] = dl;
             if (live) a.dmug[(size_t)row * net.Ap + j] = dmu;
         }
-        __syncthreads();
+        lds_barrier();
         // per-block partial sums: db_mu, dlogstd (over the 16 rows, fixed order), loss terms
         for (int j = tid; j < net.Ap; j += BLOCK_THREADS) {
             float sb = 0.f, sl = 0.f;
@@ -724,7 +785,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
                                         a.dyg[0][net.L - 1], HpL, row0, a.n, [&]() __attribute__((always_inline)) {
                                             if (net.L > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[0][net.L - 1], net.Hp[net.L - 2], net.Hp[net.L - 2], HpL);
                                         });
-        __syncthreads();
+        lds_barrier();
     } else {
         // ---- value head + clipped value loss (G:10213-10837) and its gradient (G:14975-19571) ---------------
         const float* wv = par + net.par_wv;
@@ -744,7 +805,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
             dv = gv * selv * (2.0f * e1) + gv * (1.0f - selv) * (2.0f * e2) * passv;           // AddN_1 G:19571
         }
         if (part == 0) { misc[r] = dv; misc[16 + r] = lossv; }
-        __syncthreads();
+        lds_barrier();
         STAMP(7);
         if (tid == 0) {
             float sb = 0.f, sl = 0.f;
@@ -766,7 +827,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
                 if (row0 + q < a.n) a.dyg[1][net.L - 1][(size_t)(row0 + q) * HpL + k] = d;
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     STAMP(8);
     // ---- hidden layers, top down: dnext holds dLoss/d(pre-activation of layer l) -------------------------------
@@ -786,7 +847,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
                                                 if (l > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[tower][l - 1], net.Hp[l - 2], net.Hp[l - 2], Kp);
                                             });
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(9 + (net.L - 1 - l));
     }
 }
@@ -949,7 +1010,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
 // Also emits the block's sum of squares for the global norm, and (last block) the five loss scalars.
 // ------------------------------------------------------------------------------------------------------------
 struct GradSrc { int kind; int tower; int slot_off; int count; int base;   // base = first element of the tensor
-                 int t_off, prow, pcol; };                                   // transposed copy: thetaT[t_off + c*prow + r], t_off < 0: none
+                 int t_off, prow, pcol;                                       // transposed copy: thetaT[t_off + c*prow + r], t_off < 0: none
+                 int p_off, p_count; };                                       // small-parameter mirror: par[p_off + e], e < p_count ; p_off < 0: none
 
 struct ReduceArgs {
     const GradSrc* src;          // [n_blocks]
@@ -1014,12 +1076,12 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
 }
 
 // rebuild every transposed copy from theta (after parameters were written from the host)
-__global__ __launch_bounds__(256) void transpose_refresh_kernel(const float* theta, float* thetaT, const GradSrc* src) {
+__global__ __launch_bounds__(256) void transpose_refresh_kernel(const float* theta, float* thetaT, float* par, const GradSrc* src) {
     const GradSrc gs = src[blockIdx.x];
-    if (gs.t_off < 0) return;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int e = (int)(idx - (size_t)gs.base);
-    if (e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; thetaT[gs.t_off + c * gs.prow + r] = theta[idx]; }
+    if (gs.t_off >= 0 && e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; thetaT[gs.t_off + c * gs.prow + r] = theta[idx]; }
+    if (gs.p_off >= 0 && e < gs.p_count) par[gs.p_off + e] = theta[idx];
 }
 
 // after a cross-rank all-reduce of grad the per-block sums of squares must be recomputed
@@ -1041,7 +1103,7 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* grad, floa
 // ------------------------------------------------------------------------------------------------------------
 struct AdamArgs {
     float* theta; float* m; float* v; const float* grad; const float* sumsq; int n_blocks;
-    float* thetaT; const GradSrc* src;
+    float* thetaT; float* par; const GradSrc* src;
     const float* hyper;          // {lr, cliprange}
     float* beta_pow;             // {cur b1, cur b2, next b1, next b2}
     float beta1, beta2, eps, max_norm;
@@ -1077,6 +1139,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         const int e = (int)(idx - (size_t)gs.base);
         if (e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; a.thetaT[gs.t_off + c * gs.prow + r] = th; }
     }
+    if (gs.p_off >= 0) { const int e = (int)(idx - (size_t)gs.base); if (e < gs.p_count) a.par[gs.p_off + e] = th; }
     if (blockIdx.x == 0) {
         if (tid == 0) {
             a.beta_pow[2] = b1p * a.beta1;                                      // G:31217-31342 (after the applies)

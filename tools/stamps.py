@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "ppo_cpp_amd", "libppo_hip.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                       "-DPPO_STAMPS", "-o", so, os.path.join(ROOT, "ppo_cpp_amd/csrc/ppo_hip.hip"), "-ldl"])
+                       "-DPPO_STAMPS", "-DPPO_STAMP_LAYER=" + os.environ.get("STAMP_LAYER", "1"), "-o", so, os.path.join(ROOT, "ppo_cpp_amd/csrc/ppo_hip.hip"), "-ldl"])
 import ppo_cpp_amd
 g = ppo_cpp_amd.PPOHip(18, 18, [256, 256]); g.init_orthogonal(0)
 n = 2048; rng = np.random.RandomState(0)
@@ -15,19 +15,23 @@ for _ in range(5): g.train_step(3e-4, 0.16, obs, a, adv, ret, nlp, v)
 buf = np.zeros(256 * 32, np.uint64)
 g.lib.ppo_debug_read_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size)
 st = buf.reshape(256, 32).astype(np.int64)
-t0 = st[:, 0].min()
+labels = [(0, 1, "prologue (stage)"), (1, 2, "fwd L0"), (2, 3, "fwd L1"), (3, 6, "pi head fwd"), (6, 7, "pi loss"), (3, 7, "vf head+loss"), (7, 8, "head bwd"),
+          (8, 9, "bwd L1 (dX)"), (9, 10, "bwd L0 (db)")]
 for tower in (0, 1):
     blk = st[tower * 128:(tower + 1) * 128]
-    print("tower", tower, "kernel cycles median", np.median(blk[:, 10] - blk[:, 0]))
-    seq = [16, 20, 21, 22, 23, 24, 25, 26, 27, 28, 17, 18, 19]
-    names = ["entry", "st0", "st1", "st2", "st3", "st4", "st5", "st6", "st7", "st8(tail)", "loop end", "between done", "epilogue done"]
+    print("tower", tower, "kernel cycles median", np.median(blk[:, 10] - blk[:, 0]), "max", (blk[:, 10] - blk[:, 0]).max())
+    for i, j, name in labels:
+        if (blk[:, i] > 0).all() and (blk[:, j] > 0).all():
+            d = blk[:, j] - blk[:, i]
+            print("   %-18s median %7.0f  max %7.0f" % (name, np.median(d), d.max()))
+    seq = [16, 20, 21, 22, 23, 24, 25, 26, 27, 17, 18, 19]
+    names = ["L1 entry", "st0", "st1", "st2", "st3", "st4", "st5", "st6", "st7", "loop end", "between done", "epilogue done"]
     prev = None
     for idx, nm in zip(seq, names):
         if (blk[:, idx] > 0).all():
-            if prev is not None: print("   %-14s +%6.0f (max %6.0f)" % (nm, np.median(blk[:, idx] - blk[:, prev]), (blk[:, idx] - blk[:, prev]).max()))
+            if prev is not None: print("      %-14s +%6.0f" % (nm, np.median(blk[:, idx] - blk[:, prev])))
             prev = idx
-
-buf = np.zeros(352 * 8 * 8, np.uint64)
+buf = np.zeros(256 * 8, np.uint64)
 g.lib.ppo_debug_read_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), -buf.size)
 sb = buf.reshape(-1, 8).astype(np.int64)
 big = sb[(sb[:, 4] > 0)]
