@@ -152,6 +152,12 @@ def main():
     kern = {k: {"avg_us": 1e3 * ms / n, "launches": n} for k, (ms, n) in prof.items() if n}
     dom = max((k for k in kern if k in kflops), key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
     ach = kflops[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if args.config == "cfg3" and os.path.exists(tpath):          # PMC passes cannot run inside the timed process: measured offline
+        t = json.load(open(tpath))["kernels"].get(dom)
+        if t:
+            traffic = (2.0 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024.0
     step_flops = (f_fwd + f_dx + f_dw) * M
     step_us = sum(kern[k]["avg_us"] for k in ("train_fwd_bwd", "weight_grad", "grad_reduce", "adam") if k in kern)
     out = {
@@ -164,7 +170,7 @@ def main():
         "update_samples_per_s": world * ep * B / (t_c - t_b),
         "phase_ms": {"collect": 1e3 * (t_b - t_a), "update": 1e3 * (t_c - t_b)},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                      "flop_per_launch": kflops[dom], "avg_us": kern[dom]["avg_us"],
                      "train_step": {"flop": step_flops, "kernel_us_sum": step_us,
                                     "achieved": step_flops / (step_us * 1e-6) / 1e12 if step_us else None}},
