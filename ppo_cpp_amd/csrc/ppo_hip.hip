@@ -1055,7 +1055,10 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     }
     HIP_OK(h, hipMemcpyAsync(h->d_keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     // hipGraph replay of the whole update; RCCL calls and event-bracketed profiling run eagerly
-    const bool graph_ok = h->use_graph && !h->prof && !h->comm;
+    // With a communicator the sequence runs eagerly by default (the host enqueues a step faster than the GPU runs it);
+    // PPO_HIP_GRAPH_RCCL=1 opts into capturing the ncclAllReduce calls as well.
+    static const bool graph_rccl = [] { const char* e = getenv("PPO_HIP_GRAPH_RCCL"); return e && e[0] == '1'; }();
+    const bool graph_ok = h->use_graph && !h->prof && (!h->comm || graph_rccl);
     if (graph_ok) {
         const bool same = h->upd_graph && h->g_epochs == epochs && h->g_nmb == nmb && h->g_E == h->E && h->g_T == h->T &&
                           h->g_explicit == (int)explicit_perms && h->g_world == h->world;
