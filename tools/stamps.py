@@ -7,7 +7,8 @@ so = os.path.join(ROOT, "ppo_cpp_amd", "libppo_hip.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                        "-DPPO_STAMPS", "-DPPO_STAMP_LAYER=" + os.environ.get("STAMP_LAYER", "1"), "-o", so, os.path.join(ROOT, "ppo_cpp_amd/csrc/ppo_hip.hip"), "-ldl"])
 import ppo_cpp_amd
-g = ppo_cpp_amd.PPOHip(18, 18, [256, 256]); g.init_orthogonal(0)
+H = [int(x) for x in os.environ.get("HIDDEN", "256,256").split(",")]
+g = ppo_cpp_amd.PPOHip(18, 18, H); g.init_orthogonal(0)
 n = 2048; rng = np.random.RandomState(0)
 obs = rng.uniform(-1, 1, (n, 18)).astype(np.float32); a, v, nlp = g.step(obs, rng.normal(size=(n, 18)).astype(np.float32))
 ret = (v + rng.normal(size=n)).astype(np.float32); adv = g.adv_normalize(ret, v)
