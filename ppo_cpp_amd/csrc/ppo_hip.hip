@@ -90,6 +90,8 @@ struct ppo_handle {
     float nz_gamma = 0.99f, nz_clip_obs = 10.f, nz_clip_rew = 10.f, nz_eps = 1e-8f;
     NormDev obs_rms{}, ret_rms{};
     float* nz_ret = nullptr;
+    float* stats_xch = nullptr;       // [2*D+1] cross-rank batch moments (data-parallel running statistics)
+    float* adv_xch = nullptr;         // [2*nminibatches] cross-rank advantage sums
     // rollout
     int E = 0, T = 0;
     float *ro_obs = nullptr, *ro_act = nullptr, *ro_val = nullptr, *ro_nlp = nullptr, *ro_done = nullptr, *ro_rew = nullptr,
@@ -529,7 +531,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
-                    h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->ro_obs, h->ro_act,
+                    h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->stats_xch, h->adv_xch, h->ro_obs, h->ro_act,
                     h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->cur_obs, h->cur_done, h->raw_obs, h->raw_rew, h->raw_done,
                     h->last_val, h->ro_noise, h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp, h->d_perms, h->d_inv, h->d_gidx, h->d_advstats, h->d_keys, h->d_loss_rows, h->d_loss_mean};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -758,23 +760,53 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
     if (h->net.O > STATS_THREADS) return fail(h, "ppo_norm_init: obs_dim > %d unsupported", STATS_THREADS);
     h->nz_envs = n_envs; h->nz_gamma = gamma; h->nz_clip_obs = clip_obs; h->nz_clip_rew = clip_rew; h->nz_eps = epsilon;
     if (norm_alloc_stats(h, h->obs_rms, h->net.O) || norm_alloc_stats(h, h->ret_rms, 1)) return -1;
-    if (dev_alloc(h, &h->nz_ret, n_envs)) return -1;
+    if (dev_alloc(h, &h->nz_ret, n_envs) || dev_alloc(h, &h->stats_xch, (size_t)2 * h->net.O + 8)) return -1;
     if (dev_alloc(h, &h->raw_obs, (size_t)n_envs * h->net.O) || dev_alloc(h, &h->raw_rew, n_envs) || dev_alloc(h, &h->raw_done, n_envs)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
 // device-side pieces shared by the host-pointer API and the rollout loop
-static int enqueue_obs_stats(ppo_handle* h, const float* raw_dev, int rows) {
-    ProfScope ps(h, PK_STATS);
-    hipLaunchKernelGGL(running_stats_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, raw_dev, rows, h->net.O, h->obs_rms);
-    HIP_OK(h, hipGetLastError());
+static int allreduce_f32(ppo_handle* h, float* buf, size_t count) {
+    ProfScope ps(h, PK_COMM);
+    const int rc = h->rccl.AllReduce(buf, buf, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
+    if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
     return 0;
 }
+
+// RunningStatistics::update over the rows of ALL ranks when a communicator exists (the running statistics
+// are over all environments), else the single fused kernel
+static int enqueue_stats_update(ppo_handle* h, const float* batch_dev, int rows, int D, NormDev st) {
+    if (!h->comm) {
+        ProfScope ps(h, PK_STATS);
+        hipLaunchKernelGGL(running_stats_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, batch_dev, rows, D, st);
+        HIP_OK(h, hipGetLastError());
+        return 0;
+    }
+    for (int phase = 0; phase < 3; ++phase) {
+        { ProfScope ps(h, PK_STATS);
+          hipLaunchKernelGGL(stats_phase_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, batch_dev, rows, D, st, h->stats_xch, phase);
+          HIP_OK(h, hipGetLastError()); }
+        if (phase == 0 && allreduce_f32(h, h->stats_xch, (size_t)D + 1)) return -1;
+        if (phase == 1 && allreduce_f32(h, h->stats_xch + D + 1, (size_t)D)) return -1;
+    }
+    return 0;
+}
+static int enqueue_obs_stats(ppo_handle* h, const float* raw_dev, int rows) { return enqueue_stats_update(h, raw_dev, rows, h->net.O, h->obs_rms); }
+
 static int enqueue_reward_norm(ppo_handle* h, const float* rew_dev, const float* done_dev, int rows, int training, float* out_dev) {
-    ProfScope ps(h, PK_STATS);
-    hipLaunchKernelGGL(reward_norm_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, rew_dev, done_dev, rows, training, h->nz_gamma,
-                       h->nz_clip_rew, h->nz_eps, h->nz_ret, h->ret_rms, out_dev);
+    if (!h->comm) {
+        ProfScope ps(h, PK_STATS);
+        hipLaunchKernelGGL(reward_norm_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, rew_dev, done_dev, rows, training, h->nz_gamma,
+                           h->nz_clip_rew, h->nz_eps, h->nz_ret, h->ret_rms, out_dev);
+        HIP_OK(h, hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(ret_update_kernel, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rew_dev, rows, h->nz_gamma, h->nz_ret);
+    HIP_OK(h, hipGetLastError());
+    if (training && enqueue_stats_update(h, h->nz_ret, rows, 1, h->ret_rms)) return -1;
+    hipLaunchKernelGGL(reward_apply_kernel, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rew_dev, done_dev, rows, h->nz_clip_rew, h->nz_eps,
+                       h->nz_ret, h->ret_rms, out_dev);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -782,7 +814,6 @@ static int enqueue_reward_norm(ppo_handle* h, const float* rew_dev, const float*
 int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int training, float* out) {
     if (!h->nz_envs) return fail(h, "ppo_norm_obs: call ppo_norm_init first");
     if (n_envs != h->nz_envs) return fail(h, "ppo_norm_obs: n_envs %d != %d", n_envs, h->nz_envs);
-    if (h->world > 1) return fail(h, "ppo_norm_obs: host-pointer normaliser is single-rank; use the rollout API under ppo_dist_init");
     const size_t cnt = (size_t)n_envs * h->net.O;
     if (ensure_staging(h, n_envs)) return -1;
     HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -998,8 +1029,21 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             EpochArgs ea{};
             ea.inv_perm = explicit_perms ? h->d_inv : nullptr; ea.keys = h->d_keys + 2 * ep; ea.bits = bits;
             ea.B = B; ea.M = M; ea.T = h->T; ea.E = h->E; ea.returns = h->ro_ret; ea.values = h->ro_val; ea.gidx = h->d_gidx; ea.stats = h->d_advstats;
-            hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(256), 0, h->stream, ea);
-            HIP_OK(h, hipGetLastError());
+            ea.xch = h->adv_xch; ea.n_global = (float)((int64_t)M * h->world);
+            if (!h->comm) {
+                ea.phase = 0;
+                hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(256), 0, h->stream, ea);
+                HIP_OK(h, hipGetLastError());
+            } else {
+                // the advantage statistics are over the whole (all-rank) minibatch (ppo2.hpp:401-406)
+                for (int phase = 1; phase <= 3; ++phase) {
+                    ea.phase = phase;
+                    hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(256), 0, h->stream, ea);
+                    HIP_OK(h, hipGetLastError());
+                    if (phase == 1 && allreduce_f32(h, h->adv_xch, (size_t)nmb)) return -1;
+                    if (phase == 2 && allreduce_f32(h, h->adv_xch + nmb, (size_t)nmb)) return -1;
+                }
+            }
         }
         {
             ProfScope ps(h, PK_EPOCH);
@@ -1040,7 +1084,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
             dev_alloc(h, &h->mb_ret, cr) || dev_alloc(h, &h->mb_val, cr) || dev_alloc(h, &h->mb_nlp, cr)) return -1;
         if (dev_alloc(h, &h->d_perms, (size_t)cs * cr) || dev_alloc(h, &h->d_inv, cr) || dev_alloc(h, &h->d_gidx, cr) ||
             dev_alloc(h, &h->d_advstats, (size_t)2 * cs) || dev_alloc(h, &h->d_keys, (size_t)2 * cs) || dev_alloc(h, &h->d_loss_rows, (size_t)5 * cs) ||
-            dev_alloc(h, &h->d_loss_mean, 8))
+            dev_alloc(h, &h->d_loss_mean, 8) || dev_alloc(h, &h->adv_xch, (size_t)2 * cs))
             return -1;
         h->upd_cap_rows = cr; h->upd_cap_steps = cs;
     }

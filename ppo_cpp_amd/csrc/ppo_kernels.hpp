@@ -1181,32 +1181,53 @@ struct EpochArgs {
     const float* returns; const float* values;   // [T*E] storage order
     int* gidx;               // [B]
     float* stats;            // [B/M][2]
+    int phase;               // 0: single rank, everything ; data parallel: 1 index + local sums, 2 local squared deviations, 3 finish
+    float* xch;              // [2][B/M] partial sums all-reduced by the host between the phases
+    float n_global;          // minibatch rows over all ranks
 };
 
 __global__ __launch_bounds__(256) void epoch_prepare_kernel(EpochArgs a) {
     __shared__ float red[4];
     __shared__ float s_mean;
     const int k = blockIdx.x, tid = threadIdx.x;
+    const int nmb = a.B / a.M;
+    if (a.phase == 3) {
+        if (tid == 0) {
+            a.stats[2 * k] = a.xch[k] / a.n_global;
+            a.stats[2 * k + 1] = (float)((double)sqrtf(a.xch[nmb + k] / a.n_global) + 1e-8);
+        }
+        return;
+    }
     const uint32_t mask = (a.bits >= 32) ? 0xFFFFFFFFu : ((1u << a.bits) - 1u);
     float sum = 0.f;
-    for (int i = tid; i < a.M; i += 256) {
-        const int pos = k * a.M + i;
-        int r;
-        if (a.inv_perm) r = a.inv_perm[pos];
-        else {
-            uint32_t x = (uint32_t)pos;
-            do { x = keyed_bijection(x, a.bits, mask, a.keys[0], a.keys[1]); } while (x >= (uint32_t)a.B);
-            r = (int)x;
+    if (a.phase != 2) {
+        for (int i = tid; i < a.M; i += 256) {
+            const int pos = k * a.M + i;
+            int r;
+            if (a.inv_perm) r = a.inv_perm[pos];
+            else {
+                uint32_t x = (uint32_t)pos;
+                do { x = keyed_bijection(x, a.bits, mask, a.keys[0], a.keys[1]); } while (x >= (uint32_t)a.B);
+                r = (int)x;
+            }
+            const int s = (r % a.T) * a.E + (r / a.T);
+            a.gidx[pos] = s;
+            sum += a.returns[s] - a.values[s];
         }
-        const int s = (r % a.T) * a.E + (r / a.T);
-        a.gidx[pos] = s;
-        sum += a.returns[s] - a.values[s];
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if ((tid & 63) == 0) red[tid >> 6] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+            s_mean = tot / (float)a.M;
+            if (a.phase == 1) a.xch[k] = tot;
+        }
+        __syncthreads();
+        if (a.phase == 1) return;
+    } else {
+        if (tid == 0) s_mean = a.xch[k] / a.n_global;      // global mean of this minibatch
+        __syncthreads();
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if ((tid & 63) == 0) red[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) s_mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.M;
-    __syncthreads();
     const float mean = s_mean;
     float sq = 0.f;
     for (int i = tid; i < a.M; i += 256) {
@@ -1219,9 +1240,13 @@ __global__ __launch_bounds__(256) void epoch_prepare_kernel(EpochArgs a) {
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
     if (tid == 0) {
-        const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.M;
-        a.stats[2 * k] = mean;
-        a.stats[2 * k + 1] = (float)((double)sqrtf(var) + 1e-8);
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        if (a.phase == 2) a.xch[nmb + k] = tot;
+        else {
+            const float var = tot / (float)a.M;
+            a.stats[2 * k] = mean;
+            a.stats[2 * k + 1] = (float)((double)sqrtf(var) + 1e-8);
+        }
     }
 }
 
@@ -1371,6 +1396,62 @@ __device__ __forceinline__ void running_stats_update_block(const float* __restri
 __global__ __launch_bounds__(STATS_THREADS) void running_stats_kernel(const float* batch, int rows, int D, NormDev st) {
     __shared__ float sh[STATS_THREADS + 2 * 576];
     running_stats_update_block(batch, rows, D, st, sh);
+}
+
+// Data-parallel form of RunningStatistics::update: the batch is the union of every rank's rows, so the two batch
+// moments are all-reduced between the phases (xch = [sum_0..sum_{D-1}, rows | m2_0..m2_{D-1}], summed over ranks by the
+// host between launches); phase 2 then performs the reference's Chan merge with the GLOBAL batch mean / variance / count.
+__global__ __launch_bounds__(STATS_THREADS) void stats_phase_kernel(const float* batch, int rows, int D, NormDev st, float* xch, int phase) {
+    __shared__ float part[STATS_THREADS];
+    const int tid = threadIdx.x;
+    const int rpp = STATS_THREADS / D;
+    const int col = tid % D, rsub = tid / D;
+    const bool act = rsub < rpp;
+    if (phase < 2) {
+        const float bm = phase == 1 ? xch[col] / xch[D] : 0.f;
+        float s = 0.f;
+        if (act) for (int r = rsub; r < rows; r += rpp) { const float d = batch[(size_t)r * D + col] - bm; s += phase == 1 ? d * d : d; }
+        if (act) part[rsub * D + col] = s;
+        __syncthreads();
+        if (tid < D) {
+            float t = 0.f;
+            for (int q = 0; q < rpp; ++q) t += part[q * D + tid];
+            xch[(phase == 1 ? D + 1 : 0) + tid] = t;
+        }
+        if (phase == 0 && tid == 0) xch[D] = (float)rows;
+        return;
+    }
+    if (tid < D) {
+        const double cnt = *st.count;
+        const double nb = (double)xch[D];
+        const double tot = cnt + nb;
+        const float bmean = xch[tid] / (float)nb;
+        const float bvar = xch[D + 1 + tid] / (float)nb;
+        const float delta = bmean - st.mean[tid];
+        const float new_mean = st.mean[tid] + (delta * (float)nb) / (float)tot;
+        const float m_a = st.var[tid] * (float)cnt;
+        const float m_b = bvar * (float)nb;
+        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;
+        st.mean[tid] = new_mean;
+        st.var[tid] = M2 / (float)tot;
+    }
+    __syncthreads();
+    if (tid == 0) *st.count = (double)xch[D] + *st.count;
+}
+
+__global__ void ret_update_kernel(const float* rew, int rows, float gamma, float* ret) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) ret[i] = ret[i] * gamma + rew[i];
+}
+
+__global__ void reward_apply_kernel(const float* rew, const float* dones, int rows, float clip, float eps, float* ret, NormDev st, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float inv = 1.0f / sqrtf(st.var[0] + eps);
+    float y = rew[i] * inv;
+    y = tf_min(tf_max(y, -clip), clip);
+    out[i] = y;
+    ret[i] = ret[i] * (1.0f - dones[i]);
 }
 
 // normalise + clip an [rows, D] batch with frozen statistics (env_normalize.hpp:99-104)

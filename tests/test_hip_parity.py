@@ -275,8 +275,26 @@ def test_rccl_plumbing_single_rank_communicator():
         ref_losses, _, _ = orc.train_step(LR, CR, *args)
         close(g.train_step(LR, CR, *args), ref_losses, rtol=1e-4, atol=1e-6)
     close(g.get_flat(0), orc.theta, rtol=1e-4, atol=2e-6)
-    orc2, g2, nz, ro, noise = _rollout_pair((64, 64), 16, 16, 31)
+    # the data-parallel forms of the running statistics (two all-reduced batch moments) and of the advantage statistics
+    # (all-reduced minibatch sums) must reproduce the single-rank arithmetic when the communicator has one rank
+    E, T, nmb, epochs = 16, 16, 4, 2
+    orc2, g2, nz, ro, noise = _rollout_pair((64, 64), E, T, 31)
     g2.dist_init(1, 0, ppo_cpp_amd.PPOHip.dist_unique_id())
     g2.collect_synthetic(1234, GAMMA, LAM, noise)
-    rows, mean = g2.update(LR, CR, 1, 4, None, seed=1)            # eager launch sequence with the collective in it
-    assert np.isfinite(rows).all()
+    for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+        close(g2.rollout_get(f), ro[f], rtol=2e-4, atol=2e-5, msg=f)
+    m, v, c = g2.norm_stats(0)
+    close(m, nz.obs_rms.mean, rtol=1e-5, atol=1e-6); close(v, nz.obs_rms.var, rtol=1e-5); assert c == nz.obs_rms.count
+    m, v, c = g2.norm_stats(1)
+    close(v, nz.ret_rms.var, rtol=1e-5); assert c == nz.ret_rms.count
+    for f in ("obs", "actions", "values", "neglogp", "returns"):
+        g2.rollout_set(f, ro[f])
+    rng = np.random.RandomState(5)
+    perm = np.arange(E * T, dtype=np.int32); perms = []
+    for _ in range(epochs):
+        rng.shuffle(perm); perms.append(perm.copy())
+    perms = np.stack(perms)
+    ref_rows, _ = orc2.update(ro, perms, nmb, LR, CR)
+    rows, _ = g2.update(LR, CR, epochs, nmb, perms)             # eager launch sequence with the collectives in it
+    close(rows, ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows under a communicator")
+    close(g2.get_flat(0), orc2.theta, rtol=2e-4, atol=5e-6)
