@@ -428,7 +428,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
         ProfScope ps(h, PK_ADAM);
         AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
                     h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out};
-        hipLaunchKernelGGL(adam_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, aa);
+        hipLaunchKernelGGL(adam_kernel, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
         HIP_OK(h, hipGetLastError());
     }
     return 0;

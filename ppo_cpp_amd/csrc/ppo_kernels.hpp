@@ -1111,35 +1111,62 @@ struct AdamArgs {
     float* norm_out;             // [1] (may be null)
 };
 
+// One block = 1024 consecutive parameters (4 per thread, 16-byte accesses); n_blocks counts the 256-element chunks the
+// gradient-source table and the partial sums of squares are indexed by.
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
-    __shared__ float s_norm2;
+    __shared__ float red[4];
     const int tid = threadIdx.x;
-    if (tid < 64) {
-        float s = 0.f;
-        for (int i = tid; i < a.n_blocks; i += 64) s += a.sumsq[i];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (tid == 0) s_norm2 = s;
+    const size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
+    const int chunk = (int)(idx >> 8);
+    const bool live = chunk < a.n_blocks;
+    // issue this thread's element loads BEFORE the norm reduction: both memory round trips overlap
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = g4, v4 = g4, t4 = g4;
+    GradSrc gs{};
+    gs.t_off = -1; gs.p_off = -1;
+    if (live) {
+        g4 = *reinterpret_cast<const float4*>(a.grad + idx);
+        m4 = *reinterpret_cast<const float4*>(a.m + idx);
+        v4 = *reinterpret_cast<const float4*>(a.v + idx);
+        t4 = *reinterpret_cast<const float4*>(a.theta + idx);
+        gs = a.src[chunk];
     }
+    const float b1p = a.beta_pow[0], b2p = a.beta_pow[1], lr = a.hyper[0];
+    // global norm from the per-chunk partial sums, same fixed order in every block (and on every rank)
+    float s = 0.f;
+    for (int i = tid; i < a.n_blocks; i += 256) s += a.sumsq[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    const float norm = sqrtf(s_norm2);
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
     float scale = a.max_norm * tf_min(1.0f / norm, 1.0f / a.max_norm);          // G:24289-24472
     if (!isfinite(norm)) scale = __builtin_nanf("");                            // G:24493-24543
-    const float b1p = a.beta_pow[0], b2p = a.beta_pow[1];
-    const float alpha = a.hyper[0] * sqrtf(1.0f - b2p) / (1.0f - b1p);
-    const size_t idx = (size_t)blockIdx.x * 256 + tid;
-    const float g = a.grad[idx] * scale;
-    const float m = a.m[idx] + (g - a.m[idx]) * (1.0f - a.beta1);
-    const float v = a.v[idx] + (g * g - a.v[idx]) * (1.0f - a.beta2);
-    a.m[idx] = m;
-    a.v[idx] = v;
-    const float th = a.theta[idx] - (m * alpha) / (sqrtf(v) + a.eps);
-    a.theta[idx] = th;
-    const GradSrc gs = a.src[blockIdx.x];
-    if (gs.t_off >= 0) {                                   // keep the backward pass's transposed copy current
-        const int e = (int)(idx - (size_t)gs.base);
-        if (e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; a.thetaT[gs.t_off + c * gs.prow + r] = th; }
+    const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    if (live) {
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
+        float mo[4], vo[4], to[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = gv[k] * scale;
+            mo[k] = mv[k] + (g - mv[k]) * (1.0f - a.beta1);
+            vo[k] = vv[k] + (g * g - vv[k]) * (1.0f - a.beta2);
+            to[k] = tv[k] - (mo[k] * alpha) / (sqrtf(vo[k]) + a.eps);
+        }
+        *reinterpret_cast<float4*>(a.m + idx) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+        *reinterpret_cast<float4*>(a.v + idx) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+        *reinterpret_cast<float4*>(a.theta + idx) = make_float4(to[0], to[1], to[2], to[3]);
+        const int e0 = (int)(idx - (size_t)gs.base);
+        if (gs.t_off >= 0) {                               // keep the backward pass's transposed copy current
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k;
+                if (e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; a.thetaT[gs.t_off + c * gs.prow + r] = to[k]; }
+            }
+        }
+        if (gs.p_off >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (e0 + k < gs.p_count) a.par[gs.p_off + e0 + k] = to[k];
+        }
     }
-    if (gs.p_off >= 0) { const int e = (int)(idx - (size_t)gs.base); if (e < gs.p_count) a.par[gs.p_off + e] = th; }
     if (blockIdx.x == 0) {
         if (tid == 0) {
             a.beta_pow[2] = b1p * a.beta1;                                      // G:31217-31342 (after the applies)
