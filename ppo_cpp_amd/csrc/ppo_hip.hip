@@ -329,6 +329,9 @@ int ensure_train_ws(ppo_handle* h, int rows) {
     h->dw_has_big = !big.empty();
     if (!big.empty() && strips.size() <= 2 * big.size()) {        // fold the strips into the big workgroups, round robin
         for (size_t i = 0; i < strips.size(); ++i) { DwWork& w = work[i % big.size()]; w.extra[w.n_extra++] = strips[i]; }
+        for (DwWork& w : work)                                     // dw_main_with_strips expects {first-layer strip[, head strip]}
+            w.fused = w.main.cls == 0 && ((w.n_extra == 0) || (w.n_extra == 1 && w.extra[0].cls == 4) ||
+                                          (w.n_extra == 2 && w.extra[0].cls == 4 && w.extra[1].cls == 5));
     } else {
         for (const DwTile& s : strips) { DwWork w{}; w.main = s; work.push_back(w); }
     }
@@ -401,7 +404,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
 #ifdef PPO_STAMPS
         da.stamps = g_stamps + 4096 * 16;
 #endif
-        const size_t lds = (h->dw_has_big ? 4 * 64 * 64 : 4 * 32 * 32) * sizeof(float);     // 4 waves x largest tile
+        const size_t lds = (h->dw_has_big ? 4 * (64 * 64 + 1024) : 4 * 32 * 32) * sizeof(float);     // 4 waves x (tile + strips)
         const int rows_per_wave = ta.n / split / 4;
         if (rows_per_wave % 16 == 0) hipLaunchKernelGGL(weight_grad_kernel<4>, dim3(h->n_dw_tiles * split), dim3(BLOCK_THREADS), lds, h->stream, da);
         else hipLaunchKernelGGL(weight_grad_kernel<1>, dim3(h->n_dw_tiles * split), dim3(BLOCK_THREADS), lds, h->stream, da);
@@ -508,8 +511,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     set_lds((const void*)policy_step_kernel<4, 2, 2>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2>);
     set_lds((const void*)policy_step_kernel<4, 2, 0>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0>);
     set_lds((const void*)policy_step_kernel<1, 1, 0>); set_lds((const void*)train_fwd_bwd_kernel<1, 1, 0>);
-    attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
-    attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 4) == hipSuccess;
+    attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 64 + 1024) * 4) == hipSuccess;
+    attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 64 + 1024) * 4) == hipSuccess;
     if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return bail(0); }
     const size_t P = (size_t)h->P_pad;
     if (dev_alloc(h, &h->par, (size_t)2 * h->net.par_total) || dev_alloc(h, &h->thetaT, (size_t)h->PT) || dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||

@@ -871,7 +871,7 @@ struct DwTile {
 // One workgroup's work: a main tile plus up to two thin strips of the narrow matrices (first layer, policy head).
 // Folding the strips into the 64x64 workgroups keeps the launch at one balanced workgroup per CU (extra workgroups
 // would double up on some CUs and set the kernel's critical path).
-struct DwWork { DwTile main; int n_extra; DwTile extra[2]; };
+struct DwWork { DwTile main; int n_extra; int fused; DwTile extra[2]; };   // fused: main is 64x64, extra[0] cls 4 (if any), extra[1] cls 5
 
 #ifndef PPO_DW_RING
 #define PPO_DW_RING 3              // register stages per wave in the weight-gradient kernel (operands come from the
@@ -970,6 +970,152 @@ __device__ __forceinline__ void dw_tile_body(const DwTile& t, int n, int nsplit,
     DSTAMP(4);
 }
 
+// Balanced layout body: the main 64x64 tile plus NE thin strips (extra[0] = [32x16] first-layer strip, extra[1] = [16x32]
+// head strip) over the SAME minibatch rows.  The strips' operands (a few registers) are requested before the main loop
+// so their memory latency hides under it; their matrix instructions run right after it and their partial tiles are
+// parked, reduced and stored together with the main tile (one LDS pass, one barrier).  Run one after the other, each
+// strip costs a latency-bound prologue + reduction of ~2.5 us.
+#define DW_STRIP_STEPS 16          // k-steps (of 4 rows) a wave can hold for the strips: rows_per_wave <= 64
+
+template <int KQ, int NE>
+__device__ __forceinline__ void dw_main_with_strips(const DwWork& w, int n, int nsplit, float* __restrict__ slabs, size_t slab_stride, float* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int split = blockIdx.x % nsplit;
+    const int rows_per_split = n / nsplit;
+    const int rows_per_wave = rows_per_split / 4;
+    const int rbeg = uni(split * rows_per_split + wave * rows_per_wave);
+    const int ksteps = rows_per_wave / 4;                              // <= DW_STRIP_STEPS (checked by the caller)
+    const DwTile& t = w.main;
+    const DwTile& e0 = w.extra[0];
+    const DwTile& e1 = w.extra[1];
+    // ---- strips: every operand of this wave's rows, issued now, consumed after the main loop ---------------------
+    float x0[DW_STRIP_STEPS][2], y0[DW_STRIP_STEPS][1], x1[DW_STRIP_STEPS][1], y1[DW_STRIP_STEPS][2];
+    if constexpr (NE >= 1) {
+        const int lx = uni(e0.ldx), ly = uni(e0.ldy);
+        const float* xb = uni(e0.X) + (size_t)rbeg * lx;
+        const float* yb = uni(e0.dY) + (size_t)rbeg * ly;
+#pragma unroll
+        for (int q = 0; q < DW_STRIP_STEPS; ++q) {
+            const int qq = q < ksteps ? q : ksteps - 1;
+            gload_vec<2>(x0[q], xb, (unsigned)(((g + 4 * qq) * lx + e0.i0 + 2 * c) * 4));
+            gload_vec<1>(y0[q], yb, (unsigned)(((g + 4 * qq) * ly + e0.j0 + c) * 4));
+        }
+    }
+    if constexpr (NE >= 2) {
+        const int lx = uni(e1.ldx), ly = uni(e1.ldy);
+        const float* xb = uni(e1.X) + (size_t)rbeg * lx;
+        const float* yb = uni(e1.dY) + (size_t)rbeg * ly;
+#pragma unroll
+        for (int q = 0; q < DW_STRIP_STEPS; ++q) {
+            const int qq = q < ksteps ? q : ksteps - 1;
+            gload_vec<1>(x1[q], xb, (unsigned)(((g + 4 * qq) * lx + e1.i0 + c) * 4));
+            gload_vec<2>(y1[q], yb, (unsigned)(((g + 4 * qq) * ly + e1.j0 + 2 * c) * 4));
+        }
+    }
+    // ---- main 64x64 tile: the ring-pipelined loop of dw_tile_body<4,4,KQ> ------------------------------------------
+    const int ldx = uni(t.ldx), ldy = uni(t.ldy);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* Xb = uni(t.X) + (size_t)rbeg * ldx;
+    const float* Yb = uni(t.dY) + (size_t)rbeg * ldy;
+    unsigned xo[KQ], yo[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        xo[q] = (unsigned)(((g + 4 * q) * ldx + t.i0 + 4 * c) * 4);
+        yo[q] = (unsigned)(((g + 4 * q) * ldy + t.j0 + 4 * c) * 4);
+    }
+    struct Stage { float x[KQ][4]; float y[KQ][4]; };
+    Stage st[PPO_DW_RING];
+    constexpr int RS = 4 * KQ;
+    auto ld = [&](Stage& s_, int koff) __attribute__((always_inline)) {
+        koff = koff < rows_per_wave ? koff : rows_per_wave - RS;
+        const float* xs = Xb + (size_t)koff * ldx;
+        const float* ys = Yb + (size_t)koff * ldy;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) { gload_vec<4>(s_.x[q], xs, xo[q]); gload_vec<4>(s_.y[q], ys, yo[q]); }
+    };
+    auto compute = [&](const Stage& s_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_.x[q][a], s_.y[q][b], acc[a][b], 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < PPO_DW_RING - 1; ++i) ld(st[i], i * RS);
+    for (int k = 0; k < rows_per_wave; k += PPO_DW_RING * RS) {
+#pragma unroll
+        for (int i = 0; i < PPO_DW_RING; ++i) {
+            ld(st[(i + PPO_DW_RING - 1) % PPO_DW_RING], k + (i + PPO_DW_RING - 1) * RS);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + i * RS < rows_per_wave) compute(st[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- strip matrix instructions ----------------------------------------------------------------------------------
+    f32x4 a0[2], a1[2];
+    a0[0] = a0[1] = a1[0] = a1[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < DW_STRIP_STEPS; ++q) {
+        if (q < ksteps) {
+            if constexpr (NE >= 1) {
+                a0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[q][0], y0[q][0], a0[0], 0, 0, 0);
+                a0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[q][1], y0[q][0], a0[1], 0, 0, 0);
+            }
+            if constexpr (NE >= 2) {
+                a1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[q][0], y1[q][0], a1[0], 0, 0, 0);
+                a1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[q][0], y1[q][1], a1[1], 0, 0, 0);
+            }
+        }
+    }
+    // ---- park [64x64 main | 32x16 strip 0 | 16x32 strip 1] per wave, reduce over the 4 waves, store -------------------
+    constexpr int WSZ = 64 * 64 + 512 + 512;
+    float* mine = lds + wave * WSZ;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mine[(4 * (4 * g + r) + a) * 64 + 4 * c + b] = acc[a][b][r];
+    if constexpr (NE >= 1) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[4096 + (2 * (4 * g + r) + a) * 16 + c] = a0[a][r];
+    }
+    if constexpr (NE >= 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[4608 + (4 * g + r) * 32 + 2 * c + b] = a1[b][r];
+    }
+    __syncthreads();
+    float* slab = slabs + (size_t)split * slab_stride;
+    for (int i = threadIdx.x; i < 4096; i += BLOCK_THREADS) {
+        const float s_ = ((lds[i] + lds[WSZ + i]) + lds[2 * WSZ + i]) + lds[3 * WSZ + i];
+        slab[t.out_off + (size_t)(t.i0 + (i >> 6)) * t.ldo + t.j0 + (i & 63)] = s_;
+    }
+    if constexpr (NE >= 1) {
+        for (int i = threadIdx.x; i < 512; i += BLOCK_THREADS) {
+            const int j = 4096 + i;
+            const float s_ = ((lds[j] + lds[WSZ + j]) + lds[2 * WSZ + j]) + lds[3 * WSZ + j];
+            slab[e0.out_off + (size_t)(e0.i0 + (i >> 4)) * e0.ldo + e0.j0 + (i & 15)] = s_;
+        }
+    }
+    if constexpr (NE >= 2) {
+        for (int i = threadIdx.x; i < 512; i += BLOCK_THREADS) {
+            const int j = 4608 + i;
+            const float s_ = ((lds[j] + lds[WSZ + j]) + lds[2 * WSZ + j]) + lds[3 * WSZ + j];
+            slab[e1.out_off + (size_t)(e1.i0 + (i >> 5)) * e1.ldo + e1.j0 + (i & 31)] = s_;
+        }
+    }
+}
+
 struct DwArgs {
     const DwWork* tiles;
     int n;                 // minibatch rows
@@ -982,7 +1128,20 @@ struct DwArgs {
 template <int KQ>
 __global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef PPO_STAMPS
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
     const DwWork& w = a.tiles[blockIdx.x / a.nsplit];
+    if (uni(w.fused) && a.n / a.nsplit / 4 <= 4 * DW_STRIP_STEPS) {     // balanced layout: strips ride with the main tile
+        const int ne = uni(w.n_extra);
+        if (ne == 2) dw_main_with_strips<KQ, 2>(w, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+        else if (ne == 1) dw_main_with_strips<KQ, 1>(w, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+        else dw_main_with_strips<KQ, 0>(w, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
+#ifdef PPO_STAMPS
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
+        return;
+    }
     const int n_sub = 1 + uni(w.n_extra);
     for (int e = 0; e < n_sub; ++e) {
         const DwTile t = e == 0 ? w.main : w.extra[e - 1];
@@ -999,6 +1158,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
         else if (cls == 5) dw_tile_body<1, 2, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
         else dw_tile_body<1, 1, KQ>(t, a.n, a.nsplit, a.slabs, a.slab_stride, lds);
     }
+#ifdef PPO_STAMPS
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------

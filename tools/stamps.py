@@ -41,3 +41,7 @@ print("weight_grad 64x64 tiles: %d blocks; start spread %d, last end %d cycles a
 for i, nm in enumerate(["issue prologue loads", "main loop", "lds park + barrier", "sum + slab store"]):
     d = big[:, i + 1] - big[:, i]
     print("   %-22s median %7.0f max %7.0f" % (nm, np.median(d), d.max()))
+
+print("kernel B whole-kernel: entry->end span %.2f us ; entry->body-start median %.2f us ; body median %.2f us ; after-body (strips) median %.2f us ; entry skew %.2f us" % (
+    (big[:, 6].max() - big[:, 5].min()) / 100.0, 0.0, np.median(big[:, 7] - big[:, 5]) / 100.0, np.median(big[:, 6] - big[:, 7]) / 100.0,
+    (big[:, 5].max() - big[:, 5].min()) / 100.0))
