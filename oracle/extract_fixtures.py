@@ -315,6 +315,11 @@ def main():
         print("  ckpt %-10s off=%4d size=%4d shape=%s" % (short, e["offset"], e["size"], e["shape"]))
     np.savez(os.path.join(GOLDEN, "ckpt71.npz"), **ck)
 
+    # the checkpoint itself is a DATA file of the reference tree: kept as a fixture so that the product's bundle
+    # reader / writer can be tested byte for byte where /root/reference does not exist
+    import shutil
+    shutil.copyfile(idx, os.path.join(GOLDEN, "ckpt71.index"))
+    shutil.copyfile(dat, os.path.join(GOLDEN, "ckpt71.data-00000-of-00001"))
     js = glob.glob(os.path.join(args.ref, "resources/ppo_cl/*.json"))[0]
     stats = json.load(open(js))
     json.dump(stats, open(os.path.join(GOLDEN, "ckpt71_stats.json"), "w"), indent=1, sort_keys=True)

@@ -17,6 +17,7 @@
 #include <random>
 
 #include "../env/env_normalize.hpp"
+#include "checkpoint.hpp"
 #include "runner.hpp"
 #include "utils.hpp"
 
@@ -37,6 +38,69 @@ public:
     std::vector<std::pair<int, float>>& episode_rewards() { return episodes_; }
     bool quiet = false;
     unsigned long long seed = 0;
+
+    // Checkpoint in the reference's on-disk format (ppo2.hpp:107-166): the 15 model tensors as a TF bundle
+    // (<path>[.<id>].index / .data-00000-of-00001, names "model/<tensor>"; the untrained q/w, q/b ride along so that the
+    // reference's restore_all finds every variable) and the JSON side-car with hyper-parameters + Env::serialize.
+    void save(std::string save_path, int save_id = -1) {
+        if (save_id >= 0) save_path += "." + std::to_string(save_id);
+        ckpt::Bundle b = extra_tensors_;
+        const int nt = ppo_num_tensors(h_);
+        for (int i = 0; i < nt; ++i) {
+            char name[32]; int32_t rows = 0, cols = 0;
+            check(ppo_tensor_info(h_, i, name, &rows, &cols));
+            ckpt::Tensor t;
+            t.shape.push_back(rows); if (cols) t.shape.push_back(cols);
+            t.data.resize((size_t)rows * (cols ? cols : 1));
+            check(ppo_get_tensor(h_, 0, i, t.data.data(), (int64_t)t.data.size()));
+            b[std::string("model/") + name] = t;
+        }
+        if (!b.count("model/q/w")) {                               // graph variables without gradient
+            const int A = env_.get_action_space_size();
+            char name[32]; int32_t rows = 0, cols = 0;
+            check(ppo_tensor_info(h_, nt - 3, name, &rows, &cols));                  // pi/w: [h_last, A]
+            ckpt::Tensor qw; qw.shape = {rows, A}; qw.data.assign((size_t)rows * A, 0.f);
+            ckpt::Tensor qb; qb.shape = {A}; qb.data.assign((size_t)A, 0.f);
+            b["model/q/w"] = qw; b["model/q/b"] = qb;
+        }
+        ckpt::save_bundle(save_path, b);
+        nlohmann::json json{};
+        env_.serialize(json);
+        json["gamma"] = gamma_; json["n_steps"] = n_steps_; json["vf_coef"] = vf_coef_; json["ent_coef"] = ent_coef_;
+        json["max_grad_norm"] = max_grad_norm_; json["learning_rate"] = learning_rate_; json["lam"] = lam_;
+        json["nminibatches"] = nminibatches_; json["noptepochs"] = noptepochs_; json["cliprange"] = cliprange_;
+        json["cliprange_vf"] = cliprange_vf_; json["observation_space"] = env_.get_observation_space();
+        json["action_space"] = env_.get_action_space(); json["n_envs"] = n_envs_; json["model_filename"] = model_filename;
+        std::ofstream f(save_path + ".json");
+        if (!f) throw std::runtime_error("PPO2::save: unable to open " + save_path + ".json");
+        f << json.dump();
+    }
+
+    // restores weights + hyper-parameters + normaliser statistics (ppo2.hpp:169-223); like the reference it does not
+    // restore optimiser state (the graph's saver holds no Adam slots, G:32396-32496)
+    void load(const std::string& save_path) {
+        nlohmann::json json = nlohmann::json::parse(ckpt::slurp(save_path + ".json"));
+        env_.deserialize(json);
+        gamma_ = json["gamma"].get<float>(); n_steps_ = json["n_steps"].get<int>(); vf_coef_ = json["vf_coef"].get<float>();
+        ent_coef_ = json["ent_coef"].get<float>(); max_grad_norm_ = json["max_grad_norm"].get<float>();
+        learning_rate_ = json["learning_rate"].get<float>(); lam_ = json["lam"].get<float>();
+        nminibatches_ = json["nminibatches"].get<int>(); noptepochs_ = json["noptepochs"].get<int>();
+        cliprange_ = json["cliprange"].get<float>(); cliprange_vf_ = json["cliprange_vf"].get<float>();
+        n_batch_ = n_envs_ * n_steps_;
+        const ckpt::Bundle b = ckpt::load_bundle(save_path);
+        extra_tensors_.clear();
+        const int nt = ppo_num_tensors(h_);
+        for (int i = 0; i < nt; ++i) {
+            char name[32]; int32_t rows = 0, cols = 0;
+            check(ppo_tensor_info(h_, i, name, &rows, &cols));
+            auto it = b.find(std::string("model/") + name);
+            if (it == b.end()) throw std::runtime_error(std::string("PPO2::load: checkpoint lacks model/") + name);
+            if ((int64_t)it->second.data.size() != (int64_t)rows * (cols ? cols : 1)) throw std::runtime_error(std::string("PPO2::load: shape mismatch for ") + name);
+            check(ppo_set_tensor(h_, 0, i, it->second.data.data(), (int64_t)it->second.data.size()));
+        }
+        for (const char* q : {"model/q/w", "model/q/b"}) { auto it = b.find(q); if (it != b.end()) extra_tensors_[q] = it->second; }
+    }
+    std::string model_filename;
 
     // deterministic action for one observation row (ppo2.hpp:225-237)
     Mat eval(const Mat& obs) { return act_model_.get_deterministic_action(obs); }
@@ -163,6 +227,7 @@ private:
     int n_envs_, n_batch_, num_timesteps_;
     MlpPolicy act_model_;
     Mat episode_reward_;
+    ckpt::Bundle extra_tensors_;      // q/w, q/b carried through load -> save
     std::vector<UpdateLog> history_;
     std::vector<std::pair<int, float>> episodes_;
 };

@@ -10,6 +10,7 @@
 #include "env/env_mock.hpp"
 #include "env/env_normalize.hpp"
 #include "env/vec_env.hpp"
+#include "ppo2/checkpoint.hpp"
 #include "ppo2/ppo2.hpp"
 
 extern "C" {
@@ -80,6 +81,53 @@ int ppo_host_selftest() {
         for (int j = 0; j < 18; ++j) if (o1(0, j) != o2(0, j) || o1(0, j) < -1.f || o1(0, j) >= 1.f) return 6;
     }
     return 0;
+}
+
+// read a reference checkpoint (<in_prefix>.index / .data-00000-of-00001) and write it back under out_prefix; returns the
+// number of tensors, or -1 (message on stderr).  tests/test_checkpoint.py compares the output files byte for byte.
+int ppo_host_bundle_roundtrip(const char* in_prefix, const char* out_prefix) {
+    try {
+        const ckpt::Bundle b = ckpt::load_bundle(in_prefix);
+        ckpt::save_bundle(out_prefix, b);
+        return (int)b.size();
+    } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return -1; }
+}
+
+// tensor access for tests: copies tensor `name` (at most cap floats) and its shape (up to 4 dims); returns element count
+int ppo_host_bundle_tensor(const char* prefix, const char* name, float* dst, int cap, long long shape[4]) {
+    try {
+        const ckpt::Bundle b = ckpt::load_bundle(prefix);
+        auto it = b.find(name);
+        if (it == b.end()) return -2;
+        const int n = (int)it->second.data.size();
+        if (n > cap) return -3;
+        std::memcpy(dst, it->second.data.data(), sizeof(float) * (size_t)n);
+        for (int i = 0; i < 4; ++i) shape[i] = i < (int)it->second.shape.size() ? it->second.shape[i] : 0;
+        return n;
+    } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return -1; }
+}
+
+// PPO2::load of a reference checkpoint ([4,5] net, EnvMock behind EnvNormalize) -> deterministic action + value of the
+// zero observation -> PPO2::save under out_prefix.  Returns 0; mu[18], value[1], obs_count out.
+int ppo_host_checkpoint_eval(const char* in_prefix, const char* out_prefix, float* mu, double* obs_count) {
+    ppo_handle* h = nullptr;
+    try {
+        ppo_config cfg; const int32_t hidden[2] = {4, 5};
+        ppo_config_default(&cfg, 18, 18, 2, hidden);
+        if (ppo_create(&cfg, &h) != 0) throw std::runtime_error(ppo_last_error(nullptr));
+        {
+            EnvNormalize env{std::unique_ptr<Env>(new EnvMock(1)), h, /*training=*/false};
+            PPO2 algo{h, env};
+            algo.load(in_prefix);
+            const Mat a = algo.eval(Mat::Zero(1, 18));
+            std::memcpy(mu, a.data(), sizeof(float) * 18);
+            float m[18], v[18];
+            if (ppo_norm_get_stats(h, 0, m, v, obs_count) != 0) throw std::runtime_error(ppo_last_error(h));
+            algo.save(out_prefix);
+        }
+        ppo_destroy(h);
+        return 0;
+    } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); if (h) ppo_destroy(h); return -1; }
 }
 
 struct ppo_host_args {
