@@ -54,8 +54,25 @@ def build_host(force=False, verbose=False):
     return HOST_SO
 
 
+def build_driver(force=False, verbose=False):
+    """ppo_cpp_hip: command-line driver with the reference's training flags (mock environments)."""
+    host = os.path.join(PKG, "host")
+    src = os.path.join(host, "main.cpp")
+    exe = os.path.join(PKG, "ppo_cpp_hip")
+    if not os.path.exists(src):
+        return None
+    deps = _sources(host, (".cpp", ".hpp", ".h")) + [os.path.join(ROOT, "include", "ppo_hip.h")]
+    if force or _newer(exe, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", host, "-o", exe, src,
+               "-L", PKG, "-lppo_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return exe
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_host(force, verbose)
+    return build_hip(force, verbose), build_host(force, verbose), build_driver(force, verbose)
 
 
 if __name__ == "__main__":

@@ -105,13 +105,19 @@ public:
     // deterministic action for one observation row (ppo2.hpp:225-237)
     Mat eval(const Mat& obs) { return act_model_.get_deterministic_action(obs); }
 
-    void learn(int total_timesteps) {
+    // save cadence of the reference (ppo2.hpp:256-262, 361-376): a save every ceil(n_updates / num_saves) updates with
+    // ids 0, 1, ..., plus a trailing save when the interval does not divide the number of updates
+    void learn(int total_timesteps, int num_saves = 0, const std::string& save_path = "") {
         num_timesteps_ = 0;
         const int n_updates = total_timesteps / n_batch_;
+        save_interval_ = num_saves > 0 ? static_cast<int>(std::ceil(static_cast<float>(n_updates) / static_cast<float>(num_saves))) : -1;
+        save_path_ = save_path;
+        if (num_saves > 0 && save_path.empty()) throw std::runtime_error("PPO2::learn: num_saves > 0 needs a save path");
         if (n_batch_ % nminibatches_ != 0) throw std::runtime_error("PPO2: n_batch must be divisible by nminibatches");
         EnvNormalize* nz = dynamic_cast<EnvNormalize*>(&env_);
         if (nz && nz->training()) learn_resident(*nz, n_updates);
         else learn_reference_loop(n_updates);
+        if (num_saves > 0 && save_interval_ > 0 && (n_updates % save_interval_) != 0) save(save_path, n_updates / save_interval_);
     }
 
     // PPO2::_train_step (ppo2.hpp:380-471): advantage normalisation over the minibatch, then the train op
@@ -212,6 +218,8 @@ private:
         episode_reward_ = Utils::total_episode_reward_logger(
             episode_reward_, rew_view, done_view, [this](int step, const char*, float v) { episodes_.push_back({step, v}); }, num_timesteps_ - n_batch_);
         history_.push_back(log);
+        const int update = static_cast<int>(history_.size());
+        if (save_interval_ > 0 && update % save_interval_ == 0) save(save_path_, update / save_interval_ - 1);
     }
 
     void check(int rc) { if (rc != 0) throw std::runtime_error(std::string("PPO2: ") + ppo_last_error(h_)); }
@@ -227,6 +235,8 @@ private:
     int n_envs_, n_batch_, num_timesteps_;
     MlpPolicy act_model_;
     Mat episode_reward_;
+    int save_interval_ = -1;
+    std::string save_path_;
     ckpt::Bundle extra_tensors_;      // q/w, q/b carried through load -> save
     std::vector<UpdateLog> history_;
     std::vector<std::pair<int, float>> episodes_;
