@@ -11,6 +11,7 @@
 #include "env/env_mock.hpp"
 #include "env/env_normalize.hpp"
 #include "env/vec_env.hpp"
+#include "ppo2/graph_spec.hpp"
 #include "ppo2/ppo2.hpp"
 
 namespace {
@@ -25,7 +26,7 @@ const char* kAliases[][2] = {{"-d", "dir"}, {"--dir", "dir"}, {"-p", "path"}, {"
                              {"-c", "cr"}, {"--cr", "cr"}, {"--clip_range", "cr"}, {"--cliprange", "cr"}, {"--saves", "saves"}, {"--num_saves", "saves"},
                              {"--epochs", "epochs"}, {"--num_epochs", "epochs"}, {"--batch_steps", "batch_steps"}, {"--n_steps", "batch_steps"},
                              {"-j", "threads"}, {"--threads", "threads"}, {"--jobs", "threads"}, {"--num_threads", "threads"}, {"--hidden", "hidden"},
-                             {"--minibatches", "minibatches"}, {"--seed", "seed"}};
+                             {"--minibatches", "minibatches"}, {"--seed", "seed"}, {"-g", "graph"}, {"--graph", "graph"}, {"--graph_path", "graph"}};
 const char* kSwitches[][2] = {{"-r", "resume"}, {"--resume", "resume"}, {"-v", "verbose"}, {"--verbose", "verbose"}, {"--seeded", "seeded"}};
 }  // namespace
 
@@ -51,10 +52,16 @@ int main(int argc, char** argv) {
     ppo_config cfg;
     ppo_config_default(&cfg, 18, 18, (int)hidden.size(), hidden.data());
     cfg.ent_coef = (float)f.num("ent", 0.0);                                    // live here (the reference bakes it into the graph)
-    if (ppo_create(&cfg, &h) != 0) { std::fprintf(stderr, "%s\n", ppo_last_error(nullptr)); return 2; }
     int rc = 0;
     try {
-        if (ppo_init_orthogonal(h, (uint64_t)f.num("seed", 0)) != 0) throw std::runtime_error(ppo_last_error(h));
+        if (f.has("graph")) {                                                    // -g: shape, constants and initial weights from a reference graph file
+            const graphspec::GraphSpec g = graphspec::load_graph_spec(f.str("graph", ""));
+            cfg = g.config;
+            h = graphspec::create_from_graph(g);
+        } else {
+            if (ppo_create(&cfg, &h) != 0) throw std::runtime_error(ppo_last_error(nullptr));
+            if (ppo_init_orthogonal(h, (uint64_t)f.num("seed", 0)) != 0) throw std::runtime_error(ppo_last_error(h));
+        }
         std::vector<std::shared_ptr<Env>> envs;
         for (int i = 0; i < n_envs; ++i) {
             if (f.has("seeded")) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i));
@@ -82,6 +89,6 @@ int main(int argc, char** argv) {
             }
         }
     } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); rc = 3; }
-    ppo_destroy(h);
+    if (h) ppo_destroy(h);
     return rc;
 }

@@ -11,6 +11,7 @@
 #include "env/env_normalize.hpp"
 #include "env/vec_env.hpp"
 #include "ppo2/checkpoint.hpp"
+#include "ppo2/graph_spec.hpp"
 #include "ppo2/ppo2.hpp"
 
 extern "C" {
@@ -128,6 +129,22 @@ int ppo_host_checkpoint_eval(const char* in_prefix, const char* out_prefix, floa
         ppo_destroy(h);
         return 0;
     } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); if (h) ppo_destroy(h); return -1; }
+}
+
+// Graph-spec importer: parses a reference .meta.txt; fills cfg, the betas' initial powers, and copies
+// variable `name`'s initial value (cap floats).  Returns the element count, -2 if absent, -1 on parse errors.
+int ppo_host_graph_spec(const char* path, ppo_config* cfg, float pw0[2], const char* name, float* dst, int cap) {
+    try {
+        const graphspec::GraphSpec g = graphspec::load_graph_spec(path);
+        *cfg = g.config; pw0[0] = g.beta1_power0; pw0[1] = g.beta2_power0;
+        if (!name || !name[0]) return 0;
+        auto it = g.initial.find(name);
+        if (it == g.initial.end()) return -2;
+        const int n = (int)it->second.data.size();
+        if (n > cap) return -3;
+        std::memcpy(dst, it->second.data.data(), sizeof(float) * (size_t)n);
+        return n;
+    } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return -1; }
 }
 
 struct ppo_host_args {
