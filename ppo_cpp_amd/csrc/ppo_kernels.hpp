@@ -222,6 +222,9 @@ __device__ __forceinline__ void load_w_rows(WFrag<CT, KS>& w, const float* __res
 #ifndef PPO_INTERLEAVE
 #define PPO_INTERLEAVE 1
 #endif
+#ifndef PPO_WT_STORES
+#define PPO_WT_STORES 1
+#endif
 #ifndef PPO_RING
 #define PPO_RING 3                  // register stages in flight per wave: PPO_RING-1 stages (each 16*KS k deep) ahead
 #endif
@@ -356,7 +359,19 @@ __device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int
             const bool wr = gy && (row0 + row) < nrows;
             if constexpr (CT == 4) {
                 *reinterpret_cast<float4*>(ys) = make_float4(y[0], y[1], y[2], y[3]);
-                if (wr) *reinterpret_cast<float4*>(yg) = make_float4(y[0], y[1], y[2], y[3]);
+                if (wr) {
+#if PPO_WT_STORES
+                    // write-through (sc1) 16-byte store: the activations are only read by the NEXT kernel, so they should
+                    // drain to memory while this kernel computes instead of piling up as dirty L2 lines that the
+                    // end-of-kernel release has to write back (~3 us at the boundary for 17 MB)
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const f32x4 fv = {y[0], y[1], y[2], y[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, fv), __builtin_amdgcn_make_buffer_rsrc(gy, 0, 0x7fffffff, 0x00020000),
+                                                           (int)(((size_t)(row0 + row) * ldg + col) * 4), 0, 16);
+#else
+                    *reinterpret_cast<float4*>(yg) = make_float4(y[0], y[1], y[2], y[3]);
+#endif
+                }
             } else if constexpr (CT == 2) {
                 *reinterpret_cast<float2*>(ys) = make_float2(y[0], y[1]);
                 if (wr) *reinterpret_cast<float2*>(yg) = make_float2(y[0], y[1]);
