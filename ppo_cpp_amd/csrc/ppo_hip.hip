@@ -397,15 +397,16 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
         else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
         HIP_OK(h, hipGetLastError());
     }
-    const int split = pick_split(h, ta.n);
+    const int n_pad = ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
+    const int split = pick_split(h, n_pad);
     {
         ProfScope ps(h, PK_DW);
-        DwArgs da{h->dw_tiles, ta.n, split, h->slabs, (size_t)h->P_pad, nullptr};
+        DwArgs da{h->dw_tiles, n_pad, split, h->slabs, (size_t)h->P_pad, nullptr};
 #ifdef PPO_STAMPS
         da.stamps = g_stamps + 4096 * 16;
 #endif
         const size_t lds = (h->dw_has_big ? 4 * (64 * 64 + 1024) : 4 * 32 * 32) * sizeof(float);     // 4 waves x (tile + strips)
-        const int rows_per_wave = ta.n / split / 4;
+        const int rows_per_wave = n_pad / split / 4;
         if (rows_per_wave % 16 == 0) hipLaunchKernelGGL(weight_grad_kernel<4>, dim3(h->n_dw_tiles * split), dim3(BLOCK_THREADS), lds, h->stream, da);
         else hipLaunchKernelGGL(weight_grad_kernel<1>, dim3(h->n_dw_tiles * split), dim3(BLOCK_THREADS), lds, h->stream, da);
         HIP_OK(h, hipGetLastError());
@@ -687,7 +688,7 @@ int ppo_act_deterministic(ppo_handle* h, const float* obs, int32_t n, float* act
 // ---- train op -------------------------------------------------------------------------------------------------------
 int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, const float* actions, const float* advs,
                    const float* returns, const float* old_neglogp, const float* old_values, int32_t n, float losses[5]) {
-    if (n < 16 || n % 16) return fail(h, "ppo_train_step: n=%d must be a positive multiple of 16", n);
+    if (n < 2) return fail(h, "ppo_train_step: n=%d (the reference asserts more than one row, ppo2.hpp:402)", n);
     if (ensure_staging(h, n) || ensure_train_ws(h, n)) return -1;
     const NetDev& net = h->net;
     const size_t fb = sizeof(float);
@@ -1075,7 +1076,6 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     const int B = h->E * h->T;
     if (epochs < 1 || nmb < 1 || B % nmb) return fail(h, "ppo_update: n_batch %d not divisible by nminibatches %d", B, nmb);
     const int M = B / nmb;
-    if (M % 16) return fail(h, "ppo_update: minibatch rows %d must be a multiple of 16", M);
     if (h->world > 1 && perms == nullptr && false) return fail(h, "unreachable");
     if (ensure_train_ws(h, M)) return -1;
     const int steps = epochs * nmb;

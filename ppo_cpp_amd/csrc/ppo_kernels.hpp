@@ -127,7 +127,8 @@ __device__ __forceinline__ float group16_sum(float v) {
 // Dense product on one 16-row tile:   Y[16,Np] = epilogue( X[16,K] * W[K,Np] )
 //   X  : LDS, row-major, leading dimension ldx (multiple of 4)
 //   W  : global, row-major [K][ldw]   (K multiple of 16*KS, Np multiple of 16*CT)
-//   Y  : LDS (ldy) and optionally global (gy, row stride ldg; only rows < nrows are written)
+//   Y  : LDS (ldy) and optionally global (gy, row stride ldg; rows >= nrows of the last tile are written as ZEROS so
+//        that the weight-gradient kernel can run over whole 16-row tiles for any minibatch size)
 // The forward layers use W = the layer's weights (epilogue bias + tanh); the backward pass uses W = the
 // TRANSPOSED copy the Adam kernel keeps (epilogue TanhGrad), so both directions stream weights identically:
 // each wave owns 16*CT output columns; MFMA j covers columns n0 + CT*c + j (c = lane & 15), so ONE 16-byte load per
@@ -356,7 +357,11 @@ __device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int
             }
             float* ys = Ys + row * ldy + col;
             float* yg = gy ? gy + (size_t)(row0 + row) * ldg + col : nullptr;
-            const bool wr = gy && (row0 + row) < nrows;
+            const bool wr = gy != nullptr;
+            if (wr && (row0 + row) >= nrows) {
+#pragma unroll
+                for (int j = 0; j < CT; ++j) y[j] = 0.f;
+            }
             if constexpr (CT == 4) {
                 *reinterpret_cast<float4*>(ys) = make_float4(y[0], y[1], y[2], y[3]);
                 if (wr) {
@@ -516,7 +521,7 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
             if (obs_out) obs_out[(size_t)row * O + j] = x;
         }
         Xs[r * ldx + j] = x;
-        if (x0g && row < nrows) x0g[(size_t)row * Kp0 + j] = x;
+        if (x0g) x0g[(size_t)row * Kp0 + j] = x;                    // rows >= nrows: zeros (whole tiles for the dW kernel)
     };
 #pragma unroll
     for (int k = 0; k < OK; ++k) { const int i = tid + BLOCK_THREADS * k; if (i < ROWS_PER_BLOCK * Kp0) put_obs(i, ov[k]); }
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
             }
             dcur[r * ldm + j] = dmu;
             dls[r * net.Ap + j] = dl;
-            if (live) a.dmug[(size_t)row * net.Ap + j] = dmu;
+            a.dmug[(size_t)row * net.Ap + j] = dmu;                // dead rows of the last tile: zeros
         }
         lds_barrier();
         // per-block partial sums: db_mu, dlogstd (over the 16 rows, fixed order), loss terms
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
                 const float h = hL[q * ldhL + k];
                 const float d = (misc[q] * w) * (1.0f - h * h);
                 dnext[q * ldd + k] = d;
-                if (row0 + q < a.n) a.dyg[1][net.L - 1][(size_t)(row0 + q) * HpL + k] = d;
+                a.dyg[1][net.L - 1][(size_t)(row0 + q) * HpL + k] = d;   // dead rows: d == 0
             }
         }
         lds_barrier();

@@ -82,7 +82,8 @@ def test_on_device_noise_is_standard_normal():
 
 
 @pytest.mark.parametrize("hidden,n,src", [((4, 5), 64, "ginit"), ((4, 5), 2048, "ckpt"), ((64, 64), 64, "orth"),
-                                          ((64, 64), 256, "orth"), ((256, 256), 2048, "orth"), ((16, 8, 8), 48, "orth")])
+                                          ((64, 64), 256, "orth"), ((256, 256), 2048, "orth"), ((16, 8, 8), 48, "orth"),
+                                          ((64, 64), 75, "orth"), ((256, 256), 1000, "orth"), ((4, 5), 17, "ckpt")])   # ragged: not multiples of 16
 def test_train_step_losses_gradient_and_weights(hidden, n, src):
     orc, g = pair(hidden, src)
     for it in range(3):
@@ -191,7 +192,8 @@ def test_host_env_rollout_api_matches_device_env_path():
         close(g.rollout_get(f), ro[f], rtol=2e-4, atol=2e-5, msg=f)
 
 
-@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((4, 5), 1, 256, 4, 2), ((64, 64), 16, 16, 4, 3), ((256, 256), 64, 16, 4, 2)])
+@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((4, 5), 1, 256, 4, 2), ((64, 64), 16, 16, 4, 3), ((256, 256), 64, 16, 4, 2),
+                                                   ((64, 64), 3, 100, 4, 2)])        # M = 75 rows: ragged minibatches
 def test_update_phase_matches_oracle(hidden, E, T, nmb, epochs):
     orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 23)
     for f in ("obs", "actions", "values", "neglogp", "returns"):
