@@ -202,7 +202,8 @@ int build_layout(ppo_handle* h) {
     if (h->CT == 4) for (int l = 0; l < n.L; ++l) n.Hp[l] = ru(n.Hp[l], 64);
     const int kq = h->CT == 4 ? 32 : 16;                  // reduction dims must be whole pipeline stages (16*KS)
     n.Kp0 = ru(c.obs_dim, kq); n.Ap = ru(c.act_dim, kq);
-    h->CTH = (h->CT == 4 && n.Ap == 32) ? 2 : 0;
+    // split-K policy head: each of the 4 waves takes K/4 of the reduction in whole 64-wide stages
+    h->CTH = (h->CT == 4 && n.Ap == 32 && n.Hp[n.L - 1] % 256 == 0) ? 2 : 0;
     n.ent_coef = c.ent_coef; n.vf_coef = c.vf_coef;
     int od = 0, op = 0;
     char nm[32];
@@ -227,16 +228,7 @@ int build_layout(ppo_handle* h) {
     n.wmuT_off = ot; ot += n.Ap * n.Hp[n.L - 1];
     h->PT = ot;
     n.n_theta = op; n.n_thetaT = ot;
-    // LDS carve
-    int o = 0, hmax = n.Ap;
-    n.lds_h[0] = o; o += ROWS_PER_BLOCK * (n.Kp0 + LDS_PAD);
-    for (int l = 0; l < n.L; ++l) { n.lds_h[l + 1] = o; o += ROWS_PER_BLOCK * (n.Hp[l] + LDS_PAD); hmax = std::max(hmax, n.Hp[l]); }
-    n.lds_d[0] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
-    n.lds_d[1] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
-    n.lds_mu = o; o += ROWS_PER_BLOCK * (n.Ap + LDS_PAD);
-    n.lds_head = o; o += 4 * ROWS_PER_BLOCK * n.Ap;
-    n.lds_misc = o; o += 64 + 2 * ROWS_PER_BLOCK * n.Ap + 64;
-    n.lds_par = o;
+    // small-parameter mirror layout (also the LDS copy): biases | b_mu | logstd | w_v | b_v
     {
         int po = 0;
         for (int l = 0; l < n.L; ++l) { n.par_b[l] = po; po += n.Hp[l]; }
@@ -244,11 +236,44 @@ int build_layout(ppo_handle* h) {
         n.par_ls = po; po += n.Ap;
         n.par_wv = po; po += n.Hp[n.L - 1];
         n.par_bv = po; po += 4;
-        n.par_total = po; o += po;
+        n.par_total = po;
     }
-    n.lds_total = o;
-    if ((size_t)o * sizeof(float) > 160 * 1024)
-        return fail(h, "network too wide for the LDS-resident 16-row tile (%zu bytes of LDS needed, 163840 available)", (size_t)o * 4);
+    // LDS carve.  Regular form: one activation tile per layer (the backward pass reads tanh outputs from LDS).
+    int hmax = std::max(n.Ap, n.Kp0);
+    for (int l = 0; l < n.L; ++l) hmax = std::max(hmax, n.Hp[l]);
+    auto carve = [&](bool wide) {
+        int o = 0;
+        n.wide = wide ? 1 : 0;
+        if (!wide) {
+            n.lds_h[0] = o; o += ROWS_PER_BLOCK * (n.Kp0 + LDS_PAD);
+            for (int l = 0; l < n.L; ++l) { n.lds_h[l + 1] = o; o += ROWS_PER_BLOCK * (n.Hp[l] + LDS_PAD); }
+            n.lds_d[0] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
+            n.lds_d[1] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
+            n.lds_head = 0; n.par_skip = 0;
+        } else {
+            // Wide form (nets whose per-layer tiles do not fit 160 KB): two ping-pong tiles; layer l reads tile l%2 and
+            // writes tile (l+1)%2; the backward pass re-reads tanh outputs from HBM (they are stored for the weight
+            // gradients anyway); biases are read from the global mirror; generic policy head (no split-K scratch).
+            const int tile = ROWS_PER_BLOCK * (hmax + LDS_PAD);
+            const int t0 = o; o += tile;
+            const int t1 = o; o += tile;
+            for (int l = 0; l <= n.L; ++l) n.lds_h[l] = (l % 2) ? t1 : t0;
+            n.lds_d[0] = o; o += ROWS_PER_BLOCK * (n.Ap + LDS_PAD);       // d mu tile
+            n.lds_d[1] = ((n.L + 1) % 2) ? t1 : t0;                        // first backward output: the tile h_L is not in
+            n.par_skip = n.par_bmu;
+        }
+        n.lds_mu = o; o += ROWS_PER_BLOCK * (n.Ap + LDS_PAD);
+        if (!wide) { n.lds_head = o; o += 4 * ROWS_PER_BLOCK * n.Ap; }
+        n.lds_misc = o; o += 64 + 2 * ROWS_PER_BLOCK * n.Ap + 64;
+        n.lds_par = o; o += n.par_total - n.par_skip;
+        n.lds_total = o;
+        return (size_t)o * sizeof(float) <= 160 * 1024;
+    };
+    if (!carve(false)) {
+        if (!carve(true))
+            return fail(h, "network too wide even for the two-tile LDS layout (%zu bytes needed, 163840 available)", (size_t)n.lds_total * 4);
+        h->CTH = 0;
+    }
     // slot layout
     int s = 0;
     for (int l = 0; l < n.L; ++l) { n.slot_db[l] = s; s += n.Hp[l]; }
@@ -357,14 +382,17 @@ int ensure_staging(ppo_handle* h, int rows) {
 }
 
 // ---- launches -------------------------------------------------------------------------------------------------
-template <int CT, int KS, int CTH>
+template <int CT, int KS, int CTH, bool WIDE>
 void launch_step_t(ppo_handle* h, const StepArgs& a) {
     dim3 grid((a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 2);
-    hipLaunchKernelGGL((policy_step_kernel<CT, KS, CTH>), grid, dim3(BLOCK_THREADS), (size_t)h->net.lds_total * sizeof(float), h->stream, h->net, a);
+    hipLaunchKernelGGL((policy_step_kernel<CT, KS, CTH, WIDE>), grid, dim3(BLOCK_THREADS), (size_t)h->net.lds_total * sizeof(float), h->stream, h->net, a);
 }
 int launch_step(ppo_handle* h, const StepArgs& a) {
     ProfScope ps(h, PK_STEP);
-    if (h->CT == 4 && h->CTH == 2) launch_step_t<4, 2, 2>(h, a); else if (h->CT == 4) launch_step_t<4, 2, 0>(h, a); else launch_step_t<1, 1, 0>(h, a);
+    if (h->net.wide) { if (h->CT == 4) launch_step_t<4, 2, 0, true>(h, a); else launch_step_t<1, 1, 0, true>(h, a); }
+    else if (h->CT == 4 && h->CTH == 2) launch_step_t<4, 2, 2, false>(h, a);
+    else if (h->CT == 4) launch_step_t<4, 2, 0, false>(h, a);
+    else launch_step_t<1, 1, 0, false>(h, a);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -392,9 +420,15 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     {
         ProfScope ps(h, PK_TRAIN_FB);
         dim3 grid(n_rb, 2);
-        if (h->CT == 4 && h->CTH == 2) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
-        else if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
-        else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0>), grid, dim3(BLOCK_THREADS), (size_t)n.lds_total * sizeof(float), h->stream, n, ta);
+        const size_t lds_bytes = (size_t)n.lds_total * sizeof(float);
+        const dim3 blk(BLOCK_THREADS);
+        if (n.wide) {
+            if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, true>), grid, blk, lds_bytes, h->stream, n, ta);
+            else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0, true>), grid, blk, lds_bytes, h->stream, n, ta);
+        }
+        else if (h->CT == 4 && h->CTH == 2) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2, false>), grid, blk, lds_bytes, h->stream, n, ta);
+        else if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
+        else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
         HIP_OK(h, hipGetLastError());
     }
     const int n_pad = ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
@@ -509,9 +543,11 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     const int lds_bytes = h->net.lds_total * (int)sizeof(float);
     bool attr_ok = true;
     auto set_lds = [&](const void* f) { attr_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess; };
-    set_lds((const void*)policy_step_kernel<4, 2, 2>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2>);
-    set_lds((const void*)policy_step_kernel<4, 2, 0>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0>);
-    set_lds((const void*)policy_step_kernel<1, 1, 0>); set_lds((const void*)train_fwd_bwd_kernel<1, 1, 0>);
+    set_lds((const void*)policy_step_kernel<4, 2, 2, false>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2, false>);
+    set_lds((const void*)policy_step_kernel<4, 2, 0, false>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0, false>);
+    set_lds((const void*)policy_step_kernel<1, 1, 0, false>); set_lds((const void*)train_fwd_bwd_kernel<1, 1, 0, false>);
+    set_lds((const void*)policy_step_kernel<4, 2, 0, true>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0, true>);
+    set_lds((const void*)policy_step_kernel<1, 1, 0, true>); set_lds((const void*)train_fwd_bwd_kernel<1, 1, 0, true>);
     attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 64 + 1024) * 4) == hipSuccess;
     attr_ok &= hipFuncSetAttribute((const void*)weight_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * 64 + 1024) * 4) == hipSuccess;
     if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return bail(0); }

@@ -51,6 +51,8 @@ struct NetDev {
     int lds_head;                   // split-K scratch of the policy head [4][16][Ap]
     int lds_par;                    // small parameters staged once per block: biases | b_mu | logstd | w_v | b_v
     int par_b[PPO_MAX_LAYERS], par_bmu, par_ls, par_wv, par_bv, par_total;
+    int par_skip;                   // first mirror index kept in LDS (wide form: biases stay in the global mirror)
+    int wide;                       // two ping-pong LDS tiles instead of one tile per layer
     int lds_misc;                   // loss scratch: 64 + 16*Ap (dlogstd) + 16*Ap (actions) + 64
     int lds_total;
     // per-workgroup slot layout (floats) -- partial sums a row block contributes to non-matrix gradients
@@ -485,7 +487,7 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
     float pv[PK], ov[OK], av[AK], r0 = 0.f, r1 = 0.f, r2 = 0.f, s0 = 0.f, s1 = 1.f;
     // ---- issue every load -----------------------------------------------------------------------------------------
 #pragma unroll
-    for (int k = 0; k < PK; ++k) { const int i = tid + BLOCK_THREADS * k; pv[k] = i < net.par_total ? par_src[i] : 0.f; }
+    for (int k = 0; k < PK; ++k) { const int i = net.par_skip + tid + BLOCK_THREADS * k; pv[k] = i < net.par_total ? par_src[i] : 0.f; }
 #pragma unroll
     for (int k = 0; k < OK; ++k) {
         const int i = tid + BLOCK_THREADS * k;
@@ -509,8 +511,8 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
     }
     // ---- consume ---------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int k = 0; k < PK; ++k) { const int i = tid + BLOCK_THREADS * k; if (i < net.par_total) par[i] = pv[k]; }
-    for (int i = tid + BLOCK_THREADS * PK; i < net.par_total; i += BLOCK_THREADS) par[i] = par_src[i];
+    for (int k = 0; k < PK; ++k) { const int i = net.par_skip + tid + BLOCK_THREADS * k; if (i < net.par_total) par[i] = pv[k]; }
+    for (int i = net.par_skip + tid + BLOCK_THREADS * PK; i < net.par_total; i += BLOCK_THREADS) par[i] = par_src[i];
     auto put_obs = [&](int i, float x) __attribute__((always_inline)) {
         const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
         if (row < nrows && j < O) {
@@ -569,8 +571,8 @@ __device__ __forceinline__ void policy_head(const NetDev& net, const float* __re
                                             int K, float* lds) {
     float* mus = lds + net.lds_mu;
     const int ldm = net.Ap + LDS_PAD;
-    if constexpr (CTH > 0) head_splitk<CTH>(hpre.w, theta + net.wmu_off, lds + net.lds_par + net.par_bmu, hL, ldh, K, net.Ap, lds + net.lds_head, mus, ldm);
-    else head_generic(theta + net.wmu_off, lds + net.lds_par + net.par_bmu, hL, ldh, K, net.Ap, mus, ldm);
+    if constexpr (CTH > 0) head_splitk<CTH>(hpre.w, theta + net.wmu_off, lds + net.lds_par - net.par_skip + net.par_bmu, hL, ldh, K, net.Ap, lds + net.lds_head, mus, ldm);
+    else head_generic(theta + net.wmu_off, lds + net.lds_par - net.par_skip + net.par_bmu, hL, ldh, K, net.Ap, mus, ldm);
     lds_barrier();
 }
 
@@ -592,7 +594,7 @@ struct StepArgs {
     uint32_t seed, rng_step, row_base;
 };
 
-template <int CT, int KS, int CTH>
+template <int CT, int KS, int CTH, bool WIDE>
 __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tower = blockIdx.y;
@@ -603,14 +605,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
     WRing<CT, KS> wpre;
     HeadFrag<CTH> hpre;
     dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
-    float* par = lds + net.lds_par;
+    float* par = lds + net.lds_par - net.par_skip;      // indexed with absolute mirror offsets
     stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, nullptr, row0, a.n, a.nz,
                        tower == 0 ? a.obs_out : nullptr, nullptr, RowScalars{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, nullptr);
     lds_barrier();
     int K = net.Kp0, ldx = ld0;
     for (int l = 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
-        dense_tile<CT, KS, EP_BIAS_TANH>(wpre, a.theta + net.w_off[tower][l], Np, par + net.par_b[l], lds + net.lds_h[l], ldx, K,
+        dense_tile<CT, KS, EP_BIAS_TANH>(wpre, a.theta + net.w_off[tower][l], Np, WIDE ? a.par + tower * net.par_total + net.par_b[l] : par + net.par_b[l], lds + net.lds_h[l], ldx, K,
                                          lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, nullptr, 0, row0, a.n, [&]() __attribute__((always_inline)) {
                                              if (l + 1 < net.L) dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][l + 1], net.Hp[l + 1], net.Hp[l + 1], Np);
                                              else if constexpr (CTH > 0) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, Np);   // (both towers: uniform code)
@@ -678,7 +680,7 @@ struct TrainArgs {
     unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS): [blocks][16] s_memtime stamps
 };
 
-template <int CT, int KS, int CTH>
+template <int CT, int KS, int CTH, bool WIDE>
 __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tower = blockIdx.y;
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     WRing<CT, KS> wpre;
     HeadFrag<CTH> hpre;
     dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
-    float* par = lds + net.lds_par;
+    float* par = lds + net.lds_par - net.par_skip;      // indexed with absolute mirror offsets
     ObsNorm nz = {nullptr, nullptr, 0.f, 0.f, 0};
     RowScalars rs;
     if (tower == 0) rs = RowScalars{a.actions, a.advs ? a.advs : a.returns, a.advs ? nullptr : a.old_values, a.old_neglogp, a.adv_stats, 1};
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     int K = net.Kp0, ldx = ld0;
     for (int l = 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
-        dense_tile<CT, KS, EP_BIAS_TANH>(wpre, a.theta + net.w_off[tower][l], Np, par + net.par_b[l], lds + net.lds_h[l], ldx, K,
+        dense_tile<CT, KS, EP_BIAS_TANH>(wpre, a.theta + net.w_off[tower][l], Np, WIDE ? a.par + tower * net.par_total + net.par_b[l] : par + net.par_b[l], lds + net.lds_h[l], ldx, K,
                                          lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, a.hg[tower][l], Np, row0, a.n, [&]() __attribute__((always_inline)) {
                                              if (l + 1 < net.L) dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][l + 1], net.Hp[l + 1], net.Hp[l + 1], Np);
                                              else {
@@ -851,6 +853,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     }
     STAMP(8);
     // ---- hidden layers, top down: dnext holds dLoss/d(pre-activation of layer l) -------------------------------
+    if (WIDE) dcur = lds + net.lds_h[net.L];           // wide form: h_L's tile is free now and becomes the other ping-pong tile
     for (int l = net.L - 1; l >= 0; --l) {
         float* t = dcur; dcur = dnext; dnext = t;            // dcur = dY_l
         const int Np = net.Hp[l], ldd = Np + LDS_PAD;
@@ -863,7 +866,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
             const int Kp = net.Hp[l - 1];
             // dY_{l-1} = (dY_l * W_l^T) .* (1 - h_l^2), W_l^T = transposed copy [Hp_l][Hp_{l-1}]
             dense_tile<CT, KS, EP_TANHGRAD>(wpre, a.thetaT + net.wT_off[tower][l], Kp, nullptr, dcur, ldd, Np, dnext, Kp + LDS_PAD, Kp,
-                                            lds + net.lds_h[l], Kp + LDS_PAD, a.dyg[tower][l - 1], Kp, row0, a.n, [&]() __attribute__((always_inline)) {
+                                            WIDE ? a.hg[tower][l - 1] + (size_t)row0 * Kp : lds + net.lds_h[l], WIDE ? Kp : Kp + LDS_PAD,
+                                            a.dyg[tower][l - 1], Kp, row0, a.n, [&]() __attribute__((always_inline)) {
                                                 if (l > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[tower][l - 1], net.Hp[l - 2], net.Hp[l - 2], Kp);
                                             });
         }

@@ -300,3 +300,28 @@ def test_rccl_plumbing_single_rank_communicator():
     rows, _ = g2.update(LR, CR, epochs, nmb, perms)             # eager launch sequence with the collectives in it
     close(rows, ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows under a communicator")
     close(g2.get_flat(0), orc2.theta, rtol=2e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("hidden,O,A,n", [((512, 512), 18, 18, 64), ((1024, 1024, 1024), 256, 64, 48), ((1024,), 256, 64, 40), ((1100,), 18, 18, 20),
+                                          # regular layout, 64-column wave tiles, widths that are not multiples of 256
+                                          # (generic policy head instead of the split-K one), wide obs/action vectors
+                                          ((448, 448), 18, 18, 40), ((320, 320), 256, 64, 33), ((448, 320), 18, 18, 16)])
+def test_wide_networks_use_the_two_tile_layout(hidden, O, A, n):
+    """Nets whose per-layer activation tiles exceed 160 KB of LDS ([512,512] and up; BASELINE config 5's shape in fp32)
+    run through the same kernels with two ping-pong tiles: act outputs, losses, gradients and Adam must match."""
+    orc, g = pair(hidden, "orth", O, A)
+    rng = np.random.RandomState(5)
+    obs = rng.uniform(-1, 1, (n, O)).astype(np.float32)
+    noise = rng.normal(size=(n, A)).astype(np.float32)
+    a, v, nlp = g.step(obs, noise)
+    ra, rv, rnlp = orc.step(obs, noise)
+    close(a, ra, msg="action"); close(v, rv, rtol=2e-4, msg="value"); close(nlp, rnlp, rtol=2e-4, msg="neglogp")
+    mb = H.synth_minibatch(orc, n, seed=3)
+    args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+    ref_losses, ref_grad = orc.loss_grad(*args, CR)
+    losses = g.train_step(LR, CR, *args)
+    orc.train_step(LR, CR, *args)
+    grad, _ = g.last_grad()
+    close(losses, ref_losses, rtol=2e-4, atol=1e-6, msg="losses")
+    close(grad, ref_grad, rtol=5e-4, atol=3e-6 * float(np.abs(ref_grad).max()), msg="grad")
+    close(g.get_flat(0), orc.theta, rtol=2e-4, atol=3e-6, msg="theta")
