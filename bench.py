@@ -28,7 +28,10 @@ CONFIGS = {
                  desc="1 env x 2048 steps, MLP [64,64] (launch-latency bound)"),
     "cfg4": dict(n_envs=1024, n_steps=64, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
                  desc="1024 envs x 64 steps, MLP [64,64]"),
+    "cfg5": dict(n_envs=8192, n_steps=16, hidden=[1024, 1024, 1024], obs=256, act=64, nminibatches=32, noptepochs=10,
+                 desc="synthetic 256-obs/64-act env, 8192 envs x 16 steps, MLP [1024,1024,1024] in exact fp32 (two-tile LDS layout)"),
 }
+BASELINE_INDEX = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}
 LR, CR, GAMMA, LAM = 3.93141e-4, 0.161023, 0.99, 0.95      # README.md:70-81, ppo2.cpp:215-217
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 PEAK_HBM_GBS = 8000.0
@@ -49,27 +52,30 @@ def cpu_baseline(cfg, budget_s=20.0):
     from oracle import oracle as o
     E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
     B = E * T; M = B // nmb
+    # bound the sample: about 1.5 GFLOP per call (the scalar port runs ~2-3 GFLOP/s); per-row cost is size independent
+    f_fwd, f_dx, f_dw = flops_per_row(cfg["obs"], cfg["act"], cfg["hidden"])
+    Es = int(max(16, min(E, 1.5e9 // f_fwd))); Ms = int(max(16, min(M, 1.5e9 // (f_fwd + f_dx + f_dw))))
     orc = o.Oracle(cfg["obs"], cfg["act"], cfg["hidden"])
     orc.init_orthogonal(0)
     rng = np.random.RandomState(0)
-    obs = rng.uniform(-1, 1, (E, cfg["obs"])).astype(np.float32)
-    noise = rng.normal(size=(E, cfg["act"])).astype(np.float32)
+    obs = rng.uniform(-1, 1, (Es, cfg["obs"])).astype(np.float32)
+    noise = rng.normal(size=(Es, cfg["act"])).astype(np.float32)
     t0 = time.perf_counter(); n_step = 0
     while n_step < 1 or (time.perf_counter() - t0 < 0.15 * budget_s and n_step < 8):
         a, v, nlp = orc.step(obs, noise); n_step += 1
-    t_step = (time.perf_counter() - t0) / n_step
-    mobs = rng.uniform(-1, 1, (M, cfg["obs"])).astype(np.float32)
-    act, v, nlp = orc.step(mobs, rng.normal(size=(M, cfg["act"])).astype(np.float32))
-    ret = (v + rng.normal(size=M)).astype(np.float32)
+    t_step = (time.perf_counter() - t0) / n_step * (E / Es)
+    mobs = rng.uniform(-1, 1, (Ms, cfg["obs"])).astype(np.float32)
+    act, v, nlp = orc.step(mobs, rng.normal(size=(Ms, cfg["act"])).astype(np.float32))
+    ret = (v + rng.normal(size=Ms)).astype(np.float32)
     adv = o.adv_normalize(ret, v)
     t0 = time.perf_counter(); n_tr = 0
     while n_tr < 1 or (time.perf_counter() - t0 < 0.85 * budget_s and n_tr < 64):
         orc.train_step(LR, CR, mobs, act, adv, ret, nlp, v); n_tr += 1
-    t_train = (time.perf_counter() - t0) / n_tr
+    t_train = (time.perf_counter() - t0) / n_tr * (M / Ms)
     t_update = T * t_step + ep * nmb * t_train
     return {"value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "%d policy steps at %d rows + %d train steps at %d rows of the oracle's C restatement, extrapolated to "
-                      "%d steps + %d train steps per update" % (n_step, E, n_tr, M, T, ep * nmb),
+                      "%d steps + %d train steps per update" % (n_step, Es, n_tr, Ms, T, ep * nmb) + ("" if (Es, Ms) == (E, M) else " (rows scaled to %d / %d)" % (E, M)),
             "update_samples_per_s": ep * B / (ep * nmb * t_train)}
 
 
@@ -164,7 +170,7 @@ def main():
         "metric": "PPO env-steps/s", "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2] (%s): %s" % (args.config, cfg["desc"]), "n_envs_per_gpu": E, "n_steps": T,
+        "config": {"workload": "BASELINE configs[%d] (%s): %s" % (BASELINE_INDEX[args.config], args.config, cfg["desc"]), "n_envs_per_gpu": E, "n_steps": T,
                    "n_batch_per_gpu": B, "minibatch_rows_per_gpu": M, "parallelism": "dp%d" % world,
                    "env": "on-device seeded synthetic env (env_mock shape), rollout buffers resident in HBM"},
         "update_samples_per_s": world * ep * B / (t_c - t_b),

@@ -90,13 +90,17 @@ struct ppo_handle {
     float nz_gamma = 0.99f, nz_clip_obs = 10.f, nz_clip_rew = 10.f, nz_eps = 1e-8f;
     NormDev obs_rms{}, ret_rms{};
     float* nz_ret = nullptr;
-    float* stats_xch = nullptr;       // [2*D+1] cross-rank batch moments (data-parallel running statistics)
+    float* stats_part = nullptr;      // per-workgroup (n, mean, M2) chunks of norm_batch_kernel
+    float* stats_counter = nullptr;   // its arrival counter (one unsigned)
+    float* stats_xch = nullptr;       // [world][(1+2D)+3] cross-rank batch moments (data-parallel running statistics)
+    int stats_xch_world = 0;
     float* adv_xch = nullptr;         // [2*nminibatches] cross-rank advantage sums
     // rollout
     int E = 0, T = 0;
     float *ro_obs = nullptr, *ro_act = nullptr, *ro_val = nullptr, *ro_nlp = nullptr, *ro_done = nullptr, *ro_rew = nullptr,
           *ro_ret = nullptr;
-    float *cur_obs = nullptr, *cur_done = nullptr, *raw_obs = nullptr, *raw_rew = nullptr, *raw_done = nullptr, *last_val = nullptr;
+    int done_staged = -1;             // ro_done[done_staged] already holds cur_done (written by norm_batch_kernel)
+    float *cur_done = nullptr, *raw_obs = nullptr, *raw_rew = nullptr, *raw_done = nullptr, *last_val = nullptr;
     float* ro_noise = nullptr;        // [T,E,A] staging for explicit noise
     // update
     int* d_perms = nullptr; int* d_inv = nullptr; int* d_gidx = nullptr; float* d_advstats = nullptr;
@@ -571,8 +575,8 @@ void ppo_destroy(ppo_handle* h) {
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
-                    h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->stats_xch, h->adv_xch, h->ro_obs, h->ro_act,
-                    h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->cur_obs, h->cur_done, h->raw_obs, h->raw_rew, h->raw_done,
+                    h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->stats_xch, h->stats_part, h->stats_counter, h->adv_xch, h->ro_obs, h->ro_act,
+                    h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->cur_done, h->raw_obs, h->raw_rew, h->raw_done,
                     h->last_val, h->ro_noise, h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp, h->d_perms, h->d_inv, h->d_gidx, h->d_advstats, h->d_keys, h->d_loss_rows, h->d_loss_mean};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) { if (h->hg[t][l]) (void)hipFree(h->hg[t][l]); if (h->dyg[t][l]) (void)hipFree(h->dyg[t][l]); }
@@ -797,10 +801,10 @@ static int norm_alloc_stats(ppo_handle* h, NormDev& s, int dim) {
 
 int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, float clip_rew, float epsilon) {
     if (n_envs < 1) return fail(h, "ppo_norm_init: n_envs must be positive");
-    if (h->net.O > STATS_THREADS) return fail(h, "ppo_norm_init: obs_dim > %d unsupported", STATS_THREADS);
     h->nz_envs = n_envs; h->nz_gamma = gamma; h->nz_clip_obs = clip_obs; h->nz_clip_rew = clip_rew; h->nz_eps = epsilon;
     if (norm_alloc_stats(h, h->obs_rms, h->net.O) || norm_alloc_stats(h, h->ret_rms, 1)) return -1;
-    if (dev_alloc(h, &h->nz_ret, n_envs) || dev_alloc(h, &h->stats_xch, (size_t)2 * h->net.O + 8)) return -1;
+    if (dev_alloc(h, &h->nz_ret, n_envs) || dev_alloc(h, &h->stats_counter, 4) ||
+        dev_alloc(h, &h->stats_part, (size_t)NB_MAX_OBS_BLOCKS * (1 + 2 * h->net.O) + (size_t)NB_MAX_REW_BLOCKS * 3)) return -1;
     if (dev_alloc(h, &h->raw_obs, (size_t)n_envs * h->net.O) || dev_alloc(h, &h->raw_rew, n_envs) || dev_alloc(h, &h->raw_done, n_envs)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -814,40 +818,51 @@ static int allreduce_f32(ppo_handle* h, float* buf, size_t count) {
     return 0;
 }
 
-// RunningStatistics::update over the rows of ALL ranks when a communicator exists (the running statistics
-// are over all environments), else the single fused kernel
-static int enqueue_stats_update(ppo_handle* h, const float* batch_dev, int rows, int D, NormDev st) {
-    if (!h->comm) {
+// EnvNormalize::step's statistics + reward branch for one batch of envs: one multi-block launch; with a communicator
+// the ranks' batch moments are exchanged with ONE all-reduce (slot table = all-gather) and a one-block finish, so the
+// running statistics are over the environments of ALL ranks.  obs_dev / rew_dev may be null (job absent).
+static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, const float* rew_dev, const float* done_dev, int training_rew,
+                              float* rew_out, float* done_copy) {
+    if (!obs_dev && !rew_dev) return 0;
+    NormBatchArgs a{};
+    const int D = h->net.O;
+    a.D = D; a.obs = obs_dev; a.rows = rows; a.obs_st = h->obs_rms;
+    if (obs_dev) {
+        // ~2048 values per workgroup: 8 independent loads per thread and pass
+        const int cap = D <= 32 ? NB_MAX_OBS_BLOCKS : 64;       // wide rows: the final combine walks the chunks per column
+        a.g_obs = std::max(1, std::min(cap, (int)(((int64_t)rows * D + 2047) / 2048)));
+        a.g_obs = std::min(a.g_obs, rows);
+        a.rows_per_obs_block = (rows + a.g_obs - 1) / a.g_obs;
+        a.g_obs = (rows + a.rows_per_obs_block - 1) / a.rows_per_obs_block;
+    }
+    a.rew = rew_dev; a.dones = done_dev; a.ret = h->nz_ret; a.ret_st = h->ret_rms; a.rew_out = rew_out; a.done_copy = done_copy;
+    a.rew_rows = rows; a.training_rew = training_rew;
+    if (rew_dev) {
+        a.g_rew = std::max(1, std::min(NB_MAX_REW_BLOCKS, (rows + 1023) / 1024));
+        a.rows_per_rew_block = (rows + a.g_rew - 1) / a.g_rew;
+        a.g_rew = (rows + a.rows_per_rew_block - 1) / a.rows_per_rew_block;
+    }
+    a.gamma = h->nz_gamma; a.clip_rew = h->nz_clip_rew; a.eps = h->nz_eps;
+    a.part = h->stats_part; a.counter = reinterpret_cast<unsigned*>(h->stats_counter);
+    a.world = h->world; a.rank = h->rank;
+    const size_t xw = (size_t)(1 + 2 * D) + 3;
+    if (h->comm) {
+        if (!h->stats_xch || h->stats_xch_world != h->world) {
+            if (dev_alloc(h, &h->stats_xch, xw * h->world)) return -1;
+            h->stats_xch_world = h->world;
+        }
+        a.xch = h->stats_xch;
+        HIP_OK(h, hipMemsetAsync(h->stats_xch, 0, xw * h->world * sizeof(float), h->stream));
+    }
+    { ProfScope ps(h, PK_STATS);
+      hipLaunchKernelGGL(norm_batch_kernel, dim3(a.g_obs + a.g_rew), dim3(NB_THREADS), 0, h->stream, a);
+      HIP_OK(h, hipGetLastError()); }
+    if (h->comm) {
+        if (allreduce_f32(h, h->stats_xch, xw * h->world)) return -1;
         ProfScope ps(h, PK_STATS);
-        hipLaunchKernelGGL(running_stats_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, batch_dev, rows, D, st);
+        hipLaunchKernelGGL(norm_finalize_kernel, dim3(2), dim3(NB_THREADS), 0, h->stream, a);
         HIP_OK(h, hipGetLastError());
-        return 0;
     }
-    for (int phase = 0; phase < 3; ++phase) {
-        { ProfScope ps(h, PK_STATS);
-          hipLaunchKernelGGL(stats_phase_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, batch_dev, rows, D, st, h->stats_xch, phase);
-          HIP_OK(h, hipGetLastError()); }
-        if (phase == 0 && allreduce_f32(h, h->stats_xch, (size_t)D + 1)) return -1;
-        if (phase == 1 && allreduce_f32(h, h->stats_xch + D + 1, (size_t)D)) return -1;
-    }
-    return 0;
-}
-static int enqueue_obs_stats(ppo_handle* h, const float* raw_dev, int rows) { return enqueue_stats_update(h, raw_dev, rows, h->net.O, h->obs_rms); }
-
-static int enqueue_reward_norm(ppo_handle* h, const float* rew_dev, const float* done_dev, int rows, int training, float* out_dev) {
-    if (!h->comm) {
-        ProfScope ps(h, PK_STATS);
-        hipLaunchKernelGGL(reward_norm_kernel, dim3(1), dim3(STATS_THREADS), 0, h->stream, rew_dev, done_dev, rows, training, h->nz_gamma,
-                           h->nz_clip_rew, h->nz_eps, h->nz_ret, h->ret_rms, out_dev);
-        HIP_OK(h, hipGetLastError());
-        return 0;
-    }
-    hipLaunchKernelGGL(ret_update_kernel, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rew_dev, rows, h->nz_gamma, h->nz_ret);
-    HIP_OK(h, hipGetLastError());
-    if (training && enqueue_stats_update(h, h->nz_ret, rows, 1, h->ret_rms)) return -1;
-    hipLaunchKernelGGL(reward_apply_kernel, dim3((rows + 255) / 256), dim3(256), 0, h->stream, rew_dev, done_dev, rows, h->nz_clip_rew, h->nz_eps,
-                       h->nz_ret, h->ret_rms, out_dev);
-    HIP_OK(h, hipGetLastError());
     return 0;
 }
 
@@ -857,7 +872,7 @@ int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int traini
     const size_t cnt = (size_t)n_envs * h->net.O;
     if (ensure_staging(h, n_envs)) return -1;
     HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (training && enqueue_obs_stats(h, h->raw_obs, n_envs)) return -1;
+    if (training && enqueue_norm_batch(h, h->raw_obs, n_envs, nullptr, nullptr, 0, nullptr, nullptr)) return -1;
     hipLaunchKernelGGL(obs_normalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->raw_obs, n_envs, h->net.O, h->obs_rms,
                        h->nz_eps, h->nz_clip_obs, h->st_obs);
     HIP_OK(h, hipGetLastError());
@@ -872,7 +887,7 @@ int ppo_norm_reward(ppo_handle* h, const float* raw_rew, const float* dones, int
     if (ensure_staging(h, n_envs)) return -1;
     HIP_OK(h, hipMemcpyAsync(h->raw_rew, raw_rew, (size_t)n_envs * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemcpyAsync(h->raw_done, dones, (size_t)n_envs * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (enqueue_reward_norm(h, h->raw_rew, h->raw_done, n_envs, training, h->st_vec[0])) return -1;
+    if (enqueue_norm_batch(h, nullptr, n_envs, h->raw_rew, h->raw_done, training, h->st_vec[0], nullptr)) return -1;
     HIP_OK(h, hipMemcpyAsync(out, h->st_vec[0], (size_t)n_envs * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -910,7 +925,7 @@ int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
     const NetDev& n = h->net;
     const size_t B = (size_t)E * T;
     if (dev_alloc(h, &h->ro_obs, B * n.O) || dev_alloc(h, &h->ro_act, B * n.A) || dev_alloc(h, &h->ro_val, B) || dev_alloc(h, &h->ro_nlp, B) ||
-        dev_alloc(h, &h->ro_done, B) || dev_alloc(h, &h->ro_rew, B) || dev_alloc(h, &h->ro_ret, B) || dev_alloc(h, &h->cur_obs, (size_t)E * n.O) ||
+        dev_alloc(h, &h->ro_done, B) || dev_alloc(h, &h->ro_rew, B) || dev_alloc(h, &h->ro_ret, B) ||
         dev_alloc(h, &h->cur_done, E) || dev_alloc(h, &h->last_val, E) || dev_alloc(h, &h->ro_noise, B * n.A))
         return -1;
     h->E = E; h->T = T;
@@ -918,32 +933,35 @@ int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
     return 0;
 }
 
-// normalise raw obs (update-then-normalise, env_normalize.hpp:94-105) into cur_obs
-static int enqueue_obs_normalize(ppo_handle* h, int training) {
-    const size_t cnt = (size_t)h->E * h->net.O;
-    if (training && enqueue_obs_stats(h, h->raw_obs, h->E)) return -1;
-    hipLaunchKernelGGL(obs_normalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->raw_obs, h->E, h->net.O, h->obs_rms,
-                       h->nz_eps, h->nz_clip_obs, h->cur_obs);
-    HIP_OK(h, hipGetLastError());
-    return 0;
-}
+// The current observations stay RAW in raw_obs: the statistics update runs when they arrive (update-then-normalise,
+// env_normalize.hpp:94-105) and the scale + clip happens in the policy step's input staging, which also writes the
+// normalised rows into the rollout buffer -- no separate normalise kernel, no device-to-device copy.
+static ObsNorm obs_norm(ppo_handle* h) { return ObsNorm{h->obs_rms.mean, h->obs_rms.var, h->nz_eps, h->nz_clip_obs, 1}; }
 
-// policy step on cur_obs -> rollout[t]
+// policy step on the current observations -> rollout[t]
 static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uint32_t seed, uint32_t rng_step, uint32_t row_base) {
     const NetDev& n = h->net;
     const size_t E = h->E;
-    HIP_OK(h, hipMemcpyAsync(h->ro_obs + t * E * n.O, h->cur_obs, E * n.O * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    HIP_OK(h, hipMemcpyAsync(h->ro_done + t * E, h->cur_done, E * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (h->done_staged != t) HIP_OK(h, hipMemcpyAsync(h->ro_done + t * E, h->cur_done, E * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     StepArgs a{};
-    a.theta = h->theta; a.par = h->par; a.obs = h->cur_obs; a.noise = noise_dev; a.action = h->ro_act + t * E * n.A; a.det_action = nullptr;
-    a.value = h->ro_val + t * E; a.neglogp = h->ro_nlp + t * E; a.obs_out = nullptr; a.nz = no_norm(); a.n = (int)E;
+    a.theta = h->theta; a.par = h->par; a.obs = h->raw_obs; a.noise = noise_dev; a.action = h->ro_act + t * E * n.A; a.det_action = nullptr;
+    a.value = h->ro_val + t * E; a.neglogp = h->ro_nlp + t * E; a.obs_out = h->ro_obs + t * E * n.O; a.nz = obs_norm(h); a.n = (int)E;
     a.seed = seed; a.rng_step = rng_step; a.row_base = row_base;
     return launch_step(h, a);
 }
 
+// statistics of the observations that just arrived in raw_obs, the reward branch, and the dones of the next rollout row
+static int enqueue_observe(ppo_handle* h, int t) {
+    const size_t E = h->E;
+    float* done_next = t + 1 < h->T ? h->ro_done + (size_t)(t + 1) * E : nullptr;
+    if (enqueue_norm_batch(h, h->raw_obs, (int)E, h->raw_rew, h->cur_done, 1, h->ro_rew + (size_t)t * E, done_next)) return -1;
+    h->done_staged = done_next ? t + 1 : -1;
+    return 0;
+}
+
 static int enqueue_finish(ppo_handle* h, float gamma, float lam) {
     StepArgs a{};
-    a.theta = h->theta; a.par = h->par; a.obs = h->cur_obs; a.value = h->last_val; a.nz = no_norm(); a.n = h->E;
+    a.theta = h->theta; a.par = h->par; a.obs = h->raw_obs; a.value = h->last_val; a.nz = obs_norm(h); a.n = h->E;
     if (launch_step(h, a)) return -1;
     ProfScope ps(h, PK_GAE);
     hipLaunchKernelGGL(gae_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, h->ro_rew, h->ro_val, h->ro_done, h->last_val, h->cur_done,
@@ -957,7 +975,8 @@ int ppo_rollout_reset(ppo_handle* h, const float* raw_obs) {
     HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, (size_t)h->E * h->net.O * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)h->E * sizeof(float), h->stream));          // env_normalize.hpp:114
     HIP_OK(h, hipMemsetAsync(h->cur_done, 0, (size_t)h->E * sizeof(float), h->stream));        // runner.hpp:50
-    if (enqueue_obs_normalize(h, 1)) return -1;
+    h->done_staged = -1;
+    if (enqueue_norm_batch(h, h->raw_obs, h->E, nullptr, nullptr, 0, nullptr, nullptr)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -980,8 +999,7 @@ int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const fl
     HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, E * h->net.O * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemcpyAsync(h->raw_rew, raw_rew, E * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemcpyAsync(h->cur_done, dones, E * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (enqueue_obs_normalize(h, 1)) return -1;
-    if (enqueue_reward_norm(h, h->raw_rew, h->cur_done, (int)E, 1, h->ro_rew + (size_t)t * E)) return -1;
+    if (enqueue_observe(h, t)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1006,15 +1024,15 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
           HIP_OK(h, hipGetLastError()); }
         HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)E * sizeof(float), h->stream));
         HIP_OK(h, hipMemsetAsync(h->cur_done, 0, (size_t)E * sizeof(float), h->stream));
-        if (enqueue_obs_normalize(h, 1)) return -1;
+        h->done_staged = -1;
+        if (enqueue_norm_batch(h, h->raw_obs, E, nullptr, nullptr, 0, nullptr, nullptr)) return -1;
     }
     for (int t = 0; t < T; ++t) {
         if (enqueue_rollout_act(h, t, noise ? h->ro_noise + (size_t)t * E * n.A : nullptr, seed, step0 + t, (uint32_t)env0)) return -1;
         { ProfScope ps(h, PK_ENV);
           hipLaunchKernelGGL(seeded_env_kernel, dim3((envW + 255) / 256), dim3(256), 0, h->stream, seed, env0, E, step0 + (uint32_t)t + 1u, n.O, h->raw_obs, h->raw_rew, h->cur_done);
           HIP_OK(h, hipGetLastError()); }
-        if (enqueue_obs_normalize(h, 1)) return -1;
-        if (enqueue_reward_norm(h, h->raw_rew, h->cur_done, E, 1, h->ro_rew + (size_t)t * E)) return -1;
+        if (enqueue_observe(h, t)) return -1;
     }
     if (enqueue_finish(h, gamma, lam)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));

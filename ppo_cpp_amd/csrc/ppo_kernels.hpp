@@ -1554,117 +1554,255 @@ __global__ void gae_kernel(const float* rewards, const float* values, const floa
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// RunningStatistics::update (common/running_statistics.hpp:26-54, 88-104) over a [rows, D] batch, one block.
-// Thread t owns column t % D and rows t / D + i * (threads / D): consecutive threads read consecutive addresses.
-// Two passes exactly like the reference (mean, then sum of squared deviations), then the Chan merge with the
-// reference's float/double mixing (count is double, every matrix op is fp32).
+// EnvNormalize::step for a whole batch of envs (env_normalize.hpp:64-116) in ONE multi-block launch:
+//   obs job   : obs_rms.update(raw_obs)   (:94-98; scale + clip are fused into the next policy step's input staging)
+//   reward job: ret = ret*gamma + r ; ret_rms.update(ret) ; out = clip(r / sqrt(var + eps)) ; ret *= 1 - done   (:64-92)
+// Every workgroup reduces a chunk of rows to (n, mean, M2) with the reference's two passes (mean, then squared
+// deviations: common/running_statistics.hpp:26-54).  The workgroup that finishes LAST (device-scope counter; release /
+// acquire fences around it) combines the chunks in index order with M2 = sum_k M2_k + sum_k n_k (mean_k - mean)^2 --
+// algebraically the two-pass result over the whole batch, deterministic, and better conditioned than one long fp32
+// sum -- and applies RunningStatistics::update's merge (:88-104; count is double, every matrix op fp32).
+// Data-parallel: the last workgroup instead publishes this rank's (n, mean, M2) in its slot of `xch`; ONE all-reduce
+// of the zero-padded slot table (= an all-gather) later, norm_finalize_kernel combines the ranks in rank order, so the
+// statistics are over the environments of all ranks and bit-identical on every rank.
 // ------------------------------------------------------------------------------------------------------------
-#define STATS_THREADS 576   /* = 32 * 18: whole rows for the 18-wide case; any D <= 576 works */
+#define NB_THREADS 256
+#define NB_MAX_OBS_BLOCKS 256
+#define NB_MAX_REW_BLOCKS 64
 
-__device__ __forceinline__ void running_stats_update_block(const float* __restrict__ batch, int rows, int D, NormDev st,
-                                                           float* sh /* >= STATS_THREADS + 2*D floats */) {
+struct NormBatchArgs {
+    const float* obs; int rows; int D; NormDev obs_st; int g_obs; int rows_per_obs_block;      // obs == null: no obs job
+    const float* rew; const float* dones; float* ret; NormDev ret_st; float* rew_out; float* done_copy;   // rew == null: no reward job
+    int rew_rows; int training_rew; int g_rew; int rows_per_rew_block;
+    float gamma, clip_rew, eps;
+    float* part;          // [g_obs][1 + 2D] then [g_rew][3]
+    unsigned* counter;    // zero between launches
+    float* xch;           // data-parallel: [world][(1 + 2D) + 3] slot table (this rank's slot is written here), else null
+    int world, rank;
+};
+
+__device__ __forceinline__ int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// (n, mean[D], M2[D]) of rows [r0, r1) of a row-major [*, D] matrix -> out[0], out[1 .. D], out[1+D .. 2D].
+// A thread's first 8 values stay in registers between the two passes (one memory round trip for the usual chunk size).
+__device__ __forceinline__ void chunk_moments(const float* __restrict__ x, int r0, int r1, int D, float* out, float* sh /* 2*NB_THREADS */) {
     const int tid = threadIdx.x;
-    const int rpp = STATS_THREADS / D;             // rows per pass
-    const int col = tid % D, rsub = tid / D;
-    const bool act = rsub < rpp;
-    float* part = sh;                              // [rpp][D]
-    float* bmean = sh + STATS_THREADS;             // [D]
-    float s = 0.f;
-    if (act) for (int r = rsub; r < rows; r += rpp) s += batch[(size_t)r * D + col];
-    if (act) part[rsub * D + col] = s;
-    __syncthreads();
-    if (tid < D) {
-        float t = 0.f;
-        for (int q = 0; q < rpp; ++q) t += part[q * D + tid];
-        bmean[tid] = t / (float)rows;              // colwise().mean()
-    }
-    __syncthreads();
-    float m2 = 0.f;
-    if (act) {
-        const float bm = bmean[col];
-        for (int r = rsub; r < rows; r += rpp) { const float d = batch[(size_t)r * D + col] - bm; m2 += d * d; }
-        part[rsub * D + col] = m2;
-    }
-    __syncthreads();
-    if (tid < D) {
-        float t = 0.f;
-        for (int q = 0; q < rpp; ++q) t += part[q * D + tid];
-        const double cnt = *st.count;
-        const double nb = (double)rows;
-        const double tot = cnt + nb;
-        const float bvar = t / (float)nb;                                        // :51-54
-        const float delta = bmean[tid] - st.mean[tid];                           // :90
-        const float new_mean = st.mean[tid] + (delta * (float)nb) / (float)tot;  // :94
-        const float m_a = st.var[tid] * (float)cnt;                              // :97
-        const float m_b = bvar * (float)nb;                                      // :98
-        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;  // :100
-        st.mean[tid] = new_mean;
-        st.var[tid] = M2 / (float)tot;                                           // :101
-    }
-    __syncthreads();
-    if (tid == 0) *st.count = (double)rows + *st.count;                          // :103
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(STATS_THREADS) void running_stats_kernel(const float* batch, int rows, int D, NormDev st) {
-    __shared__ float sh[STATS_THREADS + 2 * 576];
-    running_stats_update_block(batch, rows, D, st, sh);
-}
-
-// Data-parallel form of RunningStatistics::update: the batch is the union of every rank's rows, so the two batch
-// moments are all-reduced between the phases (xch = [sum_0..sum_{D-1}, rows | m2_0..m2_{D-1}], summed over ranks by the
-// host between launches); phase 2 then performs the reference's Chan merge with the GLOBAL batch mean / variance / count.
-__global__ __launch_bounds__(STATS_THREADS) void stats_phase_kernel(const float* batch, int rows, int D, NormDev st, float* xch, int phase) {
-    __shared__ float part[STATS_THREADS];
-    const int tid = threadIdx.x;
-    const int rpp = STATS_THREADS / D;
-    const int col = tid % D, rsub = tid / D;
-    const bool act = rsub < rpp;
-    if (phase < 2) {
-        const float bm = phase == 1 ? xch[col] / xch[D] : 0.f;
-        float s = 0.f;
-        if (act) for (int r = rsub; r < rows; r += rpp) { const float d = batch[(size_t)r * D + col] - bm; s += phase == 1 ? d * d : d; }
-        if (act) part[rsub * D + col] = s;
-        __syncthreads();
-        if (tid < D) {
-            float t = 0.f;
-            for (int q = 0; q < rpp; ++q) t += part[q * D + tid];
-            xch[(phase == 1 ? D + 1 : 0) + tid] = t;
+    const float n = (float)(r1 - r0);
+    if (tid == 0) out[0] = n;
+    float* cm = sh + NB_THREADS;                         // chunk means of the current column group
+    constexpr int U = 8;
+    for (int cbase = 0; cbase < D; cbase += NB_THREADS) {
+        const int Dg = min(NB_THREADS, D - cbase);
+        const int rpp = NB_THREADS / Dg;                 // rows per sweep: consecutive threads read consecutive addresses
+        const int col = cbase + tid % Dg, rsub = tid / Dg;
+        const bool act = rsub < rpp;
+        const int top = pow2_ceil(rpp) >> 1;
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int r = r0 + rsub + u * rpp; v[u] = (act && r < r1) ? x[(size_t)r * D + col] : 0.f; }
+        for (int pass = 0; pass < 2; ++pass) {
+            const float bm = pass ? cm[tid % Dg] : 0.f;
+            float t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float a0 = v[u] - bm;
+                t[u] = (act && r0 + rsub + u * rpp < r1) ? (pass ? a0 * a0 : a0) : 0.f;
+            }
+            float s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            if (act) for (int r = r0 + rsub + U * rpp; r < r1; r += rpp) { const float a0 = x[(size_t)r * D + col] - bm; s += pass ? a0 * a0 : a0; }
+            __syncthreads();                             // previous users of sh are done
+            sh[tid] = s;                                 // == sh[rsub * Dg + tid % Dg]
+            __syncthreads();
+            for (int h = top; h > 0; h >>= 1) {          // fixed-shape tree over the row sweeps
+                if (act && rsub < h && rsub + h < rpp) sh[tid] += sh[tid + h * Dg];
+                __syncthreads();
+            }
+            if (tid < Dg) {
+                if (pass == 0) cm[tid] = sh[tid] / n;    // colwise().mean()
+                else { out[1 + cbase + tid] = cm[tid]; out[1 + D + cbase + tid] = sh[tid]; }
+            }
+            __syncthreads();
         }
-        if (phase == 0 && tid == 0) xch[D] = (float)rows;
+    }
+}
+
+// Whole block: combine K <= NB_THREADS (n, mean[D], M2[D]) sets (stride floats apart) for the column group
+// [cbase, cbase + Dg).  NB_THREADS / Dg threads share a column (strided over the sets) and meet in a fixed-shape tree,
+// so the result does not depend on scheduling.  Threads tid < Dg return their column's batch (n, mean, M2).
+__device__ __forceinline__ void combine_group(const float* sets, int K, int stride, int D, int cbase, int Dg, float* sh /* 3*NB_THREADS */,
+                                              float& n, float& mean, float& M2) {
+    const int tid = threadIdx.x;
+    float* cm = sh + NB_THREADS;
+    float* shn = sh + 2 * NB_THREADS;
+    const int rpp = NB_THREADS / Dg;
+    const int cg = tid % Dg, col = cbase + cg, ksub = tid / Dg;
+    const bool act = ksub < rpp;
+    const int top = pow2_ceil(rpp) >> 1;
+    __syncthreads();
+    if (tid < K) shn[tid] = sets[(size_t)tid * stride];
+    __syncthreads();
+    float nn = 0.f;
+    for (int k = 0; k < K; ++k) nn += shn[k];
+    float q = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float bm = pass ? cm[cg] : 0.f;
+        float s = 0.f;
+        if (act) {
+#pragma unroll 4
+            for (int k = ksub; k < K; k += rpp) {
+                const float nk = shn[k], mk = sets[(size_t)k * stride + 1 + col];
+                if (pass == 0) s += nk * mk;
+                else { const float d = mk - bm; s += sets[(size_t)k * stride + 1 + D + col] + nk * (d * d); }
+            }
+        }
+        __syncthreads();
+        sh[tid] = s;
+        __syncthreads();
+        for (int h = top; h > 0; h >>= 1) {
+            if (act && ksub < h && ksub + h < rpp) sh[tid] += sh[tid + h * Dg];
+            __syncthreads();
+        }
+        if (tid < Dg) { if (pass == 0) cm[tid] = sh[tid] / nn; else q = sh[tid]; }
+        __syncthreads();
+    }
+    n = nn; mean = cm[cg]; M2 = q;
+}
+
+// RunningStatistics::update's merge of a batch (mean, M2, n) into column c (common/running_statistics.hpp:88-104)
+__device__ __forceinline__ float merge_column(NormDev st, int c, double cnt, float bmean, float bM2, float nbf) {
+    const double nb = (double)nbf;
+    const double tot = cnt + nb;
+    const float bvar = bM2 / (float)nb;                                        // :51-54
+    const float delta = bmean - st.mean[c];                                    // :90
+    const float new_mean = st.mean[c] + (delta * (float)nb) / (float)tot;      // :94
+    const float m_a = st.var[c] * (float)cnt;                                  // :97
+    const float m_b = bvar * (float)nb;                                        // :98
+    const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;  // :100
+    const float v = M2 / (float)tot;                                           // :101
+    st.mean[c] = new_mean;
+    st.var[c] = v;
+    return v;
+}
+
+// Whole block.  which = 0: obs statistics, 1: reward branch.  sets: K sets (chunks of this rank, or the ranks' slots).
+// publish != null: write the combined local set there instead of merging (data-parallel first half).
+__device__ __forceinline__ void norm_finish(const NormBatchArgs& a, int which, const float* sets, int K, int stride, float* publish,
+                                            float* sh /* 3*NB_THREADS */) {
+    const int tid = threadIdx.x;
+    const int D = a.D;
+    if (which == 0) {
+        const double cnt = *a.obs_st.count;
+        float ntot = 0.f;
+        for (int cbase = 0; cbase < D; cbase += NB_THREADS) {
+            const int Dg = min(NB_THREADS, D - cbase);
+            float n, mean, M2;
+            combine_group(sets, K, stride, D, cbase, Dg, sh, n, mean, M2);
+            if (tid < Dg) {
+                const int c = cbase + tid;
+                if (publish) { publish[0] = n; publish[1 + c] = mean; publish[1 + D + c] = M2; }
+                else merge_column(a.obs_st, c, cnt, mean, M2, n);
+            }
+            ntot = n;
+        }
+        __syncthreads();
+        if (tid == 0 && !publish) *a.obs_st.count = (double)ntot + cnt;        // :103
         return;
     }
-    if (tid < D) {
-        const double cnt = *st.count;
-        const double nb = (double)xch[D];
-        const double tot = cnt + nb;
-        const float bmean = xch[tid] / (float)nb;
-        const float bvar = xch[D + 1 + tid] / (float)nb;
-        const float delta = bmean - st.mean[tid];
-        const float new_mean = st.mean[tid] + (delta * (float)nb) / (float)tot;
-        const float m_a = st.var[tid] * (float)cnt;
-        const float m_b = bvar * (float)nb;
-        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;
-        st.mean[tid] = new_mean;
-        st.var[tid] = M2 / (float)tot;
+    // reward branch: the first batch of the apply pass is in flight while the statistics are combined
+    constexpr int U = 8;
+    float dn[U], rw[U], rt[U];
+    if (!publish) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + NB_THREADS * u;
+            const bool ok = i < a.rew_rows;
+            dn[u] = ok ? a.dones[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; rt[u] = ok ? a.ret[i] : 0.f;
+        }
     }
+    float var = a.ret_st.var[0];
+    if (a.training_rew) {
+        const double cnt = *a.ret_st.count;
+        float n, mean, M2;
+        combine_group(sets, K, stride, 1, 0, 1, sh, n, mean, M2);
+        if (tid == 0) {
+            if (publish) { publish[0] = n; publish[1] = mean; publish[2] = M2; }
+            else {
+                var = merge_column(a.ret_st, 0, cnt, mean, M2, n);
+                *a.ret_st.count = (double)n + cnt;
+            }
+        }
+    }
+    if (publish) return;
     __syncthreads();
-    if (tid == 0) *st.count = (double)xch[D] + *st.count;
+    if (tid == 0) sh[0] = var;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf(sh[0] + a.eps);                             // env_normalize.hpp:76-79
+    for (int base = 0; base < a.rew_rows; base += NB_THREADS * U) {
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + tid + NB_THREADS * u;
+                const bool ok = i < a.rew_rows;
+                dn[u] = ok ? a.dones[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; rt[u] = ok ? a.ret[i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + tid + NB_THREADS * u;
+            if (i >= a.rew_rows) continue;
+            float y = rw[u] * inv;
+            y = tf_min(tf_max(y, -a.clip_rew), a.clip_rew);
+            a.rew_out[i] = y;
+            a.ret[i] = rt[u] * (1.0f - dn[u]);                                 // :84-90
+            if (a.done_copy) a.done_copy[i] = dn[u];
+        }
+    }
 }
 
-__global__ void ret_update_kernel(const float* rew, int rows, float gamma, float* ret) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows) ret[i] = ret[i] * gamma + rew[i];
+__global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a) {
+    __shared__ float sh[3 * NB_THREADS];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int so = 1 + 2 * a.D;
+    float* part_rew = a.part + (size_t)a.g_obs * so;
+    const int which = b < a.g_obs ? 0 : 1;
+    if (which == 0) {
+        const int r0 = b * a.rows_per_obs_block, r1 = min(a.rows, r0 + a.rows_per_obs_block);
+        chunk_moments(a.obs, r0, r1, a.D, a.part + (size_t)b * so, sh);
+    } else {
+        const int k = b - a.g_obs;
+        const int r0 = k * a.rows_per_rew_block, r1 = min(a.rew_rows, r0 + a.rows_per_rew_block);
+        constexpr int U = 4;
+        for (int base = r0; base < r1; base += NB_THREADS * U) {               // :66 (the same thread re-reads its elements below)
+            float rt[U], rw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int i = base + tid + NB_THREADS * u; const bool ok = i < r1; rt[u] = ok ? a.ret[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int i = base + tid + NB_THREADS * u; if (i < r1) a.ret[i] = rt[u] * a.gamma + rw[u]; }
+        }
+        if (a.training_rew) chunk_moments(a.ret, r0, r1, 1, part_rew + (size_t)k * 3, sh);
+    }
+    // last-block-done, one counter per job: release our partials, count, and let the final arrival acquire everyone's.
+    // The two jobs finish independently (two workgroups run the two tails side by side).
+    __threadfence();
+    __syncthreads();
+    const unsigned total = which == 0 ? (unsigned)a.g_obs : (unsigned)a.g_rew;
+    if (tid == 0) is_last = (atomicAdd(a.counter + which, 1u) == total - 1u) ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    float* publish = a.xch ? a.xch + (size_t)a.rank * (so + 3) + (which ? so : 0) : nullptr;
+    if (which == 0) norm_finish(a, 0, a.part, a.g_obs, so, publish, sh);
+    else norm_finish(a, 1, part_rew, a.g_rew, 3, publish, sh);
+    if (tid == 0) a.counter[which] = 0u;
 }
 
-__global__ void reward_apply_kernel(const float* rew, const float* dones, int rows, float clip, float eps, float* ret, NormDev st, float* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    const float inv = 1.0f / sqrtf(st.var[0] + eps);
-    float y = rew[i] * inv;
-    y = tf_min(tf_max(y, -clip), clip);
-    out[i] = y;
-    ret[i] = ret[i] * (1.0f - dones[i]);
+// data-parallel second half: combine the ranks' slots (after the all-reduce) and finish; one block
+__global__ __launch_bounds__(NB_THREADS) void norm_finalize_kernel(NormBatchArgs a) {      // grid = 2: block 0 obs, block 1 reward
+    __shared__ float sh[3 * NB_THREADS];
+    const int so = 1 + 2 * a.D;
+    if (blockIdx.x == 0) { if (a.obs) norm_finish(a, 0, a.xch, a.world, so + 3, nullptr, sh); }
+    else if (a.rew) norm_finish(a, 1, a.xch + so, a.world, so + 3, nullptr, sh);
 }
 
 // normalise + clip an [rows, D] batch with frozen statistics (env_normalize.hpp:99-104)
@@ -1675,25 +1813,6 @@ __global__ void obs_normalize_kernel(const float* in, int rows, int D, NormDev s
     float x = (in[i] - st.mean[j]) * (1.0f / sqrtf(st.var[j] + eps));
     x = tf_min(tf_max(x, -clip), clip);
     out[i] = x;
-}
-
-// EnvNormalize::step reward branch (env_normalize.hpp:64-92), one block:
-//   ret = ret*gamma + r ; ret_rms.update(ret) if training ; out = clip(r / sqrt(var + eps)) ; ret *= (1 - done)
-__global__ __launch_bounds__(STATS_THREADS) void reward_norm_kernel(const float* rew, const float* dones, int rows, int training,
-                                                                    float gamma, float clip, float eps, float* ret, NormDev st,
-                                                                    float* out) {
-    __shared__ float sh[STATS_THREADS + 2 * 576];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < rows; i += STATS_THREADS) ret[i] = ret[i] * gamma + rew[i];
-    __syncthreads();
-    if (training) running_stats_update_block(ret, rows, 1, st, sh);
-    const float inv = 1.0f / sqrtf(st.var[0] + eps);
-    for (int i = tid; i < rows; i += STATS_THREADS) {
-        float y = rew[i] * inv;
-        y = tf_min(tf_max(y, -clip), clip);
-        out[i] = y;
-        ret[i] = ret[i] * (1.0f - dones[i]);
-    }
 }
 
 // on-device seeded synthetic env (oracle/ppo_oracle.c orc_seeded_env_step): thread per (env, lane)
