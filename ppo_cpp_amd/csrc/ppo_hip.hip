@@ -1189,7 +1189,11 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
 static int load_rccl(Rccl& r, std::string& err) {
     if (r.lib) return 0;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break; }   // prefer a copy torch already mapped
+    if (const char* pick = getenv("PPO_RCCL_LIBRARY")) {       // a specific RCCL build (or the tests' shared-memory stand-in)
+        r.lib = dlopen(pick, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) { err = std::string("PPO_RCCL_LIBRARY: cannot load ") + pick + ": " + dlerror(); return -1; }
+    }
+    if (!r.lib) for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break; }   // prefer a copy torch already mapped
     if (!r.lib) for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
     if (!r.lib) { err = std::string("cannot load librccl: ") + dlerror(); return -1; }
     r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");

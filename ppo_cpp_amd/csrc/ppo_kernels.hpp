@@ -684,14 +684,18 @@ template <int CT, int KS, int CTH, bool WIDE>
 __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tower = blockIdx.y;
-    const int row0 = blockIdx.x * ROWS_PER_BLOCK;
+    // XCD-aware row mapping: workgroups are dealt round-robin over the 8 XCDs; giving XCD x the CONTIGUOUS row tiles
+    // [x*G/8, (x+1)*G/8) makes the activations / gradients this kernel leaves in that XCD's L2 exactly the rows the
+    // weight-gradient kernel's row split x (also on XCD x) streams next.
+    const int rb = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+    const int row0 = rb * ROWS_PER_BLOCK;
     const int tid = threadIdx.x;
     const int ld0 = net.Kp0 + LDS_PAD;
     float* misc = lds + net.lds_misc;          // [0,64) per-row loss terms | [64, 64+16Ap) dlogstd rows | then actions | row scalars
     float* dls = misc + 64;
     float* acts = dls + ROWS_PER_BLOCK * net.Ap;
     float* rowv = acts + ROWS_PER_BLOCK * net.Ap;   // [16][2]: pi {adv, old_neglogp} ; vf {return, old_value}
-    float* slot = a.slots[tower] + (size_t)blockIdx.x * net.slot_w;
+    float* slot = a.slots[tower] + (size_t)rb * net.slot_w;
     STAMP(0);
     WRing<CT, KS> wpre;
     HeadFrag<CTH> hpre;

@@ -1,0 +1,40 @@
+"""One rank of the two-process data-parallel test (tests/test_dp_two_ranks.py); not collected by pytest.
+usage: dp_worker.py <rank> <world> <in.npz> <out.npz>      (PPO_RCCL_LIBRARY selects the collective library)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, fin, fout = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    import ppo_cpp_amd
+    d = np.load(fin)
+    hidden = [int(x) for x in d["hidden"]]
+    E, T, nmb, epochs = (int(d[k]) for k in ("E", "T", "nmb", "epochs"))
+    El = E // world
+    sl = slice(rank * El, (rank + 1) * El)
+    g = ppo_cpp_amd.PPOHip(18, 18, hidden, device=0)
+    g.set_flat(d["theta"])
+    g.dist_init(world, rank, d["uid"].tobytes())
+    g.norm_init(El, float(d["gamma"]))
+    g.rollout_alloc(El, T)
+    g.collect_synthetic(int(d["seed"]), float(d["gamma"]), float(d["lam"]), d["noise"][:, sl], env0=rank * El, step0=0, first=True)
+    out = {"ro_" + f: g.rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones")}
+    for which, nm in ((0, "obs"), (1, "ret")):
+        m, v, c = g.norm_stats(which)
+        out[nm + "_mean"], out[nm + "_var"], out[nm + "_count"] = m, v, np.float64(c)
+    for f in ("obs", "actions", "values", "neglogp", "returns"):          # identical inputs: isolate the update arithmetic
+        g.rollout_set(f, d["ref_" + f][:, sl])
+    rows, mean = g.update(float(d["lr"]), float(d["cr"]), epochs, nmb, d["perms"][rank])
+    out["rows"], out["mean"], out["theta"] = rows, mean, g.get_flat(0)
+    out["adam_m"], out["adam_v"] = g.get_flat(1), g.get_flat(2)
+    g.close()
+    np.savez(fout, **out)
+
+
+if __name__ == "__main__":
+    main()

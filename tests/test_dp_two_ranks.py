@@ -1,0 +1,89 @@
+"""Data-parallel path with TWO ranks on one GPU.
+
+RCCL refuses two ranks on the same device, so the collective library is swapped (PPO_RCCL_LIBRARY) for
+tests/fake_rccl: the same five nccl* entry points over POSIX shared memory.  Everything else is the product path: two
+processes, one ppo_handle each, ppo_dist_init, the all-reduced running statistics during the rollout, the all-reduced
+advantage moments, the gradient all-reduce between the reduce and the Adam kernels.  The reference arithmetic is the
+single-process oracle over the UNION of the ranks' environments / minibatch rows."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers as H  # noqa: F401
+from oracle import oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LR, CR, GAMMA, LAM = 3.93141e-4, 0.161023, 0.99, 0.95
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, msg=""):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol, err_msg=msg)
+
+
+def build_fake_rccl(tmp):
+    so = os.path.join(tmp, "libfake_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp"), "-lrt"])
+    return so
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((64, 64), 16, 16, 4, 2), ((256, 256), 64, 8, 4, 1)])
+def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden, E, T, nmb, epochs):
+    world = 2
+    tmp = str(tmp_path)
+    fake = build_fake_rccl(tmp)
+    orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(11)
+    theta0 = orc.theta.copy()
+    rng = np.random.RandomState(41)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    nz = o.Normalizer(E, 18)
+    ro, _, _ = o.collect(orc, nz, 1234, T, noise, GAMMA, LAM)
+    # local shuffles per rank and the equivalent global one: global minibatch k = rank 0's k-th minibatch rows, then rank 1's
+    El = E // world; Bl = El * T; m = Bl // nmb; M = m * world
+    perms = np.empty((world, epochs, Bl), np.int32); gperms = np.empty((epochs, E * T), np.int32)
+    for ep in range(epochs):
+        for r in range(world):
+            p = rng.permutation(Bl).astype(np.int32)
+            perms[r, ep] = p
+            gperms[ep, r * Bl:(r + 1) * Bl] = (p // m) * M + r * m + (p % m)
+    uid = np.zeros(128, np.uint8)
+    name = ("/ppo_dp_test_%d_%d" % (os.getpid(), rng.randint(1 << 30))).encode()
+    uid[:len(name)] = np.frombuffer(name, np.uint8)
+    fin = os.path.join(tmp, "in.npz")
+    np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
+             noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
+    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), fin, os.path.join(tmp, "out%d.npz" % r)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("data-parallel workers timed out")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    outs = [np.load(os.path.join(tmp, "out%d.npz" % r)) for r in range(world)]
+    # ---- rollout: every rank's shard equals the oracle's columns; the running statistics are over ALL environments ----
+    for r, out in enumerate(outs):
+        sl = slice(r * El, (r + 1) * El)
+        for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+            close(out["ro_" + f], ro[f][:, sl], rtol=2e-4, atol=2e-5, msg="rank %d %s" % (r, f))
+        np.testing.assert_array_equal(out["ro_dones"], ro["dones"][:, sl])
+        close(out["obs_mean"], nz.obs_rms.mean, rtol=1e-5, atol=1e-6); close(out["obs_var"], nz.obs_rms.var, rtol=1e-5)
+        close(out["ret_var"], nz.ret_rms.var, rtol=1e-5)
+        assert float(out["obs_count"]) == nz.obs_rms.count and float(out["ret_count"]) == nz.ret_rms.count
+    for k in ("obs_mean", "obs_var", "ret_mean", "ret_var"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])                 # bit-identical on every rank
+    # ---- update: loss rows and weights equal the oracle's update over the union; replicas stay bit-identical ----------
+    ref_rows, _ = orc.update(ro, gperms, nmb, LR, CR)
+    for out in outs:
+        close(out["rows"], ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows")
+        close(out["theta"], orc.theta, rtol=2e-4, atol=5e-6, msg="weights")
+    for k in ("rows", "theta", "adam_m", "adam_v"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+    assert np.abs(outs[0]["theta"] - theta0).max() > 0
