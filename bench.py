@@ -19,6 +19,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this driver
 
 CONFIGS = {
     # name: (n_envs, n_steps, hidden, obs, act, nminibatches, noptepochs)   -- SURVEY section 8 table

@@ -359,7 +359,11 @@ __device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int
             }
             float* ys = Ys + row * ldy + col;
             float* yg = gy ? gy + (size_t)(row0 + row) * ldg + col : nullptr;
+#ifdef PPO_NO_WS_STORES
+            const bool wr = false;           // timing experiment only: results are wrong
+#else
             const bool wr = gy != nullptr;
+#endif
             if (wr && (row0 + row) >= nrows) {
 #pragma unroll
                 for (int j = 0; j < CT; ++j) y[j] = 0.f;
