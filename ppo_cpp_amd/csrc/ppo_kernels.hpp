@@ -116,6 +116,20 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // stores (which only the next kernel reads).  LDS traffic is ordered by lgkmcnt alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Kernel arguments live in memory and the compiler fetches them on demand: a kernel with ~1 KB of by-value arguments
+// (NetDev + the args struct) otherwise starts with 5-7 DEPENDENT scalar-load round trips (~700 cycles each, cold) before
+// its first vector load goes out.  Touching one dword of every 64-byte line of the kernarg segment in one batch costs
+// one round trip and leaves the segment in the scalar cache for the loads the compiler emits later.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+    typedef const __attribute__((address_space(4))) unsigned* kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) acc |= ka[i * 16 < BYTES / 4 ? i * 16 : BYTES / 4 - 1];
+    asm volatile("" :: "s"(acc));
+}
+
 // reduce over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float group16_sum(float v) {
     v += __shfl_xor(v, 8);
@@ -489,13 +503,23 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
     const int Kp0 = net.Kp0, O = net.O, A = net.A, Ap = net.Ap;
     constexpr int PK = 4, OK = 2, AK = 2;
     float pv[PK], ov[OK], av[AK], r0 = 0.f, r1 = 0.f, r2 = 0.f, s0 = 0.f, s1 = 1.f;
+    // element i = tid + 256 k of a [16][W] tile is (row, col) = (i / W, i % W): one division per tile width instead of
+    // one per element (a 32-bit division is ~40 vector instructions, and this prologue is pure latency)
+    const int orow0 = tid / Kp0, ocol0 = tid - orow0 * Kp0, odq = BLOCK_THREADS / Kp0, odr = BLOCK_THREADS - odq * Kp0;
+    const int arow0 = tid / Ap, acol0 = tid - arow0 * Ap, adq = BLOCK_THREADS / Ap, adr = BLOCK_THREADS - adq * Ap;
+    auto tile_rc = [](int row0_, int col0_, int dq, int dr, int W, int k, int& r, int& j) __attribute__((always_inline)) {
+        r = row0_ + dq * k; j = col0_ + dr * k;
+#pragma unroll
+        for (int t = 0; t < k; ++t) if (j >= W) { j -= W; ++r; }
+    };
     // ---- issue every load -----------------------------------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < PK; ++k) { const int i = net.par_skip + tid + BLOCK_THREADS * k; pv[k] = i < net.par_total ? par_src[i] : 0.f; }
 #pragma unroll
     for (int k = 0; k < OK; ++k) {
         const int i = tid + BLOCK_THREADS * k;
-        const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
+        int r, j; tile_rc(orow0, ocol0, odq, odr, Kp0, k, r, j);
+        const int row = row0 + r;
         ov[k] = 0.f;
         if (i < ROWS_PER_BLOCK * Kp0 && row < nrows && j < O) ov[k] = obs[(size_t)(rowidx ? rowidx[row] : row) * O + j];
     }
@@ -503,7 +527,8 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
 #pragma unroll
         for (int k = 0; k < AK; ++k) {
             const int i = tid + BLOCK_THREADS * k;
-            const int r = i / Ap, j = i - r * Ap, row = row0 + r;
+            int r, j; tile_rc(arow0, acol0, adq, adr, Ap, k, r, j);
+            const int row = row0 + r;
             av[k] = 0.f;
             if (i < ROWS_PER_BLOCK * Ap && row < nrows && j < A) av[k] = rs.actions[(size_t)(rowidx ? rowidx[row] : row) * A + j];
         }
@@ -517,8 +542,8 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
 #pragma unroll
     for (int k = 0; k < PK; ++k) { const int i = net.par_skip + tid + BLOCK_THREADS * k; if (i < net.par_total) par[i] = pv[k]; }
     for (int i = net.par_skip + tid + BLOCK_THREADS * PK; i < net.par_total; i += BLOCK_THREADS) par[i] = par_src[i];
-    auto put_obs = [&](int i, float x) __attribute__((always_inline)) {
-        const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
+    auto put_obs = [&](int r, int j, float x) __attribute__((always_inline)) {
+        const int row = row0 + r;
         if (row < nrows && j < O) {
             if (nz.enabled) {        // env_normalize.hpp:99-104: (x - mean) * 1/sqrt(var + eps), then clamp
                 x = (x - nz.mean[j]) * (1.0f / sqrtf(nz.var[j] + nz.eps));
@@ -530,12 +555,16 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
         if (x0g) x0g[(size_t)row * Kp0 + j] = x;                    // rows >= nrows: zeros (whole tiles for the dW kernel)
     };
 #pragma unroll
-    for (int k = 0; k < OK; ++k) { const int i = tid + BLOCK_THREADS * k; if (i < ROWS_PER_BLOCK * Kp0) put_obs(i, ov[k]); }
+    for (int k = 0; k < OK; ++k) {
+        const int i = tid + BLOCK_THREADS * k;
+        int r, j; tile_rc(orow0, ocol0, odq, odr, Kp0, k, r, j);
+        if (i < ROWS_PER_BLOCK * Kp0) put_obs(r, j, ov[k]);
+    }
     for (int i = tid + BLOCK_THREADS * OK; i < ROWS_PER_BLOCK * Kp0; i += BLOCK_THREADS) {
         const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
         float x = 0.f;
         if (row < nrows && j < O) x = obs[(size_t)(rowidx ? rowidx[row] : row) * O + j];
-        put_obs(i, x);
+        put_obs(r, j, x);
     }
     if (rs.mode == 1) {
 #pragma unroll
@@ -601,6 +630,7 @@ struct StepArgs {
 template <int CT, int KS, int CTH, bool WIDE>
 __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(StepArgs)>();
     const int tower = blockIdx.y;
     if (tower == 1 && !a.value) return;
     if (tower == 0 && !a.action && !a.det_action && !a.neglogp && !a.obs_out) return;
@@ -687,6 +717,7 @@ struct TrainArgs {
 template <int CT, int KS, int CTH, bool WIDE>
 __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(TrainArgs)>();
     const int tower = blockIdx.y;
     // XCD-aware row mapping: workgroups are dealt round-robin over the 8 XCDs; giving XCD x the CONTIGUOUS row tiles
     // [x*G/8, (x+1)*G/8) makes the activations / gradients this kernel leaves in that XCD's L2 exactly the rows the
