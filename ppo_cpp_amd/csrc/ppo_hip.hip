@@ -739,7 +739,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
     if (set_hyper(h, lr, cliprange)) return -1;
     TrainArgs ta{};
     ta.obs = h->st_obs; ta.actions = h->st_act; ta.advs = h->st_vec[2]; ta.returns = h->st_vec[3]; ta.old_neglogp = h->st_vec[4];
-    ta.old_values = h->st_vec[5]; ta.adv_stats = nullptr; ta.rowidx = nullptr; ta.n = n;
+    ta.old_values = h->st_vec[5]; ta.adv_stats = nullptr; ta.n = n;
     ta.inv_n = 1.0f / (float)((int64_t)n * h->world);
     if (enqueue_train(h, ta, h->st_loss)) return -1;
     HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
@@ -1114,7 +1114,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             TrainArgs ta{};
             const size_t r0 = (size_t)k * M;
             ta.obs = h->mb_obs + r0 * h->net.O; ta.actions = h->mb_act + r0 * h->net.A; ta.returns = h->mb_ret + r0; ta.old_values = h->mb_val + r0;
-            ta.old_neglogp = h->mb_nlp + r0; ta.advs = h->mb_adv + r0; ta.adv_stats = nullptr; ta.rowidx = nullptr; ta.n = M;
+            ta.old_neglogp = h->mb_nlp + r0; ta.advs = h->mb_adv + r0; ta.adv_stats = nullptr; ta.n = M;
             ta.inv_n = 1.0f / (float)((int64_t)M * h->world);
             if (enqueue_train(h, ta, h->d_loss_rows + (size_t)(ep * nmb + k) * 5)) return -1;
         }

@@ -496,7 +496,7 @@ struct RowScalars { const float* actions; const float* v0a; const float* v0b; co
 // mode 2 (value) : v0 = returns, v1 = old_values
 
 __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const float* __restrict__ par_src, float* par, float* Xs, int ldx,
-                                                   const float* __restrict__ obs, const int* __restrict__ rowidx, int row0, int nrows,
+                                                   const float* __restrict__ obs, int row0, int nrows,
                                                    ObsNorm nz, float* __restrict__ obs_out, float* __restrict__ x0g, RowScalars rs,
                                                    float* acts, float* rowv) {
     const int tid = threadIdx.x;
@@ -521,7 +521,7 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
         int r, j; tile_rc(orow0, ocol0, odq, odr, Kp0, k, r, j);
         const int row = row0 + r;
         ov[k] = 0.f;
-        if (i < ROWS_PER_BLOCK * Kp0 && row < nrows && j < O) ov[k] = obs[(size_t)(rowidx ? rowidx[row] : row) * O + j];
+        if (i < ROWS_PER_BLOCK * Kp0 && row < nrows && j < O) ov[k] = obs[(size_t)row * O + j];
     }
     if (rs.mode == 1) {
 #pragma unroll
@@ -530,11 +530,11 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
             int r, j; tile_rc(arow0, acol0, adq, adr, Ap, k, r, j);
             const int row = row0 + r;
             av[k] = 0.f;
-            if (i < ROWS_PER_BLOCK * Ap && row < nrows && j < A) av[k] = rs.actions[(size_t)(rowidx ? rowidx[row] : row) * A + j];
+            if (i < ROWS_PER_BLOCK * Ap && row < nrows && j < A) av[k] = rs.actions[(size_t)row * A + j];
         }
     }
     if (rs.mode && tid < ROWS_PER_BLOCK && row0 + tid < nrows) {
-        const int src = rowidx ? rowidx[row0 + tid] : row0 + tid;
+        const int src = row0 + tid;
         r0 = rs.v0a[src]; r2 = rs.v1[src];
         if (rs.v0b) { r1 = rs.v0b[src]; s0 = rs.stats[0]; s1 = rs.stats[1]; }
     }
@@ -563,7 +563,7 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
     for (int i = tid + BLOCK_THREADS * OK; i < ROWS_PER_BLOCK * Kp0; i += BLOCK_THREADS) {
         const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
         float x = 0.f;
-        if (row < nrows && j < O) x = obs[(size_t)(rowidx ? rowidx[row] : row) * O + j];
+        if (row < nrows && j < O) x = obs[(size_t)row * O + j];
         put_obs(r, j, x);
     }
     if (rs.mode == 1) {
@@ -572,7 +572,7 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
         for (int i = tid + BLOCK_THREADS * AK; i < ROWS_PER_BLOCK * Ap; i += BLOCK_THREADS) {
             const int r = i / Ap, j = i - r * Ap, row = row0 + r;
             float x = 0.f;
-            if (row < nrows && j < A) x = rs.actions[(size_t)(rowidx ? rowidx[row] : row) * A + j];
+            if (row < nrows && j < A) x = rs.actions[(size_t)row * A + j];
             acts[i] = x;
         }
     }
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, 
     HeadFrag<CTH> hpre;
     dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
     float* par = lds + net.lds_par - net.par_skip;      // indexed with absolute mirror offsets
-    stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, nullptr, row0, a.n, a.nz,
+    stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, row0, a.n, a.nz,
                        tower == 0 ? a.obs_out : nullptr, nullptr, RowScalars{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, nullptr);
     lds_barrier();
     int K = net.Kp0, ldx = ld0;
@@ -697,11 +697,10 @@ struct TrainArgs {
     const float* theta;
     const float* thetaT;         // transposed copies of the matrices the backward pass streams (kept by adam_kernel)
     const float* par;            // small-parameter mirror [2][par_total] (kept by adam_kernel)
-    // minibatch sources; rowidx (null = identity) maps minibatch row -> source row
+    // minibatch sources (the epoch gather has already put the rows in minibatch order)
     const float* obs; const float* actions; const float* returns; const float* old_values; const float* old_neglogp;
     const float* advs;           // explicit normalised advantages (indexed like the others) or null
     const float* adv_stats;      // {mean, denom} of this minibatch when advs == null (ppo2.hpp:401-406)
-    const int* rowidx;
     const float* hyper;          // {lr, cliprange}
     int n;                       // rows in this minibatch on this rank
     float inv_n;                 // 1 / (global minibatch rows): gradient of the Mean nodes
@@ -740,7 +739,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     RowScalars rs;
     if (tower == 0) rs = RowScalars{a.actions, a.advs ? a.advs : a.returns, a.advs ? nullptr : a.old_values, a.old_neglogp, a.adv_stats, 1};
     else rs = RowScalars{nullptr, a.returns, nullptr, a.old_values, nullptr, 2};
-    stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, a.rowidx, row0, a.n, nz, nullptr,
+    stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, row0, a.n, nz, nullptr,
                        tower == 0 ? a.x0g : nullptr, rs, acts, rowv);
     lds_barrier();
     STAMP(1);
