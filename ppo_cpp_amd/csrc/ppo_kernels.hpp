@@ -1141,9 +1141,8 @@ __device__ __forceinline__ void dw_main_with_strips(const DwWork& w, int n, int 
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) mine[(4 * (4 * g + r) + a) * 64 + 4 * c + b] = acc[a][b][r];
+        for (int r = 0; r < 4; ++r)       // the 4 column tiles of a lane are 4 consecutive floats: one 16-byte LDS write
+            *reinterpret_cast<float4*>(mine + (4 * (4 * g + r) + a) * 64 + 4 * c) = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
     if constexpr (NE >= 1) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1158,9 +1157,13 @@ __device__ __forceinline__ void dw_main_with_strips(const DwWork& w, int n, int 
     }
     __syncthreads();
     float* slab = slabs + (size_t)split * slab_stride;
-    for (int i = threadIdx.x; i < 4096; i += BLOCK_THREADS) {
-        const float s_ = ((lds[i] + lds[WSZ + i]) + lds[2 * WSZ + i]) + lds[3 * WSZ + i];
-        slab[t.out_off + (size_t)(t.i0 + (i >> 6)) * t.ldo + t.j0 + (i & 63)] = s_;
+    for (int v = threadIdx.x; v < 1024; v += BLOCK_THREADS) {          // 16-byte LDS reads, 16-byte slab stores
+        const int i = 4 * v;
+        const float4 p0 = *reinterpret_cast<const float4*>(lds + i), p1 = *reinterpret_cast<const float4*>(lds + WSZ + i);
+        const float4 p2 = *reinterpret_cast<const float4*>(lds + 2 * WSZ + i), p3 = *reinterpret_cast<const float4*>(lds + 3 * WSZ + i);
+        const float4 s_ = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                                      ((p0.w + p1.w) + p2.w) + p3.w);
+        *reinterpret_cast<float4*>(slab + t.out_off + (size_t)(t.i0 + (i >> 6)) * t.ldo + t.j0 + (i & 63)) = s_;
     }
     if constexpr (NE >= 1) {
         for (int i = threadIdx.x; i < 512; i += BLOCK_THREADS) {
