@@ -325,3 +325,46 @@ def test_wide_networks_use_the_two_tile_layout(hidden, O, A, n):
     close(losses, ref_losses, rtol=2e-4, atol=1e-6, msg="losses")
     close(grad, ref_grad, rtol=5e-4, atol=3e-6 * float(np.abs(ref_grad).max()), msg="grad")
     close(g.get_flat(0), orc.theta, rtol=2e-4, atol=3e-6, msg="theta")
+
+
+def test_committed_golden_run():
+    """The HIP path against the committed vectors of tests/golden/g45_run.npz (reference shape [4,5], the graph's initial
+    weights; generated by oracle/make_golden_run.py, cross-checked there against float64 autograd): rollout, running
+    statistics, first-minibatch gradient and global norm, loss rows, weights and Adam slots after 8 train steps."""
+    z = np.load(H.GOLDEN + "/g45_run.npz")
+    E, T, nmb, epochs = int(z["E"]), int(z["T"]), int(z["nmb"]), int(z["epochs"])
+    lr, cr = float(z["lr"]), float(z["cr"])
+    import ppo_cpp_amd
+    g = ppo_cpp_amd.PPOHip(18, 18, [4, 5]); g.set_tensors(H.g45_init())
+    g.norm_init(E, float(z["gamma"])); g.rollout_alloc(E, T)
+    g.collect_synthetic(int(z["seed"]), float(z["gamma"]), float(z["lam"]), z["noise"])
+    for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+        close(g.rollout_get(f), z["ro_" + f], rtol=2e-4, atol=2e-5, msg=f)
+    np.testing.assert_array_equal(g.rollout_get("dones"), z["ro_dones"])
+    m, v, c = g.norm_stats(0)
+    close(m, z["obs_mean"], rtol=1e-5, atol=1e-6); close(v, z["obs_var"], rtol=1e-5); assert c == float(z["obs_count"])
+    m, v, c = g.norm_stats(1)
+    close(v, z["ret_var"], rtol=1e-5); assert c == float(z["ret_count"])
+    for f in ("obs", "actions", "values", "neglogp", "returns"):
+        g.rollout_set(f, z["ro_" + f])
+    rows, mean = g.update(lr, cr, epochs, nmb, z["perms"])
+    close(rows, z["loss_rows"], rtol=1e-4, atol=1e-6, msg="loss rows")
+    close(mean, z["loss_mean"], rtol=1e-4, atol=1e-6)
+    theta = z["theta"]
+    close(g.get_flat(0), theta, rtol=1e-4, atol=1e-6, msg="weights")
+    close(g.get_flat(1), z["adam_m"], rtol=1e-3, atol=1e-7 * float(np.abs(z["adam_m"]).max()) + 1e-9, msg="adam m")
+    close(g.get_flat(2), z["adam_v"], rtol=1e-3, atol=1e-6 * float(np.abs(z["adam_v"]).max()), msg="adam v")
+    # first-minibatch gradient through the single-step entry point
+    g2 = ppo_cpp_amd.PPOHip(18, 18, [4, 5]); g2.set_tensors(H.g45_init())
+    B = E * T; M = B // nmb
+    flat = {k: np.ascontiguousarray(np.swapaxes(z["ro_" + k], 0, 1)).reshape((B,) + z["ro_" + k].shape[2:]) for k in
+            ("obs", "actions", "values", "neglogp", "returns")}
+    mb = {}
+    for k, val in flat.items():
+        sh = np.empty_like(val); sh[z["perms"][0]] = val; mb[k] = sh[:M]
+    adv = g2.adv_normalize(mb["returns"], mb["values"])
+    losses = g2.train_step(lr, cr, mb["obs"], mb["actions"], adv, mb["returns"], mb["neglogp"], mb["values"])
+    close(losses, z["loss_rows"][0], rtol=1e-4, atol=1e-6)
+    grad, norm = g2.last_grad()
+    close(grad, z["grad0"], rtol=5e-4, atol=3e-6 * float(np.abs(z["grad0"]).max()), msg="gradient")
+    assert norm == pytest.approx(float(z["norm0"]), rel=1e-4)

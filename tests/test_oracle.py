@@ -296,3 +296,25 @@ def test_update_loop_equals_manual_minibatching():
     np.testing.assert_array_equal(rows, np.stack(got))
     np.testing.assert_array_equal(a.theta, b.theta)
     np.testing.assert_allclose(mean, np.stack(got).astype(np.float64).mean(0), rtol=1e-6)
+
+
+def test_committed_golden_run_is_reproduced():
+    """tests/golden/g45_run.npz (oracle/make_golden_run.py): the reference's shipped shape with the graph's initial weights,
+    rollout -> GAE -> 2 epochs x 4 minibatches.  The oracle must keep reproducing its committed vectors (libm differences
+    between hosts allowed for: 1e-6)."""
+    z = np.load(H.GOLDEN + "/g45_run.npz")
+    E, T, nmb = int(z["E"]), int(z["T"]), int(z["nmb"])
+    orc = make((4, 5)); orc.set_tensors(H.g45_init())
+    nz = o.Normalizer(E, 18)
+    ro, _, last_v = o.collect(orc, nz, int(z["seed"]), T, z["noise"], float(z["gamma"]), float(z["lam"]))
+    for k in ("obs", "actions", "values", "neglogp", "rewards", "dones", "returns"):
+        np.testing.assert_allclose(ro[k], z["ro_" + k], rtol=1e-6, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(nz.obs_rms.mean, z["obs_mean"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(nz.ret_rms.var, z["ret_var"], rtol=1e-6)
+    assert nz.obs_rms.count == float(z["obs_count"])
+    rows, mean = orc.update(ro, z["perms"], nmb, float(z["lr"]), float(z["cr"]))
+    np.testing.assert_allclose(rows, z["loss_rows"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(orc.theta, z["theta"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(orc.m, z["adam_m"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(orc.v, z["adam_v"], rtol=1e-5, atol=1e-12)
+    assert rows[0, 2] == pytest.approx(18 * 1.4189385, rel=1e-6) and rows[0, 3] == 0.0 and rows[0, 4] == 0.0
