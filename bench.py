@@ -99,15 +99,17 @@ def main():
 
     import ppo_cpp_amd
     dist = None
+    device = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only; data path = RCCL in libppo_hip
+        device = local_rank % max(torch.cuda.device_count(), 1)           # (counting devices does not initialise the GPU)
 
     E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
     B = E * T; M = B // nmb
-    g = ppo_cpp_amd.PPOHip(cfg["obs"], cfg["act"], cfg["hidden"], device=local_rank)
+    g = ppo_cpp_amd.PPOHip(cfg["obs"], cfg["act"], cfg["hidden"], device=device)
     g.init_orthogonal(0)                                                   # same seed on every rank: replicated weights
     if world > 1:
         g.dist_init(world, rank, ppodist.broadcast_unique_id(dist, rank, ppo_cpp_amd.PPOHip.dist_unique_id))
