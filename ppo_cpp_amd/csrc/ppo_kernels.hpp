@@ -131,11 +131,17 @@ __device__ __forceinline__ void warm_kernargs() {
 }
 
 // reduce over the 16 lanes that share (lane >> 4)
+// DPP lane permutes (vector-ALU data path, ~4 cycles each) instead of __shfl_xor's ds_bpermute (an LDS-crossbar round
+// trip each): pairs, quads, then the two mirrors -- every lane of the 16 ends with the same total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror: lane i <-> 7 - i within each 8
+    v += dpp_move<0x140>(v);     // row_mirror:      lane i <-> 15 - i within each 16
     return v;
 }
 
