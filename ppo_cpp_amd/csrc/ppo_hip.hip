@@ -1130,7 +1130,6 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     const int B = h->E * h->T;
     if (epochs < 1 || nmb < 1 || B % nmb) return fail(h, "ppo_update: n_batch %d not divisible by nminibatches %d", B, nmb);
     const int M = B / nmb;
-    if (h->world > 1 && perms == nullptr && false) return fail(h, "unreachable");
     if (ensure_train_ws(h, M)) return -1;
     const int steps = epochs * nmb;
     if (B > h->upd_cap_rows || steps > h->upd_cap_steps || !h->d_keys) {

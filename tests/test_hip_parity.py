@@ -368,3 +368,36 @@ def test_committed_golden_run():
     grad, norm = g2.last_grad()
     close(grad, z["grad0"], rtol=5e-4, atol=3e-6 * float(np.abs(z["grad0"]).max()), msg="gradient")
     assert norm == pytest.approx(float(z["norm0"]), rel=1e-4)
+
+
+def test_error_paths_and_minimal_sizes():
+    """Error convention of the boundary (non-zero status + ppo_last_error) and the smallest legal inputs:
+    empty batches are refused, one row steps, two rows train (the reference asserts more than one, ppo2.hpp:402), a
+    batch that the minibatch count does not divide is refused, and the handle keeps working after a refused call."""
+    import ppo_cpp_amd
+    orc, g = pair((64, 64))
+    rng = np.random.RandomState(0)
+    with pytest.raises(ppo_cpp_amd.PPOHipError, match="positive"):
+        g.step(np.zeros((0, 18), np.float32), np.zeros((0, 18), np.float32))
+    obs = rng.uniform(-1, 1, (1, 18)).astype(np.float32); noise = rng.normal(size=(1, 18)).astype(np.float32)
+    a, v, nlp = g.step(obs, noise); ra, rv, rnlp = orc.step(obs, noise)
+    close(a, ra); close(v, rv); close(nlp, rnlp)
+    mb = H.synth_minibatch(orc, 2, seed=5)
+    args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+    with pytest.raises(ppo_cpp_amd.PPOHipError, match="more than one row"):
+        g.train_step(LR, CR, *[x[:1] for x in args])
+    ref_losses, _, _ = orc.train_step(LR, CR, *args)
+    close(g.train_step(LR, CR, *args), ref_losses, rtol=1e-4, atol=1e-6)
+    close(g.get_flat(0), orc.theta, rtol=1e-4, atol=2e-6)
+    with pytest.raises(ppo_cpp_amd.PPOHipError, match="rollout"):
+        g.update(LR, CR, 1, 4)
+    g.norm_init(3); g.rollout_alloc(3, 5)
+    g.collect_synthetic(7, GAMMA, LAM)
+    with pytest.raises(ppo_cpp_amd.PPOHipError, match="not divisible"):
+        g.update(LR, CR, 1, 4)                                       # 15 rows, 4 minibatches
+    rows, mean = g.update(LR, CR, 2, 3, None, seed=1)                # 5-row minibatches: ragged tiles, still fine
+    assert rows.shape == (6, 5) and np.isfinite(rows).all() and np.isfinite(g.get_flat()).all()
+    import ctypes as C
+    seven = np.zeros(7, np.float32)
+    rc = g.lib.ppo_set_flat(g.h, 0, seven.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(7))
+    assert rc != 0 and b"count" in g.lib.ppo_last_error(g.h)
