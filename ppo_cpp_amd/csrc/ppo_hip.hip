@@ -78,6 +78,7 @@ struct ppo_handle {
     float* slots[2]{};
     float* slabs = nullptr;
     int max_split = 8;
+    int lds_step_total = 0;           // floats of dynamic LDS the act kernel needs (the train layout minus the gradient tiles)
     DwWork* dw_tiles = nullptr;
     int n_dw_tiles = 0;
     bool dw_has_big = false;
@@ -251,8 +252,6 @@ int build_layout(ppo_handle* h) {
         if (!wide) {
             n.lds_h[0] = o; o += ROWS_PER_BLOCK * (n.Kp0 + LDS_PAD);
             for (int l = 0; l < n.L; ++l) { n.lds_h[l + 1] = o; o += ROWS_PER_BLOCK * (n.Hp[l] + LDS_PAD); }
-            n.lds_d[0] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
-            n.lds_d[1] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
             n.lds_head = 0; n.par_skip = 0;
         } else {
             // Wide form (nets whose per-layer tiles do not fit 160 KB): two ping-pong tiles; layer l reads tile l%2 and
@@ -262,7 +261,6 @@ int build_layout(ppo_handle* h) {
             const int t0 = o; o += tile;
             const int t1 = o; o += tile;
             for (int l = 0; l <= n.L; ++l) n.lds_h[l] = (l % 2) ? t1 : t0;
-            n.lds_d[0] = o; o += ROWS_PER_BLOCK * (n.Ap + LDS_PAD);       // d mu tile
             n.lds_d[1] = ((n.L + 1) % 2) ? t1 : t0;                        // first backward output: the tile h_L is not in
             n.par_skip = n.par_bmu;
         }
@@ -270,6 +268,15 @@ int build_layout(ppo_handle* h) {
         if (!wide) { n.lds_head = o; o += 4 * ROWS_PER_BLOCK * n.Ap; }
         n.lds_misc = o; o += 64 + 2 * ROWS_PER_BLOCK * n.Ap + 64;
         n.lds_par = o; o += n.par_total - n.par_skip;
+        // the gradient tiles come LAST: the act kernel never touches them and is launched with the smaller size, which
+        // lets two of its workgroups share a compute unit
+        h->lds_step_total = o;
+        if (!wide) {
+            n.lds_d[0] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
+            n.lds_d[1] = o; o += ROWS_PER_BLOCK * (hmax + LDS_PAD);
+        } else {
+            n.lds_d[0] = o; o += ROWS_PER_BLOCK * (n.Ap + LDS_PAD);       // d mu tile
+        }
         n.lds_total = o;
         return (size_t)o * sizeof(float) <= 160 * 1024;
     };
@@ -389,7 +396,7 @@ int ensure_staging(ppo_handle* h, int rows) {
 template <int CT, int KS, int CTH, bool WIDE>
 void launch_step_t(ppo_handle* h, const StepArgs& a) {
     dim3 grid((a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 2);
-    hipLaunchKernelGGL((policy_step_kernel<CT, KS, CTH, WIDE>), grid, dim3(BLOCK_THREADS), (size_t)h->net.lds_total * sizeof(float), h->stream, h->net, a);
+    hipLaunchKernelGGL((policy_step_kernel<CT, KS, CTH, WIDE>), grid, dim3(BLOCK_THREADS), (size_t)h->lds_step_total * sizeof(float), h->stream, h->net, a);
 }
 int launch_step(ppo_handle* h, const StepArgs& a) {
     ProfScope ps(h, PK_STEP);

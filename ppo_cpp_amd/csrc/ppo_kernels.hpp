@@ -634,7 +634,7 @@ struct StepArgs {
 };
 
 template <int CT, int KS, int CTH, bool WIDE>
-__global__ __launch_bounds__(BLOCK_THREADS) void policy_step_kernel(NetDev net, StepArgs a) {
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void policy_step_kernel(NetDev net, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     warm_kernargs<sizeof(NetDev) + sizeof(StepArgs)>();
     const int tower = blockIdx.y;
