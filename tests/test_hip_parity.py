@@ -305,7 +305,10 @@ def test_rccl_plumbing_single_rank_communicator():
 @pytest.mark.parametrize("hidden,O,A,n", [((512, 512), 18, 18, 64), ((1024, 1024, 1024), 256, 64, 48), ((1024,), 256, 64, 40), ((1100,), 18, 18, 20),
                                           # regular layout, 64-column wave tiles, widths that are not multiples of 256
                                           # (generic policy head instead of the split-K one), wide obs/action vectors
-                                          ((448, 448), 18, 18, 40), ((320, 320), 256, 64, 33), ((448, 320), 18, 18, 16)])
+                                          ((448, 448), 18, 18, 40), ((320, 320), 256, 64, 33), ((448, 320), 18, 18, 16),
+                                          # odd observation / action / hidden widths (16-column path), four layers in the regular
+                                          # layout, and the maximum depth (eight layers: two-tile layout at width 256)
+                                          ((100, 60), 7, 3, 21), ((256, 256, 256, 256), 18, 18, 32), ((256,) * 8, 18, 18, 16)])
 def test_wide_networks_use_the_two_tile_layout(hidden, O, A, n):
     """Nets whose per-layer activation tiles exceed 160 KB of LDS ([512,512] and up; BASELINE config 5's shape in fp32)
     run through the same kernels with two ping-pong tiles: act outputs, losses, gradients and Adam must match."""
