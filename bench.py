@@ -105,7 +105,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only; data path = RCCL in libppo_hip
-        device = local_rank % max(torch.cuda.device_count(), 1)           # (counting devices does not initialise the GPU)
+        device = -1                                                       # the library picks LOCAL_RANK % (its own device count)
 
     E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
     B = E * T; M = B // nmb
