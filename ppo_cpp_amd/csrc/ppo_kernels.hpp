@@ -456,9 +456,10 @@ __device__ __forceinline__ void head_splitk(WFrag<CTH, HEAD_KS>& w, const float*
 #pragma unroll
         for (int j = 0; j < CTH; ++j) mine[(4 * g + r) * Ap + CTH * c + j] = acc[j][r];
     lds_barrier();
-    for (int i = threadIdx.x; i < ROWS_PER_BLOCK * Ap; i += BLOCK_THREADS) {
-        const int row = i / Ap, col = i - row * Ap;
-        const float sum = ((scratch[i] + scratch[ROWS_PER_BLOCK * Ap + i]) + scratch[2 * ROWS_PER_BLOCK * Ap + i]) + scratch[3 * ROWS_PER_BLOCK * Ap + i];
+    constexpr int APC = 16 * CTH;                       // == Ap on this path: compile-time row / column split (no division)
+    for (int i = threadIdx.x; i < ROWS_PER_BLOCK * APC; i += BLOCK_THREADS) {
+        const int row = i / APC, col = i - row * APC;
+        const float sum = ((scratch[i] + scratch[ROWS_PER_BLOCK * APC + i]) + scratch[2 * ROWS_PER_BLOCK * APC + i]) + scratch[3 * ROWS_PER_BLOCK * APC + i];
         mus[row * ldm + col] = sum + bmu[col];
     }
 }
