@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] side measurement")
     ap.add_argument("--host-env", action="store_true", help="also time the Env-on-host path (PCIe inclusive)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -188,11 +189,32 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg)
+    if world == 1 and args.config == "cfg3" and not args.no_extra:
+        # BASELINE configs[1] (one environment, MLP [64,64], 2048 steps per update: launch-latency bound) measured in the
+        # same run, so that both single-GPU configurations of the baseline are on record; `value` stays configs[2]
+        g.close()
+        c2 = CONFIGS["cfg2"]
+        g2 = ppo_cpp_amd.PPOHip(c2["obs"], c2["act"], c2["hidden"], device=device)
+        g2.init_orthogonal(0); g2.norm_init(c2["n_envs"], GAMMA); g2.rollout_alloc(c2["n_envs"], c2["n_steps"])
+        def step2(i, first=False):
+            g2.collect_synthetic(1234, GAMMA, LAM, None, env0=0, step0=i * c2["n_steps"], first=first)
+            g2.update(LR, CR, c2["noptepochs"], c2["nminibatches"], None, seed=2000 + i, want_rows=False)
+        step2(0, True); g2.sync()
+        t0 = time.perf_counter()
+        for i in range(3):
+            step2(1 + i)
+        g2.sync()
+        dt2 = (time.perf_counter() - t0) / 3
+        out["also"] = {"BASELINE configs[1] (cfg2)": {"workload": c2["desc"], "value": c2["n_envs"] * c2["n_steps"] / dt2, "unit": "env-steps/s",
+                                                      "ms_per_step": 1e3 * dt2, "steps": 3, "warmup": 1}}
+        g2.close()
+        g = None
     if args.host_env and world == 1:
         # PCIe-inclusive: the reference's own stack (N x mock Env -> VecEnv -> EnvNormalize -> PPO2::learn) on the host,
         # actions D2H / observations H2D every env step.  Reported beside `value`, never as `value`.
         from ppo_cpp_amd import hostapi
-        g.close()
+        if g is not None:
+            g.close()
         r = hostapi.learn(E, T, cfg["hidden"], n_updates=4, nminibatches=nmb, noptepochs=ep, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM)
         out["host_env"] = {"env_steps_per_s": r["env_steps_per_s"], "collect_ms": r["collect_ms"], "update_ms": r["update_ms"],
                            "note": "SeededEnvMock x %d behind the pooled VecEnv on the host cores, PCIe round trip per env step" % E}
