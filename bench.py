@@ -155,6 +155,14 @@ def main():
     g.update(LR, CR, ep, nmb, None, seed=998, want_rows=False)
     t_c = time.perf_counter()
 
+    if world > 1:
+        # orderly shutdown: every rank is past its last collective before any communicator is torn down
+        barrier()
+        g.close()
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     if rank != 0:
         return
     f_fwd, f_dx, f_dw = flops_per_row(cfg["obs"], cfg["act"], cfg["hidden"])
@@ -218,7 +226,9 @@ def main():
         r = hostapi.learn(E, T, cfg["hidden"], n_updates=4, nminibatches=nmb, noptepochs=ep, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM)
         out["host_env"] = {"env_steps_per_s": r["env_steps_per_s"], "collect_ms": r["collect_ms"], "update_ms": r["update_ms"],
                            "note": "SeededEnvMock x %d behind the pooled VecEnv on the host cores, PCIe round trip per env step" % E}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
