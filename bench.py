@@ -197,7 +197,9 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg)
-    if world == 1 and args.config == "cfg3" and not args.no_extra:
+    # (skipped under rocprofv3: instantiating a second handle's hipGraph in one traced process crashes the profiler)
+    profiled = any("ROCPROF" in k for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and args.config == "cfg3" and not args.no_extra and not profiled:
         # BASELINE configs[1] (one environment, MLP [64,64], 2048 steps per update: launch-latency bound) measured in the
         # same run, so that both single-GPU configurations of the baseline are on record; `value` stays configs[2]
         g.close()

@@ -943,7 +943,7 @@ struct DwTile {
 struct DwWork { DwTile main; int n_extra; int fused; DwTile extra[2]; };   // fused: main is 64x64, extra[0] cls 4 (if any), extra[1] cls 5
 
 #ifndef PPO_DW_RING
-#define PPO_DW_RING 3              // register stages per wave in the weight-gradient kernel (operands come from the
+#define PPO_DW_RING 4              // register stages per wave in the weight-gradient kernel (operands come from the
 #endif                             // Infinity Cache / HBM: the producer kernel ran on other XCDs)
 
 template <int N>
