@@ -270,6 +270,105 @@ __device__ __forceinline__ void dense_prefetch(WRing<CT, KS>& w, const float* W,
 
 enum { EP_BIAS_TANH = 0, EP_TANHGRAD = 1 };
 
+// epilogue of one 16 x (16*CT) output chunk: accumulator register r of MFMA j holds Y[row 4g + r][col + j], col = n0 + CT*c
+template <int CT, int EP>
+__device__ __forceinline__ void tile_epilogue(const f32x4 (&acc)[CT], int g, int col, const float* __restrict__ bias, const float* Hs, int ldh,
+                                              float* Ys, int ldy, float* __restrict__ gy, int ldg, int row0, int nrows) {
+    float bv[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) bv[j] = (EP == EP_BIAS_TANH) ? bias[col + j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float y[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            if constexpr (EP == EP_BIAS_TANH) y[j] = fast_tanh(acc[j][r] + bv[j]);
+            else { const float h = Hs[row * ldh + col + j]; y[j] = acc[j][r] * (1.0f - h * h); }   // TanhGrad
+        }
+        float* ys = Ys + row * ldy + col;
+        float* yg = gy ? gy + (size_t)(row0 + row) * ldg + col : nullptr;
+#ifdef PPO_NO_WS_STORES
+        const bool wr = false;           // timing experiment only: results are wrong
+#else
+        const bool wr = gy != nullptr;
+#endif
+        if (wr && (row0 + row) >= nrows) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) y[j] = 0.f;
+        }
+        if constexpr (CT == 4) {
+            *reinterpret_cast<float4*>(ys) = make_float4(y[0], y[1], y[2], y[3]);
+            if (wr) {
+#if PPO_WT_STORES
+                // write-through (sc1) 16-byte store: the activations are only read by the NEXT kernel, so they should
+                // drain to memory while this kernel computes instead of piling up as dirty L2 lines that the
+                // end-of-kernel release has to write back (~3 us at the boundary for 17 MB)
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 fv = {y[0], y[1], y[2], y[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, fv), __builtin_amdgcn_make_buffer_rsrc(gy, 0, 0x7fffffff, 0x00020000),
+                                                       (int)(((size_t)(row0 + row) * ldg + col) * 4), 0, 16);
+#else
+                *reinterpret_cast<float4*>(yg) = make_float4(y[0], y[1], y[2], y[3]);
+#endif
+            }
+        } else if constexpr (CT == 2) {
+            *reinterpret_cast<float2*>(ys) = make_float2(y[0], y[1]);
+            if (wr) *reinterpret_cast<float2*>(yg) = make_float2(y[0], y[1]);
+        } else {
+            *ys = y[0];
+            if (wr) *yg = y[0];
+        }
+    }
+}
+
+// A product whose reduction is exactly ONE pipeline stage deep (16*KS), computed from ring slot SLOT.  With SLOT =
+// PPO_RING-1 the slots 0..PPO_RING-2 are free for the NEXT product's first stages, which can then be requested long
+// before this one runs instead of in a burst right after its matrix instructions (every CU of an XCD asks for its first
+// two stages at the same moment: ~2.6 k cycles of L2-bandwidth-bound issue).  Used for the policy head's backward
+// product (K = padded action width): the transposed second-layer weights stream in under the loss arithmetic.
+template <int CT, int KS, int EP, int SLOT>
+__device__ __forceinline__ void dense_tile_one_stage(WRing<CT, KS>& w, const float* W, int ldw, const float* __restrict__ bias,
+                                                     const float* Xs, int ldx, float* Ys, int ldy, int Np, const float* Hs, int ldh,
+                                                     float* __restrict__ gy, int ldg, int row0, int nrows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    constexpr int CW = 16 * CT;
+    constexpr int NSTRIDE = (BLOCK_THREADS / 64) * CW;
+    W = uni(W); ldw = uni(ldw); Np = uni(Np);
+    bool first = true;
+    for (int n0 = wave * CW; n0 < Np; n0 += NSTRIDE) {
+        f32x4 acc[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int col = n0 + CT * c;
+        WFrag<CT, KS>& wf = w.s[SLOT];
+        if (!first) load_w_stage<CT, KS>(wf, W, make_woff<KS>(ldw, g, col));
+        first = false;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) wf.a[q] = *reinterpret_cast<const float4*>(Xs + c * ldx + 16 * q + 4 * g);
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const float av[4] = {wf.a[q].x, wf.a[q].y, wf.a[q].z, wf.a[q].w};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_], wf.v[4 * q + s_][j], acc[j], 0, 0, 0);
+        }
+        tile_epilogue<CT, EP>(acc, g, col, bias, Hs, ldh, Ys, ldy, gy, ldg, row0, nrows);
+    }
+}
+
+// this wave's first-chunk weights of a one-stage product -> ring slot SLOT
+template <int CT, int KS, int SLOT>
+__device__ __forceinline__ void prefetch_one_stage(WRing<CT, KS>& w, const float* W, int ldw, int Np) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    W = uni(W); ldw = uni(ldw);
+    int n0 = wave * 16 * CT;
+    if (n0 >= Np) n0 = 0;
+    load_w_stage<CT, KS>(w.s[SLOT], W, make_woff<KS>(ldw, lane >> 4, n0 + CT * (lane & 15)));
+}
+
 template <int CT, int KS, int EP, class Between>
 __device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int ldw, const float* __restrict__ bias,
                                            const float* Xs, int ldx, int K, float* Ys, int ldy, int Np, const float* Hs, int ldh,
@@ -364,53 +463,7 @@ __device__ __forceinline__ void dense_tile(WRing<CT, KS>& w, const float* W, int
         if (n0 + NSTRIDE >= Np) { between(); called = true; }       // next layer's first stage goes out before this epilogue
         __builtin_amdgcn_sched_barrier(0);
         DSTAMP(2);
-        // epilogue: accumulator register r of MFMA j holds Y[row 4g + r][col n0 + CT*c + j]
-        float bv[CT];
-#pragma unroll
-        for (int j = 0; j < CT; ++j) bv[j] = (EP == EP_BIAS_TANH) ? bias[col + j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * g + r;
-            float y[CT];
-#pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                if constexpr (EP == EP_BIAS_TANH) y[j] = fast_tanh(acc[j][r] + bv[j]);
-                else { const float h = Hs[row * ldh + col + j]; y[j] = acc[j][r] * (1.0f - h * h); }   // TanhGrad
-            }
-            float* ys = Ys + row * ldy + col;
-            float* yg = gy ? gy + (size_t)(row0 + row) * ldg + col : nullptr;
-#ifdef PPO_NO_WS_STORES
-            const bool wr = false;           // timing experiment only: results are wrong
-#else
-            const bool wr = gy != nullptr;
-#endif
-            if (wr && (row0 + row) >= nrows) {
-#pragma unroll
-                for (int j = 0; j < CT; ++j) y[j] = 0.f;
-            }
-            if constexpr (CT == 4) {
-                *reinterpret_cast<float4*>(ys) = make_float4(y[0], y[1], y[2], y[3]);
-                if (wr) {
-#if PPO_WT_STORES
-                    // write-through (sc1) 16-byte store: the activations are only read by the NEXT kernel, so they should
-                    // drain to memory while this kernel computes instead of piling up as dirty L2 lines that the
-                    // end-of-kernel release has to write back (~3 us at the boundary for 17 MB)
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    const f32x4 fv = {y[0], y[1], y[2], y[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, fv), __builtin_amdgcn_make_buffer_rsrc(gy, 0, 0x7fffffff, 0x00020000),
-                                                           (int)(((size_t)(row0 + row) * ldg + col) * 4), 0, 16);
-#else
-                    *reinterpret_cast<float4*>(yg) = make_float4(y[0], y[1], y[2], y[3]);
-#endif
-                }
-            } else if constexpr (CT == 2) {
-                *reinterpret_cast<float2*>(ys) = make_float2(y[0], y[1]);
-                if (wr) *reinterpret_cast<float2*>(yg) = make_float2(y[0], y[1]);
-            } else {
-                *ys = y[0];
-                if (wr) *yg = y[0];
-            }
-        }
+        tile_epilogue<CT, EP>(acc, g, col, bias, Hs, ldh, Ys, ldy, gy, ldg, row0, nrows);
     }
     DSTAMP(3);
     if (!called) between();                                          // waves without a column chunk
@@ -782,8 +835,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     if (tower == 0) {
         // ---- policy head + surrogate loss (G:9428-11290) and its gradient (G:12609-22656) -------------------
         policy_head<CTH>(net, a.theta, hpre, hL, ldhL, HpL, lds);
-        // the head's backward weights (transposed copy) stream in under the loss arithmetic
-        dense_prefetch<CT, KS>(wpre, a.thetaT + net.wmuT_off, HpL, HpL, net.Ap);
+        // the head's backward weights (transposed copy) stream in under the loss arithmetic; when that product is one
+        // pipeline stage deep (Ap == 16*KS) it goes to the last ring slot and the transposed weights of the layer
+        // below take slots 0.. right away (see dense_tile_one_stage)
+        constexpr bool ONE = CTH > 0 && CTH == KS;
+        if constexpr (ONE) {
+            prefetch_one_stage<CT, KS, PPO_RING - 1>(wpre, a.thetaT + net.wmuT_off, HpL, HpL);
+            if (net.L > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[0][net.L - 1], net.Hp[net.L - 2], net.Hp[net.L - 2], HpL);
+        } else dense_prefetch<CT, KS>(wpre, a.thetaT + net.wmuT_off, HpL, HpL, net.Ap);
         STAMP(6);
         const float* mus = lds + net.lds_mu;
         const int ldm = net.Ap + LDS_PAD;
@@ -848,6 +907,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
         }
         STAMP(7);
         // dh_L = (dmu * W_mu^T) .* (1 - h_L^2): a dense product against the transposed head weights [Ap][HpL]
+        if constexpr (ONE)
+            dense_tile_one_stage<CT, KS, EP_TANHGRAD, PPO_RING - 1>(wpre, a.thetaT + net.wmuT_off, HpL, nullptr, dcur, ldm, dnext, HpL + LDS_PAD, HpL, hL, ldhL,
+                                                                    a.dyg[0][net.L - 1], HpL, row0, a.n);
+        else
         dense_tile<CT, KS, EP_TANHGRAD>(wpre, a.thetaT + net.wmuT_off, HpL, nullptr, dcur, ldm, net.Ap, dnext, HpL + LDS_PAD, HpL, hL, ldhL,
                                         a.dyg[0][net.L - 1], HpL, row0, a.n, [&]() __attribute__((always_inline)) {
                                             if (net.L > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[0][net.L - 1], net.Hp[net.L - 2], net.Hp[net.L - 2], HpL);
