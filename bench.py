@@ -48,7 +48,60 @@ def flops_per_row(O, A, hidden):
     return 2 * fwd, 2 * dx, 2 * fwd
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def _cpu_worker(args):
+    """One host core's share of a policy step and of a train step (rows split evenly, as a row-parallel port would)."""
+    cfg, e_rows, m_rows, reps, t_start = args
+    from oracle import oracle as o
+    orc = o.Oracle(cfg["obs"], cfg["act"], cfg["hidden"]); orc.init_orthogonal(0)
+    rng = np.random.RandomState(1)
+    obs = rng.uniform(-1, 1, (e_rows, cfg["obs"])).astype(np.float32); noise = rng.normal(size=(e_rows, cfg["act"])).astype(np.float32)
+    mobs = rng.uniform(-1, 1, (m_rows, cfg["obs"])).astype(np.float32)
+    act, v, nlp = orc.step(mobs, rng.normal(size=(m_rows, cfg["act"])).astype(np.float32))
+    ret = (v + rng.normal(size=m_rows)).astype(np.float32); adv = o.adv_normalize(ret, v)
+    while time.time() < t_start:                             # all workers start together: the cores are loaded at once
+        time.sleep(0.005)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.step(obs, noise)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        orc.train_step(LR, CR, mobs, act, adv, ret, nlp, v)
+    t2 = time.perf_counter()
+    return (t1 - t0) / reps, (t2 - t1) / reps
+
+
+def cpu_baseline_all_cores(cfg, name, Es, Ms):
+    """The same port with the rows of every call split over all host cores (one child process per core, started
+    together; the cross-core gradient reduction a real multi-threaded port needs is not charged)."""
+    import subprocess
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, 16))                                   # bounded: a container may report far more cores than it may use
+    E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
+    B = E * T; M = B // nmb
+    e_rows, m_rows = max(1, Es // n), max(2, Ms // n)
+    t_start = time.time() + 4.0
+    deadline = time.time() + 45.0
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")    # numpy's BLAS pool would oversubscribe
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", name, str(e_rows), str(m_rows), "3", repr(t_start)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(n)]
+    res = []
+    try:
+        for pr in procs:
+            out, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+            res.append([float(x) for x in out.split()[-2:]])
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    t_step = max(r[0] for r in res) * (E / (e_rows * n)); t_train = max(r[1] for r in res) * (M / (m_rows * n))
+    return {"value": B / (T * t_step + ep * nmb * t_train), "unit": "env-steps/s", "cores": n,
+            "sample": "%d processes (capped at 16) x (3 policy steps at %d rows + 3 train steps at %d rows), slowest process, scaled" % (n, e_rows, m_rows)}
+
+
+def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
     """The oracle's C restatement (a scalar port, 1 thread) timed on a bounded sample of the same workload."""
     from oracle import oracle as o
     E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
@@ -74,13 +127,22 @@ def cpu_baseline(cfg, budget_s=20.0):
         orc.train_step(LR, CR, mobs, act, adv, ret, nlp, v); n_tr += 1
     t_train = (time.perf_counter() - t0) / n_tr * (M / Ms)
     t_update = T * t_step + ep * nmb * t_train
-    return {"value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    all_cores = None
+    try:
+        all_cores = cpu_baseline_all_cores(cfg, name, Es, Ms)
+    except Exception as e:                                   # the single-thread leg is the contract; this one is extra
+        all_cores = {"error": repr(e)}
+    return {"all_cores": all_cores, "value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "%d policy steps at %d rows + %d train steps at %d rows of the oracle's C restatement, extrapolated to "
                       "%d steps + %d train steps per update" % (n_step, Es, n_tr, Ms, T, ep * nmb) + ("" if (Es, Ms) == (E, M) else " (rows scaled to %d / %d)" % (E, M)),
             "update_samples_per_s": ep * B / (ep * nmb * t_train)}
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":          # child of cpu_baseline_all_cores: CPU only
+        name, e_rows, m_rows, reps, t_start = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
+        print("%r %r" % _cpu_worker((CONFIGS[name], e_rows, m_rows, reps, t_start)))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -196,7 +258,7 @@ def main():
         "losses": [float(x) for x in losses],
     }
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(cfg)
+        out["cpu_baseline"] = cpu_baseline(cfg, args.config)
     # (skipped under rocprofv3: instantiating a second handle's hipGraph in one traced process crashes the profiler)
     profiled = any("ROCPROF" in k for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
     if world == 1 and args.config == "cfg3" and not args.no_extra and not profiled:
