@@ -13,12 +13,45 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <memory>
 #include <mutex>
 #include <thread>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include "env.hpp"
+
+// CPUs this process may actually use: hardware threads, narrowed by the affinity mask and by the cgroup CPU quota
+// (a container often sees every core of the host but is throttled to a few; a worker per visible core then only
+// adds contention)
+inline int usable_cpus() {
+    int n = static_cast<int>(std::thread::hardware_concurrency());
+    if (n < 1) n = 1;
+#if defined(__linux__)
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
+    auto quota = [](const char* quota_file, const char* period_file) -> int {
+        FILE* f = std::fopen(quota_file, "r");
+        if (!f) return 0;
+        char a[64] = {0}; long long period = 0, q = 0;
+        int got = period_file ? std::fscanf(f, "%63s", a) : std::fscanf(f, "%63s %lld", a, &period);
+        std::fclose(f);
+        if (got < 1 || a[0] == 'm' || a[0] == '-') return 0;            // "max" / -1: unlimited
+        q = std::atoll(a);
+        if (period_file) { FILE* g = std::fopen(period_file, "r"); if (!g) return 0; if (std::fscanf(g, "%lld", &period) != 1) period = 0; std::fclose(g); }
+        if (q <= 0 || period <= 0) return 0;
+        return static_cast<int>((q + period - 1) / period);
+    };
+    int q = quota("/sys/fs/cgroup/cpu.max", nullptr);                                               // cgroup v2
+    if (q == 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");   // v1
+    if (q > 0) n = std::min(n, q);
+#endif
+    return n;
+}
 
 class VecEnv : public virtual Env {
 public:
@@ -27,8 +60,7 @@ public:
           observations_(Mat::Zero(n_, envs[0]->get_observation_space_size())), rewards_(Mat::Zero(n_, 1)), dones_(Mat::Zero(n_, 1)),
           original_rewards_(Mat::Zero(n_, 1)) {
         assert(!envs.empty());
-        int hw = static_cast<int>(std::thread::hardware_concurrency());
-        if (hw < 1) hw = 1;
+        const int hw = usable_cpus();
         int workers = std::min(n_, max_workers > 0 ? max_workers : hw);
         const int per = (n_ + workers - 1) / workers;
         workers = (n_ + per - 1) / per;
