@@ -1173,16 +1173,26 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
             if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
             HIP_OK(h, hipStreamSynchronize(h->stream));
             hipGraph_t graph = nullptr;
-            HIP_OK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = enqueue_update(h, epochs, nmb, explicit_perms);
-            const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
-            if (rc) { if (graph) (void)hipGraphDestroy(graph); return -1; }
-            HIP_OK(h, ce);
-            HIP_OK(h, hipGraphInstantiate(&h->upd_graph, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            h->g_epochs = epochs; h->g_nmb = nmb; h->g_E = h->E; h->g_T = h->T; h->g_explicit = (int)explicit_perms; h->g_world = h->world;
+            // a runtime that cannot capture or instantiate this sequence is not fatal: the same launches run eagerly
+            // (nothing has executed yet -- capture only records)
+            bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const int rc = enqueue_update(h, epochs, nmb, explicit_perms);
+                const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+                ok = rc == 0 && ce == hipSuccess && graph != nullptr && hipGraphInstantiate(&h->upd_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                h->upd_graph = nullptr;
+                h->use_graph = false;
+                fprintf(stderr, "libppo_hip: hipGraph capture of the update failed (%s); continuing with eager launches\n", h->err.c_str());
+            } else {
+                h->g_epochs = epochs; h->g_nmb = nmb; h->g_E = h->E; h->g_T = h->T; h->g_explicit = (int)explicit_perms; h->g_world = h->world;
+            }
         }
-        HIP_OK(h, hipGraphLaunch(h->upd_graph, h->stream));
+        if (h->upd_graph) HIP_OK(h, hipGraphLaunch(h->upd_graph, h->stream));
+        else if (enqueue_update(h, epochs, nmb, explicit_perms)) return -1;
     } else if (enqueue_update(h, epochs, nmb, explicit_perms)) return -1;
     if (loss_rows) HIP_OK(h, hipMemcpyAsync(loss_rows, h->d_loss_rows, (size_t)steps * 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
