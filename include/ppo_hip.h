@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define PPO_MAX_LAYERS 8
-#define PPO_ABI_VERSION 1
+#define PPO_ABI_VERSION 2
 
 typedef struct ppo_handle ppo_handle;
 
@@ -76,6 +76,11 @@ int ppo_set_beta_powers(ppo_handle* h, const float pw[2]);
 /* orthogonal init of the same family as the constants in G (gain sqrt2 hidden, 0.01 pi, 1.0 vf; biases,
  * logstd, Adam slots zero; beta powers = beta) */
 int ppo_init_orthogonal(ppo_handle* h, uint64_t seed);
+/* seed of the on-device action-noise generator that stands in for G:5894 RandomStandardNormal when no explicit noise
+ * is passed (the reference seeds TF from the clock, ppo2.cpp:159-162; PPO2::seed / --seed end up here).  The draw for
+ * a row is keyed by (seed, global row = rank * n_envs + row, call counter, action index), so data-parallel ranks
+ * draw independent noise. */
+int ppo_seed(ppo_handle* h, uint64_t seed);
 
 /* ---- act model ------------------------------------------------------------------------------------------
  * MlpPolicy::step (ppo2/policies.hpp:33-46): feeds input/Ob:0, fetches output/_action, _value_flat, _neglogp.
@@ -110,6 +115,12 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
 int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int training, float* out);
 int ppo_norm_reward(ppo_handle* h, const float* raw_rew, const float* dones, int32_t n_envs, int training,
                     float* out);
+/* the norm_obs / norm_reward constructor flags of EnvNormalize (env_normalize.hpp:24-27, honoured at :75 and :95): with
+ * norm_obs == 0 observations pass through unscaled and obs_rms is never updated; with norm_reward == 0 rewards pass
+ * through and ret_rms is never updated (the discounted return is still accumulated, :66).  Default 1, 1. */
+int ppo_norm_set_flags(ppo_handle* h, int norm_obs, int norm_reward);
+/* EnvNormalize::reset's `ret = Zero` (env_normalize.hpp:111-116) without touching the statistics */
+int ppo_norm_reset_returns(ppo_handle* h);
 /* which: 0 = obs_rms, 1 = ret_rms; serialise / deserialise of env_normalize.hpp:134-146 */
 int ppo_norm_get_stats(ppo_handle* h, int which, float* mean, float* var, double* count);
 int ppo_norm_set_stats(ppo_handle* h, int which, const float* mean, const float* var, double count);

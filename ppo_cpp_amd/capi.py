@@ -121,6 +121,9 @@ class PPOHip:
     def init_orthogonal(self, seed=0):
         self._ck(self.lib.ppo_init_orthogonal(self.h, C.c_uint64(seed)))
 
+    def seed(self, seed):
+        self._ck(self.lib.ppo_seed(self.h, C.c_uint64(seed)))
+
     def beta_powers(self):
         pw = np.empty(2, np.float32)
         self._ck(self.lib.ppo_get_beta_powers(self.h, _fp(pw)))
@@ -179,6 +182,12 @@ class PPOHip:
     # ---- normaliser -------------------------------------------------------------------------------
     def norm_init(self, n_envs, gamma=0.99, clip_obs=10.0, clip_rew=10.0, eps=1e-8):
         self._ck(self.lib.ppo_norm_init(self.h, n_envs, C.c_float(gamma), C.c_float(clip_obs), C.c_float(clip_rew), C.c_float(eps)))
+
+    def norm_set_flags(self, norm_obs=True, norm_reward=True):
+        self._ck(self.lib.ppo_norm_set_flags(self.h, int(norm_obs), int(norm_reward)))
+
+    def norm_reset_returns(self):
+        self._ck(self.lib.ppo_norm_reset_returns(self.h))
 
     def norm_obs(self, raw, training=True):
         x = _f32(raw); out = np.empty_like(x)

@@ -112,6 +112,14 @@ struct ppo_handle {
     int g_epochs = 0, g_nmb = 0, g_E = 0, g_T = 0, g_explicit = -1, g_world = 0;
     bool use_graph = true;
     uint32_t rng_calls = 0;
+    uint32_t rng_seed = 0x5EEDu;      // ppo_seed
+    int norm_obs_flag = 1, norm_rew_flag = 1;   // EnvNormalize's norm_obs / norm_reward (env_normalize.hpp:75,95)
+    float* env_in = nullptr;          // [E*O | E | E] raw obs | raw reward | dones of the current env step, one block: one H2D per env step
+    float* pin_in = nullptr;          // pinned host mirror of env_in (hipHostMalloc, owned by the handle)
+    float* pin_out = nullptr;         // pinned host landing buffer for the actions of one env step [E*A]
+    size_t pin_in_n = 0, pin_out_n = 0;
+    bool pin_in_busy = false;         // an H2D copy out of pin_in may still be in flight (cleared by every stream synchronisation of the rollout calls)
+    int upd_cap_epochs = 0;
     // dist
     Rccl rccl;
     void* comm = nullptr;
@@ -141,6 +149,13 @@ int fail(ppo_handle* h, const char* fmt, ...) {
     do {                                                                                             \
         hipError_t e_ = (expr);                                                                      \
         if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// every entry point that allocates or launches makes the handle's device current on the calling thread first (another
+// handle, torch or another thread may have changed it)
+#define ENTER(h)                                                                                      \
+    do {                                                                                             \
+        if (hipSetDevice((h)->device) != hipSuccess) return fail(h, "hipSetDevice(%d) failed", (h)->device); \
     } while (0)
 
 template <typename T>
@@ -550,8 +565,9 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     const char* ng = getenv("PPO_HIP_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
     if (build_layout(h)) return bail(0);
-    // large dynamic LDS needs an explicit opt-in
-    const int lds_bytes = h->net.lds_total * (int)sizeof(float);
+    // large dynamic LDS needs an explicit opt-in.  The attribute is per function, not per handle: it is set to the
+    // hardware maximum (160 KB) so that a later, narrower handle cannot lower the limit under a live wider one.
+    const int lds_bytes = 160 * 1024;
     bool attr_ok = true;
     auto set_lds = [&](const void* f) { attr_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess; };
     set_lds((const void*)policy_step_kernel<4, 2, 2, false>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2, false>);
@@ -583,17 +599,19 @@ void ppo_destroy(ppo_handle* h) {
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
                     h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->stats_xch, h->stats_part, h->stats_counter, h->adv_xch, h->ro_obs, h->ro_act,
-                    h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->cur_done, h->raw_obs, h->raw_rew, h->raw_done,
+                    h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->env_in /* raw_obs, raw_rew, cur_done live inside */, h->raw_done,
                     h->last_val, h->ro_noise, h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp, h->d_perms, h->d_inv, h->d_gidx, h->d_advstats, h->d_keys, h->d_loss_rows, h->d_loss_mean};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) { if (h->hg[t][l]) (void)hipFree(h->hg[t][l]); if (h->dyg[t][l]) (void)hipFree(h->dyg[t][l]); }
     for (int i = 0; i < 6; ++i) if (h->st_vec[i]) (void)hipFree(h->st_vec[i]);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
-int ppo_sync(ppo_handle* h) { HIP_OK(h, hipStreamSynchronize(h->stream)); return 0; }
+int ppo_sync(ppo_handle* h) { ENTER(h); HIP_OK(h, hipStreamSynchronize(h->stream)); return 0; }
 
 // ---- variables ----------------------------------------------------------------------------------------------------
 int ppo_num_tensors(const ppo_handle* h) { return (int)h->tensors.size(); }
@@ -609,6 +627,7 @@ int ppo_tensor_info(const ppo_handle* h, int index, char name[32], int32_t* rows
 }
 
 int ppo_get_tensor(ppo_handle* h, int which, int index, float* dst, int64_t count) {
+    ENTER(h);
     float* base = which_buf(h, which);
     if (!base || index < 0 || index >= (int)h->tensors.size()) return fail(h, "ppo_get_tensor: bad which/index");
     const Tensor& t = h->tensors[index];
@@ -618,6 +637,7 @@ int ppo_get_tensor(ppo_handle* h, int which, int index, float* dst, int64_t coun
 }
 
 int ppo_set_tensor(ppo_handle* h, int which, int index, const float* src, int64_t count) {
+    ENTER(h);
     float* base = which_buf(h, which);
     if (!base || index < 0 || index >= (int)h->tensors.size()) return fail(h, "ppo_set_tensor: bad which/index");
     const Tensor& t = h->tensors[index];
@@ -646,6 +666,7 @@ int ppo_set_flat(ppo_handle* h, int which, const float* src, int64_t count) {
 }
 
 int ppo_get_beta_powers(ppo_handle* h, float pw[2]) {
+    ENTER(h);
     float v[4];
     HIP_OK(h, hipStreamSynchronize(h->stream));
     HIP_OK(h, hipMemcpy(v, h->beta_pow, sizeof v, hipMemcpyDeviceToHost));
@@ -654,6 +675,7 @@ int ppo_get_beta_powers(ppo_handle* h, float pw[2]) {
 }
 
 int ppo_set_beta_powers(ppo_handle* h, const float pw[2]) {
+    ENTER(h);
     const float v[4] = {pw[0], pw[1], pw[0], pw[1]};
     HIP_OK(h, hipStreamSynchronize(h->stream));
     HIP_OK(h, hipMemcpy(h->beta_pow, v, sizeof v, hipMemcpyHostToDevice));
@@ -698,9 +720,18 @@ int ppo_init_orthogonal(ppo_handle* h, uint64_t seed) {
     return ppo_set_beta_powers(h, pw);
 }
 
+int ppo_seed(ppo_handle* h, uint64_t seed) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    h->rng_seed = (uint32_t)(z ^ (z >> 32));
+    h->rng_calls = 0;
+    return 0;
+}
+
 // ---- act model ----------------------------------------------------------------------------------------------------
 static int step_common(ppo_handle* h, const float* obs, int n, const float* noise, bool sample, float* action, float* det_action,
                        float* value, float* neglogp) {
+    ENTER(h);
     if (n < 1) return fail(h, "step: n must be positive");
     if (ensure_staging(h, n)) return -1;
     const NetDev& net = h->net;
@@ -713,7 +744,7 @@ static int step_common(ppo_handle* h, const float* obs, int n, const float* nois
     a.value = value ? h->st_vec[0] : nullptr;
     a.neglogp = neglogp ? h->st_vec[1] : nullptr;
     a.obs_out = nullptr; a.nz = no_norm(); a.n = n;
-    a.seed = 0x5EEDu; a.rng_step = h->rng_calls++; a.row_base = 0;
+    a.seed = h->rng_seed; a.rng_step = h->rng_calls++; a.row_base = (uint32_t)h->rank * (uint32_t)(h->nz_envs > 0 ? h->nz_envs : n);
     if (launch_step(h, a)) return -1;
     if (action || det_action) HIP_OK(h, hipMemcpyAsync(action ? action : det_action, h->st_act, (size_t)n * net.A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (value) HIP_OK(h, hipMemcpyAsync(value, h->st_vec[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -735,6 +766,7 @@ int ppo_act_deterministic(ppo_handle* h, const float* obs, int32_t n, float* act
 // ---- train op -------------------------------------------------------------------------------------------------------
 int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, const float* actions, const float* advs,
                    const float* returns, const float* old_neglogp, const float* old_values, int32_t n, float losses[5]) {
+    ENTER(h);
     if (n < 2) return fail(h, "ppo_train_step: n=%d (the reference asserts more than one row, ppo2.hpp:402)", n);
     if (ensure_staging(h, n) || ensure_train_ws(h, n)) return -1;
     const NetDev& net = h->net;
@@ -756,6 +788,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
 }
 
 int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm) {
+    ENTER(h);
     if (count != h->P_dense) return fail(h, "ppo_get_last_grad: count %lld != %d", (long long)count, h->P_dense);
     HIP_OK(h, hipStreamSynchronize(h->stream));
     for (const Tensor& t : h->tensors) if (copy_tensor(h, h->grad, t, dst + t.off_dense, false)) return -1;
@@ -765,6 +798,7 @@ int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_no
 
 // ---- host-loop numerics on the device -------------------------------------------------------------------------------
 int ppo_adv_normalize(ppo_handle* h, const float* returns, const float* values, int32_t n, float* advs) {
+    ENTER(h);
     if (n < 1) return fail(h, "ppo_adv_normalize: n must be positive");
     if (ensure_staging(h, n)) return -1;
     HIP_OK(h, hipMemcpyAsync(h->st_vec[0], returns, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -778,6 +812,7 @@ int ppo_adv_normalize(ppo_handle* h, const float* returns, const float* values, 
 
 int ppo_gae(ppo_handle* h, const float* rewards, const float* values, const float* dones, const float* last_values,
             const float* last_dones, int32_t T, int32_t E, float gamma, float lam, float* returns) {
+    ENTER(h);
     if (T < 1 || E < 1) return fail(h, "ppo_gae: bad shape");
     const size_t n = (size_t)T * E;
     if (n > (size_t)1 << 30) return fail(h, "ppo_gae: too large");
@@ -807,13 +842,37 @@ static int norm_alloc_stats(ppo_handle* h, NormDev& s, int dim) {
 }
 
 int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, float clip_rew, float epsilon) {
+    ENTER(h);
     if (n_envs < 1) return fail(h, "ppo_norm_init: n_envs must be positive");
     h->nz_envs = n_envs; h->nz_gamma = gamma; h->nz_clip_obs = clip_obs; h->nz_clip_rew = clip_rew; h->nz_eps = epsilon;
     if (norm_alloc_stats(h, h->obs_rms, h->net.O) || norm_alloc_stats(h, h->ret_rms, 1)) return -1;
     if (dev_alloc(h, &h->nz_ret, n_envs) || dev_alloc(h, &h->stats_counter, 4) ||
         dev_alloc(h, &h->stats_part, (size_t)NB_MAX_OBS_BLOCKS * (1 + 2 * h->net.O) + (size_t)NB_MAX_REW_BLOCKS * 3)) return -1;
-    if (dev_alloc(h, &h->raw_obs, (size_t)n_envs * h->net.O) || dev_alloc(h, &h->raw_rew, n_envs) || dev_alloc(h, &h->raw_done, n_envs)) return -1;
+    // raw observations | raw rewards | dones of the current env step in ONE block (one H2D copy per env step on the
+    // host-Env path) with a pinned host mirror owned by the handle (replaces the pageable Utils::convert_* copies of
+    // ppo2/utils.hpp:17-73)
+    const size_t in_n = (size_t)n_envs * (h->net.O + 2);
+    if (dev_alloc(h, &h->env_in, in_n) || dev_alloc(h, &h->raw_done, n_envs)) return -1;
+    h->raw_obs = h->env_in; h->raw_rew = h->env_in + (size_t)n_envs * h->net.O; h->cur_done = h->raw_rew + n_envs;
+    if (h->pin_in) { (void)hipHostFree(h->pin_in); h->pin_in = nullptr; }
+    if (h->pin_out) { (void)hipHostFree(h->pin_out); h->pin_out = nullptr; }
+    HIP_OK(h, hipHostMalloc((void**)&h->pin_in, in_n * sizeof(float), hipHostMallocDefault));
+    HIP_OK(h, hipHostMalloc((void**)&h->pin_out, (size_t)n_envs * h->net.A * sizeof(float), hipHostMallocDefault));
+    h->pin_in_n = in_n; h->pin_out_n = (size_t)n_envs * h->net.A;
     HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ppo_norm_set_flags(ppo_handle* h, int norm_obs, int norm_reward) {
+    h->norm_obs_flag = norm_obs ? 1 : 0;
+    h->norm_rew_flag = norm_reward ? 1 : 0;
+    return 0;
+}
+
+int ppo_norm_reset_returns(ppo_handle* h) {
+    ENTER(h);
+    if (!h->nz_envs) return fail(h, "ppo_norm_reset_returns: call ppo_norm_init first");
+    HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)h->nz_envs * sizeof(float), h->stream));      // env_normalize.hpp:114
     return 0;
 }
 
@@ -843,7 +902,7 @@ static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, con
         a.g_obs = (rows + a.rows_per_obs_block - 1) / a.rows_per_obs_block;
     }
     a.rew = rew_dev; a.dones = done_dev; a.ret = h->nz_ret; a.ret_st = h->ret_rms; a.rew_out = rew_out; a.done_copy = done_copy;
-    a.rew_rows = rows; a.training_rew = training_rew;
+    a.rew_rows = rows; a.training_rew = (training_rew && h->norm_rew_flag) ? 1 : 0; a.scale_rew = h->norm_rew_flag;
     if (rew_dev) {
         a.g_rew = std::max(1, std::min(NB_MAX_REW_BLOCKS, (rows + 1023) / 1024));
         a.rows_per_rew_block = (rows + a.g_rew - 1) / a.g_rew;
@@ -874,11 +933,16 @@ static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, con
 }
 
 int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int training, float* out) {
+    ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_obs: call ppo_norm_init first");
     if (n_envs != h->nz_envs) return fail(h, "ppo_norm_obs: n_envs %d != %d", n_envs, h->nz_envs);
     const size_t cnt = (size_t)n_envs * h->net.O;
     if (ensure_staging(h, n_envs)) return -1;
     HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (!h->norm_obs_flag) {                                  // env_normalize.hpp:107-109: pass-through
+        if (out != raw_obs) memcpy(out, raw_obs, cnt * sizeof(float));
+        return 0;
+    }
     if (training && enqueue_norm_batch(h, h->raw_obs, n_envs, nullptr, nullptr, 0, nullptr, nullptr)) return -1;
     hipLaunchKernelGGL(obs_normalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->raw_obs, n_envs, h->net.O, h->obs_rms,
                        h->nz_eps, h->nz_clip_obs, h->st_obs);
@@ -889,6 +953,7 @@ int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int traini
 }
 
 int ppo_norm_reward(ppo_handle* h, const float* raw_rew, const float* dones, int32_t n_envs, int training, float* out) {
+    ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_reward: call ppo_norm_init first");
     if (n_envs != h->nz_envs) return fail(h, "ppo_norm_reward: n_envs %d != %d", n_envs, h->nz_envs);
     if (ensure_staging(h, n_envs)) return -1;
@@ -901,6 +966,7 @@ int ppo_norm_reward(ppo_handle* h, const float* raw_rew, const float* dones, int
 }
 
 int ppo_norm_get_stats(ppo_handle* h, int which, float* mean, float* var, double* count) {
+    ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_get_stats: call ppo_norm_init first");
     NormDev& s = which == 0 ? h->obs_rms : h->ret_rms;
     const int dim = which == 0 ? h->net.O : 1;
@@ -912,6 +978,7 @@ int ppo_norm_get_stats(ppo_handle* h, int which, float* mean, float* var, double
 }
 
 int ppo_norm_set_stats(ppo_handle* h, int which, const float* mean, const float* var, double count) {
+    ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_set_stats: call ppo_norm_init first");
     NormDev& s = which == 0 ? h->obs_rms : h->ret_rms;
     const int dim = which == 0 ? h->net.O : 1;
@@ -924,6 +991,7 @@ int ppo_norm_set_stats(ppo_handle* h, int which, const float* mean, const float*
 
 // ---- rollout ----------------------------------------------------------------------------------------------------------
 int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
+    ENTER(h);
     if (E < 1 || T < 1) return fail(h, "ppo_rollout_alloc: bad shape");
     if (!h->nz_envs && ppo_norm_init(h, E, 0.99f, 10.f, 10.f, 1e-8f)) return -1;
     if (h->nz_envs != E) return fail(h, "ppo_rollout_alloc: n_envs %d != normaliser's %d", E, h->nz_envs);
@@ -933,7 +1001,7 @@ int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
     const size_t B = (size_t)E * T;
     if (dev_alloc(h, &h->ro_obs, B * n.O) || dev_alloc(h, &h->ro_act, B * n.A) || dev_alloc(h, &h->ro_val, B) || dev_alloc(h, &h->ro_nlp, B) ||
         dev_alloc(h, &h->ro_done, B) || dev_alloc(h, &h->ro_rew, B) || dev_alloc(h, &h->ro_ret, B) ||
-        dev_alloc(h, &h->cur_done, E) || dev_alloc(h, &h->last_val, E) || dev_alloc(h, &h->ro_noise, B * n.A))
+        dev_alloc(h, &h->last_val, E) || dev_alloc(h, &h->ro_noise, B * n.A))
         return -1;
     h->E = E; h->T = T;
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -943,7 +1011,7 @@ int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
 // The current observations stay RAW in raw_obs: the statistics update runs when they arrive (update-then-normalise,
 // env_normalize.hpp:94-105) and the scale + clip happens in the policy step's input staging, which also writes the
 // normalised rows into the rollout buffer -- no separate normalise kernel, no device-to-device copy.
-static ObsNorm obs_norm(ppo_handle* h) { return ObsNorm{h->obs_rms.mean, h->obs_rms.var, h->nz_eps, h->nz_clip_obs, 1}; }
+static ObsNorm obs_norm(ppo_handle* h) { return ObsNorm{h->obs_rms.mean, h->obs_rms.var, h->nz_eps, h->nz_clip_obs, h->norm_obs_flag}; }
 
 // policy step on the current observations -> rollout[t]
 static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uint32_t seed, uint32_t rng_step, uint32_t row_base) {
@@ -961,7 +1029,7 @@ static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uin
 static int enqueue_observe(ppo_handle* h, int t) {
     const size_t E = h->E;
     float* done_next = t + 1 < h->T ? h->ro_done + (size_t)(t + 1) * E : nullptr;
-    if (enqueue_norm_batch(h, h->raw_obs, (int)E, h->raw_rew, h->cur_done, 1, h->ro_rew + (size_t)t * E, done_next)) return -1;
+    if (enqueue_norm_batch(h, h->norm_obs_flag ? h->raw_obs : nullptr, (int)E, h->raw_rew, h->cur_done, 1, h->ro_rew + (size_t)t * E, done_next)) return -1;
     h->done_staged = done_next ? t + 1 : -1;
     return 0;
 }
@@ -979,39 +1047,55 @@ static int enqueue_finish(ppo_handle* h, float gamma, float lam) {
 
 int ppo_rollout_reset(ppo_handle* h, const float* raw_obs) {
     if (!h->E) return fail(h, "ppo_rollout_reset: call ppo_rollout_alloc first");
-    HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, (size_t)h->E * h->net.O * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    ENTER(h);
+    const size_t on = (size_t)h->E * h->net.O;
+    if (h->pin_in_busy) HIP_OK(h, hipStreamSynchronize(h->stream));
+    h->pin_in_busy = false;
+    memcpy(h->pin_in, raw_obs, on * sizeof(float));
+    HIP_OK(h, hipMemcpyAsync(h->raw_obs, h->pin_in, on * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)h->E * sizeof(float), h->stream));          // env_normalize.hpp:114
     HIP_OK(h, hipMemsetAsync(h->cur_done, 0, (size_t)h->E * sizeof(float), h->stream));        // runner.hpp:50
     h->done_staged = -1;
-    if (enqueue_norm_batch(h, h->raw_obs, h->E, nullptr, nullptr, 0, nullptr, nullptr)) return -1;
+    if (h->norm_obs_flag && enqueue_norm_batch(h, h->raw_obs, h->E, nullptr, nullptr, 0, nullptr, nullptr)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
 int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions_out) {
     if (!h->E || t < 0 || t >= h->T) return fail(h, "ppo_rollout_act: bad step %d", t);
+    ENTER(h);
     const NetDev& n = h->net;
     const size_t cnt = (size_t)h->E * n.A;
     float* nd = nullptr;
     if (noise) { nd = h->ro_noise; HIP_OK(h, hipMemcpyAsync(nd, noise, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream)); }
-    if (enqueue_rollout_act(h, t, nd, 0x5EEDu, h->rng_calls++, 0)) return -1;
-    HIP_OK(h, hipMemcpyAsync(actions_out, h->ro_act + (size_t)t * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (enqueue_rollout_act(h, t, nd, h->rng_seed, h->rng_calls++, (uint32_t)(h->rank * h->E))) return -1;
+    // one D2H into the handle's pinned landing buffer and the ONLY stream synchronisation of an env step: the statistics
+    // kernel of the previous ppo_rollout_observe, this policy step and the copy drain together
+    HIP_OK(h, hipMemcpyAsync(h->pin_out, h->ro_act + (size_t)t * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
+    h->pin_in_busy = false;
+    memcpy(actions_out, h->pin_out, cnt * sizeof(float));
     return 0;
 }
 
 int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const float* raw_rew, const float* dones) {
     if (!h->E || t < 0 || t >= h->T) return fail(h, "ppo_rollout_observe: bad step %d", t);
-    const size_t E = h->E;
-    HIP_OK(h, hipMemcpyAsync(h->raw_obs, raw_obs, E * h->net.O * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIP_OK(h, hipMemcpyAsync(h->raw_rew, raw_rew, E * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIP_OK(h, hipMemcpyAsync(h->cur_done, dones, E * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    ENTER(h);
+    const size_t E = h->E, on = E * h->net.O;
+    // obs | reward | dones packed into the pinned mirror, ONE H2D copy; no synchronisation here: nothing of this call is
+    // read by the host, and the pinned block is not rewritten before the next ppo_rollout_act has drained the stream
+    if (h->pin_in_busy) HIP_OK(h, hipStreamSynchronize(h->stream));
+    memcpy(h->pin_in, raw_obs, on * sizeof(float));
+    memcpy(h->pin_in + on, raw_rew, E * sizeof(float));
+    memcpy(h->pin_in + on + E, dones, E * sizeof(float));
+    HIP_OK(h, hipMemcpyAsync(h->env_in, h->pin_in, (on + 2 * E) * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->pin_in_busy = true;
     if (enqueue_observe(h, t)) return -1;
-    HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
 int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
+    ENTER(h);
     if (!h->E) return fail(h, "ppo_rollout_finish: call ppo_rollout_alloc first");
     if (enqueue_finish(h, gamma, lam)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -1020,6 +1104,7 @@ int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
 }
 
 int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t step0, int first, const float* noise, float gamma, float lam) {
+    ENTER(h);
     if (!h->E) return fail(h, "ppo_collect_synthetic: call ppo_rollout_alloc first");
     const NetDev& n = h->net;
     const int E = h->E, T = h->T;
@@ -1062,6 +1147,7 @@ static float* rollout_field(ppo_handle* h, int field, size_t* count) {
 }
 
 int ppo_rollout_download(ppo_handle* h, int field, float* dst, int64_t count) {
+    ENTER(h);
     size_t c = 0;
     float* p = h->E ? rollout_field(h, field, &c) : nullptr;
     if (!p || (size_t)count != c) return fail(h, "ppo_rollout_download: bad field/count");
@@ -1071,6 +1157,7 @@ int ppo_rollout_download(ppo_handle* h, int field, float* dst, int64_t count) {
 }
 
 int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count) {
+    ENTER(h);
     size_t c = 0;
     float* p = h->E ? rollout_field(h, field, &c) : nullptr;
     if (!p || (size_t)count != c) return fail(h, "ppo_rollout_upload: bad field/count");
@@ -1133,6 +1220,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
 
 int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t nmb, const int32_t* perms, uint64_t seed, float* loss_rows,
                float mean_losses[5]) {
+    ENTER(h);
     if (!h->E) return fail(h, "ppo_update: no rollout (ppo_rollout_alloc + collect first)");
     const int B = h->E * h->T;
     if (epochs < 1 || nmb < 1 || B % nmb) return fail(h, "ppo_update: n_batch %d not divisible by nminibatches %d", B, nmb);
@@ -1145,7 +1233,8 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
         const int cr = std::max(B, h->upd_cap_rows), cs = std::max(steps, h->upd_cap_steps);
         if (dev_alloc(h, &h->mb_obs, (size_t)cr * h->net.O) || dev_alloc(h, &h->mb_act, (size_t)cr * h->net.A) || dev_alloc(h, &h->mb_adv, cr) ||
             dev_alloc(h, &h->mb_ret, cr) || dev_alloc(h, &h->mb_val, cr) || dev_alloc(h, &h->mb_nlp, cr)) return -1;
-        if (dev_alloc(h, &h->d_perms, (size_t)cs * cr) || dev_alloc(h, &h->d_inv, cr) || dev_alloc(h, &h->d_gidx, cr) ||
+        if (h->d_perms) { (void)hipFree(h->d_perms); h->d_perms = nullptr; h->upd_cap_epochs = 0; }      // sized on demand below
+        if (dev_alloc(h, &h->d_inv, cr) || dev_alloc(h, &h->d_gidx, cr) ||
             dev_alloc(h, &h->d_advstats, (size_t)2 * cs) || dev_alloc(h, &h->d_keys, (size_t)2 * cs) || dev_alloc(h, &h->d_loss_rows, (size_t)5 * cs) ||
             dev_alloc(h, &h->d_loss_mean, 8) || dev_alloc(h, &h->adv_xch, (size_t)2 * cs))
             return -1;
@@ -1153,7 +1242,27 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     }
     if (set_hyper(h, lr, cliprange)) return -1;
     const bool explicit_perms = perms != nullptr;
-    if (explicit_perms) HIP_OK(h, hipMemcpyAsync(h->d_perms, perms, (size_t)epochs * B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (explicit_perms) {
+        // every epoch's row must be a permutation of [0, B): invert_perm_kernel scatters inv[perm[i]] = i
+        std::vector<unsigned char> seen((size_t)B);
+        for (int ep = 0; ep < epochs; ++ep) {
+            std::fill(seen.begin(), seen.end(), 0);
+            const int32_t* pe = perms + (size_t)ep * B;
+            for (int i = 0; i < B; ++i) {
+                const int32_t d = pe[i];
+                if (d < 0 || d >= B || seen[(size_t)d]) return fail(h, "ppo_update: perms[%d] is not a permutation of [0,%d) (entry %d = %d)", ep, B, i, (int)d);
+                seen[(size_t)d] = 1;
+            }
+        }
+        // [epochs, B] ints, allocated only when explicit permutations are used (on-device shuffles need none)
+        if (!h->d_perms || epochs > h->upd_cap_epochs) {
+            HIP_OK(h, hipStreamSynchronize(h->stream));
+            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            if (dev_alloc(h, &h->d_perms, (size_t)epochs * h->upd_cap_rows)) return -1;
+            h->upd_cap_epochs = epochs;
+        }
+        HIP_OK(h, hipMemcpyAsync(h->d_perms, perms, (size_t)epochs * B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
     std::vector<uint32_t> keys(2 * (size_t)epochs);
     for (int ep = 0; ep < epochs; ++ep) {
         uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(ep + 1);
@@ -1252,6 +1361,7 @@ int ppo_dist_world(const ppo_handle* h) { return h->world; }
 
 // ---- measurement ----------------------------------------------------------------------------------------------------------
 int ppo_prof_enable(ppo_handle* h, int on) {
+    ENTER(h);
     prof_collect(h);
     h->prof = on != 0;
     for (int i = 0; i < PK_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
@@ -1259,6 +1369,7 @@ int ppo_prof_enable(ppo_handle* h, int on) {
 }
 
 int ppo_prof_read(ppo_handle* h, int max, char names[][32], double* total_ms, int64_t* launches) {
+    ENTER(h);
     prof_collect(h);
     int n = 0;
     for (int i = 0; i < PK_COUNT && n < max; ++i) {

@@ -1685,6 +1685,7 @@ struct NormBatchArgs {
     const float* obs; int rows; int D; NormDev obs_st; int g_obs; int rows_per_obs_block;      // obs == null: no obs job
     const float* rew; const float* dones; float* ret; NormDev ret_st; float* rew_out; float* done_copy;   // rew == null: no reward job
     int rew_rows; int training_rew; int g_rew; int rows_per_rew_block;
+    int scale_rew;        // EnvNormalize::norm_reward (env_normalize.hpp:75): 0 = rewards pass through unscaled and unclipped
     float gamma, clip_rew, eps;
     float* part;          // [g_obs][1 + 2D] then [g_rew][3]
     unsigned* counter;    // zero between launches
@@ -1861,8 +1862,8 @@ __device__ __forceinline__ void norm_finish(const NormBatchArgs& a, int which, c
         for (int u = 0; u < U; ++u) {
             const int i = base + tid + NB_THREADS * u;
             if (i >= a.rew_rows) continue;
-            float y = rw[u] * inv;
-            y = tf_min(tf_max(y, -a.clip_rew), a.clip_rew);
+            float y = rw[u];
+            if (a.scale_rew) { y = y * inv; y = tf_min(tf_max(y, -a.clip_rew), a.clip_rew); }
             a.rew_out[i] = y;
             a.ret[i] = rt[u] * (1.0f - dn[u]);                                 // :84-90
             if (a.done_copy) a.done_copy[i] = dn[u];

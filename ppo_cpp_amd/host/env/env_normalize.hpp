@@ -16,6 +16,7 @@ public:
                  float clip_reward = 10, float clip_obs = 10, float gamma = 0.99f, float epsilon = 1e-8f)
         : env_(std::move(env)), h_(handle), training_(training), norm_obs_(norm_obs), norm_reward_(norm_reward) {
         check(ppo_norm_init(h_, env_->get_num_envs(), gamma, clip_obs, clip_reward, epsilon));
+        check(ppo_norm_set_flags(h_, norm_obs_ ? 1 : 0, norm_reward_ ? 1 : 0));     // honoured by the device-resident rollout too
     }
 
     std::string get_action_space() override { return env_->get_action_space(); }
@@ -28,14 +29,15 @@ public:
         std::vector<Mat> r = env_->step(actions);
         Mat obs = normalize_observation(r[0]);
         Mat rew = r[1];
-        if (norm_reward_) check(ppo_norm_reward(h_, r[1].data(), r[2].data(), get_num_envs(), training_ ? 1 : 0, rew.data()));
+        // always called: the discounted return accumulates whether or not rewards are scaled (env_normalize.hpp:66,91);
+        // with norm_reward == false the library passes the rewards through and leaves ret_rms alone (:75)
+        check(ppo_norm_reward(h_, r[1].data(), r[2].data(), get_num_envs(), training_ ? 1 : 0, rew.data()));
         return {obs, rew, r[2]};
     }
 
     Mat reset() override {
         const Mat obs = env_->reset();
-        // a fresh normaliser state for the discounted return (env_normalize.hpp:114) is part of ppo_rollout_reset;
-        // for the plain Env path the return accumulator restarts with the statistics kept
+        check(ppo_norm_reset_returns(h_));                        // ret = Zero (env_normalize.hpp:114); statistics kept
         return normalize_observation(obs);
     }
 
@@ -56,6 +58,8 @@ public:
     }
     Env& inner() { return *env_; }
     bool training() const { return training_; }
+    bool norm_obs() const { return norm_obs_; }
+    bool norm_reward() const { return norm_reward_; }
 
 private:
     Mat normalize_observation(const Mat& obs) {

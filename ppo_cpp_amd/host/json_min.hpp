@@ -75,11 +75,44 @@ private:
         switch (kind_) {
             case Null: o << "null"; break;
             case Bool: o << (b_ ? "true" : "false"); break;
-            case Number: { char buf[40]; snprintf(buf, sizeof buf, "%.17g", num_); o << buf; break; }
-            case String: o << '"' << str_ << '"'; break;
+            case Number: {
+                if (!(num_ == num_) || num_ - num_ != 0.0) { o << "null"; break; }   // NaN / inf have no JSON spelling (nlohmann::json dumps null too)
+                char buf[40]; snprintf(buf, sizeof buf, "%.17g", num_); o << buf; break;
+            }
+            case String: write_string(o, str_); break;
             case Array: { o << '['; bool f = true; for (const json& e : arr_) { if (!f) o << ','; f = false; nl(depth + 1); e.write(o, indent, depth + 1); } if (!arr_.empty()) nl(depth); o << ']'; break; }
-            case Object: { o << '{'; bool f = true; for (const auto& kv : obj_) { if (!f) o << ','; f = false; nl(depth + 1); o << '"' << kv.first << "\":"; if (indent >= 0) o << ' '; kv.second.write(o, indent, depth + 1); } if (!obj_.empty()) nl(depth); o << '}'; break; }
+            case Object: { o << '{'; bool f = true; for (const auto& kv : obj_) { if (!f) o << ','; f = false; nl(depth + 1); write_string(o, kv.first); o << ':'; if (indent >= 0) o << ' '; kv.second.write(o, indent, depth + 1); } if (!obj_.empty()) nl(depth); o << '}'; break; }
         }
+    }
+    static void write_string(std::ostream& o, const std::string& t) {
+        o << '"';
+        for (const char ch : t) {
+            const unsigned char c = (unsigned char)ch;
+            if (c == '"') o << "\\\"";
+            else if (c == '\\') o << "\\\\";
+            else if (c == '\n') o << "\\n";
+            else if (c == '\t') o << "\\t";
+            else if (c == '\r') o << "\\r";
+            else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o << b; }
+            else o << ch;
+        }
+        o << '"';
+    }
+    static std::string parse_string(const std::string& s, size_t& p) {       // s[p] == '"'
+        std::string out;
+        for (++p; p < s.size(); ++p) {
+            const char c = s[p];
+            if (c == '"') { ++p; return out; }
+            if (c != '\\') { out += c; continue; }
+            if (++p >= s.size()) break;
+            switch (s[p]) {
+                case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                case 'u': { if (p + 4 >= s.size()) throw std::runtime_error("json: bad \\u escape"); out += (char)strtol(s.substr(p + 1, 4).c_str(), nullptr, 16); p += 4; break; }
+                default: out += s[p];
+            }
+        }
+        throw std::runtime_error("json: unterminated string");
     }
     static void skip(const std::string& s, size_t& p) { while (p < s.size() && isspace((unsigned char)s[p])) ++p; }
     static json parse_value(const std::string& s, size_t& p) {
@@ -108,7 +141,7 @@ private:
                 throw std::runtime_error("json: expected ',' or ']'");
             }
         }
-        if (c == '"') { size_t e = s.find('"', p + 1); if (e == std::string::npos) throw std::runtime_error("json: unterminated string"); json j(s.substr(p + 1, e - p - 1)); p = e + 1; return j; }
+        if (c == '"') { json j(parse_string(s, p)); return j; }
         if (!s.compare(p, 4, "true")) { p += 4; return json(true); }
         if (!s.compare(p, 5, "false")) { p += 5; return json(false); }
         if (!s.compare(p, 4, "null")) { p += 4; return json(); }

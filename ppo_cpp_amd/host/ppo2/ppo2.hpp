@@ -38,6 +38,8 @@ public:
     std::vector<std::pair<int, float>>& episode_rewards() { return episodes_; }
     bool quiet = false;
     unsigned long long seed = 0;
+    // host-Env collect split, summed over the updates after the first (which pays allocation + graph capture)
+    double phase_env_ms = 0, phase_act_ms = 0, phase_observe_ms = 0;
 
     // Checkpoint in the reference's on-disk format (ppo2.hpp:107-166): the 15 model tensors as a TF bundle
     // (<path>[.<id>].index / .data-00000-of-00001, names "model/<tensor>"; the untrained q/w, q/b ride along so that the
@@ -109,6 +111,8 @@ public:
     // ids 0, 1, ..., plus a trailing save when the interval does not divide the number of updates
     void learn(int total_timesteps, int num_saves = 0, const std::string& save_path = "") {
         num_timesteps_ = 0;
+        updates_this_learn_ = 0;
+        check(ppo_seed(h_, seed));                                 // exploration noise follows PPO2::seed / --seed
         const int n_updates = total_timesteps / n_batch_;
         save_interval_ = num_saves > 0 ? static_cast<int>(std::ceil(static_cast<float>(n_updates) / static_cast<float>(num_saves))) : -1;
         save_path_ = save_path;
@@ -145,9 +149,14 @@ private:
             const auto t0 = clk::now();
             for (int t = 0; t < T; ++t) {
                 for (int e = 0; e < E; ++e) done_view(e, t) = dones(e, 0);
+                const auto p0 = clk::now();
                 check(ppo_rollout_act(h_, t, nullptr, actions.data()));
+                const auto p1 = clk::now();
                 const std::vector<Mat> r = raw.step(actions);
+                const auto p2 = clk::now();
                 check(ppo_rollout_observe(h_, t, r[0].data(), r[1].data(), r[2].data()));
+                const auto p3 = clk::now();
+                if (update > 1) { phase_act_ms += ms(p0, p1); phase_env_ms += ms(p1, p2); phase_observe_ms += ms(p2, p3); }
                 dones = r[2];
                 const Mat orig = raw.get_original_rew();
                 for (int e = 0; e < E; ++e) rew_view(e, t) = orig(e, 0);
@@ -218,7 +227,7 @@ private:
         episode_reward_ = Utils::total_episode_reward_logger(
             episode_reward_, rew_view, done_view, [this](int step, const char*, float v) { episodes_.push_back({step, v}); }, num_timesteps_ - n_batch_);
         history_.push_back(log);
-        const int update = static_cast<int>(history_.size());
+        const int update = ++updates_this_learn_;                   // save ids / cadence count from the start of THIS learn() call
         if (save_interval_ > 0 && update % save_interval_ == 0) save(save_path_, update / save_interval_ - 1);
     }
 
@@ -236,6 +245,7 @@ private:
     MlpPolicy act_model_;
     Mat episode_reward_;
     int save_interval_ = -1;
+    int updates_this_learn_ = 0;
     std::string save_path_;
     ckpt::Bundle extra_tensors_;      // q/w, q/b carried through load -> save
     std::vector<UpdateLog> history_;

@@ -155,12 +155,16 @@ struct ppo_host_args {
     int device;
     int max_workers;
     int reference_loop;      // 1: force the literal reference loop (Runner::run + host shuffle + _train_step)
+    int norm_obs, norm_reward;   // EnvNormalize constructor flags (env_normalize.hpp:24-27)
+    unsigned long long seed;     // PPO2::seed (exploration noise + epoch shuffles)
 };
 struct ppo_host_result {
     double env_steps_per_s, collect_ms, update_ms;
     float losses[5];
     int fps_last;
     char error[256];
+    double obs_count, ret_count;     // running-statistics counts after the run (1e-6 = never updated)
+    double phase_env_ms, phase_act_ms, phase_observe_ms;   // host-Env collect split per update: Env::step | ppo_rollout_act (kernel + D2H + sync) | ppo_rollout_observe (pack + H2D enqueue)
 };
 
 int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
@@ -181,7 +185,7 @@ int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
         if (a->n_envs > 1) inner.reset(new VecEnv(envs, a->max_workers));
         else inner.reset(a->seeded_env ? static_cast<Env*>(new SeededEnvMock(1234u, 0)) : static_cast<Env*>(new EnvMock(1)));
         {
-            EnvNormalize env{std::move(inner), h, /*training=*/true, true, true, 10.f, 10.f, a->gamma};
+            EnvNormalize env{std::move(inner), h, /*training=*/true, a->norm_obs != 0, a->norm_reward != 0, 10.f, 10.f, a->gamma};
             PPO2 algorithm{h, env, a->gamma, a->n_steps, cfg.ent_coef, a->lr, 0.5f, 0.5f, a->lam, a->nminibatches, a->noptepochs, a->cliprange};
             algorithm.quiet = true;
             struct Plain : Env {       // hides the EnvNormalize type to force the reference loop
@@ -203,6 +207,7 @@ int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
             PPO2 literal{h, plain, a->gamma, a->n_steps, cfg.ent_coef, a->lr, 0.5f, 0.5f, a->lam, a->nminibatches, a->noptepochs, a->cliprange};
             literal.quiet = true;
             PPO2& algo = a->reference_loop ? literal : algorithm;
+            algo.seed = a->seed;
             const auto t0 = std::chrono::steady_clock::now();
             algo.learn(a->n_updates * a->n_envs * a->n_steps);
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -218,8 +223,10 @@ int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
             std::memcpy(out->losses, hist.back().losses, sizeof out->losses);
             out->fps_last = hist.back().fps;
             (void)sec;
+            out->phase_env_ms = algo.phase_env_ms / n; out->phase_act_ms = algo.phase_act_ms / n; out->phase_observe_ms = algo.phase_observe_ms / n;
             nlohmann::json j;                                   // serialise round trip of the normaliser
             env.serialize(j);
+            out->obs_count = j["obs_rms"]["count"].get<double>(); out->ret_count = j["ret_rms"]["count"].get<double>();
             env.deserialize(j);
         }
         ppo_destroy(h);

@@ -10,12 +10,15 @@ class HostArgs(C.Structure):
     _fields_ = [("n_envs", C.c_int), ("n_steps", C.c_int), ("n_hidden", C.c_int), ("hidden", C.c_int * 8),
                 ("nminibatches", C.c_int), ("noptepochs", C.c_int), ("n_updates", C.c_int),
                 ("lr", C.c_float), ("cliprange", C.c_float), ("gamma", C.c_float), ("lam", C.c_float),
-                ("seeded_env", C.c_int), ("device", C.c_int), ("max_workers", C.c_int), ("reference_loop", C.c_int)]
+                ("seeded_env", C.c_int), ("device", C.c_int), ("max_workers", C.c_int), ("reference_loop", C.c_int),
+                ("norm_obs", C.c_int), ("norm_reward", C.c_int), ("seed", C.c_ulonglong)]
 
 
 class HostResult(C.Structure):
     _fields_ = [("env_steps_per_s", C.c_double), ("collect_ms", C.c_double), ("update_ms", C.c_double),
-                ("losses", C.c_float * 5), ("fps_last", C.c_int), ("error", C.c_char * 256)]
+                ("losses", C.c_float * 5), ("fps_last", C.c_int), ("error", C.c_char * 256),
+                ("obs_count", C.c_double), ("ret_count", C.c_double),
+                ("phase_env_ms", C.c_double), ("phase_act_ms", C.c_double), ("phase_observe_ms", C.c_double)]
 
 
 def load_host_library(build=True):
@@ -32,7 +35,7 @@ def load_host_library(build=True):
 
 
 def learn(n_envs, n_steps, hidden, n_updates, nminibatches=32, noptepochs=10, lr=3.93141e-4, cliprange=0.161023, gamma=0.99,
-          lam=0.95, seeded_env=True, device=-1, max_workers=0, reference_loop=False):
+          lam=0.95, seeded_env=True, device=-1, max_workers=0, reference_loop=False, norm_obs=True, norm_reward=True, seed=0):
     lib = load_host_library()
     a = HostArgs()
     a.n_envs, a.n_steps, a.n_hidden = n_envs, n_steps, len(hidden)
@@ -41,8 +44,10 @@ def learn(n_envs, n_steps, hidden, n_updates, nminibatches=32, noptepochs=10, lr
     a.nminibatches, a.noptepochs, a.n_updates = nminibatches, noptepochs, n_updates
     a.lr, a.cliprange, a.gamma, a.lam = lr, cliprange, gamma, lam
     a.seeded_env, a.device, a.max_workers, a.reference_loop = int(seeded_env), device, max_workers, int(reference_loop)
+    a.norm_obs, a.norm_reward, a.seed = int(norm_obs), int(norm_reward), seed
     r = HostResult()
     if lib.ppo_host_learn(C.byref(a), C.byref(r)) != 0:
         raise RuntimeError(r.error.decode())
     return {"env_steps_per_s": r.env_steps_per_s, "collect_ms": r.collect_ms, "update_ms": r.update_ms,
-            "losses": [float(x) for x in r.losses], "fps_last": r.fps_last}
+            "losses": [float(x) for x in r.losses], "fps_last": r.fps_last, "obs_count": r.obs_count, "ret_count": r.ret_count,
+            "phase_ms": {"env_step": r.phase_env_ms, "act_kernel_d2h_sync": r.phase_act_ms, "observe_pack_h2d_enqueue": r.phase_observe_ms}}

@@ -404,3 +404,75 @@ def test_error_paths_and_minimal_sizes():
     seven = np.zeros(7, np.float32)
     rc = g.lib.ppo_set_flat(g.h, 0, seven.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(7))
     assert rc != 0 and b"count" in g.lib.ppo_last_error(g.h)
+
+
+def test_normaliser_flags_and_return_reset():
+    """EnvNormalize's norm_obs / norm_reward constructor flags (env_normalize.hpp:75,95) on the device-resident rollout:
+    a switched-off branch passes its data through untouched and never updates its statistics; the other branch is the
+    oracle's.  ppo_norm_reset_returns zeroes the discounted-return accumulator and keeps the statistics (:111-116)."""
+    E, T = 8, 5
+    for norm_obs, norm_rew in ((False, True), (True, False)):
+        orc, g, nz, ro, noise = _rollout_pair((64, 64), E, T, 31)
+        g.norm_set_flags(norm_obs, norm_rew)
+        raws, rews = [], []
+        raw, _, _ = o.seeded_env_step(1234, 0, E, 0, 18)
+        g.rollout_reset(raw)
+        for t in range(T):
+            raws.append(raw)
+            g.rollout_act(t, noise[t])
+            raw, rew, dn = o.seeded_env_step(1234, 0, E, t + 1, 18)
+            rews.append(rew)
+            g.rollout_observe(t, raw, rew, dn)
+        g.rollout_finish(GAMMA, LAM)
+        _, _, c_obs = g.norm_stats(0); _, _, c_ret = g.norm_stats(1)
+        if not norm_obs:
+            np.testing.assert_array_equal(g.rollout_get("obs"), np.stack(raws))          # raw observations reach the policy
+            assert c_obs == 1e-6 and c_ret == pytest.approx(E * T, rel=1e-6)
+            close(g.rollout_get("rewards"), ro["rewards"], rtol=2e-5, atol=2e-6)         # reward branch unaffected
+        else:
+            np.testing.assert_array_equal(g.rollout_get("rewards"), np.stack(rews))      # unscaled, unclipped rewards
+            assert c_ret == 1e-6 and c_obs == pytest.approx(E * (T + 1), rel=1e-6)
+            close(g.rollout_get("obs"), ro["obs"], rtol=2e-5, atol=2e-6)
+        g.close()
+    _, g = pair((4, 5), "ginit")
+    g.norm_init(4)
+    nz = o.Normalizer(4, 18)
+    r1 = np.float32([1, 2, 3, 4]); d0 = np.zeros(4, np.float32)
+    close(g.norm_reward(r1, d0), nz.reward(r1, d0), rtol=2e-5, atol=2e-6)
+    g.norm_reset_returns(); nz.ret[:] = 0                                                # EnvNormalize::reset
+    close(g.norm_reward(r1, d0), nz.reward(r1, d0), rtol=2e-5, atol=2e-6)
+    m, v, c = g.norm_stats(1)
+    assert c == nz.ret_rms.count and v[0] == pytest.approx(float(nz.ret_rms.var[0]), rel=1e-5)
+
+
+def test_seed_reaches_the_action_sampler():
+    """ppo_seed (PPO2::seed / --seed): the same seed reproduces the exploration noise, another seed changes it, and the
+    draws stay standard normal."""
+    orc, g = pair((64, 64))
+    obs = np.random.RandomState(0).uniform(-1, 1, (256, 18)).astype(np.float32)
+    mu = g.act_deterministic(obs)
+    g.seed(11); a1, _, _ = g.step(obs); a1b, _, _ = g.step(obs)
+    g.seed(11); a2, _, _ = g.step(obs)
+    g.seed(12); a3, _, _ = g.step(obs)
+    np.testing.assert_array_equal(a1, a2)
+    assert np.abs(a1 - a3).max() > 1e-3 and np.abs(a1 - a1b).max() > 1e-3              # new seed / next call: fresh noise
+    sigma = np.exp(orc.tensor("pi/logstd"))
+    z = (a3 - mu) / sigma
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05
+
+
+def test_update_rejects_a_bad_permutation():
+    import ppo_cpp_amd
+    orc, g, nz, ro, noise = _rollout_pair((64, 64), 4, 8, 33)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    perms = np.stack([np.random.RandomState(i).permutation(32) for i in range(2)]).astype(np.int32)
+    before = g.get_flat()
+    bad = perms.copy(); bad[1, 3] = bad[1, 4]                                            # duplicate destination
+    with pytest.raises(ppo_cpp_amd.PPOHipError, match="not a permutation"):
+        g.update(LR, CR, 2, 4, bad)
+    bad = perms.copy(); bad[0, 0] = 32                                                   # out of range
+    with pytest.raises(ppo_cpp_amd.PPOHipError, match="not a permutation"):
+        g.update(LR, CR, 2, 4, bad)
+    np.testing.assert_array_equal(g.get_flat(), before)                                  # nothing ran
+    rows, _ = g.update(LR, CR, 2, 4, perms)
+    assert np.isfinite(rows).all()

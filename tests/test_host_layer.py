@@ -62,3 +62,18 @@ def test_command_line_driver_trains_saves_and_plays_back(tmp_path):
     play = subprocess.run([exe, "--path", str(tmp_path / "run.pkl.1"), "--hidden", "64,64", "--seeded"], capture_output=True, text=True, timeout=120)
     assert play.returncode == 0, play.stderr
     assert play.stdout.count("action[0..3]") == 5
+
+
+@pytest.mark.gpu
+def test_learn_honours_the_normaliser_flags():
+    """EnvNormalize(norm_obs=false) / (norm_reward=false) on the HBM-resident learn() path (env_normalize.hpp:75,95):
+    the switched-off statistics are never updated, the other ones see every env step."""
+    E, T = 8, 16
+    a = hostapi.learn(E, T, [64, 64], n_updates=2, nminibatches=4, noptepochs=2, norm_obs=False)
+    assert a["obs_count"] == 1e-6 and a["ret_count"] == pytest.approx(2 * E * T, rel=1e-6) and np.isfinite(a["losses"]).all()
+    b = hostapi.learn(E, T, [64, 64], n_updates=2, nminibatches=4, noptepochs=2, norm_reward=False)
+    assert b["ret_count"] == 1e-6 and b["obs_count"] == pytest.approx(E * (2 * T + 1), rel=1e-6) and np.isfinite(b["losses"]).all()
+    c = hostapi.learn(E, T, [64, 64], n_updates=2, nminibatches=4, noptepochs=2, seed=5)
+    d = hostapi.learn(E, T, [64, 64], n_updates=2, nminibatches=4, noptepochs=2, seed=5)
+    e = hostapi.learn(E, T, [64, 64], n_updates=2, nminibatches=4, noptepochs=2, seed=6)
+    assert c["losses"] == d["losses"] and c["losses"] != e["losses"]                    # PPO2::seed drives noise + shuffles
