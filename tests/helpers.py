@@ -44,3 +44,38 @@ def synth_minibatch(orc, n, seed, adv_normalized=True):
     ret = (v + rng.normal(scale=0.5, size=n)).astype(np.float32)
     adv = o.adv_normalize(ret, old_v) if adv_normalized else (ret - old_v).astype(np.float32)
     return dict(obs=obs, actions=act, advs=adv, returns=ret, old_neglogp=old_nlp, old_values=old_v)
+
+
+G_TENSORS = ["pi_fc0/w", "pi_fc0/b", "vf_fc0/w", "vf_fc0/b", "pi_fc1/w", "pi_fc1/b", "vf_fc1/w", "vf_fc1/b", "vf/w", "vf/b", "pi/w", "pi/b", "pi/logstd"]
+
+
+def graph_run():
+    """tests/golden/g45_graph_run.npz: outputs of the reference's graph file executed node by node
+    (oracle/graph_interp.py + oracle/make_graph_golden.py); keys like 'train0/losses', 'train1/w:pi/w'."""
+    return load_npz_named("g45_graph_run.npz")
+
+
+def graph_state(z, prefix, kind):
+    """{tensor name: array} of the weights ('w'), Adam m ('m') or Adam v ('v') stored under `prefix`."""
+    return {t: z["%s/%s:%s" % (prefix, kind, t)] for t in G_TENSORS}
+
+
+def golden_run(tag):
+    """(z, hidden, stride, weights): a committed golden run (oracle/make_golden_run.py) and how to rebuild its initial weights:
+    'g45' = the reference graph's own constants; 'g6464' / 'g256' = seeded weights (oracle/make_golden_run.seeded_weights)."""
+    z = np.load(os.path.join(GOLDEN, tag + "_run.npz"))
+    if tag == "g45":
+        return z, (4, 5), 1, None
+    return z, tuple(int(x) for x in z["hidden"]), int(z["stride"]), int(z["weight_seed"])
+
+
+def golden_weights(orc, z_seed):
+    """initial weights of a golden run into an oracle.Oracle (returns its flat theta)"""
+    if z_seed is None:
+        orc.set_tensors(g45_init())
+    else:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "oracle"))
+        from oracle import make_golden_run as mg
+        mg.seeded_weights(orc, z_seed)
+    return orc.theta

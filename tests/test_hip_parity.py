@@ -330,15 +330,18 @@ def test_wide_networks_use_the_two_tile_layout(hidden, O, A, n):
     close(g.get_flat(0), orc.theta, rtol=2e-4, atol=3e-6, msg="theta")
 
 
-def test_committed_golden_run():
-    """The HIP path against the committed vectors of tests/golden/g45_run.npz (reference shape [4,5], the graph's initial
-    weights; generated by oracle/make_golden_run.py, cross-checked there against float64 autograd): rollout, running
-    statistics, first-minibatch gradient and global norm, loss rows, weights and Adam slots after 8 train steps."""
-    z = np.load(H.GOLDEN + "/g45_run.npz")
+@pytest.mark.parametrize("tag", ["g45", "g6464", "g256"])
+def test_committed_golden_run(tag):
+    """The HIP path against the committed vectors of tests/golden/{g45,g6464,g256}_run.npz (the reference's shipped [4,5]
+    shape with the graph's initial weights; its real network shape [64,64]; BASELINE configs[2]'s [256,256] -- generated by
+    oracle/make_golden_run.py, cross-checked there against float64 autograd): rollout, running statistics,
+    first-minibatch gradient and global norm, loss rows, weights and Adam slots after 8 train steps."""
+    z, hidden, st, wseed = H.golden_run(tag)
     E, T, nmb, epochs = int(z["E"]), int(z["T"]), int(z["nmb"]), int(z["epochs"])
     lr, cr = float(z["lr"]), float(z["cr"])
     import ppo_cpp_amd
-    g = ppo_cpp_amd.PPOHip(18, 18, [4, 5]); g.set_tensors(H.g45_init())
+    theta0 = H.golden_weights(o.Oracle(18, 18, list(hidden)), wseed).copy()
+    g = ppo_cpp_amd.PPOHip(18, 18, list(hidden)); g.set_flat(theta0)
     g.norm_init(E, float(z["gamma"])); g.rollout_alloc(E, T)
     g.collect_synthetic(int(z["seed"]), float(z["gamma"]), float(z["lam"]), z["noise"])
     for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
@@ -353,12 +356,13 @@ def test_committed_golden_run():
     rows, mean = g.update(lr, cr, epochs, nmb, z["perms"])
     close(rows, z["loss_rows"], rtol=1e-4, atol=1e-6, msg="loss rows")
     close(mean, z["loss_mean"], rtol=1e-4, atol=1e-6)
-    theta = z["theta"]
-    close(g.get_flat(0), theta, rtol=1e-4, atol=1e-6, msg="weights")
-    close(g.get_flat(1), z["adam_m"], rtol=1e-3, atol=1e-7 * float(np.abs(z["adam_m"]).max()) + 1e-9, msg="adam m")
-    close(g.get_flat(2), z["adam_v"], rtol=1e-3, atol=1e-6 * float(np.abs(z["adam_v"]).max()), msg="adam v")
+    close(g.get_flat(0)[::st], z["theta"], rtol=1e-4, atol=1e-6, msg="weights")
+    close(g.get_flat(1)[::st], z["adam_m"], rtol=1e-3, atol=1e-7 * float(np.abs(z["adam_m"]).max()) + 1e-9, msg="adam m")
+    close(g.get_flat(2)[::st], z["adam_v"], rtol=1e-3, atol=1e-6 * float(np.abs(z["adam_v"]).max()), msg="adam v")
+    if wseed is not None:
+        assert np.sqrt(np.sum(g.get_flat(0).astype(np.float64) ** 2)) == pytest.approx(float(z["theta_l2"]), rel=1e-5)
     # first-minibatch gradient through the single-step entry point
-    g2 = ppo_cpp_amd.PPOHip(18, 18, [4, 5]); g2.set_tensors(H.g45_init())
+    g2 = ppo_cpp_amd.PPOHip(18, 18, list(hidden)); g2.set_flat(theta0)
     B = E * T; M = B // nmb
     flat = {k: np.ascontiguousarray(np.swapaxes(z["ro_" + k], 0, 1)).reshape((B,) + z["ro_" + k].shape[2:]) for k in
             ("obs", "actions", "values", "neglogp", "returns")}
@@ -369,8 +373,10 @@ def test_committed_golden_run():
     losses = g2.train_step(lr, cr, mb["obs"], mb["actions"], adv, mb["returns"], mb["neglogp"], mb["values"])
     close(losses, z["loss_rows"][0], rtol=1e-4, atol=1e-6)
     grad, norm = g2.last_grad()
-    close(grad, z["grad0"], rtol=5e-4, atol=3e-6 * float(np.abs(z["grad0"]).max()), msg="gradient")
+    close(grad[::st], z["grad0"], rtol=5e-4, atol=3e-6 * float(np.abs(z["grad0"]).max()), msg="gradient")
     assert norm == pytest.approx(float(z["norm0"]), rel=1e-4)
+    if wseed is not None:
+        assert np.sqrt(np.sum(grad.astype(np.float64) ** 2)) == pytest.approx(float(z["grad0_l2"]), rel=1e-4)
 
 
 def test_error_paths_and_minimal_sizes():
@@ -476,3 +482,35 @@ def test_update_rejects_a_bad_permutation():
     np.testing.assert_array_equal(g.get_flat(), before)                                  # nothing ran
     rows, _ = g.update(LR, CR, 2, 4, perms)
     assert np.isfinite(rows).all()
+
+
+def test_hip_path_matches_the_interpreted_reference_graph():
+    """The HIP path against what the reference's graph file itself computes (tests/golden/g45_graph_run.npz, produced by
+    executing G node by node -- oracle/graph_interp.py), without the hand-written oracle in between: act outputs, the
+    five losses, raw gradients, the global norm, and weights / Adam slots / beta powers after three train steps with
+    exact-tie rows and both clip branches; then the non-finite-norm poisoning.  North-star tolerance: 1e-4 rel."""
+    z = H.graph_run()
+    g = hip((4, 5))
+    g.set_tensors(H.graph_state(z, "init", "w"))
+    a, v, nlp = g.step(z["act/obs"], z["act/noise"])
+    close(a, z["act/action"]); close(v, z["act/value"]); close(nlp, z["act/neglogp"])
+    close(g.act_deterministic(z["act/obs"]), z["act/det_action"])
+    lr, cr = [float(x) for x in z["meta/lr_cr"]]
+    names = [n for n, _ in g.tensors]
+    def flat(prefix, kind):
+        return np.concatenate([np.asarray(z["%s/%s:%s" % (prefix, kind, n)], np.float32).reshape(-1) for n in names])
+    for s in range(3):
+        p = "train%d" % s
+        losses = g.train_step(lr, cr, z[p + "/obs"], z[p + "/actions"], z[p + "/advs"], z[p + "/returns"], z[p + "/old_neglogp"], z[p + "/old_values"])
+        close(losses, z[p + "/losses"], rtol=1e-4, atol=1e-6, msg=p)
+        grad, norm = g.last_grad()
+        gref = flat(p, "grad")
+        close(grad, gref, rtol=2e-4, atol=3e-6 * float(np.abs(gref).max()), msg=p + " gradient")
+        assert norm == pytest.approx(float(z[p + "/global_norm"]), rel=1e-4)
+        close(g.get_flat(0), flat(p, "w"), rtol=1e-4, atol=2e-6, msg=p + " weights")
+        close(g.get_flat(1), flat(p, "m"), rtol=2e-4, atol=1e-7, msg=p + " adam m")
+        close(g.get_flat(2), flat(p, "v"), rtol=4e-4, atol=1e-9, msg=p + " adam v")
+        close(g.beta_powers(), z[p + "/beta_pow"], rtol=1e-6)
+    bad = z["train2/advs"].copy(); bad[0] = np.inf
+    g.train_step(lr, cr, z["train2/obs"], z["train2/actions"], bad, z["train2/returns"], z["train2/old_neglogp"], z["train2/old_values"])
+    assert np.isnan(g.get_flat(0)).all() and z["poison/all_nan"].all()

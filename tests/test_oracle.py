@@ -1,7 +1,10 @@
 """Pins the CPU oracle (oracle/ppo_oracle.c) against everything the reference tree offers for this path
 (SURVEY 8c): the initial weights embedded in G, the trained checkpoint ...pkl.71 + its JSON running stats,
 analytic known answers, and an independent torch-float64 autograd restatement.  CPU only."""
+import os
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 from oracle import oracle as o
@@ -298,13 +301,15 @@ def test_update_loop_equals_manual_minibatching():
     np.testing.assert_allclose(mean, np.stack(got).astype(np.float64).mean(0), rtol=1e-6)
 
 
-def test_committed_golden_run_is_reproduced():
-    """tests/golden/g45_run.npz (oracle/make_golden_run.py): the reference's shipped shape with the graph's initial weights,
+@pytest.mark.parametrize("tag", ["g45", "g6464", "g256"])
+def test_committed_golden_run_is_reproduced(tag):
+    """tests/golden/{g45,g6464,g256}_run.npz (oracle/make_golden_run.py): the reference's shipped [4,5] shape with the graph's
+    initial weights, its real network shape [64,64] and BASELINE configs[2]'s [256,256] (seeded weights):
     rollout -> GAE -> 2 epochs x 4 minibatches.  The oracle must keep reproducing its committed vectors (libm differences
     between hosts allowed for: 1e-6)."""
-    z = np.load(H.GOLDEN + "/g45_run.npz")
+    z, hidden, st, wseed = H.golden_run(tag)
     E, T, nmb = int(z["E"]), int(z["T"]), int(z["nmb"])
-    orc = make((4, 5)); orc.set_tensors(H.g45_init())
+    orc = make(hidden); H.golden_weights(orc, wseed)
     nz = o.Normalizer(E, 18)
     ro, _, last_v = o.collect(orc, nz, int(z["seed"]), T, z["noise"], float(z["gamma"]), float(z["lam"]))
     for k in ("obs", "actions", "values", "neglogp", "rewards", "dones", "returns"):
@@ -314,7 +319,80 @@ def test_committed_golden_run_is_reproduced():
     assert nz.obs_rms.count == float(z["obs_count"])
     rows, mean = orc.update(ro, z["perms"], nmb, float(z["lr"]), float(z["cr"]))
     np.testing.assert_allclose(rows, z["loss_rows"], rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose(orc.theta, z["theta"], rtol=1e-6, atol=1e-7)
-    np.testing.assert_allclose(orc.m, z["adam_m"], rtol=1e-5, atol=1e-9)
-    np.testing.assert_allclose(orc.v, z["adam_v"], rtol=1e-5, atol=1e-12)
-    assert rows[0, 2] == pytest.approx(18 * 1.4189385, rel=1e-6) and rows[0, 3] == 0.0 and rows[0, 4] == 0.0
+    np.testing.assert_allclose(orc.theta[::st], z["theta"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(orc.m[::st], z["adam_m"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(orc.v[::st], z["adam_v"], rtol=1e-5, atol=1e-12)
+    if tag == "g45":
+        assert rows[0, 2] == pytest.approx(18 * 1.4189385, rel=1e-6) and rows[0, 3] == 0.0 and rows[0, 4] == 0.0
+    else:
+        assert np.sqrt(np.sum(orc.theta.astype(np.float64) ** 2)) == pytest.approx(float(z["theta_l2"]), rel=1e-6)
+
+
+# ---- the oracle against the reference's graph file EXECUTED node by node -------------------------------------------
+def _flat(orc, named):
+    out = np.zeros(orc.P, np.float32)
+    for n, off, shape in orc.tensors:
+        out[off:off + int(np.prod(shape))] = np.asarray(named[n], np.float32).reshape(-1)
+    return out
+
+
+def test_oracle_matches_the_interpreted_graph():
+    """tests/golden/g45_graph_run.npz holds what G itself computes (every node evaluated from its op, wiring and attrs
+    by oracle/graph_interp.py; only TF's op-kernel semantics are restated there, no PPO formula).  The hand-written C
+    restatement must reproduce it: act outputs, the five losses, all 13 raw gradients, the global norm, and weights /
+    Adam slots / beta powers after each of three ApplyAdam rounds -- including exact-tie rows and both clip branches."""
+    z = H.graph_run()
+    spread = float(z["meta/matmul_order_spread"])          # how far two MatMul accumulation orders move G's own outputs
+    assert spread < 5e-5
+    orc = o.Oracle(18, 18, [4, 5])
+    orc.set_tensors(H.graph_state(z, "init", "w"))
+    np.testing.assert_array_equal(orc.theta, _flat(orc, H.g45_init()))          # the extractor and the interpreter agree on init
+    np.testing.assert_array_equal(z["init/beta_pow"], orc.pow)
+    a, v, nlp = orc.step(z["act/obs"], z["act/noise"])
+    mu, _ = orc.forward(z["act/obs"])
+    np.testing.assert_allclose(a, z["act/action"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mu, z["act/det_action"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v, z["act/value"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(nlp, z["act/neglogp"], rtol=1e-5, atol=1e-5)
+    lr, cr = [float(x) for x in z["meta/lr_cr"]]
+    for s in range(3):
+        p = "train%d" % s
+        _, grad = orc.loss_grad(z[p + "/obs"], z[p + "/actions"], z[p + "/advs"], z[p + "/returns"], z[p + "/old_neglogp"], z[p + "/old_values"], cr)
+        losses, norm, _clipped = orc.train_step(lr, cr, z[p + "/obs"], z[p + "/actions"], z[p + "/advs"], z[p + "/returns"], z[p + "/old_neglogp"],
+                                            z[p + "/old_values"])
+        np.testing.assert_allclose(losses, z[p + "/losses"], rtol=1e-5, atol=1e-7, err_msg=p)
+        assert losses[4] == z[p + "/losses"][4]                                   # clipfrac: a count, exact
+        gref = _flat(orc, {t: z["%s/grad:%s" % (p, t)] for t in H.G_TENSORS})
+        np.testing.assert_allclose(grad, gref, rtol=2e-5, atol=2e-6 * float(np.abs(gref).max()), err_msg=p + " gradient")
+        assert norm == pytest.approx(float(z[p + "/global_norm"]), rel=1e-5)
+        for kind, arr in (("w", orc.theta), ("m", orc.m), ("v", orc.v)):
+            ref = _flat(orc, H.graph_state(z, p, kind))
+            np.testing.assert_allclose(arr, ref, rtol=2e-5, atol=1e-7 if kind != "w" else 2e-6, err_msg="%s %s" % (p, kind))
+        np.testing.assert_allclose(orc.pow, z[p + "/beta_pow"], rtol=1e-7)
+    assert z["poison/all_nan"].all()
+    bad = z["train2/advs"].copy(); bad[0] = np.inf
+    orc.train_step(lr, cr, z["train2/obs"], z["train2/actions"], bad, z["train2/returns"], z["train2/old_neglogp"], z["train2/old_values"])
+    assert np.isnan(orc.theta).all()                                              # G:24493-24543, as the graph itself does
+
+
+def test_interpreted_graph_covers_the_hot_path_ops():
+    """The golden run really executed the graph's train op: 13 ApplyAdam, 13 L2Loss, 4 TanhGrad, 22 MatMul (8 forward of
+    the act model, 6 of the train model... as G wires them), the IsFinite guard, and no summary / saver node."""
+    z = H.graph_run()
+    census = dict(kv.split("=") for kv in z["meta/op_census"])
+    assert census["ApplyAdam"] == "13" and census["L2Loss"] == "13" and census["TanhGrad"] == "4" and census["IsFinite"] == "1"
+    assert int(census["MatMul"]) >= 20 and "ScalarSummary" not in census and "SaveV2" not in census
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only mounted in the build container")
+def test_graph_golden_regenerates_from_the_reference_graph():
+    """Build-container check that the committed vectors are what the interpreter produces from G today."""
+    import subprocess, sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_graph_golden as mg
+    fresh = mg.run("f64round")
+    z = H.graph_run()
+    for k, v in fresh.items():
+        if k.startswith("meta/op_census"):
+            continue
+        np.testing.assert_array_equal(np.asarray(v), z[k], err_msg=k)
