@@ -47,7 +47,12 @@ typedef struct ppo_config {
     float adam_eps;
     int32_t device;                   /* HIP device ordinal, -1 = current/LOCAL_RANK */
     int32_t max_rows;                 /* largest row count ever passed to step/value/train_step (0 = 65536) */
+    int32_t compute_dtype;            /* PPO_F32 (0, default): the reference's arithmetic on the exact-fp32 matrix cores.
+                                         PPO_BF16 (1): bf16 operands, fp32 accumulation, fp32 master weights / Adam, layer-by-layer
+                                         128x128-tile GEMMs -- BASELINE configs[4]'s mode for wide nets; no reference counterpart */
 } ppo_config;
+#define PPO_F32 0
+#define PPO_BF16 1
 
 /* fills the graph-baked defaults of the reference's shipped graph (ent 0.00071602932, vf 0.5, clip 0.5,
  * Adam 0.9 / 0.999 / 1e-5) for the given shape */

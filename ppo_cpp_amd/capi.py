@@ -17,7 +17,7 @@ class PPOConfig(C.Structure):
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_hidden", C.c_int32),
                 ("hidden", C.c_int32 * MAX_LAYERS), ("ent_coef", C.c_float), ("vf_coef", C.c_float),
                 ("max_grad_norm", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
-                ("adam_eps", C.c_float), ("device", C.c_int32), ("max_rows", C.c_int32)]
+                ("adam_eps", C.c_float), ("device", C.c_int32), ("max_rows", C.c_int32), ("compute_dtype", C.c_int32)]
 
 
 def load_library(build=True):

@@ -4,6 +4,7 @@
 // There is NO CPU fallback in this library: every entry point needs a HIP device and fails loudly without one.
 #include "../../include/ppo_hip.h"
 #include "ppo_kernels.hpp"
+#include "ppo_bf16.hpp"
 
 #include <dlfcn.h>
 
@@ -120,6 +121,21 @@ struct ppo_handle {
     size_t pin_in_n = 0, pin_out_n = 0;
     bool pin_in_busy = false;         // an H2D copy out of pin_in may still be in flight (cleared by every stream synchronisation of the rollout calls)
     int upd_cap_epochs = 0;
+    // bf16 matrix-core path (ppo_config::compute_dtype == PPO_BF16; kernels in ppo_bf16.hpp)
+    struct Bf16 {
+        bool on = false;
+        int Rcap = 0;                                   // row capacity of the workspaces (multiple of 128)
+        bf16_t* theta_bf = nullptr;                     // straight cast of theta (same padded offsets): B operand of the backward products
+        bf16_t* thetaT_bf = nullptr;                    // W^T of every matrix: B operand of the forward products
+        int wt_off[2][PPO_MAX_LAYERS]{}; int whT_off[2]{}; int nT = 0;
+        TrMat* d_trmats = nullptr; int n_trmats = 0, n_trtiles = 0;
+        bf16_t *x0 = nullptr, *x0T = nullptr;
+        bf16_t *hb[2][PPO_MAX_LAYERS]{}, *hT[2][PPO_MAX_LAYERS]{}, *dy[2][PPO_MAX_LAYERS]{}, *dyT[2][PPO_MAX_LAYERS]{};
+        float* head_out[2]{};                           // [Rcap][Ap] fp32
+        bf16_t *dhead[2]{}, *dheadT[2]{};
+        float* dbias = nullptr; int db_off[2][PPO_MAX_LAYERS]{}; int n_dbias = 0;
+        DwTileB* dw_tiles = nullptr; int n_dw_tiles = 0;
+    } bf;
     // dist
     Rccl rccl;
     void* comm = nullptr;
@@ -222,6 +238,12 @@ int build_layout(ppo_handle* h) {
     if (h->CT == 4) for (int l = 0; l < n.L; ++l) n.Hp[l] = ru(n.Hp[l], 64);
     const int kq = h->CT == 4 ? 32 : 16;                  // reduction dims must be whole pipeline stages (16*KS)
     n.Kp0 = ru(c.obs_dim, kq); n.Ap = ru(c.act_dim, kq);
+    const bool bf = h->bf.on;
+    if (bf) {                                             // GEMM path: every dimension is a whole number of 128-wide tiles
+        for (int l = 0; l < n.L; ++l) n.Hp[l] = ru(c.hidden[l], GB_PAD);
+        n.Kp0 = ru(c.obs_dim, GB_PAD); n.Ap = ru(c.act_dim, GB_PAD);
+        h->CT = 1;
+    }
     // split-K policy head: each of the 4 waves takes K/4 of the reduction in whole 64-wide stages
     h->CTH = (h->CT == 4 && n.Ap == 32 && n.Hp[n.L - 1] % 256 == 0) ? 2 : 0;
     n.ent_coef = c.ent_coef; n.vf_coef = c.vf_coef;
@@ -235,8 +257,10 @@ int build_layout(ppo_handle* h) {
         snprintf(nm, sizeof nm, "vf_fc%d/b", l); n.b_off[1][l] = op; add_tensor(h, nm, n.H[l], 0, 1, n.Hp[l], od, op);
     }
     const int HL = n.H[n.L - 1], HpL = n.Hp[n.L - 1];
-    n.wv_off = op;  add_tensor(h, "vf/w", HL, 1, HpL, 1, od, op);
-    n.bv_off = op;  add_tensor(h, "vf/b", 1, 0, 1, 1, od, op);
+    // bf16 path: the value head is stored like the policy head, [HpL][Ap] with only column 0 in use, so that both towers
+    // run through the same batched GEMM launches (the padding columns are zero and provably stay zero)
+    n.wv_off = op;  add_tensor(h, "vf/w", HL, 1, HpL, bf ? n.Ap : 1, od, op);
+    n.bv_off = op;  add_tensor(h, "vf/b", 1, 0, 1, bf ? n.Ap : 1, od, op);
     n.wmu_off = op; add_tensor(h, "pi/w", HL, n.A, HpL, n.Ap, od, op);
     n.bmu_off = op; add_tensor(h, "pi/b", n.A, 0, 1, n.Ap, od, op);
     n.ls_off = op;  add_tensor(h, "pi/logstd", 1, n.A, 1, n.Ap, od, op);
@@ -295,6 +319,21 @@ int build_layout(ppo_handle* h) {
         n.lds_total = o;
         return (size_t)o * sizeof(float) <= 160 * 1024;
     };
+    if (bf) {
+        // bf16 operand mirrors: offsets of the transposed copies (the straight copy shares theta's offsets)
+        int o = 0;
+        for (int tw = 0; tw < 2; ++tw)
+            for (int l = 0; l < n.L; ++l) { h->bf.wt_off[tw][l] = o; o += n.Hp[l] * (l ? n.Hp[l - 1] : n.Kp0); }
+        for (int tw = 0; tw < 2; ++tw) { h->bf.whT_off[tw] = o; o += n.Ap * HpL; }
+        h->bf.nT = o;
+        int d = 0;
+        for (int tw = 0; tw < 2; ++tw)
+            for (int l = 0; l < n.L; ++l) { h->bf.db_off[tw][l] = d; d += n.Hp[l]; }
+        h->bf.n_dbias = d;
+        n.lds_total = 0; h->lds_step_total = 0; h->CTH = 0;
+        n.slot_head = 0; n.slot_aux = n.Ap; n.slot_loss = 2 * n.Ap; n.slot_w = 2 * n.Ap + 8;
+        return 0;
+    }
     if (!carve(false)) {
         if (!carve(true))
             return fail(h, "network too wide even for the two-tile LDS layout (%zu bytes needed, 163840 available)", (size_t)n.lds_total * 4);
@@ -329,6 +368,17 @@ int upload_grad_src(ppo_handle* h) {
         else if (nm == "vf/b") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_aux; g.count = 1; g.p_off = n.par_total + n.par_bv; g.p_count = 1; }
         else if (nm == "pi/b") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_head; g.count = n.Ap; g.p_off = n.par_bmu; g.p_count = n.Ap; }
         else if (nm == "pi/logstd") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_aux; g.count = n.Ap; g.p_off = n.par_ls; g.p_count = n.Ap; }
+        if (h->bf.on) {
+            // matrices (value head included) come from the split-K slabs of the grouped weight-gradient GEMM, hidden biases
+            // from the row-sum kernel's vector (kind 3), head bias / logstd / value bias from the loss kernel's per-block slots;
+            // the fp32 transposed copies and the small-parameter mirror do not exist on this path
+            g.t_off = -1; g.p_off = -1; g.p_count = 0;
+            if (nm.size() > 2 && nm.substr(nm.size() - 2) == "/w") g.kind = 0;
+            else if (l >= 0) { g.kind = 3; g.slot_off = h->bf.db_off[tower][l]; g.count = n.Hp[l]; }
+            else if (nm == "vf/b") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_head; g.count = 1; }
+            else if (nm == "pi/b") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_head; g.count = n.Ap; }
+            else if (nm == "pi/logstd") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_aux; g.count = n.Ap; }
+        }
         const int nb = ru(t.prow * t.pcol, 256) / 256;
         for (int b = 0; b < nb; ++b) src[t.off_pad / 256 + b] = g;
     }
@@ -338,7 +388,9 @@ int upload_grad_src(ppo_handle* h) {
     return 0;
 }
 
+int bf16_ensure_ws(ppo_handle* h, int rows);
 int ensure_train_ws(ppo_handle* h, int rows) {
+    if (h->bf.on) return bf16_ensure_ws(h, rows);
     rows = ru(rows, 16);
     if (rows <= h->ws_rows) return 0;
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
@@ -407,6 +459,185 @@ int ensure_staging(ppo_handle* h, int rows) {
     return 0;
 }
 
+ObsNorm no_norm_fwd() { return ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}; }
+
+// ---- bf16 matrix-core path (ppo_bf16.hpp) ------------------------------------------------------------------------
+// bf16 operand copies of the fp32 master weights: a cast of the whole padded vector + the transposed copies
+int bf16_refresh_mirrors(ppo_handle* h) {
+    ppo_handle::Bf16& b = h->bf;
+    const size_t n4 = (size_t)h->P_pad / 4;
+    hipLaunchKernelGGL(bf16_cast_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->stream, h->theta, b.theta_bf, n4);
+    HIP_OK(h, hipGetLastError());
+    TrArgs ta{b.d_trmats, b.n_trmats, h->theta, b.thetaT_bf};
+    hipLaunchKernelGGL(bf16_transpose_kernel, dim3(b.n_trtiles), dim3(256), 0, h->stream, ta);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int bf16_create(ppo_handle* h) {
+    ppo_handle::Bf16& b = h->bf;
+    const NetDev& n = h->net;
+    if (dev_alloc(h, &b.theta_bf, (size_t)h->P_pad) || dev_alloc(h, &b.thetaT_bf, (size_t)b.nT) || dev_alloc(h, &b.dbias, (size_t)b.n_dbias)) return -1;
+    std::vector<TrMat> mats;
+    int tiles = 0;
+    auto add = [&](int src_off, int dst_off, int rows, int cols) { mats.push_back(TrMat{src_off, dst_off, rows, cols, tiles}); tiles += (rows / 32) * (cols / 32); };
+    for (int tw = 0; tw < 2; ++tw)
+        for (int l = 0; l < n.L; ++l) add(n.w_off[tw][l], b.wt_off[tw][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l]);
+    add(n.wmu_off, b.whT_off[0], n.Hp[n.L - 1], n.Ap);
+    add(n.wv_off, b.whT_off[1], n.Hp[n.L - 1], n.Ap);
+    b.n_trmats = (int)mats.size(); b.n_trtiles = tiles;
+    if (dev_alloc(h, &b.d_trmats, mats.size())) return -1;
+    HIP_OK(h, hipMemcpyAsync(b.d_trmats, mats.data(), mats.size() * sizeof(TrMat), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    bool ok = hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<GEPI_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<GEPI_TANHGRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<GEPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES) == hipSuccess;
+    ok &= hipFuncSetAttribute((const void*)gemm_dw_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES) == hipSuccess;
+    if (!ok) return fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 GEMM kernels");
+    return 0;
+}
+
+int bf16_ensure_ws(ppo_handle* h, int rows) {
+    ppo_handle::Bf16& b = h->bf;
+    const int R = ru(rows, GB_PAD);
+    if (R <= b.Rcap) return 0;
+    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    const NetDev& n = h->net;
+    if (dev_alloc(h, &b.x0, (size_t)R * n.Kp0) || dev_alloc(h, &b.x0T, (size_t)R * n.Kp0)) return -1;
+    for (int t = 0; t < 2; ++t) {
+        for (int l = 0; l < n.L; ++l) {
+            const size_t cnt = (size_t)R * n.Hp[l];
+            if (dev_alloc(h, &b.hb[t][l], cnt) || dev_alloc(h, &b.hT[t][l], cnt) || dev_alloc(h, &b.dy[t][l], cnt) || dev_alloc(h, &b.dyT[t][l], cnt)) return -1;
+        }
+        if (dev_alloc(h, &b.head_out[t], (size_t)R * n.Ap) || dev_alloc(h, &b.dhead[t], (size_t)R * n.Ap) || dev_alloc(h, &b.dheadT[t], (size_t)R * n.Ap)) return -1;
+        if (dev_alloc(h, &h->slots[t], (size_t)(R / 16) * n.slot_w)) return -1;
+    }
+    if (!h->slabs && dev_alloc(h, &h->slabs, (size_t)h->max_split * h->P_pad)) return -1;
+    // grouped weight-gradient tile table: dW = X^T dY for every layer and both heads, operands in the [features][rows] layout
+    std::vector<DwTileB> tiles;
+    auto add = [&](const bf16_t* A, const bf16_t* B, int Kp, int Np, int out_off) {
+        for (int i = 0; i < Kp; i += GB_M) for (int j = 0; j < Np; j += GB_N) tiles.push_back(DwTileB{A, B, R, R, i, j, out_off, Np});
+    };
+    for (int t = 0; t < 2; ++t) {
+        for (int l = 0; l < n.L; ++l) add(l ? b.hT[t][l - 1] : b.x0T, b.dyT[t][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l], n.w_off[t][l]);
+        add(b.hT[t][n.L - 1], b.dheadT[t], n.Hp[n.L - 1], n.Ap, t ? n.wv_off : n.wmu_off);
+    }
+    b.n_dw_tiles = (int)tiles.size();
+    if (dev_alloc(h, &b.dw_tiles, tiles.size())) return -1;
+    HIP_OK(h, hipMemcpyAsync(b.dw_tiles, tiles.data(), tiles.size() * sizeof(DwTileB), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    b.Rcap = R;
+    return 0;
+}
+
+template <int EPI>
+int bf16_gemm(ppo_handle* h, const GemmArgs& a, int I, int J) {
+    GemmArgs g = a;
+    g.tiles_i = I / GB_M;
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI>), dim3((I / GB_M) * (J / GB_N), 2), dim3(GB_THREADS), GB_LDS_BYTES, h->stream, g);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+// forward of both towers on `rows` staged rows: hidden layers (bias + tanh) and the padded heads (fp32 out)
+int bf16_forward(ppo_handle* h, int Rp, bool want_transposed) {
+    ppo_handle::Bf16& b = h->bf;
+    const NetDev& n = h->net;
+    for (int l = 0; l < n.L; ++l) {
+        GemmArgs a{};
+        const int Kp = l ? n.Hp[l - 1] : n.Kp0;
+        for (int t = 0; t < 2; ++t) {
+            a.A[t] = l ? b.hb[t][l - 1] : b.x0; a.B[t] = b.thetaT_bf + b.wt_off[t][l]; a.bias[t] = h->theta + n.b_off[t][l];
+            a.C[t] = b.hb[t][l]; a.CT[t] = want_transposed ? b.hT[t][l] : nullptr;
+        }
+        a.lda = Kp; a.ldb = Kp; a.K = Kp; a.ldc = n.Hp[l]; a.ldct = b.Rcap;
+        if (bf16_gemm<GEPI_TANH>(h, a, Rp, n.Hp[l])) return -1;
+    }
+    GemmArgs a{};
+    const int HpL = n.Hp[n.L - 1];
+    for (int t = 0; t < 2; ++t) {
+        a.A[t] = b.hb[t][n.L - 1]; a.B[t] = b.thetaT_bf + b.whT_off[t]; a.bias[t] = h->theta + (t ? n.bv_off : n.bmu_off); a.F[t] = b.head_out[t];
+    }
+    a.lda = HpL; a.ldb = HpL; a.K = HpL; a.ldf = n.Ap;
+    return bf16_gemm<GEPI_F32>(h, a, Rp, n.Ap);
+}
+
+int bf16_stage(ppo_handle* h, const float* obs, int nrows, int Rp, ObsNorm nz, float* obs_out, bool want_transposed) {
+    ppo_handle::Bf16& b = h->bf;
+    const NetDev& n = h->net;
+    StageArgsB sa{obs, nrows, n.O, n.Kp0, Rp, nz, obs_out, b.x0, want_transposed ? b.x0T : nullptr};
+    // the transposed copy has leading dimension Rcap: the kernel writes XT[j * rows_pad + row], so stage over the capacity
+    sa.rows_pad = want_transposed ? b.Rcap : Rp;
+    const size_t cnt = (size_t)sa.rows_pad * n.Kp0;
+    hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int launch_step_bf16(ppo_handle* h, const StepArgs& a) {
+    if (bf16_ensure_ws(h, a.n)) return -1;
+    ProfScope ps(h, PK_STEP);
+    const NetDev& n = h->net;
+    const int Rp = ru(a.n, GB_PAD);
+    if (bf16_stage(h, a.obs, a.n, Rp, a.nz, a.obs_out, false) || bf16_forward(h, Rp, false)) return -1;
+    SampleArgsB sa{};
+    sa.head[0] = h->bf.head_out[0]; sa.head[1] = h->bf.head_out[1]; sa.ldh = n.Ap; sa.logstd = h->theta + n.ls_off;
+    sa.noise = a.noise; sa.action = a.action; sa.det_action = a.det_action; sa.value = a.value; sa.neglogp = a.neglogp;
+    sa.n = a.n; sa.A = n.A; sa.seed = a.seed; sa.rng_step = a.rng_step; sa.row_base = a.row_base;
+    hipLaunchKernelGGL(bf16_sample_kernel, dim3((a.n + 15) / 16), dim3(256), 0, h->stream, sa);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
+    ppo_handle::Bf16& b = h->bf;
+    const NetDev& n = h->net;
+    if (bf16_stage(h, ta.obs, ta.n, Rp, no_norm_fwd(), nullptr, true) || bf16_forward(h, Rp, true)) return -1;
+    LossArgsB la{};
+    for (int t = 0; t < 2; ++t) { la.head[t] = b.head_out[t]; la.dhead[t] = b.dhead[t]; la.dheadT[t] = b.dheadT[t]; la.slots[t] = h->slots[t]; }
+    la.ldh = n.Ap; la.logstd = h->theta + n.ls_off; la.actions = ta.actions; la.advs = ta.advs; la.returns = ta.returns; la.old_values = ta.old_values;
+    la.old_neglogp = ta.old_neglogp; la.hyper = h->hyper; la.n = ta.n; la.A = n.A; la.Ap = n.Ap; la.rows_pad = b.Rcap; la.inv_n = ta.inv_n;
+    la.ent_coef = n.ent_coef; la.vf_coef = n.vf_coef; la.slot_w = n.slot_w; la.slot_head = n.slot_head; la.slot_aux = n.slot_aux; la.slot_loss = n.slot_loss;
+    hipLaunchKernelGGL(bf16_loss_kernel, dim3(Rp / 16), dim3(256), (size_t)(2 * 16 * n.Ap + 64 + 32) * sizeof(float), h->stream, la);
+    HIP_OK(h, hipGetLastError());
+    // dY_{L-1} = (d head * W_head^T) .* (1 - h_L^2), then down the hidden layers
+    const int HpL = n.Hp[n.L - 1];
+    {
+        GemmArgs a{};
+        for (int t = 0; t < 2; ++t) {
+            a.A[t] = b.dhead[t]; a.B[t] = b.theta_bf + (t ? n.wv_off : n.wmu_off); a.HT[t] = b.hT[t][n.L - 1]; a.C[t] = b.dy[t][n.L - 1]; a.CT[t] = b.dyT[t][n.L - 1];
+        }
+        a.lda = n.Ap; a.ldb = n.Ap; a.K = n.Ap; a.ldht = b.Rcap; a.ldc = HpL; a.ldct = b.Rcap;
+        if (bf16_gemm<GEPI_TANHGRAD>(h, a, Rp, HpL)) return -1;
+    }
+    for (int l = n.L - 1; l >= 1; --l) {
+        GemmArgs a{};
+        for (int t = 0; t < 2; ++t) {
+            a.A[t] = b.dy[t][l]; a.B[t] = b.theta_bf + n.w_off[t][l]; a.HT[t] = b.hT[t][l - 1]; a.C[t] = b.dy[t][l - 1]; a.CT[t] = b.dyT[t][l - 1];
+        }
+        a.lda = n.Hp[l]; a.ldb = n.Hp[l]; a.K = n.Hp[l]; a.ldht = b.Rcap; a.ldc = n.Hp[l - 1]; a.ldct = b.Rcap;
+        if (bf16_gemm<GEPI_TANHGRAD>(h, a, Rp, n.Hp[l - 1])) return -1;
+    }
+    return 0;
+}
+
+int bf16_weight_grads(ppo_handle* h, int Rp, int nsplit) {
+    ppo_handle::Bf16& b = h->bf;
+    const NetDev& n = h->net;
+    DwArgsB da{b.dw_tiles, nsplit, Rp / nsplit, h->slabs, (size_t)h->P_pad};
+    hipLaunchKernelGGL(gemm_dw_bf16_kernel, dim3(b.n_dw_tiles * nsplit), dim3(GB_THREADS), GB_LDS_BYTES, h->stream, da);
+    HIP_OK(h, hipGetLastError());
+    RowSumArgsB ra{};
+    int m = 0, first = 0;
+    for (int t = 0; t < 2; ++t)
+        for (int l = 0; l < n.L; ++l) { ra.src[m] = b.dyT[t][l]; ra.dst[m] = b.dbias + b.db_off[t][l]; ra.rows[m] = n.Hp[l]; ra.first[m] = first; first += n.Hp[l]; ++m; }
+    ra.first[m] = first; ra.n_mats = m; ra.ld = b.Rcap; ra.len = Rp;
+    hipLaunchKernelGGL(bf16_rowsum_kernel, dim3((first + 3) / 4), dim3(256), 0, h->stream, ra);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
 // ---- launches -------------------------------------------------------------------------------------------------
 template <int CT, int KS, int CTH, bool WIDE>
 void launch_step_t(ppo_handle* h, const StepArgs& a) {
@@ -414,6 +645,7 @@ void launch_step_t(ppo_handle* h, const StepArgs& a) {
     hipLaunchKernelGGL((policy_step_kernel<CT, KS, CTH, WIDE>), grid, dim3(BLOCK_THREADS), (size_t)h->lds_step_total * sizeof(float), h->stream, h->net, a);
 }
 int launch_step(ppo_handle* h, const StepArgs& a) {
+    if (h->bf.on) return launch_step_bf16(h, a);
     ProfScope ps(h, PK_STEP);
     if (h->net.wide) { if (h->CT == 4) launch_step_t<4, 2, 0, true>(h, a); else launch_step_t<1, 1, 0, true>(h, a); }
     else if (h->CT == 4 && h->CTH == 2) launch_step_t<4, 2, 2, false>(h, a);
@@ -442,6 +674,36 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     for (int t = 0; t < 2; ++t) {
         ta.slots[t] = h->slots[t];
         for (int l = 0; l < n.L; ++l) { ta.hg[t][l] = h->hg[t][l]; ta.dyg[t][l] = h->dyg[t][l]; }
+    }
+    if (h->bf.on) {
+        const int Rp = ru(ta.n, GB_PAD);
+        int nsplit = 1;
+        while (nsplit < h->max_split && nsplit < 4 && (Rp / (2 * nsplit)) % GB_K == 0 && Rp / (2 * nsplit) >= 512) nsplit *= 2;
+        { ProfScope ps(h, PK_TRAIN_FB); if (bf16_train_fwd_bwd(h, ta, Rp)) return -1; }
+        { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, Rp, nsplit)) return -1; }
+        {
+            ProfScope ps(h, PK_REDUCE);
+            ReduceArgs ra{};
+            ra.src = h->grad_src; ra.n_blocks = h->n_blocks; ra.slabs = h->slabs; ra.slab_stride = (size_t)h->P_pad; ra.nsplit = nsplit;
+            ra.slots[0] = h->slots[0]; ra.slots[1] = h->slots[1]; ra.n_rowblocks = Rp / 16; ra.slot_w = n.slot_w; ra.slot_loss = n.slot_loss;
+            ra.grad = h->grad; ra.sumsq = h->sumsq; ra.n_local = (float)ta.n; ra.beta_pow = h->beta_pow; ra.direct = h->bf.dbias;
+            hipLaunchKernelGGL(grad_reduce_kernel, dim3(h->n_blocks + 1), dim3(256), 0, h->stream, ra);
+            HIP_OK(h, hipGetLastError());
+        }
+        if (h->comm) {
+            ProfScope ps(h, PK_COMM);
+            const size_t cnt = (size_t)h->P_pad + 8;
+            const int rc = h->rccl.AllReduce(h->grad, h->grad, cnt, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
+            if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
+            hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
+            HIP_OK(h, hipGetLastError());
+        }
+        ProfScope ps(h, PK_ADAM);
+        AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
+                    h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out};
+        hipLaunchKernelGGL(adam_kernel, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
+        HIP_OK(h, hipGetLastError());
+        return bf16_refresh_mirrors(h);
     }
     {
         ProfScope ps(h, PK_TRAIN_FB);
@@ -564,6 +826,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { fail(h, "hipStreamCreate failed"); return bail(0); }
     const char* ng = getenv("PPO_HIP_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
+    if (cfg->compute_dtype != PPO_F32 && cfg->compute_dtype != PPO_BF16) { fail(h, "ppo_create: compute_dtype must be PPO_F32 or PPO_BF16"); return bail(0); }
+    h->bf.on = cfg->compute_dtype == PPO_BF16;
     if (build_layout(h)) return bail(0);
     // large dynamic LDS needs an explicit opt-in.  The attribute is per function, not per handle: it is set to the
     // hardware maximum (160 KB) so that a later, narrower handle cannot lower the limit under a live wider one.
@@ -584,6 +848,7 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         dev_alloc(h, &h->norm_out, 1) || dev_alloc(h, &h->st_loss, 8))
         return bail(0);
     if (upload_grad_src(h)) return bail(0);
+    if (h->bf.on && bf16_create(h)) return bail(0);
     const float pw[2] = {cfg->adam_beta1, cfg->adam_beta2};
     if (ppo_set_beta_powers(h, pw)) return bail(0);
     *out = h;
@@ -604,6 +869,12 @@ void ppo_destroy(ppo_handle* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) { if (h->hg[t][l]) (void)hipFree(h->hg[t][l]); if (h->dyg[t][l]) (void)hipFree(h->dyg[t][l]); }
     for (int i = 0; i < 6; ++i) if (h->st_vec[i]) (void)hipFree(h->st_vec[i]);
+    {
+        ppo_handle::Bf16& b = h->bf;
+        void* bp[] = {b.theta_bf, b.thetaT_bf, b.d_trmats, b.x0, b.x0T, b.head_out[0], b.head_out[1], b.dhead[0], b.dhead[1], b.dheadT[0], b.dheadT[1], b.dbias, b.dw_tiles};
+        for (void* p : bp) if (p) (void)hipFree(p);
+        for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) for (bf16_t* p : {b.hb[t][l], b.hT[t][l], b.dy[t][l], b.dyT[t][l]}) if (p) (void)hipFree(p);
+    }
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -647,6 +918,7 @@ int ppo_set_tensor(ppo_handle* h, int which, int index, const float* src, int64_
     if (which == 0) {
         hipLaunchKernelGGL(transpose_refresh_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->theta, h->thetaT, h->par, h->grad_src);
         HIP_OK(h, hipGetLastError());
+        if (h->bf.on && bf16_refresh_mirrors(h)) return -1;
     }
     return 0;
 }

@@ -1304,6 +1304,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
 //   kind 0: matrix -> sum of the split-K slabs (fixed order)
 //   kind 1: slot   -> sum over the row blocks' slots (fixed order), `count` valid elements, rest are padding
 //   kind 2: padding / untrained -> 0
+//   kind 3: finished vector (bf16 path: bias gradients from its row-sum kernel)
 // Also emits the block's sum of squares for the global norm, and (last block) the five loss scalars.
 // ------------------------------------------------------------------------------------------------------------
 struct GradSrc { int kind; int tower; int slot_off; int count; int base;   // base = first element of the tensor
@@ -1316,6 +1317,7 @@ struct ReduceArgs {
     const float* slabs; size_t slab_stride; int nsplit;
     const float* slots[2]; int n_rowblocks; int slot_w;
     int slot_loss;
+    const float* direct;         // kind 3: finished sums (bias gradients of the bf16 path's row-sum kernel), indexed slot_off + e
     float* grad;                 // [P_pad]  (+ 8 tail floats: 5 loss sums, row count)
     float* sumsq;                // [n_blocks]
     float n_local;               // rows summed on this rank
@@ -1363,6 +1365,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
             for (; b < a.n_rowblocks; ++b) s0 += p[(size_t)b * a.slot_w];
             gsum = (s0 + s1) + (s2 + s3);
         }
+    } else if (s.kind == 3) {
+        const int e = (int)(idx - (size_t)s.base);
+        if (e < s.count) gsum = a.direct[s.slot_off + e];
     }
     a.grad[idx] = gsum;
     float q = gsum * gsum;

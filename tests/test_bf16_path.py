@@ -1,0 +1,128 @@
+"""GPU tests of the bf16 matrix-core path (ppo_config.compute_dtype = PPO_BF16; BASELINE configs[4]: 256 obs / 64 act,
+MLP [1024,1024,1024], 8192 envs).  The reference has no bf16 arithmetic, so parity is against the build's own exact-fp32
+path / the oracle at a STATED tolerance (~1e-2 relative on the losses): bf16 operands carry 8
+significant bits, accumulation, loss arithmetic, gradients' reduction, clip and Adam are fp32."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CR = 0.16102319955825806
+LR = 0.000393141177482903
+GAMMA, LAM = 0.99, 0.95
+BF16 = 1
+
+
+def pair_bf16(hidden, O, A, seed=3):
+    import ppo_cpp_amd
+    orc = o.Oracle(O, A, list(hidden))
+    orc.init_orthogonal(seed)
+    orc.tensor("pi/logstd")[:] = np.random.RandomState(seed + 1).uniform(-1.0, 0.2, (1, A))
+    g = ppo_cpp_amd.PPOHip(O, A, list(hidden), compute_dtype=BF16)
+    g.set_flat(orc.theta)
+    return orc, g
+
+
+def cosine(a, b):
+    a, b = a.astype(np.float64).ravel(), b.astype(np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+@pytest.mark.parametrize("hidden,O,A,n", [((1024, 1024, 1024), 256, 64, 256), ((256, 256), 18, 18, 200), ((300, 200), 40, 7, 130)])
+def test_bf16_step_and_train_step_against_fp32_oracle(hidden, O, A, n):
+    """act outputs, the five losses, every gradient tensor and one Adam step of the bf16 path against the fp32 oracle.
+    Tolerances: values 3e-2, actions / neglogp 5e-3 (the policy head's gain is 0.01), vf_loss 3 % relative, entropy exact
+    (it only involves logstd), gradient direction cosine > 0.995 per tensor and global norm within 3 %."""
+    orc, g = pair_bf16(hidden, O, A)
+    np.testing.assert_array_equal(g.get_flat(0), orc.theta)               # fp32 master weights round-trip untouched
+    rng = np.random.RandomState(5)
+    obs = rng.uniform(-1, 1, (n, O)).astype(np.float32)
+    noise = rng.normal(size=(n, A)).astype(np.float32)
+    a, v, nlp = g.step(obs, noise)
+    ra, rv, rnlp = orc.step(obs, noise)
+    np.testing.assert_allclose(a, ra, rtol=0, atol=5e-3, err_msg="action")
+    np.testing.assert_allclose(v, rv, rtol=3e-2, atol=3e-2, err_msg="value")
+    np.testing.assert_allclose(nlp, rnlp, rtol=1e-4, atol=5e-3, err_msg="neglogp")
+    np.testing.assert_allclose(g.act_deterministic(obs), orc.forward(obs)[0], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(g.value(obs), rv, rtol=3e-2, atol=3e-2)
+    mb = H.synth_minibatch(orc, n, seed=3)
+    args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+    ref_losses, ref_grad = orc.loss_grad(*args, CR)
+    losses = g.train_step(LR, CR, *args)
+    grad, norm = g.last_grad()
+    _, ref_norm = orc.clip(ref_grad.copy())
+    assert losses[1] == pytest.approx(ref_losses[1], rel=3e-2), "vf_loss"
+    assert losses[0] == pytest.approx(ref_losses[0], abs=1e-2), "pg_loss"
+    assert losses[2] == pytest.approx(ref_losses[2], rel=1e-5), "entropy"
+    assert losses[3] == pytest.approx(ref_losses[3], rel=5e-2, abs=1e-4), "approxkl"
+    assert losses[4] == pytest.approx(ref_losses[4], abs=0.03), "clipfrac"
+    assert norm == pytest.approx(ref_norm, rel=3e-2)
+    for name, off, shape in orc.tensors:
+        cnt = int(np.prod(shape))
+        gt, rt = grad[off:off + cnt], ref_grad[off:off + cnt]
+        if np.linalg.norm(rt) > 1e-3 * ref_norm:                          # tensors that matter to the step
+            assert cosine(gt, rt) > 0.995, (name, cosine(gt, rt))
+    orc.train_step(LR, CR, *args)
+    th = g.get_flat(0)
+    # first Adam step moves every weight by ~lr * sign(g): the two paths agree wherever the gradient's sign is resolved
+    frac = np.mean(np.abs(th - orc.theta) < 0.2 * LR)
+    assert frac > 0.93, frac
+    assert np.abs(th - orc.theta).max() <= 2.2 * LR
+    np.testing.assert_allclose(g.beta_powers(), orc.pow, rtol=1e-6)
+
+
+def test_bf16_matches_the_fp32_hip_path_over_an_update():
+    """Same rollout inputs, same permutations: loss rows of the bf16 path track the library's exact-fp32 path within 1e-2
+    (relative on vf_loss / entropy, absolute on the near-zero terms) over 2 epochs x 4 minibatches at 256/64/[1024]^3."""
+    import ppo_cpp_amd
+    hidden, O, A, E, T, nmb, epochs = (1024, 1024, 1024), 256, 64, 64, 8, 4, 2
+    orc, gb = pair_bf16(hidden, O, A)
+    gf = ppo_cpp_amd.PPOHip(O, A, list(hidden)); gf.set_flat(orc.theta)
+    rng = np.random.RandomState(9)
+    noise = rng.normal(size=(T, E, A)).astype(np.float32)
+    perms = np.stack([rng.permutation(E * T) for _ in range(epochs)]).astype(np.int32)
+    rows = {}
+    for name, g in (("f32", gf), ("bf16", gb)):
+        g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+        g.collect_synthetic(1234, GAMMA, LAM, noise)
+        rows[name] = g.update(LR, CR, epochs, nmb, perms)[0]
+    np.testing.assert_allclose(gb.rollout_get("obs"), gf.rollout_get("obs"), rtol=1e-6, atol=1e-6)       # normalisation stays fp32
+    np.testing.assert_allclose(gb.rollout_get("values"), gf.rollout_get("values"), rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(gb.rollout_get("returns"), gf.rollout_get("returns"), rtol=3e-2, atol=5e-2)
+    rb, rf = rows["bf16"], rows["f32"]
+    np.testing.assert_allclose(rb[:, 1], rf[:, 1], rtol=2e-2, err_msg="vf_loss")
+    np.testing.assert_allclose(rb[:, 2], rf[:, 2], rtol=1e-4, err_msg="entropy")
+    np.testing.assert_allclose(rb[:, 0], rf[:, 0], atol=1e-2, err_msg="pg_loss")
+    np.testing.assert_allclose(rb[:, 3], rf[:, 3], atol=2e-3, err_msg="approxkl")
+    np.testing.assert_allclose(rb[:, 4], rf[:, 4], atol=0.06, err_msg="clipfrac")
+    assert cosine(gb.get_flat(0) - orc.theta, gf.get_flat(0) - orc.theta) > 0.9          # the two runs moved the weights the same way
+
+
+def test_bf16_full_size_config4_properties():
+    """BASELINE configs[4] at its per-GPU size (8192 envs x 16 steps, 256 obs / 64 act, MLP [1024,1024,1024], 32 minibatches of
+    4096 rows): too large for the oracle, so size-independent properties -- first-epoch ratios are exactly one (act and
+    train forward are the same bf16 GEMMs: approxkl = clipfrac = 0, pg_loss ~ 0 because advantages are normalised),
+    entropy is the closed form, the loss rows are finite, the value loss falls over the epochs, every rank-local shuffle is
+    a permutation (returns unchanged), and a second update from the same state with the same seed is bitwise identical."""
+    import ppo_cpp_amd
+    hidden, O, A, E, T, nmb, epochs = (1024, 1024, 1024), 256, 64, 8192, 16, 32, 2
+    g = ppo_cpp_amd.PPOHip(O, A, list(hidden), compute_dtype=BF16)
+    g.init_orthogonal(0)
+    g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+    g.collect_synthetic(1234, GAMMA, LAM, None)
+    ret0 = g.rollout_get("returns")
+    theta0, m0, v0, pw0 = g.get_flat(0), g.get_flat(1), g.get_flat(2), g.beta_powers()
+    rows, mean = g.update(LR, CR, epochs, nmb, None, seed=77)
+    assert rows.shape == (epochs * nmb, 5) and np.isfinite(rows).all()
+    assert rows[0, 3] == 0.0 and rows[0, 4] == 0.0 and abs(rows[0, 0]) < 1e-5            # ratio == 1 on the first minibatch
+    np.testing.assert_allclose(rows[:, 2], 64 * 1.4189385175704956, rtol=1e-3)           # entropy: logstd ~ 0 after a few steps
+    assert rows[nmb:, 1].mean() < rows[:nmb, 1].mean()                                    # value loss goes down
+    np.testing.assert_array_equal(g.rollout_get("returns"), ret0)
+    th1 = g.get_flat(0)
+    assert np.isfinite(th1).all() and 0 < np.abs(th1 - theta0).max() <= 2 * epochs * nmb * LR
+    g.set_flat(theta0); g.set_flat(m0, 1); g.set_flat(v0, 2); g.set_beta_powers(pw0)
+    rows2, _ = g.update(LR, CR, epochs, nmb, None, seed=77)
+    np.testing.assert_array_equal(rows2, rows); np.testing.assert_array_equal(g.get_flat(0), th1)
