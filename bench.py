@@ -30,11 +30,15 @@ CONFIGS = {
     "cfg4": dict(n_envs=1024, n_steps=64, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
                  desc="1024 envs x 64 steps, MLP [64,64]"),
     "cfg5": dict(n_envs=8192, n_steps=16, hidden=[1024, 1024, 1024], obs=256, act=64, nminibatches=32, noptepochs=10,
-                 desc="synthetic 256-obs/64-act env, 8192 envs x 16 steps, MLP [1024,1024,1024] in exact fp32 (two-tile LDS layout)"),
+                 dtype="bf16",
+                 desc="synthetic 256-obs/64-act env, 8192 envs x 16 steps, MLP [1024,1024,1024], bf16 MFMA operands / fp32 accumulate, master weights and Adam"),
+    "cfg5f32": dict(n_envs=8192, n_steps=16, hidden=[1024, 1024, 1024], obs=256, act=64, nminibatches=32, noptepochs=10,
+                    desc="synthetic 256-obs/64-act env, 8192 envs x 16 steps, MLP [1024,1024,1024] in exact fp32 (two-tile LDS layout)"),
 }
-BASELINE_INDEX = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}
+BASELINE_INDEX = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4, "cfg5f32": 4}
 LR, CR, GAMMA, LAM = 3.93141e-4, 0.161023, 0.99, 0.95      # README.md:70-81, ppo2.cpp:215-217
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0                              # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -101,6 +105,65 @@ def cpu_baseline_all_cores(cfg, name, Es, Ms):
             "sample": "%d processes (capped at 16) x (3 policy steps at %d rows + 3 train steps at %d rows), slowest process, scaled" % (n, e_rows, m_rows)}
 
 
+def cpu_baseline_vectorised(cfg, budget_s=6.0):
+    """A second CPU leg that is not the double-accumulating scalar port: the dense products of one policy step and one
+    train step (forward, dX, dW of both towers; fp32, tanh included, the O(rows) loss arithmetic left out) on NumPy's
+    BLAS sgemm pinned to ONE thread.  An optimistic stand-in for what TF-Eigen's single-thread contraction could do."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
+    B = E * T; M = B // nmb
+    dims = [cfg["obs"]] + list(cfg["hidden"])
+    rng = np.random.RandomState(0)
+    Ws = [[(rng.normal(size=(a, b)) / np.sqrt(a)).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])] for _ in range(2)]
+    heads = [(rng.normal(size=(dims[-1], cfg["act"])) * 0.01).astype(np.float32), rng.normal(size=(dims[-1], 1)).astype(np.float32)]
+    f_fwd, f_dx, f_dw = flops_per_row(cfg["obs"], cfg["act"], cfg["hidden"])
+    rows = int(max(64, min(M, 2.0e9 // (f_fwd + f_dx + f_dw))))
+    x = rng.uniform(-1, 1, (rows, cfg["obs"])).astype(np.float32)
+
+    def fwd(keep):
+        acts = []
+        for t in range(2):
+            h = x; hs = [h]
+            for W in Ws[t]:
+                h = np.tanh(h @ W); hs.append(h)
+            out = h @ heads[t]
+            acts.append((hs, out))
+        return acts if keep else None
+
+    def train():
+        acts = fwd(True)
+        for t in range(2):
+            hs, out = acts[t]
+            d = out * np.float32(1e-3)
+            _ = hs[-1].T @ d                                  # head dW
+            dh = (d @ heads[t].T) * (1 - hs[-1] * hs[-1])
+            for l in range(len(Ws[t]) - 1, -1, -1):
+                _ = hs[l].T @ dh                              # dW_l
+                if l:
+                    dh = (dh @ Ws[t][l].T) * (1 - hs[l] * hs[l])
+
+    def timed(fn, share):
+        t0 = time.perf_counter(); n = 0
+        while n < 1 or (time.perf_counter() - t0 < share * budget_s and n < 50):
+            fn(); n += 1
+        return (time.perf_counter() - t0) / n
+
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    try:
+        if ctx is not None:
+            ctx.__enter__()
+        t_step = timed(lambda: fwd(False), 0.25) * (E / rows)
+        t_train = timed(train, 0.75) * (M / rows)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    return {"value": B / (T * t_step + ep * nmb * t_train), "unit": "env-steps/s", "cores": 1, "kind": "port (NumPy/BLAS sgemm, 1 thread, dense products + tanh only)",
+            "sample": "policy-step and train-step products at %d rows, scaled to %d / %d rows" % (rows, E, M), "blas_threads_pinned": threadpool_limits is not None}
+
+
 def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
     """The oracle's C restatement (a scalar port, 1 thread) timed on a bounded sample of the same workload."""
     from oracle import oracle as o
@@ -132,7 +195,11 @@ def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
         all_cores = cpu_baseline_all_cores(cfg, name, Es, Ms)
     except Exception as e:                                   # the single-thread leg is the contract; this one is extra
         all_cores = {"error": repr(e)}
-    return {"all_cores": all_cores, "value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    try:
+        vect = cpu_baseline_vectorised(cfg)
+    except Exception as e:
+        vect = {"error": repr(e)}
+    return {"all_cores": all_cores, "vectorised": vect, "value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "%d policy steps at %d rows + %d train steps at %d rows of the oracle's C restatement, extrapolated to "
                       "%d steps + %d train steps per update" % (n_step, Es, n_tr, Ms, T, ep * nmb) + ("" if (Es, Ms) == (E, M) else " (rows scaled to %d / %d)" % (E, M)),
             "update_samples_per_s": ep * B / (ep * nmb * t_train)}
@@ -151,6 +218,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] side measurement")
     ap.add_argument("--host-env", action="store_true", help="also time the Env-on-host path (PCIe inclusive)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank runs the config's n_envs; strong: the config's n_envs are divided over the ranks "
+                         "(BASELINE configs[3] as written: 1024 envs in total over 8 GPUs)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     from ppo_cpp_amd import dist as ppodist
@@ -171,14 +241,20 @@ def main():
         device = -1                                                       # the library picks LOCAL_RANK % (its own device count)
 
     E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
+    if args.scaling == "strong":
+        if E % world:
+            sys.exit("--scaling strong: %d envs do not divide over %d ranks" % (E, world))
+        E //= world                                                        # per-rank share; minibatch rows per rank shrink with it
     B = E * T; M = B // nmb
-    g = ppo_cpp_amd.PPOHip(cfg["obs"], cfg["act"], cfg["hidden"], device=device)
+    bf16 = cfg.get("dtype") == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    g = ppo_cpp_amd.PPOHip(cfg["obs"], cfg["act"], cfg["hidden"], device=device, compute_dtype=1 if bf16 else 0)
     g.init_orthogonal(0)                                                   # same seed on every rank: replicated weights
     if world > 1:
         g.dist_init(world, rank, ppodist.broadcast_unique_id(dist, rank, ppo_cpp_amd.PPOHip.dist_unique_id))
     g.norm_init(E, GAMMA)
     g.rollout_alloc(E, T)
-    env0 = ppodist.env_offset(E, rank)                                     # weak scaling: every rank owns E more envs
+    env0 = ppodist.env_offset(E, rank)                                     # every rank owns its own E environments (global ids rank*E ..)
 
     def one_step(i, first=False):
         g.collect_synthetic(1234, GAMMA, LAM, None, env0=env0, step0=i * T, first=first)
@@ -233,7 +309,9 @@ def main():
     dom = max((k for k in kern if k in kflops), key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
     ach = kflops[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e12
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     if args.config == "cfg3" and os.path.exists(tpath):          # PMC passes cannot run inside the timed process: measured offline
         t = json.load(open(tpath))["kernels"].get(dom)
         if t:
@@ -243,17 +321,21 @@ def main():
     out = {
         "metric": "PPO env-steps/s", "value": world * B * args.steps / dt, "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[%d] (%s): %s" % (BASELINE_INDEX[args.config], args.config, cfg["desc"]), "n_envs_per_gpu": E, "n_steps": T,
                    "n_batch_per_gpu": B, "minibatch_rows_per_gpu": M, "parallelism": "dp%d" % world,
                    "env": "on-device seeded synthetic env (env_mock shape), rollout buffers resident in HBM"},
         "update_samples_per_s": world * ep * B / (t_c - t_b),
         "phase_ms": {"collect": 1e3 * (t_b - t_a), "update": 1e3 * (t_c - t_b)},
-        "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                     "frac": ach / peak, "traffic": traffic,
                      "flop_per_launch": kflops[dom], "avg_us": kern[dom]["avg_us"],
-                     "train_step": {"flop": step_flops, "kernel_us_sum": step_us,
-                                    "achieved": step_flops / (step_us * 1e-6) / 1e12 if step_us else None}},
+                     "timing": "HIP events on the handle's stream around every launch of an eager pass right after the timed region: "
+                               "an UPPER bound on kernel time (launch gaps included); the rocprofv3 kernel-trace of the same command is in profiles/",
+                     # whole train step against the same peak, from the graph-replayed update phase (no launch gaps, device paced)
+                     "step_frac": step_flops / ((t_c - t_b) / (ep * nmb)) / 1e12 / peak,
+                     "train_step": {"flop": step_flops, "us_from_update_phase": 1e6 * (t_c - t_b) / (ep * nmb), "event_us_sum_upper_bound": step_us,
+                                    "achieved": step_flops / ((t_c - t_b) / (ep * nmb)) / 1e12}},
         "kernels": kern,
         "losses": [float(x) for x in losses],
     }
@@ -291,6 +373,7 @@ def main():
                 g.close()
             r = hostapi.learn(E, T, cfg["hidden"], n_updates=4, nminibatches=nmb, noptepochs=ep, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM)
             out["host_env"] = {"env_steps_per_s": r["env_steps_per_s"], "collect_ms": r["collect_ms"], "update_ms": r["update_ms"],
+                               "collect_phase_ms": r["phase_ms"],
                                "note": "SeededEnvMock x %d behind the pooled VecEnv on the host cores, PCIe round trip per env step" % E}
         except Exception as e:                               # extra leg: never fatal for the contract line
             out["host_env"] = {"error": repr(e)}

@@ -26,13 +26,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-#define GB_M 128                   // output tile rows (index i)
 #define GB_N 128                   // output tile columns (index j)
 #define GB_K 64                    // reduction depth per LDS stage: 128-byte rows
-#define GB_THREADS 256             // 4 waves as 2 x 2, each a 64 x 64 accumulator block (4 x 4 MFMA tiles)
-#define GB_STAGE_BYTES ((GB_M + GB_N) * GB_K * 2)          // 32 KB: A tile then B tile
-#define GB_LDS_BYTES (2 * GB_STAGE_BYTES)                   // two stages: 64 KB, two workgroups per CU
+#define GB_STAGES 3                // LDS ring: stage t+2 is in flight while stage t is multiplied
 #define GB_PAD 128                 // every dimension of the bf16 path is padded to this
+// WM = waves along i (2 or 4): tile rows BM = 64 WM, 2 WM waves (WM x 2), each a 64 x 64 accumulator block (4 x 4 MFMA tiles)
+#define GB_BM(WM) (64 * (WM))
+#define GB_THREADS(WM) (128 * (WM))
+#define GB_STAGE_BYTES(WM) ((GB_BM(WM) + GB_N) * GB_K * 2)         // A tile then B tile: 48 KB (WM 4) / 32 KB (WM 2)
+#define GB_LDS_BYTES(WM) (GB_STAGES * GB_STAGE_BYTES(WM))          // 144 KB / 96 KB: one workgroup per CU
+#define GB_PIECES(WM) ((GB_BM(WM) + GB_N) / 8 / (2 * (WM)))        // 1-KB LDS-DMA pieces per wave and stage: 6 / 8
 
 enum { GEPI_TANH = 0, GEPI_TANHGRAD = 1, GEPI_F32 = 2, GEPI_DW = 3 };
 
@@ -53,18 +56,21 @@ struct GemmArgs {
 // LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address and again on the read.
 __device__ __forceinline__ int gb_swz(int row, int chunk) { return chunk ^ (row & 7); }
 
-// stage one [128][64] operand tile: 16 KB = 16 wave-instructions of 1 KB; wave w issues pieces w*4 .. w*4+3, a piece
-// is 8 rows x 128 B; lane l lands on (row 8p + l/8, chunk l%8) and fetches the chunk that belongs there.
-__device__ __forceinline__ void gb_stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int k0, char* lds_tile) {
+// One stage = the [BM][64] A tile followed by the [128][64] B tile, (BM + 128) / 8 pieces of 1 KB (8 rows x 128 B), dealt
+// to the waves round robin; lane l of a piece lands on (row 8p + l/8, chunk l%8) and fetches the chunk that belongs there.
+template <int WM>
+__device__ __forceinline__ void gb_stage(const bf16_t* __restrict__ A, int lda, int i0, const bf16_t* __restrict__ B, int ldb, int j0, int k0, char* st) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PA = GB_BM(WM) / 8;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int piece = wave * 4 + q;
-        const int r = piece * 8 + (lane >> 3), c = lane & 7;
-        const bf16_t* src = g + (size_t)(row0 + r) * ld + k0 + gb_swz(r, c) * 8;
+    for (int q = 0; q < GB_PIECES(WM); ++q) {
+        const int piece = wave + 2 * WM * q;                 // wave-uniform
+        const bool isA = piece < PA;
+        const int r = (isA ? piece : piece - PA) * 8 + (lane >> 3), c = lane & 7;
+        const bf16_t* src = isA ? A + (size_t)(i0 + r) * lda + k0 + gb_swz(r, c) * 8 : B + (size_t)(j0 + r) * ldb + k0 + gb_swz(r, c) * 8;
         typedef const __attribute__((address_space(1))) void* gptr;
         typedef __attribute__((address_space(3))) void* lptr;
-        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(lds_tile + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(st + piece * 1024), 16, 0, 0);
     }
 }
 
@@ -78,57 +84,69 @@ __device__ __forceinline__ bf16x8 gb_frag(const char* lds_tile, int r0, int ks) 
 
 struct GemmAcc { f32x4 v[4][4]; };           // [mi][ni]: rows 16 mi + 4 g + reg, column 16 ni + (lane & 15) of the wave's 64 x 64 block
 
+template <int N> __device__ __forceinline__ void gb_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Main loop.  Per step ONE barrier: [wait until this wave's pieces of stage t have landed: all but the youngest stage's
+// loads] -> barrier (every wave's pieces of stage t are in LDS; every wave is done multiplying stage t-1) -> issue stage
+// t+2 into the buffer stage t-1 used -> read fragments of stage t, 32 MFMAs per wave.  A __syncthreads() would drain the
+// LDS-DMA queue (it waits vmcnt(0)), so the barrier is the raw instruction and the wait is counted.
+template <int WM>
 __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restrict__ A, int lda, int i0, const bf16_t* __restrict__ B, int ldb, int j0,
                                             int kbeg, int K, char* lds) {
     const int wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    constexpr int SB = GB_STAGE_BYTES(WM), NP = GB_PIECES(WM);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc.v[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nt = K / GB_K;
-    gb_stage_tile(A, lda, i0, kbeg, lds);
-    gb_stage_tile(B, ldb, j0, kbeg, lds + GB_M * GB_K * 2);
-    __syncthreads();                                         // (drains the DMA: vmcnt(0) + barrier)
+    gb_stage<WM>(A, lda, i0, B, ldb, j0, kbeg, lds);
+    if (nt > 1) gb_stage<WM>(A, lda, i0, B, ldb, j0, kbeg + GB_K, lds + SB);
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
-        char* st = lds + cur * GB_STAGE_BYTES;
-        if (t + 1 < nt) {                                    // next stage goes out before this one's reads and MFMAs
-            char* nx = lds + (cur ^ 1) * GB_STAGE_BYTES;
-            gb_stage_tile(A, lda, i0, kbeg + (t + 1) * GB_K, nx);
-            gb_stage_tile(B, ldb, j0, kbeg + (t + 1) * GB_K, nx + GB_M * GB_K * 2);
+        if (t + 1 < nt) gb_wait_vm<NP>(); else gb_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt) {
+            int nb = cur + 2; if (nb >= GB_STAGES) nb -= GB_STAGES;
+            gb_stage<WM>(A, lda, i0, B, ldb, j0, kbeg + (t + 2) * GB_K, lds + nb * SB);
         }
-        const char* at = st;
-        const char* bt = st + GB_M * GB_K * 2;
+        const char* at = lds + cur * SB;
+        const char* bt = at + GB_BM(WM) * GB_K * 2;
+        // all 16 fragment reads of the stage go out first; the first k-step's MFMAs start when its 8 have landed while the
+        // second k-step's are still in flight (two register sets: 64 accumulator + 64 fragment VGPRs per lane)
+        bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) af[a] = gb_frag(at, wm + 16 * a, ks);
+            for (int a = 0; a < 4; ++a) af[ks][a] = gb_frag(at, wm + 16 * a, ks);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bfr[b] = gb_frag(bt, wn + 16 * b, ks);
-            __builtin_amdgcn_s_setprio(1);
+            for (int b = 0; b < 4; ++b) bfr[ks][b] = gb_frag(bt, wn + 16 * b, ks);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc.v[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc.v[a][b], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();                                     // next stage landed (vmcnt(0)) and everyone is done reading this one
-        cur ^= 1;
+                for (int b = 0; b < 4; ++b) acc.v[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][a], bfr[ks][b], acc.v[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (++cur == GB_STAGES) cur = 0;
     }
+    __syncthreads();                                         // the epilogue reuses the ring as its staging tile
 }
 
 // Epilogue through LDS: the accumulator layout has 4 consecutive ROWS per lane for one column, i.e. 8 contiguous bytes
-// of the [column][row] image; that image is parked in LDS (row stride 136 elements: 272 B, conflict-free 8-byte
-// writes), streamed out as the [J][I] output with 16-byte stores, and gathered column-wise for the [I][J] output.
-#define GB_TLD 136
-template <int EPI>
+// of the [column][row] image; that image is parked in LDS (row stride BM + 8 elements: conflict-light 8-byte writes),
+// streamed out as the [J][I] output with 16-byte stores, and gathered column-wise for the [I][J] output.
+template <int WM, int EPI>
 __device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a, int tw, int i0, int j0, char* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int g = lane >> 4, c = lane & 15;
-    bf16_t* tt = reinterpret_cast<bf16_t*>(lds);              // [128 cols j][GB_TLD rows i]
+    constexpr int BM = GB_BM(WM), TLD = BM + 8, NT = GB_THREADS(WM);
+    bf16_t* tt = reinterpret_cast<bf16_t*>(lds);              // [128 cols j][TLD rows i]
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         const int j = wn + 16 * nb + c;
@@ -149,40 +167,41 @@ __device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (bf16_t)y[r];
-            *reinterpret_cast<bf16x4*>(tt + j * GB_TLD + i) = o;
+            *reinterpret_cast<bf16x4*>(tt + j * TLD + i) = o;
         }
     }
     __syncthreads();
-    if (a.CT[tw]) {                                           // [J][I]: rows of the parked image, 16 chunks of 16 B per row
+    if (a.CT[tw]) {                                           // [J][I]: rows of the parked image, BM/8 chunks of 16 B per row
+        constexpr int CH = BM / 8;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int id = tid + GB_THREADS * q;
-            const int j = id >> 4, ch = id & 15;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(tt + j * GB_TLD + ch * 8);
+        for (int q = 0; q < GB_N * CH / NT; ++q) {
+            const int id = tid + NT * q;
+            const int j = id / CH, ch = id % CH;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(tt + j * TLD + ch * 8);
             *reinterpret_cast<bf16x8*>(a.CT[tw] + (size_t)(j0 + j) * a.ldct + i0 + ch * 8) = v;
         }
     }
     if (a.C[tw]) {                                            // [I][J]: 8 consecutive j of one row i = 8 two-byte LDS gathers
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int id = tid + GB_THREADS * q;
-            const int i = id & 127, ch = id >> 7;            // consecutive lanes = consecutive i: same LDS dwords pairwise, no conflicts
+        for (int q = 0; q < BM * 16 / NT; ++q) {
+            const int id = tid + NT * q;
+            const int i = id % BM, ch = id / BM;              // consecutive lanes = consecutive i: same LDS dwords pairwise, no conflicts
             bf16x8 v;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tt[(ch * 8 + e) * GB_TLD + i];
+            for (int e = 0; e < 8; ++e) v[e] = tt[(ch * 8 + e) * TLD + i];
             *reinterpret_cast<bf16x8*>(a.C[tw] + (size_t)(i0 + i) * a.ldc + j0 + ch * 8) = v;
         }
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmArgs a) {
+template <int WM, int EPI>
+__global__ __launch_bounds__(GB_THREADS(WM)) void gemm_nt_bf16_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char gb_lds[];
     const int tw = blockIdx.y;
     const int ti = blockIdx.x % a.tiles_i, tj = blockIdx.x / a.tiles_i;
-    const int i0 = ti * GB_M, j0 = tj * GB_N;
+    const int i0 = ti * GB_BM(WM), j0 = tj * GB_N;
     GemmAcc acc;
-    gb_mainloop(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, 0, a.K, gb_lds);
+    gb_mainloop<WM>(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, 0, a.K, gb_lds);
     if constexpr (EPI == GEPI_F32) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, g = lane >> 4, c = lane & 15;
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmArgs a)
                 for (int r = 0; r < 4; ++r) a.F[tw][(size_t)(i0 + wm + 16 * ma + 4 * g + r) * a.ldf + j] = acc.v[ma][nb][r] + bj;
         }
     } else {
-        gb_epilogue_bf16<EPI>(acc, a, tw, i0, j0, gb_lds);
+        gb_epilogue_bf16<WM, EPI>(acc, a, tw, i0, j0, gb_lds);
     }
 }
 
@@ -204,12 +223,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmArgs a)
 struct DwTileB { const bf16_t* A; const bf16_t* B; int lda, ldb; int i0, j0; int out_off, ldo; };
 struct DwArgsB { const DwTileB* tiles; int nsplit; int rows_per_split; float* slabs; size_t slab_stride; };
 
-__global__ __launch_bounds__(GB_THREADS, 2) void gemm_dw_bf16_kernel(DwArgsB a) {
+template <int WM>
+__global__ __launch_bounds__(GB_THREADS(WM)) void gemm_dw_bf16_kernel(DwArgsB a) {
     extern __shared__ __attribute__((aligned(16))) char gb_lds[];
     const DwTileB t = a.tiles[blockIdx.x / a.nsplit];
     const int split = blockIdx.x % a.nsplit;                 // the splits of one tile sit on different XCDs; tiles of one split share X^T / dY^T panels
     GemmAcc acc;
-    gb_mainloop(acc, t.A, t.lda, t.i0, t.B, t.ldb, t.j0, split * a.rows_per_split, a.rows_per_split, gb_lds);
+    gb_mainloop<WM>(acc, t.A, t.lda, t.i0, t.B, t.ldb, t.j0, split * a.rows_per_split, a.rows_per_split, gb_lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, g = lane >> 4, c = lane & 15;
     float* out = a.slabs + (size_t)split * a.slab_stride + t.out_off;
@@ -226,7 +246,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_dw_bf16_kernel(DwArgsB a) 
 // ---- input staging: fp32 observations -> bf16 [rows_pad][Kp0] (+ the [Kp0][rows_pad] copy the first layer's weight
 // gradient needs); the act path normalises here (env_normalize.hpp:99-104) and writes the normalised fp32 rows into
 // the rollout buffer, as stage_block_inputs does for the fused kernels --------------------------------------------------
-struct StageArgsB { const float* obs; int n, O, Kp0, rows_pad; ObsNorm nz; float* obs_out; bf16_t* X; bf16_t* XT; };
+struct StageArgsB { const float* obs; int n, O, Kp0, rows_pad; ObsNorm nz; float* obs_out; bf16_t* X; bf16_t* XT; int ldt; };
 
 __global__ __launch_bounds__(256) void bf16_stage_kernel(StageArgsB a) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(256) void bf16_stage_kernel(StageArgsB a) {
         if (a.obs_out) a.obs_out[(size_t)row * a.O + j] = x;
     }
     a.X[idx] = (bf16_t)x;
-    if (a.XT) a.XT[(size_t)j * a.rows_pad + row] = (bf16_t)x;
+    if (a.XT) a.XT[(size_t)j * a.ldt + row] = (bf16_t)x;
 }
 
 // ---- act epilogue: sampling + neglogp (G:5894-6672) from the head GEMM's fp32 outputs ---------------------------------

@@ -65,7 +65,7 @@ struct ppo_handle {
     float* thetaT = nullptr;          // transposed copies (layout: NetDev::wT_off / wmuT_off)
     float* par = nullptr;             // small-parameter mirror [2][par_total] (layout: NetDev::par_*)
     // parameters + optimiser state (padded layout)
-    float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad = nullptr, *sumsq = nullptr;
+    float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad = nullptr, *sumsq = nullptr, *sumsq2 = nullptr;
     float* beta_pow = nullptr;        // {cur b1, cur b2, next b1, next b2}
     float* hyper = nullptr;           // {lr, cliprange}
     float* norm_out = nullptr;        // [1]
@@ -134,7 +134,7 @@ struct ppo_handle {
         float* head_out[2]{};                           // [Rcap][Ap] fp32
         bf16_t *dhead[2]{}, *dheadT[2]{};
         float* dbias = nullptr; int db_off[2][PPO_MAX_LAYERS]{}; int n_dbias = 0;
-        DwTileB* dw_tiles = nullptr; int n_dw_tiles = 0;
+        DwTileB* dw_tiles = nullptr; int n_dw_tiles = 0; int dw_wm = 4;
     } bf;
     // dist
     Rccl rccl;
@@ -463,6 +463,14 @@ ObsNorm no_norm_fwd() { return ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}; }
 
 // ---- bf16 matrix-core path (ppo_bf16.hpp) ------------------------------------------------------------------------
 // bf16 operand copies of the fp32 master weights: a cast of the whole padded vector + the transposed copies
+int bf16_refresh_transposes(ppo_handle* h) {
+    ppo_handle::Bf16& b = h->bf;
+    TrArgs ta{b.d_trmats, b.n_trmats, h->theta, b.thetaT_bf};
+    hipLaunchKernelGGL(bf16_transpose_kernel, dim3(b.n_trtiles), dim3(256), 0, h->stream, ta);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
 int bf16_refresh_mirrors(ppo_handle* h) {
     ppo_handle::Bf16& b = h->bf;
     const size_t n4 = (size_t)h->P_pad / 4;
@@ -489,10 +497,16 @@ int bf16_create(ppo_handle* h) {
     if (dev_alloc(h, &b.d_trmats, mats.size())) return -1;
     HIP_OK(h, hipMemcpyAsync(b.d_trmats, mats.data(), mats.size() * sizeof(TrMat), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    bool ok = hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<GEPI_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES) == hipSuccess;
-    ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<GEPI_TANHGRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES) == hipSuccess;
-    ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<GEPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES) == hipSuccess;
-    ok &= hipFuncSetAttribute((const void*)gemm_dw_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES) == hipSuccess;
+    bool ok = true;
+    auto lds_attr = [&](const void* f, int bytes) { ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
+    lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_TANH>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_TANH>, GB_LDS_BYTES(2));
+    lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_TANHGRAD>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_TANHGRAD>, GB_LDS_BYTES(2));
+    lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_F32>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_F32>, GB_LDS_BYTES(2));
+    lds_attr((const void*)gemm_dw_bf16_kernel<4>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_dw_bf16_kernel<2>, GB_LDS_BYTES(2));
+    // the weight-gradient tiles are 256 features tall when every reduction-side width allows it
+    b.dw_wm = 4;
+    if (n.Kp0 % 256) b.dw_wm = 2;
+    for (int l = 0; l < n.L; ++l) if (n.Hp[l] % 256) b.dw_wm = 2;
     if (!ok) return fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 GEMM kernels");
     return 0;
 }
@@ -517,7 +531,7 @@ int bf16_ensure_ws(ppo_handle* h, int rows) {
     // grouped weight-gradient tile table: dW = X^T dY for every layer and both heads, operands in the [features][rows] layout
     std::vector<DwTileB> tiles;
     auto add = [&](const bf16_t* A, const bf16_t* B, int Kp, int Np, int out_off) {
-        for (int i = 0; i < Kp; i += GB_M) for (int j = 0; j < Np; j += GB_N) tiles.push_back(DwTileB{A, B, R, R, i, j, out_off, Np});
+        for (int i = 0; i < Kp; i += GB_BM(b.dw_wm)) for (int j = 0; j < Np; j += GB_N) tiles.push_back(DwTileB{A, B, R, R, i, j, out_off, Np});
     };
     for (int t = 0; t < 2; ++t) {
         for (int l = 0; l < n.L; ++l) add(l ? b.hT[t][l - 1] : b.x0T, b.dyT[t][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l], n.w_off[t][l]);
@@ -534,8 +548,13 @@ int bf16_ensure_ws(ppo_handle* h, int rows) {
 template <int EPI>
 int bf16_gemm(ppo_handle* h, const GemmArgs& a, int I, int J) {
     GemmArgs g = a;
-    g.tiles_i = I / GB_M;
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI>), dim3((I / GB_M) * (J / GB_N), 2), dim3(GB_THREADS), GB_LDS_BYTES, h->stream, g);
+    if (I % 256 == 0) {                                      // 256 x 128 tiles, 8 waves
+        g.tiles_i = I / 256;
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<4, EPI>), dim3((I / 256) * (J / GB_N), 2), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, g);
+    } else {
+        g.tiles_i = I / 128;
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, EPI>), dim3((I / 128) * (J / GB_N), 2), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, g);
+    }
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -566,10 +585,8 @@ int bf16_forward(ppo_handle* h, int Rp, bool want_transposed) {
 int bf16_stage(ppo_handle* h, const float* obs, int nrows, int Rp, ObsNorm nz, float* obs_out, bool want_transposed) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
-    StageArgsB sa{obs, nrows, n.O, n.Kp0, Rp, nz, obs_out, b.x0, want_transposed ? b.x0T : nullptr};
-    // the transposed copy has leading dimension Rcap: the kernel writes XT[j * rows_pad + row], so stage over the capacity
-    sa.rows_pad = want_transposed ? b.Rcap : Rp;
-    const size_t cnt = (size_t)sa.rows_pad * n.Kp0;
+    StageArgsB sa{obs, nrows, n.O, n.Kp0, Rp, nz, obs_out, b.x0, want_transposed ? b.x0T : nullptr, b.Rcap};
+    const size_t cnt = (size_t)Rp * n.Kp0;
     hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -626,7 +643,8 @@ int bf16_weight_grads(ppo_handle* h, int Rp, int nsplit) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
     DwArgsB da{b.dw_tiles, nsplit, Rp / nsplit, h->slabs, (size_t)h->P_pad};
-    hipLaunchKernelGGL(gemm_dw_bf16_kernel, dim3(b.n_dw_tiles * nsplit), dim3(GB_THREADS), GB_LDS_BYTES, h->stream, da);
+    if (b.dw_wm == 4) hipLaunchKernelGGL(gemm_dw_bf16_kernel<4>, dim3(b.n_dw_tiles * nsplit), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, da);
+    else hipLaunchKernelGGL(gemm_dw_bf16_kernel<2>, dim3(b.n_dw_tiles * nsplit), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, da);
     HIP_OK(h, hipGetLastError());
     RowSumArgsB ra{};
     int m = 0, first = 0;
@@ -659,6 +677,24 @@ int pick_split(ppo_handle* h, int n) {
     int s = h->max_split;
     while (s > 1 && (n % (16 * s) != 0)) s >>= 1;
     return s;
+}
+
+// clip + Adam on the assembled gradient (after the optional all-reduce)
+int enqueue_adam(ppo_handle* h, float* loss_row) {
+    ProfScope ps(h, PK_ADAM);
+    const float* parts = h->sumsq; int n_parts = h->n_blocks;
+    if (h->n_blocks > 2048) {                              // very large nets: fold the per-chunk partials first
+        n_parts = (h->n_blocks + 1023) / 1024;
+        hipLaunchKernelGGL(sumsq_fold_kernel, dim3(n_parts), dim3(256), 0, h->stream, h->sumsq, h->n_blocks, h->sumsq2);
+        HIP_OK(h, hipGetLastError());
+        parts = h->sumsq2;
+    }
+    AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
+                h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out, parts, n_parts,
+                h->bf.on ? h->bf.theta_bf : nullptr};
+    hipLaunchKernelGGL(adam_kernel, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
+    HIP_OK(h, hipGetLastError());
+    return 0;
 }
 
 // the per-minibatch launch sequence: fwd+loss+bwd -> weight grads -> reduce [-> all-reduce] -> clip+Adam
@@ -698,12 +734,9 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
             hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
             HIP_OK(h, hipGetLastError());
         }
+        if (enqueue_adam(h, loss_row)) return -1;
         ProfScope ps(h, PK_ADAM);
-        AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
-                    h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out};
-        hipLaunchKernelGGL(adam_kernel, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
-        HIP_OK(h, hipGetLastError());
-        return bf16_refresh_mirrors(h);
+        return bf16_refresh_transposes(h);                 // (adam_kernel itself keeps the straight bf16 copy current)
     }
     {
         ProfScope ps(h, PK_TRAIN_FB);
@@ -750,14 +783,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
         hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
         HIP_OK(h, hipGetLastError());
     }
-    {
-        ProfScope ps(h, PK_ADAM);
-        AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
-                    h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out};
-        hipLaunchKernelGGL(adam_kernel, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
-        HIP_OK(h, hipGetLastError());
-    }
-    return 0;
+    return enqueue_adam(h, loss_row);
 }
 
 int set_hyper(ppo_handle* h, float lr, float cr) {
@@ -844,7 +870,7 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return bail(0); }
     const size_t P = (size_t)h->P_pad;
     if (dev_alloc(h, &h->par, (size_t)2 * h->net.par_total) || dev_alloc(h, &h->thetaT, (size_t)h->PT) || dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||
-        dev_alloc(h, &h->sumsq, (size_t)h->n_blocks) || dev_alloc(h, &h->beta_pow, 4) || dev_alloc(h, &h->hyper, 2) ||
+        dev_alloc(h, &h->sumsq, (size_t)h->n_blocks) || dev_alloc(h, &h->sumsq2, (size_t)(h->n_blocks + 1023) / 1024) || dev_alloc(h, &h->beta_pow, 4) || dev_alloc(h, &h->hyper, 2) ||
         dev_alloc(h, &h->norm_out, 1) || dev_alloc(h, &h->st_loss, 8))
         return bail(0);
     if (upload_grad_src(h)) return bail(0);
@@ -861,7 +887,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->upd_graph) (void)hipGraphExecDestroy(h->upd_graph);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
-    void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
+    void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->sumsq2, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
                     h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->stats_xch, h->stats_part, h->stats_counter, h->adv_xch, h->ro_obs, h->ro_act,
                     h->ro_val, h->ro_nlp, h->ro_done, h->ro_rew, h->ro_ret, h->env_in /* raw_obs, raw_rew, cur_done live inside */, h->raw_done,

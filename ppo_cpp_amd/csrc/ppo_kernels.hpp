@@ -1411,7 +1411,24 @@ struct AdamArgs {
     float beta1, beta2, eps, max_norm;
     float* loss_row;             // [5] destination for this train step (may be null)
     float* norm_out;             // [1] (may be null)
+    const float* norm_parts; int n_parts;   // what the norm is summed from: sumsq itself, or its 1024-wide folds for very large nets
+    __bf16* theta_bf;            // bf16 path: straight bf16 copy of theta kept current here (null otherwise)
 };
+
+// second-level partial sums of the per-chunk sums of squares: with millions of parameters every Adam block re-reading
+// every chunk's partial is hundreds of MB of L2 traffic per step; 1024-wide folds in a fixed order keep the norm
+// reproducible and the re-read a few dozen floats
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* sumsq, int n, float* parts) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, base = blockIdx.x * 1024;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = base + tid + 256 * k; if (i < n) s += sumsq[i]; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) parts[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 
 // One block = 1024 consecutive parameters (4 per thread, 16-byte accesses); n_blocks counts the 256-element chunks the
 // gradient-source table and the partial sums of squares are indexed by.
@@ -1435,7 +1452,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     const float b1p = a.beta_pow[0], b2p = a.beta_pow[1], lr = a.hyper[0];
     // global norm from the per-chunk partial sums, same fixed order in every block (and on every rank)
     float s = 0.f;
-    for (int i = tid; i < a.n_blocks; i += 256) s += a.sumsq[i];
+    for (int i = tid; i < a.n_parts; i += 256) s += a.norm_parts[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
@@ -1456,6 +1473,11 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         *reinterpret_cast<float4*>(a.m + idx) = make_float4(mo[0], mo[1], mo[2], mo[3]);
         *reinterpret_cast<float4*>(a.v + idx) = make_float4(vo[0], vo[1], vo[2], vo[3]);
         *reinterpret_cast<float4*>(a.theta + idx) = make_float4(to[0], to[1], to[2], to[3]);
+        if (a.theta_bf) {
+            typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+            bf16x4_t o4; o4[0] = (__bf16)to[0]; o4[1] = (__bf16)to[1]; o4[2] = (__bf16)to[2]; o4[3] = (__bf16)to[3];
+            *reinterpret_cast<bf16x4_t*>(a.theta_bf + idx) = o4;
+        }
         const int e0 = (int)(idx - (size_t)gs.base);
         if (gs.t_off >= 0) {                               // keep the backward pass's transposed copy current
 #pragma unroll

@@ -96,7 +96,7 @@ def test_bf16_matches_the_fp32_hip_path_over_an_update():
     np.testing.assert_allclose(rb[:, 1], rf[:, 1], rtol=2e-2, err_msg="vf_loss")
     np.testing.assert_allclose(rb[:, 2], rf[:, 2], rtol=1e-4, err_msg="entropy")
     np.testing.assert_allclose(rb[:, 0], rf[:, 0], atol=1e-2, err_msg="pg_loss")
-    np.testing.assert_allclose(rb[:, 3], rf[:, 3], atol=2e-3, err_msg="approxkl")
+    np.testing.assert_allclose(rb[:, 3], rf[:, 3], rtol=1e-2, atol=2e-3, err_msg="approxkl")
     np.testing.assert_allclose(rb[:, 4], rf[:, 4], atol=0.06, err_msg="clipfrac")
     assert cosine(gb.get_flat(0) - orc.theta, gf.get_flat(0) - orc.theta) > 0.9          # the two runs moved the weights the same way
 
