@@ -5,6 +5,7 @@
 #include "../../include/ppo_hip.h"
 #include "ppo_kernels.hpp"
 #include "ppo_bf16.hpp"
+#include "ppo_narrow.hpp"
 
 #include <dlfcn.h>
 
@@ -136,6 +137,12 @@ struct ppo_handle {
         float* dbias = nullptr; int db_off[2][PPO_MAX_LAYERS]{}; int n_dbias = 0;
         DwTileB* dw_tiles = nullptr; int n_dw_tiles = 0; int dw_wm = 4;
     } bf;
+    // narrow-network path (every hidden width <= 64; kernels in ppo_narrow.hpp)
+    bool narrow = false;
+    NwLayout nw{};
+    bool nw_static = false;
+    float* nw_img = nullptr;          // [2][w_total] packed weight images (kept current by adam_kernel / transpose_refresh_kernel)
+    float* nw_partials = nullptr; int nw_groups_cap = 0; int nw_stride = 0;
     // dist
     Rccl rccl;
     void* comm = nullptr;
@@ -349,15 +356,57 @@ int build_layout(ppo_handle* h) {
     return 0;
 }
 
+// LDS image of the narrow path: the tower's weights (both directions) + small parameters, then NW_PIPES sets of tiles
+void build_narrow_layout(ppo_handle* h) {
+    const NetDev& n = h->net;
+    h->narrow = false;
+    if (h->bf.on || n.L > NW_MAXL || n.Kp0 > 64 || n.Ap > 64) return;
+    for (int l = 0; l < n.L; ++l) if (n.Hp[l] > 64) return;
+    const char* off = getenv("PPO_HIP_NO_NARROW");
+    if (off && off[0] == '1') return;
+    NwLayout lay{};
+    int o = 0;
+    auto region = [&](int rows, int cols, int pad, int& dst, int& ld) { dst = o; ld = cols + pad; o += rows * (cols + pad); };
+    int dummy;
+    for (int l = 0; l < n.L; ++l) region(l ? n.Hp[l - 1] : n.Kp0, n.Hp[l], NW_WPAD, lay.wf[l], lay.wf_ld[l]);
+    region(n.Hp[n.L - 1], n.Ap, NW_WPAD, lay.wh, lay.wh_ld);
+    region(1, n.par_total, 0, lay.par, dummy);
+    lay.w_fwd = ru(o, 4); o = lay.w_fwd;
+    for (int l = 1; l < n.L; ++l) region(n.Hp[l], n.Hp[l - 1], NW_WPAD, lay.wt[l], lay.wt_ld[l]);
+    region(n.Ap, n.Hp[n.L - 1], NW_WPAD, lay.wht, lay.wht_ld);
+    lay.w_total = ru(o, 4);
+    int p = 0;
+    lay.x[0] = p; lay.ldx[0] = n.Kp0 + NW_XPAD; p += 16 * lay.ldx[0];
+    for (int l = 0; l < n.L; ++l) { lay.x[l + 1] = p; lay.ldx[l + 1] = n.Hp[l] + NW_XPAD; p += 16 * lay.ldx[l + 1]; }
+    for (int l = 0; l < n.L; ++l) { lay.dy[l] = p; lay.ldy[l] = n.Hp[l] + NW_XPAD; p += 16 * lay.ldy[l]; }
+    lay.ldm = n.Ap + NW_XPAD;
+    lay.mu = p; p += 16 * lay.ldm;
+    lay.dmu = p; p += 16 * lay.ldm;
+    lay.acts = p; p += 16 * n.Ap;
+    lay.dls = p; p += 16 * n.Ap;
+    lay.rowv = p; p += 32;
+    lay.misc = p; p += 64;
+    lay.pipe_total = ru(p, 4);
+    lay.lds_total = lay.w_total + NW_PIPES * lay.pipe_total;
+    if ((size_t)lay.lds_total * sizeof(float) > 160 * 1024) return;
+    h->nw = lay;
+    h->nw_stride = ru(h->P_pad + 8, 64);
+    // compile-time shape of the reference's own network (18 obs / 18 act padded to 32, [64,64]); anything else runs the
+    // runtime-shape instantiation
+    h->nw_static = n.L == 2 && n.Kp0 == 32 && n.Ap == 32 && n.Hp[0] == 64 && n.Hp[1] == 64;
+    h->narrow = true;
+}
+
 int upload_grad_src(ppo_handle* h) {
     const NetDev& n = h->net;
     std::vector<GradSrc> src(h->n_blocks);
     for (const Tensor& t : h->tensors) {
-        GradSrc g{2, 0, 0, 0, t.off_pad, -1, t.prow, t.pcol, -1, 0};
+        GradSrc g{2, 0, 0, 0, t.off_pad, -1, t.prow, t.pcol, -1, 0, -1, 0, -1, 0, -1};
         const std::string nm = t.name;
         int l = -1;
         if (nm.find("_fc") != std::string::npos) l = atoi(nm.c_str() + 5);
         const int tower = nm[0] == 'v' ? 1 : 0;
+        g.tower = tower;
         if (nm.size() > 2 && nm.substr(nm.size() - 2) == "/w" && nm != "vf/w") {
             g.kind = 0;
             if (nm == "pi/w") g.t_off = n.wmuT_off;
@@ -379,6 +428,17 @@ int upload_grad_src(ppo_handle* h) {
             else if (nm == "pi/b") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_head; g.count = n.Ap; }
             else if (nm == "pi/logstd") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_aux; g.count = n.Ap; }
         }
+        g.i_off = g.it_off = g.ip_off = -1; g.i_ld = g.it_ld = 0;
+        if (h->narrow) {
+            const NwLayout& lay = h->nw;
+            const int ib = tower * lay.w_total;
+            const bool is_w = nm.size() > 2 && nm.substr(nm.size() - 2) == "/w";
+            if (is_w && l >= 0) {
+                g.i_off = ib + lay.wf[l]; g.i_ld = lay.wf_ld[l];
+                if (l >= 1) { g.it_off = ib + lay.wt[l]; g.it_ld = lay.wt_ld[l]; }
+            } else if (nm == "pi/w") { g.i_off = lay.wh; g.i_ld = lay.wh_ld; g.it_off = lay.wht; g.it_ld = lay.wht_ld; }
+            else if (g.p_off >= 0) g.ip_off = ib + lay.par + (g.p_off - tower * n.par_total);
+        }
         const int nb = ru(t.prow * t.pcol, 256) / 256;
         for (int b = 0; b < nb; ++b) src[t.off_pad / 256 + b] = g;
     }
@@ -391,6 +451,16 @@ int upload_grad_src(ppo_handle* h) {
 int bf16_ensure_ws(ppo_handle* h, int rows);
 int ensure_train_ws(ppo_handle* h, int rows) {
     if (h->bf.on) return bf16_ensure_ws(h, rows);
+    if (h->narrow) {
+        const int groups = (rows + NW_ROWS - 1) / NW_ROWS;
+        if (groups <= h->nw_groups_cap) return 0;
+        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+        if (dev_alloc(h, &h->nw_partials, (size_t)2 * groups * h->nw_stride)) return -1;     // zero-filled: padding elements stay zero
+        h->nw_groups_cap = groups;
+        h->ws_rows = std::max(h->ws_rows, groups * NW_ROWS);
+        return 0;
+    }
     rows = ru(rows, 16);
     if (rows <= h->ws_rows) return 0;
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
@@ -665,6 +735,16 @@ void launch_step_t(ppo_handle* h, const StepArgs& a) {
 int launch_step(ppo_handle* h, const StepArgs& a) {
     if (h->bf.on) return launch_step_bf16(h, a);
     ProfScope ps(h, PK_STEP);
+    if (h->narrow) {
+        dim3 grid((a.n + NW_ROWS - 1) / NW_ROWS, 2);
+        StepArgs sa = a;
+        sa.theta = h->nw_img;                                  // the packed weight image stands in for the padded parameter vector
+        const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
+        if (h->nw_static) hipLaunchKernelGGL((narrow_step_kernel<32, 64, 32, 2>), grid, dim3(NW_THREADS), lds, h->stream, h->net, h->nw, sa);
+        else hipLaunchKernelGGL((narrow_step_kernel<0, 0, 0, 0>), grid, dim3(NW_THREADS), lds, h->stream, h->net, h->nw, sa);
+        HIP_OK(h, hipGetLastError());
+        return 0;
+    }
     if (h->net.wide) { if (h->CT == 4) launch_step_t<4, 2, 0, true>(h, a); else launch_step_t<1, 1, 0, true>(h, a); }
     else if (h->CT == 4 && h->CTH == 2) launch_step_t<4, 2, 2, false>(h, a);
     else if (h->CT == 4) launch_step_t<4, 2, 0, false>(h, a);
@@ -680,10 +760,10 @@ int pick_split(ppo_handle* h, int n) {
 }
 
 // clip + Adam on the assembled gradient (after the optional all-reduce)
-int enqueue_adam(ppo_handle* h, float* loss_row) {
+int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0) {      // n_sumsq: entries of h->sumsq (0 = one per 256-element chunk)
     ProfScope ps(h, PK_ADAM);
-    const float* parts = h->sumsq; int n_parts = h->n_blocks;
-    if (h->n_blocks > 2048) {                              // very large nets: fold the per-chunk partials first
+    const float* parts = h->sumsq; int n_parts = n_sumsq ? n_sumsq : h->n_blocks;
+    if (!n_sumsq && h->n_blocks > 2048) {                  // very large nets: fold the per-chunk partials first
         n_parts = (h->n_blocks + 1023) / 1024;
         hipLaunchKernelGGL(sumsq_fold_kernel, dim3(n_parts), dim3(256), 0, h->stream, h->sumsq, h->n_blocks, h->sumsq2);
         HIP_OK(h, hipGetLastError());
@@ -691,7 +771,7 @@ int enqueue_adam(ppo_handle* h, float* loss_row) {
     }
     AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
                 h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out, parts, n_parts,
-                h->bf.on ? h->bf.theta_bf : nullptr};
+                h->bf.on ? h->bf.theta_bf : nullptr, h->narrow ? h->nw_img : nullptr};
     hipLaunchKernelGGL(adam_kernel, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -711,10 +791,45 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
         ta.slots[t] = h->slots[t];
         for (int l = 0; l < n.L; ++l) { ta.hg[t][l] = h->hg[t][l]; ta.dyg[t][l] = h->dyg[t][l]; }
     }
+    if (h->narrow) {
+        const int groups = (ta.n + NW_ROWS - 1) / NW_ROWS;
+        {
+            ProfScope ps(h, PK_TRAIN_FB);
+            NwTrainArgs na{h->nw_img, ta.obs, ta.actions, ta.advs, ta.returns, ta.old_values, ta.old_neglogp, h->hyper, ta.n, ta.inv_n,
+                           h->nw_partials, groups, h->nw_stride, nullptr};
+#ifdef PPO_STAMPS
+            if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+            na.stamps = g_stamps;
+#endif
+            const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
+            if (h->nw_static) hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na);
+            else hipLaunchKernelGGL((narrow_train_kernel<0, 0, 0, 0>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na);
+            HIP_OK(h, hipGetLastError());
+        }
+        const int n_chunks = h->P_pad / 64;
+        {
+            ProfScope ps(h, PK_REDUCE);
+            NwReduceArgs ra{h->grad_src, n_chunks, h->nw_partials, groups, h->nw_stride, h->P_pad, h->grad, h->sumsq, (float)ta.n, h->beta_pow};
+            hipLaunchKernelGGL(narrow_reduce_kernel, dim3(n_chunks + 1), dim3(256), 0, h->stream, ra);
+            HIP_OK(h, hipGetLastError());
+        }
+        if (h->comm) {
+            ProfScope ps(h, PK_COMM);
+            const size_t cnt = (size_t)h->P_pad + 8;
+            const int rc = h->rccl.AllReduce(h->grad, h->grad, cnt, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
+            if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
+            hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
+            HIP_OK(h, hipGetLastError());
+            return enqueue_adam(h, loss_row);
+        }
+        return enqueue_adam(h, loss_row, n_chunks);
+    }
     if (h->bf.on) {
         const int Rp = ru(ta.n, GB_PAD);
+        // row splits of the weight-gradient GEMM: just enough workgroups for two rounds on 256 CUs -- every extra split is
+        // another P_pad floats of slab written and read back (HBM write bandwidth, not the matrix cores, prices it)
         int nsplit = 1;
-        while (nsplit < h->max_split && nsplit < 4 && (Rp / (2 * nsplit)) % GB_K == 0 && Rp / (2 * nsplit) >= 512) nsplit *= 2;
+        while (nsplit < h->max_split && h->bf.n_dw_tiles * nsplit < 512 && (Rp / (2 * nsplit)) % GB_K == 0 && Rp / (2 * nsplit) >= 256) nsplit *= 2;
         { ProfScope ps(h, PK_TRAIN_FB); if (bf16_train_fwd_bwd(h, ta, Rp)) return -1; }
         { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, Rp, nsplit)) return -1; }
         {
@@ -870,11 +985,20 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return bail(0); }
     const size_t P = (size_t)h->P_pad;
     if (dev_alloc(h, &h->par, (size_t)2 * h->net.par_total) || dev_alloc(h, &h->thetaT, (size_t)h->PT) || dev_alloc(h, &h->theta, P) || dev_alloc(h, &h->adam_m, P) || dev_alloc(h, &h->adam_v, P) || dev_alloc(h, &h->grad, P + 256) ||
-        dev_alloc(h, &h->sumsq, (size_t)h->n_blocks) || dev_alloc(h, &h->sumsq2, (size_t)(h->n_blocks + 1023) / 1024) || dev_alloc(h, &h->beta_pow, 4) || dev_alloc(h, &h->hyper, 2) ||
+        dev_alloc(h, &h->sumsq, (size_t)4 * h->n_blocks) || dev_alloc(h, &h->sumsq2, (size_t)(h->n_blocks + 1023) / 1024) || dev_alloc(h, &h->beta_pow, 4) || dev_alloc(h, &h->hyper, 2) ||
         dev_alloc(h, &h->norm_out, 1) || dev_alloc(h, &h->st_loss, 8))
         return bail(0);
+    build_narrow_layout(h);
     if (upload_grad_src(h)) return bail(0);
     if (h->bf.on && bf16_create(h)) return bail(0);
+    if (h->narrow) {
+        attr_ok = hipFuncSetAttribute((const void*)narrow_train_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_train_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
+        if (dev_alloc(h, &h->nw_img, (size_t)2 * h->nw.w_total)) return bail(0);
+    }
     const float pw[2] = {cfg->adam_beta1, cfg->adam_beta2};
     if (ppo_set_beta_powers(h, pw)) return bail(0);
     *out = h;
@@ -887,6 +1011,8 @@ void ppo_destroy(ppo_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->upd_graph) (void)hipGraphExecDestroy(h->upd_graph);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    if (h->nw_partials) (void)hipFree(h->nw_partials);
+    if (h->nw_img) (void)hipFree(h->nw_img);
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->sumsq2, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
                     h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->stats_xch, h->stats_part, h->stats_counter, h->adv_xch, h->ro_obs, h->ro_act,
@@ -942,7 +1068,7 @@ int ppo_set_tensor(ppo_handle* h, int which, int index, const float* src, int64_
     HIP_OK(h, hipStreamSynchronize(h->stream));
     if (copy_tensor(h, base, t, const_cast<float*>(src), true)) return -1;
     if (which == 0) {
-        hipLaunchKernelGGL(transpose_refresh_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->theta, h->thetaT, h->par, h->grad_src);
+        hipLaunchKernelGGL(transpose_refresh_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->theta, h->thetaT, h->par, h->grad_src, h->narrow ? h->nw_img : nullptr);
         HIP_OK(h, hipGetLastError());
         if (h->bf.on && bf16_refresh_mirrors(h)) return -1;
     }

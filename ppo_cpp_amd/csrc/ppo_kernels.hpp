@@ -1309,7 +1309,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void weight_grad_kernel(DwArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 struct GradSrc { int kind; int tower; int slot_off; int count; int base;   // base = first element of the tensor
                  int t_off, prow, pcol;                                       // transposed copy: thetaT[t_off + c*prow + r], t_off < 0: none
-                 int p_off, p_count; };                                       // small-parameter mirror: par[p_off + e], e < p_count ; p_off < 0: none
+                 int p_off, p_count;                                          // small-parameter mirror: par[p_off + e], e < p_count ; p_off < 0: none
+                 // narrow path: packed LDS images (one per tower, [2][img_stride]) of the weights in exactly the layout its kernels
+                 // copy into LDS; a tensor's element (r, c) lives at img[i_off + r*i_ld + c] (forward copy), img[it_off + c*it_ld + r]
+                 // (transposed copy) and a small parameter e at img[ip_off + e]; < 0: none
+                 int i_off, i_ld, it_off, it_ld, ip_off; };
 
 struct ReduceArgs {
     const GradSrc* src;          // [n_blocks]
@@ -1378,12 +1382,22 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
 }
 
 // rebuild every transposed copy from theta (after parameters were written from the host)
-__global__ __launch_bounds__(256) void transpose_refresh_kernel(const float* theta, float* thetaT, float* par, const GradSrc* src) {
+__device__ __forceinline__ void write_images(const GradSrc& gs, float* img, int e, float x) {
+    if (gs.ip_off >= 0) { if (e < gs.p_count) img[gs.ip_off + e] = x; return; }
+    if ((gs.i_off >= 0 || gs.it_off >= 0) && e < gs.prow * gs.pcol) {
+        const int r = e / gs.pcol, c = e - r * gs.pcol;
+        if (gs.i_off >= 0) img[gs.i_off + r * gs.i_ld + c] = x;
+        if (gs.it_off >= 0) img[gs.it_off + c * gs.it_ld + r] = x;
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_refresh_kernel(const float* theta, float* thetaT, float* par, const GradSrc* src, float* img) {
     const GradSrc gs = src[blockIdx.x];
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int e = (int)(idx - (size_t)gs.base);
     if (gs.t_off >= 0 && e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; thetaT[gs.t_off + c * gs.prow + r] = theta[idx]; }
     if (gs.p_off >= 0 && e < gs.p_count) par[gs.p_off + e] = theta[idx];
+    if (img) write_images(gs, img, e, theta[idx]);
 }
 
 // after a cross-rank all-reduce of grad the per-block sums of squares must be recomputed
@@ -1413,6 +1427,7 @@ struct AdamArgs {
     float* norm_out;             // [1] (may be null)
     const float* norm_parts; int n_parts;   // what the norm is summed from: sumsq itself, or its 1024-wide folds for very large nets
     __bf16* theta_bf;            // bf16 path: straight bf16 copy of theta kept current here (null otherwise)
+    float* img;                  // narrow path: packed LDS images kept current here (null otherwise)
 };
 
 // second-level partial sums of the per-chunk sums of squares: with millions of parameters every Adam block re-reading
@@ -1489,6 +1504,10 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         if (gs.p_off >= 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (e0 + k < gs.p_count) a.par[gs.p_off + e0 + k] = to[k];
+        }
+        if (a.img) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) write_images(gs, a.img, e0 + k, to[k]);
         }
     }
     if (blockIdx.x == 0) {

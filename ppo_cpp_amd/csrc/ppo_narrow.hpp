@@ -1,0 +1,519 @@
+// ppo_narrow.hpp -- dedicated kernels for NARROW networks (every hidden width <= 64: the reference's real shape
+// [64,64], ppo2.cpp:114; BASELINE configs[1] and [3]).  gfx950 only.
+//
+// At these widths a whole tower (both directions: W_l and the transposed copies the backward pass multiplies by) is
+// 45 KB: it is copied into LDS ONCE per workgroup with every load issued before the first LDS store (one memory round
+// trip), and every matrix instruction of the step then takes its B operand from LDS.  Nothing streams, nothing waits on
+// memory between layers, and the activations / gradients a row tile produces never leave LDS, so the weight gradients are
+// formed in the same workgroup (dW = X^T dY over its 32 rows, 8 k-steps of v_mfma_f32_16x16x4_f32 per 16x16 tile) and
+// leave as ONE partial gradient vector per workgroup.  The four-kernel sequence of the wide nets (A: forward/backward with
+// X_l / dY_l workspaces, B: weight gradients, C1: slabs + slots, C2: Adam) becomes: narrow_train_kernel ->
+// narrow_reduce_kernel -> adam_kernel.  Same arithmetic, same operation order per row as train_fwd_bwd_kernel (exact fp32
+// MFMA, k-ordered); the reduction over row tiles is again a fixed-order sum, so results are bitwise reproducible.
+//
+// Reference arithmetic replaced: G:6889-23699 (train forward, loss, backward incl. the .../MatMul_grad/MatMul_1 and
+// .../Add_grad/Sum_1 nodes), G:1859-6866 (act model), ppo2/policies.hpp:33-77.
+#pragma once
+
+#include "ppo_kernels.hpp"
+
+#define NW_MAXL 4                  // hidden layers the narrow path accepts
+#define NW_PIPES 2                 // 16-row tiles per workgroup (4 waves each)
+#define NW_THREADS (256 * NW_PIPES)
+#define NW_ROWS (16 * NW_PIPES)
+#define NW_WPAD 16                 // LDS row padding of the weight images: B-operand reads of the 4 k-groups hit disjoint banks
+#define NW_XPAD 4                  // row padding of the activation tiles
+
+// LDS layout.  The weight image (identical layout for both towers) is kept PACKED in global memory by adam_kernel /
+// transpose_refresh_kernel (GradSrc::i_off ...), so the prologue is one flat copy: [forward matrices | policy head |
+// small parameters | transposed matrices | transposed head].  The act kernel copies the first `w_fwd` floats only.
+struct NwLayout {
+    int wf[NW_MAXL], wf_ld[NW_MAXL];         // forward weights  [K_l][Hp_l + pad]
+    int wt[NW_MAXL], wt_ld[NW_MAXL];         // transposed copies W_l^T [Hp_l][Hp_{l-1} + pad], l >= 1
+    int wh, wh_ld, wht, wht_ld;              // policy head [HpL][Ap + pad] and its transpose [Ap][HpL + pad]
+    int par;                                  // small parameters, indexed with NetDev::par_* offsets
+    int w_fwd;                                // floats the act kernel needs (multiple of 4)
+    int w_total;                              // floats of the whole image (multiple of 4) = image stride between the towers
+    // per-pipe tiles (offsets relative to the pipe's base)
+    int x[NW_MAXL + 1]; int ldx[NW_MAXL + 1]; // x[0] = input tile, x[l+1] = h_{l+1}
+    int dy[NW_MAXL]; int ldy[NW_MAXL];        // dLoss/d(pre-activation of layer l)
+    int mu, ldm, dmu, acts, dls, rowv, misc;
+    int pipe_total;
+    int lds_total;                            // floats: w_total + NW_PIPES * pipe_total
+};
+
+struct NwTrainArgs {
+    const float* img;              // [2][w_total] packed weight images
+    const float* obs; const float* actions; const float* advs; const float* returns; const float* old_values; const float* old_neglogp;
+    const float* hyper;            // {lr, cliprange}
+    int n; float inv_n;
+    float* partials;               // [2 towers][n_groups][part_stride]; a workgroup writes its tower's tensors + 8 tail floats
+    int n_groups; int part_stride;
+    unsigned long long* stamps;    // diagnostic builds only (-DPPO_STAMPS): [workgroups][32] cycle stamps
+};
+#ifdef PPO_STAMPS
+#define NSTAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NSTAMP(i) do { } while (0)
+#endif
+
+// Compile-time shape of a kernel instantiation: <KP0, HP, AP, L> (every hidden layer HP wide); all zero = runtime shape
+// (any widths <= 64 that are multiples of 16).  With constants every loop below unrolls, the LDS reads of a product are
+// all issued before its first matrix instruction and tile offsets fold into immediates.
+template <int KP0_, int HP_, int AP_, int L_>
+struct NwShape {
+    static constexpr bool fixed = L_ > 0;
+    __device__ static __forceinline__ int L(const NetDev& n) { return fixed ? L_ : n.L; }
+    __device__ static __forceinline__ int Kp0(const NetDev& n) { return fixed ? KP0_ : n.Kp0; }
+    __device__ static __forceinline__ int Ap(const NetDev& n) { return fixed ? AP_ : n.Ap; }
+    __device__ static __forceinline__ int Hp(const NetDev& n, int l) { return fixed ? HP_ : n.Hp[l]; }
+};
+
+// Y[16 x Np] (this pipe) = X[16 x K] * W[K x Np], W in LDS; wave w of the pipe takes the 16-column tiles w, w+4, ...
+// acc register r of lane (g = lane >> 4, c = lane & 15) = Y[4g + r][n0 + c].  CK > 0: compile-time depth, every operand
+// read issued first, four interleaved accumulator chains (the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 is
+// hidden and the result is ((c0 + c1) + (c2 + c3)): fp32 reassociation of the k-ordered sum, nothing else).
+template <int CK, class Ep>
+__device__ __forceinline__ void nw_dense(const float* Xs, int ldx, int K, const float* Ws, int ldw, int Np, Ep&& ep) {
+    const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;
+    const int g = lane >> 4, c = lane & 15;
+    for (int n0 = 16 * w; n0 < Np; n0 += 64) {
+        const float* xp = Xs + c * ldx + g;
+        const float* wp = Ws + g * ldw + n0 + c;
+        f32x4 acc;
+        if constexpr (CK > 0) {
+            float xa[CK / 4], wb[CK / 4];
+#pragma unroll
+            for (int s = 0; s < CK / 4; ++s) { xa[s] = xp[4 * s]; wb[s] = wp[4 * s * ldw]; }
+            f32x4 ch[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ch[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < CK / 4; ++s) ch[s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wb[s], ch[s & 3], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = (ch[0][r] + ch[1][r]) + (ch[2][r] + ch[3][r]);
+        } else {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            int kb = 0;
+            for (; kb + 8 <= K; kb += 8) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[kb], wp[kb * ldw], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[kb + 4], wp[(kb + 4) * ldw], a1, 0, 0, 0);
+            }
+            for (; kb < K; kb += 4) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[kb], wp[kb * ldw], a0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = a0[r] + a1[r];
+        }
+        ep(acc, g, n0 + c);
+    }
+}
+
+// block prologue: the tower's packed weight image (flat copy) + this workgroup's rows, every global load issued before the
+// first LDS store: one memory round trip
+template <class S>
+__device__ __forceinline__ void nw_stage(const NetDev& net, const NwLayout& lay, const float* __restrict__ img, int n_img, float* lds,
+                                         const float* __restrict__ obs, int row0, int nrows, ObsNorm nz, float* __restrict__ obs_out, int tower,
+                                         const float* __restrict__ actions, const float* __restrict__ v0, const float* __restrict__ v1, int mode) {
+    const int tid = threadIdx.x;
+    constexpr int WV = 8;                                   // float4 loads per thread: 8 * 512 * 16 B = 64 KB covers the image
+    float4 wv[WV];
+    const int n4 = n_img / 4;
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+        const int e = tid + NW_THREADS * k;
+        wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < n4) wv[k] = reinterpret_cast<const float4*>(img)[e];
+    }
+    constexpr int OV = 2;
+    float ov[OV], av[OV], r0 = 0.f, r1 = 0.f;
+    const int O = net.O, A = net.A, Kp0 = S::Kp0(net), Ap = S::Ap(net);
+#pragma unroll
+    for (int k = 0; k < OV; ++k) {
+        const int i = tid + NW_THREADS * k;
+        const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
+        ov[k] = 0.f;
+        if (i < NW_ROWS * Kp0 && row < nrows && j < O) ov[k] = obs[(size_t)row * O + j];
+    }
+    if (mode == 1) {
+#pragma unroll
+        for (int k = 0; k < OV; ++k) {
+            const int i = tid + NW_THREADS * k;
+            const int r = i / Ap, j = i - r * Ap, row = row0 + r;
+            av[k] = 0.f;
+            if (i < NW_ROWS * Ap && row < nrows && j < A) av[k] = actions[(size_t)row * A + j];
+        }
+    }
+    if (mode && tid < NW_ROWS && row0 + tid < nrows) { r0 = v0[row0 + tid]; r1 = v1[row0 + tid]; }
+    // ---- consume ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+        const int e = tid + NW_THREADS * k;
+        if (e < n4) reinterpret_cast<float4*>(lds)[e] = wv[k];
+    }
+    for (int e = tid + NW_THREADS * WV; e < n4; e += NW_THREADS) reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(img)[e];
+    auto put_obs = [&](int i, float x) __attribute__((always_inline)) {
+        const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
+        if (row < nrows && j < O) {
+            if (nz.enabled) {                                // env_normalize.hpp:99-104
+                x = (x - nz.mean[j]) * (1.0f / sqrtf(nz.var[j] + nz.eps));
+                x = tf_min(tf_max(x, -nz.clip), nz.clip);
+            }
+            if (obs_out && tower == 0) obs_out[(size_t)row * O + j] = x;
+        }
+        lds[lay.w_total + (r >> 4) * lay.pipe_total + lay.x[0] + (r & 15) * lay.ldx[0] + j] = x;
+    };
+#pragma unroll
+    for (int k = 0; k < OV; ++k) { const int i = tid + NW_THREADS * k; if (i < NW_ROWS * Kp0) put_obs(i, ov[k]); }
+    for (int i = tid + NW_THREADS * OV; i < NW_ROWS * Kp0; i += NW_THREADS) {
+        const int r = i / Kp0, j = i - r * Kp0, row = row0 + r;
+        put_obs(i, (row < nrows && j < O) ? obs[(size_t)row * O + j] : 0.f);
+    }
+    if (mode == 1) {
+        auto put_act = [&](int i, float x) __attribute__((always_inline)) {
+            const int r = i / Ap, j = i - r * Ap;
+            lds[lay.w_total + (r >> 4) * lay.pipe_total + lay.acts + (r & 15) * Ap + j] = x;
+        };
+#pragma unroll
+        for (int k = 0; k < OV; ++k) { const int i = tid + NW_THREADS * k; if (i < NW_ROWS * Ap) put_act(i, av[k]); }
+        for (int i = tid + NW_THREADS * OV; i < NW_ROWS * Ap; i += NW_THREADS) {
+            const int r = i / Ap, j = i - r * Ap, row = row0 + r;
+            put_act(i, (row < nrows && j < A) ? actions[(size_t)row * A + j] : 0.f);
+        }
+    }
+    if (mode && tid < NW_ROWS) {
+        const bool live = row0 + tid < nrows;
+        float* rv = lds + lay.w_total + (tid >> 4) * lay.pipe_total + lay.rowv;
+        rv[2 * (tid & 15)] = live ? r0 : 0.f;
+        rv[2 * (tid & 15) + 1] = live ? r1 : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Train step, first launch: forward + loss + backward + weight gradients of 32 rows of ONE tower (blockIdx.y).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int KP0, int HP, int AP, int LL>
+__global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, NwLayout lay, NwTrainArgs a) {
+    typedef NwShape<KP0, HP, AP, LL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwTrainArgs)>();
+    const int tower = blockIdx.y, grp = blockIdx.x;
+    const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
+    const int row0 = grp * NW_ROWS;
+    const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
+    NSTAMP(0);
+    nw_stage<S>(net, lay, a.img + (size_t)tower * lay.w_total, lay.w_total, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
+                a.actions, tower == 0 ? a.advs : a.returns, tower == 0 ? a.old_neglogp : a.old_values, tower == 0 ? 1 : 2);
+    __syncthreads();
+    NSTAMP(1);
+    float* P = lds + lay.w_total + pipe * lay.pipe_total;            // this pipe's tiles
+    const float* par = lds + lay.par;
+    // ---- forward (G:6889-9187) -----------------------------------------------------------------------------------------
+    for (int l = 0; l < L; ++l) {
+        const float* bias = par + net.par_b[l];
+        float* Ys = P + lay.x[l + 1]; const int ldy = lay.ldx[l + 1];
+        auto ep = [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+            const float b = bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ys[(4 * g + r) * ldy + col] = fast_tanh(acc[r] + b);
+        };
+        if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
+        else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+        __syncthreads();
+        NSTAMP(2 + l);
+    }
+    const float* hL = P + lay.x[L]; const int ldh = lay.ldx[L]; const int HpL = S::Hp(net, L - 1);
+    const float cr = a.hyper[1];
+    const int r = ptid >> 4, part = ptid & 15;
+    const int row = row0 + 16 * pipe + r;
+    const bool live = row < a.n;
+    float* misc = P + lay.misc;
+    float* dls = P + lay.dls; float* acts = P + lay.acts; float* rowv = P + lay.rowv;
+    float* dYtop = P + lay.dy[L - 1]; const int ldt = lay.ldy[L - 1];
+    if (tower == 0) {
+        // ---- policy head + surrogate loss (G:9428-11290) and its gradient (G:12609-22656) ----------------------------
+        float* mus = P + lay.mu; const int ldm = lay.ldm;
+        nw_dense<HP>(hL, ldh, HpL, lds + lay.wh, lay.wh_ld, Ap, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+            const float b = par[net.par_bmu + col];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mus[(4 * g + q) * ldm + col] = acc[q] + b;
+        });
+        __syncthreads();
+        NSTAMP(6);
+        float ssq = 0.f, slog = 0.f, sent = 0.f;
+        for (int j = part; j < net.A; j += 16) {
+            const float mu = mus[r * ldm + j];
+            const float logstd = mu * 0.0f + par[net.par_ls + j];
+            const float act = live ? acts[r * Ap + j] : mu;
+            const float z = (act - mu) / expf(logstd);
+            ssq += z * z; slog += logstd; sent += logstd + HALF_LOG_2PIE;
+        }
+        ssq = group16_sum(ssq); slog = group16_sum(slog); sent = group16_sum(sent);
+        const float nlp = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
+        const float adv = live ? rowv[2 * r] : 0.f;
+        const float old_nlp = live ? rowv[2 * r + 1] : nlp;
+        const float lo = 1.0f - cr, hi = 1.0f + cr;
+        const float ratio = expf(old_nlp - nlp);
+        const float rmin = tf_min(ratio, hi);
+        const float rclip = tf_max(rmin, lo);
+        const float m1 = -adv * ratio, m2 = -adv * rclip;
+        const float gg = a.inv_n;
+        const float sel = (m1 >= m2) ? 1.0f : 0.0f;                                       // G:12609
+        const float pass = ((rmin >= lo) ? 1.0f : 0.0f) * ((ratio <= hi) ? 1.0f : 0.0f);  // G:15357, 16113
+        float d_ratio = (-adv) * gg * sel;
+        d_ratio += (-adv) * gg * (1.0f - sel) * pass;
+        const float d_nlp = live ? -(d_ratio * ratio) : 0.0f;
+        if (part == 0) {
+            const float dk = nlp - old_nlp;
+            misc[r * 4 + 0] = live ? tf_max(m1, m2) : 0.f;
+            misc[r * 4 + 1] = live ? sent : 0.f;
+            misc[r * 4 + 2] = live ? dk * dk : 0.f;
+            misc[r * 4 + 3] = (live && fabsf(ratio - 1.0f) > cr) ? 1.0f : 0.f;
+        }
+        float* dmu_t = P + lay.dmu;
+        for (int j = part; j < Ap; j += 16) {
+            float dmu = 0.f, dl = 0.f;
+            if (j < net.A && live) {
+                const float mu = mus[r * ldm + j];
+                const float sigma = expf(mu * 0.0f + par[net.par_ls + j]);
+                const float z = (acts[r * Ap + j] - mu) / sigma;
+                dl = d_nlp * (1.0f - z * z) - net.ent_coef * gg;                          // AddN_2 G:21299
+                dmu = d_nlp * (-(z / sigma)) + dl * 0.0f;                                 // AddN_3 G:22656
+            }
+            dmu_t[r * ldm + j] = dmu;
+            dls[r * Ap + j] = dl;
+        }
+        __syncthreads();
+        NSTAMP(7);
+        // dh_L = (dmu * W_mu^T) .* (1 - h_L^2)
+        nw_dense<AP>(dmu_t, ldm, Ap, lds + lay.wht, lay.wht_ld, HpL, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float h = hL[(4 * g + q) * ldh + col]; dYtop[(4 * g + q) * ldt + col] = acc[q] * (1.0f - h * h); }
+        });
+    } else {
+        // ---- value head + clipped value loss (G:10213-10837) and its gradient (G:14975-19571) ------------------------
+        const float* wv = par + net.par_wv;
+        float s = 0.f;
+        for (int k = part; k < HpL; k += 16) s = fmaf(hL[r * ldh + k], wv[k], s);
+        s = group16_sum(s);
+        const float v = s + par[net.par_bv];
+        float dv = 0.f, lossv = 0.f;
+        if (live) {
+            const float R = rowv[2 * r], vo = rowv[2 * r + 1];
+            const float dvo = v - vo;
+            const float vmin = tf_min(dvo, cr);
+            const float vclip = vo + tf_max(vmin, -cr);
+            const float e1 = v - R, e2 = vclip - R;
+            const float s1 = e1 * e1, s2 = e2 * e2;
+            lossv = tf_max(s1, s2);
+            const float gv = net.vf_coef * 0.5f * a.inv_n;
+            const float selv = (s1 >= s2) ? 1.0f : 0.0f;                                       // G:14975
+            const float passv = ((vmin >= -cr) ? 1.0f : 0.0f) * ((dvo <= cr) ? 1.0f : 0.0f);   // G:17477, 18071
+            dv = gv * selv * (2.0f * e1) + gv * (1.0f - selv) * (2.0f * e2) * passv;           // AddN_1 G:19571
+        }
+        if (part == 0) { misc[r] = dv; misc[16 + r] = lossv; }
+        __syncthreads();
+        for (int i = ptid; i < 16 * HpL; i += 256) {                  // dh_L = dv (x) w_v .* (1 - h_L^2)
+            const int q = i / HpL, k = i - q * HpL;
+            const float h = hL[q * ldh + k];
+            dYtop[q * ldt + k] = (misc[q] * wv[k]) * (1.0f - h * h);
+        }
+    }
+    __syncthreads();
+    NSTAMP(8);
+    // ---- hidden layers, top down ---------------------------------------------------------------------------------------
+    for (int l = L - 1; l >= 1; --l) {
+        const float* hl = P + lay.x[l]; const int ldhl = lay.ldx[l];
+        float* dn = P + lay.dy[l - 1]; const int ldn = lay.ldy[l - 1];
+        nw_dense<HP>(P + lay.dy[l], lay.ldy[l], S::Hp(net, l), lds + lay.wt[l], lay.wt_ld[l], S::Hp(net, l - 1),
+                     [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+#pragma unroll
+                         for (int q = 0; q < 4; ++q) { const float h = hl[(4 * g + q) * ldhl + col]; dn[(4 * g + q) * ldn + col] = acc[q] * (1.0f - h * h); }
+                     });
+        __syncthreads();
+    }
+    NSTAMP(9);
+    // ---- gradients of this workgroup's 32 rows: one partial vector ------------------------------------------------------
+    float* out = a.partials + ((size_t)tower * a.n_groups + grp) * a.part_stride;
+    const float* PB = lds + lay.w_total;                              // pipe q's tiles at PB + q * pipe_total
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    constexpr int NWV = NW_THREADS / 64;
+    // dW = X^T dY: tile (i0, j0), reduction over the NW_ROWS rows: k-step s covers rows 4s .. 4s+3 (pipe = s >> 2).  A wave
+    // walks tiles t = wave, wave + 8, ... of the concatenated tile list of all matrices (balanced: 32 tiles at [64,64]).
+    auto dw_mat = [&](int xoff, int ldx_, int Kd, int yoff, int ldy_, int Nd, int out_off, int ldo, int first_tile) __attribute__((always_inline)) {
+        const int tj = Nd / 16, nt = (Kd / 16) * tj;
+        for (int t = (wave + NWV - (first_tile % NWV)) % NWV; t < nt; t += NWV) {
+            const int i0 = (t / tj) * 16, j0 = (t % tj) * 16;
+            float xa[4 * NW_PIPES], yb[4 * NW_PIPES];
+#pragma unroll
+            for (int s = 0; s < 4 * NW_PIPES; ++s) {
+                const float* p = PB + (s >> 2) * lay.pipe_total;
+                const int m = 4 * (s & 3) + g;
+                xa[s] = p[xoff + m * ldx_ + i0 + c]; yb[s] = p[yoff + m * ldy_ + j0 + c];
+            }
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4 * NW_PIPES; s += 2) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], yb[s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s + 1], yb[s + 1], a1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[out_off + (i0 + 4 * g + q) * ldo + j0 + c] = a0[q] + a1[q];
+        }
+        return first_tile + nt;
+    };
+    int ft = 0;
+    for (int l = 0; l < L; ++l)
+        ft = dw_mat(lay.x[l], lay.ldx[l], l ? S::Hp(net, l - 1) : Kp0, lay.dy[l], lay.ldy[l], S::Hp(net, l), net.w_off[tower][l], S::Hp(net, l), ft);
+    if (tower == 0) ft = dw_mat(lay.x[L], lay.ldx[L], HpL, lay.dmu, lay.ldm, Ap, net.wmu_off, Ap, ft);
+    NSTAMP(10);
+    // vectors: one per WAVE, lanes = elements, the NW_ROWS rows added in index order (fixed order, all reads independent)
+    auto colsum = [&](int off, int ld_, int j) __attribute__((always_inline)) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW_ROWS; ++q) s += PB[(q >> 4) * lay.pipe_total + off + (q & 15) * ld_ + j];
+        return s;
+    };
+    const int vec = (wave + NWV - (ft % NWV)) % NWV;                  // continue the round robin after the matrix tiles
+    if (vec < L) { if (lane < S::Hp(net, vec)) out[net.b_off[tower][vec] + lane] = colsum(lay.dy[vec], lay.ldy[vec], lane); }
+    if (tower == 0) {
+        if (vec == L) { if (lane < Ap) out[net.bmu_off + lane] = colsum(lay.dmu, lay.ldm, lane); }
+        if (vec == L + 1) { if (lane < Ap) out[net.ls_off + lane] = colsum(lay.dls, Ap, lane); }
+        if (vec == L + 2 && lane < 4) out[net.n_theta + lane] = colsum(lay.misc, 4, lane);       // pg, entropy, kl, clipfrac sums
+    } else {
+        if (vec == L && lane < HpL) {                                 // dW_v[k] = sum_rows h_L[row,k] * dv[row]
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW_ROWS; ++q) { const float* pq = PB + (q >> 4) * lay.pipe_total; s = fmaf(pq[lay.x[L] + (q & 15) * ldh + lane], pq[lay.misc + (q & 15)], s); }
+            out[net.wv_off + lane] = s;
+        }
+        if (vec == L + 1 && lane < 2) {                               // lane 0: db_v = sum dv ; lane 1: sum of max((v-R)^2, (vclip-R)^2)
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW_ROWS; ++q) s += PB[(q >> 4) * lay.pipe_total + lay.misc + 16 * lane + (q & 15)];
+            out[lane == 0 ? net.bv_off : net.n_theta] = s;
+        }
+    }
+    NSTAMP(11);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Gradient assembly for the narrow path: 64 consecutive elements per block, 4 threads per element (each adds a quarter of
+// the row groups in index order, the four meet in a fixed order).  Emits the sum of squares per 64-element chunk for the
+// global norm (adam_kernel sums these `norm_parts`) and, in the last block, the loss tail.
+// ------------------------------------------------------------------------------------------------------------------------
+struct NwReduceArgs {
+    const GradSrc* src; int n_chunks;          // chunks of 64 covering P_pad ; block n_chunks = loss tail
+    const float* partials; int n_groups; int part_stride; int n_theta;
+    float* grad; float* sumsq; float n_local; float* beta_pow;
+};
+
+__global__ __launch_bounds__(256) void narrow_reduce_kernel(NwReduceArgs a) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    if (blk == a.n_chunks) {
+        // tail = {pg, vf, ent, kl, cf, rows}: policy tower holds pg, ent, kl, cf at n_theta + 0..3, value tower vf at n_theta
+        if (tid < 5 * 32) {
+            const int q = tid >> 5, ln = tid & 31;
+            const int tower = (q == 1) ? 1 : 0;
+            const int off = a.n_theta + (q <= 1 ? 0 : q - 1);
+            float s = 0.f;
+            for (int gidx = ln; gidx < a.n_groups; gidx += 32) s += a.partials[((size_t)tower * a.n_groups + gidx) * a.part_stride + off];
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (ln == 0) a.grad[a.n_theta + q] = s;
+        }
+        if (tid == 160) a.grad[a.n_theta + 5] = a.n_local;
+        if (tid == 161) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }
+        return;
+    }
+    const int e = tid >> 2, sub = tid & 3;
+    const int idx = blk * 64 + e;
+    const GradSrc s = a.src[idx >> 8];
+    float sum = 0.f;
+    if (s.kind != 2) {
+        const float* p = a.partials + (size_t)s.tower * a.n_groups * a.part_stride + idx;
+        const int per = (a.n_groups + 3) / 4, g0 = sub * per, g1 = min(a.n_groups, g0 + per);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int gi = g0;
+        for (; gi + 4 <= g1; gi += 4) {
+            s0 += p[(size_t)gi * a.part_stride]; s1 += p[(size_t)(gi + 1) * a.part_stride];
+            s2 += p[(size_t)(gi + 2) * a.part_stride]; s3 += p[(size_t)(gi + 3) * a.part_stride];
+        }
+        for (; gi < g1; ++gi) s0 += p[(size_t)gi * a.part_stride];
+        sum = (s0 + s1) + (s2 + s3);
+    }
+    sum += __shfl_xor(sum, 1);                  // (x0 + x1) + (x2 + x3): identical in all four lanes
+    sum += __shfl_xor(sum, 2);
+    if (sub == 0) a.grad[idx] = sum;
+    float q = (sub == 0) ? sum * sum : 0.f;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) a.sumsq[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Act model for narrow nets: the same forward on 32 rows per workgroup and tower, weights from the packed image.
+// `img` rides in StepArgs::theta (the narrow launch passes the image instead of the padded parameter vector).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int KP0, int HP, int AP, int LL>
+__global__ __launch_bounds__(NW_THREADS) void narrow_step_kernel(NetDev net, NwLayout lay, StepArgs a) {
+    typedef NwShape<KP0, HP, AP, LL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(StepArgs)>();
+    const int tower = blockIdx.y;
+    if (tower == 1 && !a.value) return;
+    if (tower == 0 && !a.action && !a.det_action && !a.neglogp && !a.obs_out) return;
+    const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
+    const int row0 = blockIdx.x * NW_ROWS;
+    const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
+    nw_stage<S>(net, lay, a.theta + (size_t)tower * lay.w_total, lay.w_fwd, lds, a.obs, row0, a.n, a.nz, a.obs_out, tower, nullptr, nullptr, nullptr, 0);
+    __syncthreads();
+    float* P = lds + lay.w_total + pipe * lay.pipe_total;
+    const float* par = lds + lay.par;
+    for (int l = 0; l < L; ++l) {
+        const float* bias = par + net.par_b[l];
+        float* Ys = P + lay.x[l + 1]; const int ldy = lay.ldx[l + 1];
+        auto ep = [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+            const float b = bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ys[(4 * g + r) * ldy + col] = fast_tanh(acc[r] + b);
+        };
+        if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
+        else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+        __syncthreads();
+    }
+    const float* hL = P + lay.x[L]; const int ldh = lay.ldx[L]; const int HpL = S::Hp(net, L - 1);
+    const int r = ptid >> 4, part = ptid & 15;
+    const int row = row0 + 16 * pipe + r;
+    if (tower == 1) {
+        const float* wv = par + net.par_wv;
+        float s = 0.f;
+        for (int k = part; k < HpL; k += 16) s = fmaf(hL[r * ldh + k], wv[k], s);
+        s = group16_sum(s);
+        if (part == 0 && row < a.n) a.value[row] = s + par[net.par_bv];
+        return;
+    }
+    float* mus = P + lay.mu; const int ldm = lay.ldm;
+    nw_dense<HP>(hL, ldh, HpL, lds + lay.wh, lay.wh_ld, Ap, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+        const float b = par[net.par_bmu + col];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mus[(4 * g + q) * ldm + col] = acc[q] + b;
+    });
+    __syncthreads();
+    float ssq = 0.f, slog = 0.f;
+    for (int j = part; j < net.A; j += 16) {
+        const float mu = mus[r * ldm + j];
+        const float logstd = mu * 0.0f + par[net.par_ls + j];
+        const float sigma = expf(logstd);
+        float eps = 0.f;
+        if (row < a.n) eps = a.noise ? a.noise[(size_t)row * net.A + j] : ctr_normal(a.seed, a.row_base + row, a.rng_step, j);
+        const float act = mu + sigma * eps;
+        const float z = (act - mu) / sigma;
+        ssq += z * z; slog += logstd;
+        if (row < a.n) {
+            if (a.action) a.action[(size_t)row * net.A + j] = act;
+            if (a.det_action) a.det_action[(size_t)row * net.A + j] = mu;
+        }
+    }
+    ssq = group16_sum(ssq); slog = group16_sum(slog);
+    if (part == 0 && row < a.n && a.neglogp) a.neglogp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
+}

@@ -31,7 +31,7 @@ def ckpt71_stats():
     return json.load(open(os.path.join(GOLDEN, "ckpt71_stats.json")))
 
 
-def synth_minibatch(orc, n, seed, adv_normalized=True):
+def synth_minibatch(orc, n, seed, adv_normalized=True, cr=0.16102319955825806):
     """A seeded minibatch that exercises BOTH clip branches: old_neglogp/old_values are perturbed copies of the
     current model's outputs so that ratio and v - v_old straddle the clip range."""
     from oracle import oracle as o
@@ -42,6 +42,21 @@ def synth_minibatch(orc, n, seed, adv_normalized=True):
     old_nlp = (nlp + rng.normal(scale=0.15, size=n)).astype(np.float32)
     old_v = (v + rng.normal(scale=0.2, size=n)).astype(np.float32)
     ret = (v + rng.normal(scale=0.5, size=n)).astype(np.float32)
+    # Keep every row CLEAR of the discontinuities of the loss (ratio == 1 +- cr, |v - v_old| == cr, (v-R)^2 == (vclip-R)^2):
+    # within ~1e-5 of one of them, which side a row falls on is decided by the last bits of a 64-term fp32 sum, i.e. by
+    # the summation order, and one flipped row moves the whole gradient by ~1/sqrt(n).  Rows inside a 1e-3 band are pushed
+    # away (exact ties, ratio == 1 and v == v_old, stay: they are the common case and have their own deterministic rule).
+    ratio = np.exp(old_nlp.astype(np.float64) - nlp)
+    near = np.abs(np.abs(ratio - 1.0) - cr) < 1e-3
+    old_nlp[near] += np.float32(0.01)
+    dvo = v.astype(np.float64) - old_v
+    near = np.abs(np.abs(dvo) - cr) < 1e-3
+    old_v[near] -= np.float32(0.01) * np.sign(dvo[near]).astype(np.float32)
+    dvo = v.astype(np.float64) - old_v
+    vclip = old_v + np.clip(dvo, -cr, cr)
+    s1, s2 = (v - ret.astype(np.float64)) ** 2, (vclip - ret) ** 2
+    near = (np.abs(dvo) > cr) & (np.abs(s1 - s2) < 1e-3 * np.maximum(s1, 1e-6))
+    ret[near] += np.float32(0.05)
     adv = o.adv_normalize(ret, old_v) if adv_normalized else (ret - old_v).astype(np.float32)
     return dict(obs=obs, actions=act, advs=adv, returns=ret, old_neglogp=old_nlp, old_values=old_v)
 

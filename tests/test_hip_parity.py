@@ -95,7 +95,10 @@ def test_train_step_losses_gradient_and_weights(hidden, n, src):
         orc.train_step(LR, CR, *args)
         grad, norm = g.last_grad()
         assert 0.02 < ref_losses[4] < 0.98
-        close(losses, ref_losses, rtol=1e-4, atol=1e-6, msg="losses it=%d" % it)
+        close(losses[:4], ref_losses[:4], rtol=1e-4, atol=1e-6, msg="losses it=%d" % it)
+        # clipfrac is a COUNT of rows with |ratio - 1| > cliprange: a row whose ratio sits within an ulp of the boundary may fall
+        # on either side under any fp32 summation order (the oracle accumulates in double), so one row of n is the resolution
+        assert abs(float(losses[4]) - float(ref_losses[4])) <= 1.01 / n, "clipfrac it=%d" % it
         gs = float(np.abs(ref_grad).max())
         close(grad, ref_grad, rtol=2e-4, atol=2e-6 * gs, msg="grad it=%d" % it)
         assert norm == pytest.approx(ref_norm, rel=1e-4)
