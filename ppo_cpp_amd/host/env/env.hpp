@@ -2,6 +2,10 @@
 // (reference env/env.hpp:16-56) so existing environments drop in: every method, its name, argument and return type
 // match; `Mat` is the same row-major float matrix (host/mat.hpp).
 #pragma once
+// the reference's own include guard as well: a translation unit that pulls the reference's env/env.hpp first (through one
+// of its environment headers) keeps that definition, and this file becomes a no-op
+#ifndef PPO_CPP_ENV_HPP
+#define PPO_CPP_ENV_HPP
 #include <cassert>
 #include <string>
 #include <vector>
@@ -41,3 +45,4 @@ public:
 };
 inline const std::string Env::SPACE_CONTINOUS = "continous";
 inline const std::string Env::SPACE_DISCRETE = "discrete";
+#endif  // PPO_CPP_ENV_HPP

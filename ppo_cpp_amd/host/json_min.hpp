@@ -3,7 +3,9 @@
 // If the reference's vendored ../json.hpp (nlohmann 3.6.1) is on the include path it is used instead.
 #pragma once
 
-#if defined(__has_include)
+#if defined(INCLUDE_NLOHMANN_JSON_HPP_)
+#define PPO_HAVE_NLOHMANN 1            // the real nlohmann::json is already in this translation unit
+#elif defined(__has_include)
 #if __has_include("json.hpp") && !defined(PPO_FORCE_JSON_MIN)
 #include "json.hpp"
 #define PPO_HAVE_NLOHMANN 1
