@@ -168,6 +168,9 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t noptepochs, int
 int ppo_dist_unique_id(char uid[128]);
 int ppo_dist_init(ppo_handle* h, int32_t world_size, int32_t rank, const char uid[128]);
 int ppo_dist_world(const ppo_handle* h);
+/* 1 when ppo_update replays the collectives from its hipGraph (the communicator's library passed the capture probe of
+ * ppo_dist_init, or PPO_HIP_GRAPH_RCCL=1), 0 when they are issued eagerly between the launches */
+int ppo_dist_graph_collectives(const ppo_handle* h);
 
 /* ---- measurement hooks ----------------------------------------------------------------------------------
  * per-kernel device time (ms) accumulated with hipEvents on the handle's stream since the last reset;

@@ -271,6 +271,9 @@ class PPOHip:
         assert len(uid) == 128
         self._ck(self.lib.ppo_dist_init(self.h, world, rank, C.c_char_p(uid) if False else C.create_string_buffer(uid, 128)))
 
+    def dist_graph_collectives(self):
+        return bool(self.lib.ppo_dist_graph_collectives(self.h))
+
     def prof_enable(self, on=True):
         self._ck(self.lib.ppo_prof_enable(self.h, int(on)))
 

@@ -147,6 +147,7 @@ struct ppo_handle {
     Rccl rccl;
     void* comm = nullptr;
     int world = 1, rank = 0;
+    bool graph_rccl = false;          // the collectives can be captured into the update's hipGraph (probed in ppo_dist_init)
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
@@ -1697,8 +1698,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     // hipGraph replay of the whole update; RCCL calls and event-bracketed profiling run eagerly
     // With a communicator the sequence runs eagerly by default (the host enqueues a step faster than the GPU runs it);
     // PPO_HIP_GRAPH_RCCL=1 opts into capturing the ncclAllReduce calls as well.
-    static const bool graph_rccl = [] { const char* e = getenv("PPO_HIP_GRAPH_RCCL"); return e && e[0] == '1'; }();
-    const bool graph_ok = h->use_graph && !h->prof && (!h->comm || graph_rccl);
+    const bool graph_ok = h->use_graph && !h->prof && (!h->comm || h->graph_rccl);
     if (graph_ok) {
         const bool same = h->upd_graph && h->g_epochs == epochs && h->g_nmb == nmb && h->g_E == h->E && h->g_T == h->T &&
                           h->g_explicit == (int)explicit_perms && h->g_world == h->world;
@@ -1708,7 +1708,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
             hipGraph_t graph = nullptr;
             // a runtime that cannot capture or instantiate this sequence is not fatal: the same launches run eagerly
             // (nothing has executed yet -- capture only records)
-            bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            bool ok = hipStreamBeginCapture(h->stream, h->comm ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 const int rc = enqueue_update(h, epochs, nmb, explicit_perms);
                 const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
@@ -1778,10 +1778,44 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
     if (rc) return fail(h, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
     h->world = world; h->rank = rank;
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    // Collectives inside the update's hipGraph: with a communicator the eager sequence is 5-6 launches and up to three
+    // collectives per train step issued from the host, which at narrow networks is slower than the GPU runs them.  Whether
+    // this RCCL build can be stream-captured is PROBED here, collectively (every rank runs the same probe in the same order):
+    // capture one small all-reduce, instantiate, replay twice, check the sum.  PPO_HIP_GRAPH_RCCL=0 / 1 overrides the probe.
+    const char* ge = getenv("PPO_HIP_GRAPH_RCCL");
+    if (ge && (ge[0] == '0' || ge[0] == '1')) h->graph_rccl = ge[0] == '1';
+    else {
+        // on a stream of its own: a library that cannot be captured (e.g. one that synchronises the stream inside the call)
+        // invalidates the capture, and the handle's stream must not be left in that state
+        h->graph_rccl = false;
+        float* buf = nullptr;
+        hipStream_t ps = nullptr;
+        if (hipMalloc((void**)&buf, 64 * sizeof(float)) == hipSuccess && hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) == hipSuccess) {
+            hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, ps, buf, 1.0f, (size_t)64);
+            (void)hipStreamSynchronize(ps);
+            hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+            bool ok = hipStreamBeginCapture(ps, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                const int arc = h->rccl.AllReduce(buf, buf, 64, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, ps);
+                const hipError_t ce = hipStreamEndCapture(ps, &graph);
+                ok = arc == 0 && ce == hipSuccess && graph != nullptr && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            }
+            if (ok) ok = hipGraphLaunch(exec, ps) == hipSuccess && hipGraphLaunch(exec, ps) == hipSuccess && hipStreamSynchronize(ps) == hipSuccess;
+            float got = 0.f;
+            if (ok) ok = hipMemcpy(&got, buf, sizeof got, hipMemcpyDeviceToHost) == hipSuccess && got == (float)world * (float)world;
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+            h->graph_rccl = ok;
+        }
+        if (ps) (void)hipStreamDestroy(ps);
+        (void)hipGetLastError();
+        if (buf) (void)hipFree(buf);
+    }
     return 0;
 }
 
 int ppo_dist_world(const ppo_handle* h) { return h->world; }
+int ppo_dist_graph_collectives(const ppo_handle* h) { return h->comm && h->graph_rccl && h->use_graph ? 1 : 0; }
 
 // ---- measurement ----------------------------------------------------------------------------------------------------------
 int ppo_prof_enable(ppo_handle* h, int on) {

@@ -147,6 +147,20 @@ int ppo_host_graph_spec(const char* path, ppo_config* cfg, float pw0[2], const c
     } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return -1; }
 }
 
+// load_graph + Run("init") on the DEVICE (session_creator.hpp:40-58): create a handle from a graph file, assign the graph's
+// initial weights, and evaluate deterministic action [n,A], value [n] and the beta powers for the given observations.
+int ppo_host_graph_eval(const char* path, const float* obs, int n, float* actions, float* values, float pw[2]) {
+    ppo_handle* h = nullptr;
+    try {
+        const graphspec::GraphSpec g = graphspec::load_graph_spec(path);
+        h = graphspec::create_from_graph(g);
+        if (ppo_act_deterministic(h, obs, n, actions) != 0 || ppo_value(h, obs, n, values) != 0 || ppo_get_beta_powers(h, pw) != 0)
+            throw std::runtime_error(ppo_last_error(h));
+        ppo_destroy(h);
+        return 0;
+    } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); if (h) ppo_destroy(h); return -1; }
+}
+
 struct ppo_host_args {
     int n_envs, n_steps, n_hidden, hidden[8];
     int nminibatches, noptepochs, n_updates;

@@ -300,7 +300,8 @@ def test_rccl_plumbing_single_rank_communicator():
         rng.shuffle(perm); perms.append(perm.copy())
     perms = np.stack(perms)
     ref_rows, _ = orc2.update(ro, perms, nmb, LR, CR)
-    rows, _ = g2.update(LR, CR, epochs, nmb, perms)             # eager launch sequence with the collectives in it
+    print("collectives captured into the update graph:", g2.dist_graph_collectives())
+    rows, _ = g2.update(LR, CR, epochs, nmb, perms)             # the collectives ride in the graph when the probe of ppo_dist_init passed, eagerly otherwise
     close(rows, ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows under a communicator")
     close(g2.get_flat(0), orc2.theta, rtol=2e-4, atol=5e-6)
 
