@@ -371,7 +371,7 @@ def main():
             from ppo_cpp_amd import hostapi
             if g is not None:
                 g.close()
-            r = hostapi.learn(E, T, cfg["hidden"], n_updates=4, nminibatches=nmb, noptepochs=ep, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM)
+            r = hostapi.learn(E, T, cfg["hidden"], n_updates=6, nminibatches=nmb, noptepochs=ep, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM)
             out["host_env"] = {"env_steps_per_s": r["env_steps_per_s"], "collect_ms": r["collect_ms"], "update_ms": r["update_ms"],
                                "collect_phase_ms": r["phase_ms"],
                                "note": "SeededEnvMock x %d behind the pooled VecEnv on the host cores, PCIe round trip per env step" % E}

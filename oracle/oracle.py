@@ -1,6 +1,7 @@
 """ctypes binding of oracle/libppo_oracle.so (the C restatement in ppo_oracle.c).
 
-TEST INFRASTRUCTURE - "parity unpinned" at the TensorFlow boundary (see ppo_oracle.h).
+TEST INFRASTRUCTURE - pinned to the reference graph as executed by oracle/graph_interp.py; no TensorFlow-produced vector
+exists, so parity is "unpinned" at the TensorFlow boundary in that strict sense (see ppo_oracle.h).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
 """
 import ctypes as C

@@ -1,6 +1,6 @@
 /*
  * ppo_oracle.c  --  CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See ppo_oracle.h for the
- * parity status ("parity unpinned" at the TensorFlow boundary), conventions and citations.
+ * parity status (pinned to the reference graph as executed by oracle/graph_interp.py; no TensorFlow-produced vector exists), conventions and citations.
  *
  * "G:" line numbers refer to the reference's TF MetaGraphDef text proto
  *   /root/reference/resources/ppo_cl/graphs/ppo_cpp_[4_5]_lr_0.0004_cr_0.1610_ent_0.0007.meta.txt

@@ -5,13 +5,18 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call into this file; the
  * product path (ppo_cpp_amd/csrc, libppo_hip.so) never links or loads it.
  *
- * PARITY STATUS: "parity unpinned" at the TensorFlow boundary.  The reference executes a TF-1.14 graph
- * ("G" = resources/ppo_cl/graphs/ppo_cpp_[4_5]_lr_0.0004_cr_0.1610_ent_0.0007.meta.txt) and TF cannot be
- * built or imported here; the reference tree holds no TF-produced activation / loss / gradient value.
- * This restatement is pinned instead against (tests/test_oracle.py):
+ * PARITY STATUS: pinned to the reference's graph AS EXECUTED, not to TensorFlow's own output.  The reference runs a
+ * TF-1.14 graph ("G" = resources/ppo_cl/graphs/ppo_cpp_[4_5]_lr_0.0004_cr_0.1610_ent_0.0007.meta.txt); TF cannot be
+ * built or imported here and the reference tree holds no TF-produced activation / loss / gradient value, so no vector
+ * produced by TensorFlow itself exists ("parity unpinned" in that strict sense).  What pins this restatement
+ * (tests/test_oracle.py):
+ *   - G executed node by node by oracle/graph_interp.py (a NumPy interpreter of the 55 op kinds G uses: only TF's
+ *     op-kernel semantics are restated there, no PPO formula; every wiring, tie rule, reduction axis, clip and
+ *     ApplyAdam order comes from the file): act outputs, 5 losses, 13 gradients, global norm, weights / Adam slots /
+ *     beta powers over three train steps and the NaN poisoning -> tests/golden/g45_graph_run.npz,
  *   - the initial weights embedded in G and the trained checkpoint ...pkl.71 (tests/golden/ npz files),
  *   - analytic known answers (initial entropy 18*1.4189385, neglogp(a=mu) 18*0.9189385, ...),
- *   - an independent torch-CPU autograd restatement of the same formulas (oracle/torch_check.py),
+ *   - an independent torch-CPU float64 autograd restatement of the same formulas (oracle/torch_check.py),
  *   - the checkpoint JSON running statistics (normaliser fixture).
  *
  * Accumulation convention: element-wise ops are fp32 exactly as the graph's DT_FLOAT nodes; every

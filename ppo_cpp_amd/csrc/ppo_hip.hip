@@ -1497,7 +1497,14 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
     // one D2H into the handle's pinned landing buffer and the ONLY stream synchronisation of an env step: the statistics
     // kernel of the previous ppo_rollout_observe, this policy step and the copy drain together
     HIP_OK(h, hipMemcpyAsync(h->pin_out, h->ro_act + (size_t)t * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(h, hipStreamSynchronize(h->stream));
+    // busy-wait on the stream: the blocking synchronise parks the thread on an interrupt and wakes it ~100-200 us late,
+    // several times the whole GPU-side cost of an env step; this thread has nothing else to do until the actions are here
+    {
+        hipError_t q;
+        int spins = 0;
+        while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) { if (++spins > 200000) { HIP_OK(h, hipStreamSynchronize(h->stream)); q = hipSuccess; break; } }
+        if (q != hipSuccess) return fail(h, "hipStreamQuery failed: %s", hipGetErrorString(q));
+    }
     h->pin_in_busy = false;
     memcpy(actions_out, h->pin_out, cnt * sizeof(float));
     return 0;

@@ -38,7 +38,8 @@ public:
     std::vector<std::pair<int, float>>& episode_rewards() { return episodes_; }
     bool quiet = false;
     unsigned long long seed = 0;
-    // host-Env collect split, summed over the updates after the first (which pays allocation + graph capture)
+    // host-Env collect split, summed over the updates after the second (the first pays allocation + graph capture, the first
+    // env step after that capture a one-off runtime hiccup)
     double phase_env_ms = 0, phase_act_ms = 0, phase_observe_ms = 0;
 
     // Checkpoint in the reference's on-disk format (ppo2.hpp:107-166): the 15 model tensors as a TF bundle
@@ -156,7 +157,7 @@ private:
                 const auto p2 = clk::now();
                 check(ppo_rollout_observe(h_, t, r[0].data(), r[1].data(), r[2].data()));
                 const auto p3 = clk::now();
-                if (update > 1) { phase_act_ms += ms(p0, p1); phase_env_ms += ms(p1, p2); phase_observe_ms += ms(p2, p3); }
+                if (update > 2) { phase_act_ms += ms(p0, p1); phase_env_ms += ms(p1, p2); phase_observe_ms += ms(p2, p3); }
                 dones = r[2];
                 const Mat orig = raw.get_original_rew();
                 for (int e = 0; e < E; ++e) rew_view(e, t) = orig(e, 0);

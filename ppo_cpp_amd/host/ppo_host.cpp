@@ -227,8 +227,9 @@ int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             const auto& hist = algo.history();
             if (hist.empty()) throw std::runtime_error("no update ran");
-            // the first update pays allocation + graph capture: report the steady state when there is one
-            size_t from = hist.size() > 1 ? 1 : 0;
+            // the first update pays allocation + graph capture, and the first env step after that capture pays a one-off
+            // ~8 ms in the runtime: report the steady state (from the third update on) when there is one
+            size_t from = hist.size() > 2 ? 2 : hist.size() > 1 ? 1 : 0;
             double c = 0, u = 0;
             for (size_t i = from; i < hist.size(); ++i) { c += hist[i].collect_ms; u += hist[i].update_ms; }
             const double n = (double)(hist.size() - from);

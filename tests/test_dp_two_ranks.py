@@ -30,7 +30,10 @@ def build_fake_rccl(tmp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((64, 64), 16, 16, 4, 2), ((256, 256), 64, 8, 4, 1)])
+@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((64, 64), 16, 16, 4, 2), ((256, 256), 64, 8, 4, 1),
+                                                   # BASELINE configs[3] at its per-rank workload (1024 envs over 8 GPUs = 128 envs x 64 steps
+                                                   # per rank, MLP [64,64], 32 minibatches of 256 rows per rank)
+                                                   ((64, 64), 256, 64, 32, 1)])
 def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden, E, T, nmb, epochs):
     world = 2
     tmp = str(tmp_path)

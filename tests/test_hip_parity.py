@@ -518,3 +518,40 @@ def test_hip_path_matches_the_interpreted_reference_graph():
     bad = z["train2/advs"].copy(); bad[0] = np.inf
     g.train_step(lr, cr, z["train2/obs"], z["train2/actions"], bad, z["train2/returns"], z["train2/old_neglogp"], z["train2/old_values"])
     assert np.isnan(g.get_flat(0)).all() and z["poison/all_nan"].all()
+
+
+def test_full_size_config4_single_rank_properties():
+    """BASELINE configs[3]'s workload on ONE rank (1024 envs x 64 steps, MLP [64,64], 32 minibatches x 2 epochs: the narrow
+    kernels at 2048-row minibatches; the per-rank shard of the 8-GPU layout is covered by tests/test_dp_two_ranks.py).
+    Rollout against the oracle; then size-independent properties of the update: first-minibatch ratios are exactly one,
+    entropy is the closed form, the shuffle leaves the rollout untouched, and a second update from the same state with the
+    same seed is bitwise identical (hipGraph replay == first run)."""
+    E, T, nmb, epochs = 1024, 64, 32, 2
+    orc, g, nz, ro, noise = _rollout_pair((64, 64), E, T, 41)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+        close(g.rollout_get(f), ro[f], rtol=2e-4, atol=2e-5, msg=f)
+    np.testing.assert_array_equal(g.rollout_get("dones"), ro["dones"])
+    theta0, m0, v0, pw0 = g.get_flat(0), g.get_flat(1), g.get_flat(2), g.beta_powers()
+    ret0 = g.rollout_get("returns")
+    rows, mean = g.update(LR, CR, epochs, nmb, None, seed=5)
+    assert rows.shape == (epochs * nmb, 5) and np.isfinite(rows).all()
+    assert rows[0, 3] == pytest.approx(0.0, abs=1e-9) and rows[0, 4] == 0.0 and abs(rows[0, 0]) < 1e-6
+    logstd = orc.tensor("pi/logstd")
+    assert rows[0, 2] == pytest.approx(float(logstd.sum()) + 18 * 1.4189385175704956, rel=1e-5)
+    assert (rows[1:, 3] > 0).all() and rows[nmb:, 1].mean() < rows[:nmb, 1].mean()
+    np.testing.assert_array_equal(g.rollout_get("returns"), ret0)
+    th1 = g.get_flat(0)
+    g.set_flat(theta0); g.set_flat(m0, 1); g.set_flat(v0, 2); g.set_beta_powers(pw0)
+    rows2, _ = g.update(LR, CR, epochs, nmb, None, seed=5)
+    np.testing.assert_array_equal(rows2, rows); np.testing.assert_array_equal(g.get_flat(0), th1)
+    # one explicit-permutation epoch against the oracle at the full size (2048-row minibatches)
+    g.set_flat(theta0); g.set_flat(m0, 1); g.set_flat(v0, 2); g.set_beta_powers(pw0)
+    perms = np.random.RandomState(1).permutation(E * T).astype(np.int32)[None]
+    ref_rows, _ = orc.update(ro, perms, nmb, LR, CR)
+    for f in ("obs", "actions", "values", "neglogp", "returns"):
+        g.rollout_set(f, ro[f])
+    rows3, _ = g.update(LR, CR, 1, nmb, perms)
+    close(rows3[:, :4], ref_rows[:, :4], rtol=2e-4, atol=2e-6, msg="loss rows")
+    assert np.abs(rows3[:, 4] - ref_rows[:, 4]).max() <= 2.01 / (E * T // nmb)          # clipfrac: a count (see test_train_step...)
+    close(g.get_flat(0), orc.theta, rtol=2e-4, atol=5e-6)
