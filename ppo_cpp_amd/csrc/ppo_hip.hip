@@ -143,6 +143,7 @@ struct ppo_handle {
     bool nw_static = false;
     float* nw_img = nullptr;          // [2][w_total] packed weight images (kept current by adam_kernel / transpose_refresh_kernel)
     float* nw_partials = nullptr; int nw_groups_cap = 0; int nw_stride = 0;
+    float* nw_alt = nullptr; double* nw_alt_counts = nullptr; int nw_alt_envs = 0;   // second env/normaliser state set of the fused collect step
     // dist
     Rccl rccl;
     void* comm = nullptr;
@@ -997,6 +998,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         attr_ok &= hipFuncSetAttribute((const void*)narrow_train_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         if (dev_alloc(h, &h->nw_img, (size_t)2 * h->nw.w_total)) return bail(0);
     }
@@ -1014,6 +1017,8 @@ void ppo_destroy(ppo_handle* h) {
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
     if (h->nw_partials) (void)hipFree(h->nw_partials);
     if (h->nw_img) (void)hipFree(h->nw_img);
+    if (h->nw_alt) (void)hipFree(h->nw_alt);
+    if (h->nw_alt_counts) (void)hipFree(h->nw_alt_counts);
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->sumsq2, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
                     h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->stats_xch, h->stats_part, h->stats_counter, h->adv_xch, h->ro_obs, h->ro_act,
@@ -1551,7 +1556,51 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
         h->done_staged = -1;
         if (enqueue_norm_batch(h, h->raw_obs, E, nullptr, nullptr, 0, nullptr, nullptr)) return -1;
     }
-    for (int t = 0; t < T; ++t) {
+    // small environment counts on the narrow path: one fused launch per env step (policy step + env + EnvNormalize bookkeeping)
+    static const bool no_fused = [] { const char* e = getenv("PPO_HIP_NO_FUSED_COLLECT"); return e && e[0] == '1'; }();
+    const bool fused = h->narrow && !h->comm && !no_fused && E <= NW_ROWS && n.O <= 64;
+    if (fused) {
+        if (h->nw_alt_envs != E) {
+            HIP_OK(h, hipStreamSynchronize(h->stream));
+            if (dev_alloc(h, &h->nw_alt, (size_t)E * n.O + 2 * n.O + 2 + 2 * (size_t)E) || dev_alloc(h, &h->nw_alt_counts, 2)) return -1;
+            h->nw_alt_envs = E;
+        }
+        float* alt = h->nw_alt;
+        NwEnvState st[2];
+        st[0] = NwEnvState{h->raw_obs, h->obs_rms.mean, h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->cur_done};
+        st[1] = NwEnvState{alt, alt + (size_t)E * n.O, alt + (size_t)E * n.O + n.O, h->nw_alt_counts, alt + (size_t)E * n.O + 2 * n.O, alt + (size_t)E * n.O + 2 * n.O + 1,
+                           h->nw_alt_counts + 1, alt + (size_t)E * n.O + 2 * n.O + 2, alt + (size_t)E * n.O + 2 * n.O + 2 + E};
+        const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
+        for (int t = 0; t < T; ++t) {
+            const NwEnvState& in = st[t & 1];
+            StepArgs a{};
+            a.theta = h->nw_img; a.obs = in.raw_obs; a.noise = noise ? h->ro_noise + (size_t)t * E * n.A : nullptr;
+            a.action = h->ro_act + (size_t)t * E * n.A; a.value = h->ro_val + (size_t)t * E; a.neglogp = h->ro_nlp + (size_t)t * E;
+            a.obs_out = h->ro_obs + (size_t)t * E * n.O; a.nz = ObsNorm{in.obs_mean, in.obs_var, h->nz_eps, h->nz_clip_obs, h->norm_obs_flag}; a.n = E;
+            a.seed = seed; a.rng_step = step0 + (uint32_t)t; a.row_base = (uint32_t)env0;
+            NwCollectArgs c{in, st[(t + 1) & 1], seed, step0 + (uint32_t)t + 1u, env0, h->nz_gamma, h->nz_clip_rew, h->nz_eps, h->norm_obs_flag, h->norm_rew_flag,
+                            h->ro_rew + (size_t)t * E, h->ro_done + (size_t)t * E};
+            ProfScope ps(h, PK_STEP);
+            if (h->nw_static) hipLaunchKernelGGL((narrow_collect_kernel<32, 64, 32, 2>), dim3(1, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, a, c);
+            else hipLaunchKernelGGL((narrow_collect_kernel<0, 0, 0, 0>), dim3(1, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, a, c);
+            HIP_OK(h, hipGetLastError());
+        }
+        if (T & 1) {                                           // the live state sits in the second set: bring it home
+            const NwEnvState& s1 = st[1]; const NwEnvState& s0 = st[0];
+            const size_t fb = sizeof(float);
+            HIP_OK(h, hipMemcpyAsync(s0.raw_obs, s1.raw_obs, (size_t)E * n.O * fb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(h, hipMemcpyAsync(s0.obs_mean, s1.obs_mean, n.O * fb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(h, hipMemcpyAsync(s0.obs_var, s1.obs_var, n.O * fb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(h, hipMemcpyAsync(s0.obs_count, s1.obs_count, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(h, hipMemcpyAsync(s0.ret_mean, s1.ret_mean, fb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(h, hipMemcpyAsync(s0.ret_var, s1.ret_var, fb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(h, hipMemcpyAsync(s0.ret_count, s1.ret_count, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(h, hipMemcpyAsync(s0.ret, s1.ret, (size_t)E * fb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(h, hipMemcpyAsync(s0.done, s1.done, (size_t)E * fb, hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->done_staged = -1;
+    }
+    for (int t = 0; t < T && !fused; ++t) {
         if (enqueue_rollout_act(h, t, noise ? h->ro_noise + (size_t)t * E * n.A : nullptr, seed, step0 + t, (uint32_t)env0)) return -1;
         { ProfScope ps(h, PK_ENV);
           hipLaunchKernelGGL(seeded_env_kernel, dim3((envW + 255) / 256), dim3(256), 0, h->stream, seed, env0, E, step0 + (uint32_t)t + 1u, n.O, h->raw_obs, h->raw_rew, h->cur_done);

@@ -517,3 +517,139 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_step_kernel(NetDev net, NwL
     ssq = group16_sum(ssq); slog = group16_sum(slog);
     if (part == 0 && row < a.n && a.neglogp) a.neglogp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Fused collect step for small environment counts (n_envs <= 32: BASELINE configs[1], one environment) against the
+// on-device seeded env: ONE launch per env step instead of three (policy step, env, running statistics).
+//   both workgroups : act on the CURRENT raw observations (state S_in: normalise with S_in's statistics, forward, tower 0
+//                     samples and writes rollout row t, tower 1 writes the values)
+//   tower-0 workgroup, afterwards: the env transition (counter hash, step `env_step`), EnvNormalize::step's statistics
+//                     (obs_rms.update, ret = ret*gamma + r, ret_rms.update, reward scale + clip, ret *= 1 - done;
+//                     env/env_normalize.hpp:64-116, common/running_statistics.hpp:26-104) -> state S_out
+// S_in is only read and S_out only written during a launch (the host alternates two state sets), so the two workgroups
+// never race.  The batch moments are the reference's two passes over the E rows, one thread per column.
+// ------------------------------------------------------------------------------------------------------------------------
+struct NwEnvState { float* raw_obs; float* obs_mean; float* obs_var; double* obs_count; float* ret_mean; float* ret_var; double* ret_count; float* ret; float* done; };
+struct NwCollectArgs {
+    NwEnvState in, out;
+    uint32_t seed, env_step; int env0;
+    float gamma, clip_rew, eps; int norm_obs, norm_rew;
+    float* rew_out;              // rollout rewards row t
+    float* done_row;             // rollout dones row t (the flags that arrived with obs_t)
+};
+
+template <int KP0, int HP, int AP, int LL>
+__global__ __launch_bounds__(NW_THREADS) void narrow_collect_kernel(NetDev net, NwLayout lay, StepArgs a, NwCollectArgs c) {
+    typedef NwShape<KP0, HP, AP, LL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(StepArgs) + sizeof(NwCollectArgs)>();
+    const int tower = blockIdx.y;
+    const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
+    const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
+    const int E = a.n, O = net.O;
+    nw_stage<S>(net, lay, a.theta + (size_t)tower * lay.w_total, lay.w_fwd, lds, a.obs, 0, E, a.nz, a.obs_out, tower, nullptr, nullptr, nullptr, 0);
+    __syncthreads();
+    float* P = lds + lay.w_total + pipe * lay.pipe_total;
+    const float* par = lds + lay.par;
+    for (int l = 0; l < L; ++l) {
+        const float* bias = par + net.par_b[l];
+        float* Ys = P + lay.x[l + 1]; const int ldy = lay.ldx[l + 1];
+        auto ep = [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+            const float b = bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ys[(4 * g + r) * ldy + col] = fast_tanh(acc[r] + b);
+        };
+        if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
+        else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+        __syncthreads();
+    }
+    const float* hL = P + lay.x[L]; const int ldh = lay.ldx[L]; const int HpL = S::Hp(net, L - 1);
+    const int r = ptid >> 4, part = ptid & 15;
+    const int row = 16 * pipe + r;
+    if (tower == 1) {
+        const float* wv = par + net.par_wv;
+        float s = 0.f;
+        for (int k = part; k < HpL; k += 16) s = fmaf(hL[r * ldh + k], wv[k], s);
+        s = group16_sum(s);
+        if (part == 0 && row < E) a.value[row] = s + par[net.par_bv];
+        return;
+    }
+    float* mus = P + lay.mu; const int ldm = lay.ldm;
+    nw_dense<HP>(hL, ldh, HpL, lds + lay.wh, lay.wh_ld, Ap, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+        const float b = par[net.par_bmu + col];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mus[(4 * g + q) * ldm + col] = acc[q] + b;
+    });
+    __syncthreads();
+    float ssq = 0.f, slog = 0.f;
+    for (int j = part; j < net.A; j += 16) {
+        const float mu = mus[r * ldm + j];
+        const float logstd = mu * 0.0f + par[net.par_ls + j];
+        const float sigma = expf(logstd);
+        float eps = 0.f;
+        if (row < E) eps = a.noise ? a.noise[(size_t)row * net.A + j] : ctr_normal(a.seed, a.row_base + row, a.rng_step, j);
+        const float act = mu + sigma * eps;
+        const float z = (act - mu) / sigma;
+        ssq += z * z; slog += logstd;
+        if (row < E && a.action) a.action[(size_t)row * net.A + j] = act;
+    }
+    ssq = group16_sum(ssq); slog = group16_sum(slog);
+    if (part == 0 && row < E) a.neglogp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
+    if (tid < E) c.done_row[tid] = c.in.done[tid];
+    // ---- env transition + EnvNormalize::step bookkeeping -> S_out (the tiles of the forward pass are free now) -------------
+    __syncthreads();
+    float* xs = lds + lay.w_total;                          // [E][O] raw observations of the NEW state
+    float* rs = xs + NW_ROWS * 64;                          // [E] rewards | [E] dones | [E] returns
+    for (int i = tid; i < E * (O + 2); i += NW_THREADS) {
+        const int e = i / (O + 2), j = i - e * (O + 2);
+        const uint32_t hsh = ctr_hash(c.seed, (uint32_t)(c.env0 + e), c.env_step, (uint32_t)j);
+        if (j < O) { const float x = u32_to_sym_unit(hsh); xs[e * O + j] = x; c.out.raw_obs[(size_t)e * O + j] = x; }
+        else if (j == O) rs[e] = u32_to_sym_unit(hsh);
+        else { const float d = (hsh % 300u == 0u) ? 1.0f : 0.0f; rs[NW_ROWS + e] = d; c.out.done[e] = d; }
+    }
+    __syncthreads();
+    // RunningStatistics::update's merge of a batch (mean, M2, n) (common/running_statistics.hpp:88-104), reading S_in, writing S_out
+    auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
+        const double nb = (double)nbf, tot = cnt + nb;
+        const float bvar = bM2 / (float)nb;                                        // :51-54
+        const float delta = bmean - mean0;                                         // :90
+        mean1 = mean0 + (delta * (float)nb) / (float)tot;                          // :94
+        const float m_a = var0 * (float)cnt, m_b = bvar * (float)nb;               // :97-98
+        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;   // :100
+        var1 = M2 / (float)tot;                                                    // :101
+    };
+    if (tid < O) {
+        float m1 = c.in.obs_mean[tid], v1 = c.in.obs_var[tid];
+        if (c.norm_obs) {
+            float sum = 0.f;
+            for (int e = 0; e < E; ++e) sum += xs[e * O + tid];
+            const float bmean = sum / (float)E;                                    // colwise().mean()  (:38-39)
+            float m2 = 0.f;
+            for (int e = 0; e < E; ++e) { const float d = xs[e * O + tid] - bmean; m2 += d * d; }
+            merge(c.in.obs_mean[tid], c.in.obs_var[tid], *c.in.obs_count, bmean, m2, (float)E, m1, v1);
+        }
+        c.out.obs_mean[tid] = m1; c.out.obs_var[tid] = v1;
+        if (tid == 0) *c.out.obs_count = c.norm_obs ? (double)(float)E + *c.in.obs_count : *c.in.obs_count;     // :103
+    }
+    if (tid == 64) {                                        // (a different wave than the observation columns)
+        float* ret = rs + 2 * NW_ROWS;
+        float sum = 0.f;
+        for (int e = 0; e < E; ++e) { ret[e] = c.in.ret[e] * c.gamma + rs[e]; sum += ret[e]; }        // env_normalize.hpp:66
+        float m1 = *c.in.ret_mean, v1 = *c.in.ret_var;
+        if (c.norm_rew) {                                                                              // :75-77 (training)
+            const float bmean = sum / (float)E;
+            float m2 = 0.f;
+            for (int e = 0; e < E; ++e) { const float d = ret[e] - bmean; m2 += d * d; }
+            merge(*c.in.ret_mean, *c.in.ret_var, *c.in.ret_count, bmean, m2, (float)E, m1, v1);
+        }
+        *c.out.ret_mean = m1; *c.out.ret_var = v1;
+        *c.out.ret_count = c.norm_rew ? (double)(float)E + *c.in.ret_count : *c.in.ret_count;
+        const float inv = 1.0f / sqrtf(v1 + c.eps);                                                    // :79
+        for (int e = 0; e < E; ++e) {
+            float y = rs[e];
+            if (c.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -c.clip_rew), c.clip_rew); }
+            c.rew_out[e] = y;
+            c.out.ret[e] = ret[e] * (1.0f - rs[NW_ROWS + e]);                                          // :88-91
+        }
+    }
+}
