@@ -60,6 +60,7 @@ struct ppo_handle {
     hipStream_t stream = nullptr;
     int CT = 1;                       // column tiles per wave in the dense layers (4 for wide nets)
     int CTH = 0;                      // split-K policy head column tiles (2 when Ap == 32 on the wide path), 0 = generic
+    bool early = false;               // train kernel keeps the small products' weights in registers from kernel entry (18-obs / [256, ...] shape)
     NetDev net{};
     std::vector<Tensor> tensors;
     int P_dense = 0, P_pad = 0, n_blocks = 0, PT = 0;
@@ -864,6 +865,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
             if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, true>), grid, blk, lds_bytes, h->stream, n, ta);
             else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0, true>), grid, blk, lds_bytes, h->stream, n, ta);
         }
+        else if (h->CT == 4 && h->CTH == 2 && h->early) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2, false, true>), grid, blk, lds_bytes, h->stream, n, ta);
         else if (h->CT == 4 && h->CTH == 2) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2, false>), grid, blk, lds_bytes, h->stream, n, ta);
         else if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
         else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
@@ -978,6 +980,9 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     bool attr_ok = true;
     auto set_lds = [&](const void* f) { attr_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess; };
     set_lds((const void*)policy_step_kernel<4, 2, 2, false>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2, false>);
+    set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2, false, true>);
+    { const char* e = getenv("PPO_HIP_NO_EARLY"); const NetDev& nn = h->net;
+      h->early = !(e && e[0] == '1') && !nn.wide && h->CT == 4 && h->CTH == 2 && nn.L >= 2 && nn.Kp0 == 32 && nn.Ap == 32 && nn.Hp[0] == 256 && nn.Hp[nn.L - 1] == 256; }
     set_lds((const void*)policy_step_kernel<4, 2, 0, false>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0, false>);
     set_lds((const void*)policy_step_kernel<1, 1, 0, false>); set_lds((const void*)train_fwd_bwd_kernel<1, 1, 0, false>);
     set_lds((const void*)policy_step_kernel<4, 2, 0, true>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0, true>);

@@ -359,6 +359,38 @@ __device__ __forceinline__ void dense_tile_one_stage(WRing<CT, KS>& w, const flo
     }
 }
 
+// The same from a fragment OUTSIDE the ring that the caller loaded earlier (kernel entry): exactly one 16*CT-column chunk per
+// wave (Np == 4 waves * 16 * CT), nothing is fetched here.
+template <int CT, int KS, int EP>
+__device__ __forceinline__ void dense_tile_frag(WFrag<CT, KS>& wf, const float* __restrict__ bias, const float* Xs, int ldx, float* Ys, int ldy,
+                                                const float* Hs, int ldh, float* __restrict__ gy, int ldg, int row0, int nrows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int col = wave * 16 * CT + CT * c;
+    f32x4 acc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KS; ++q) wf.a[q] = *reinterpret_cast<const float4*>(Xs + c * ldx + 16 * q + 4 * g);
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+        const float av[4] = {wf.a[q].x, wf.a[q].y, wf.a[q].z, wf.a[q].w};
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_], wf.v[4 * q + s_][j], acc[j], 0, 0, 0);
+    }
+    tile_epilogue<CT, EP>(acc, g, col, bias, Hs, ldh, Ys, ldy, gy, ldg, row0, nrows);
+}
+
+// this wave's chunk of a one-stage product's weights -> an explicit fragment
+template <int CT, int KS>
+__device__ __forceinline__ void load_frag(WFrag<CT, KS>& wf, const float* W, int ldw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    W = uni(W); ldw = uni(ldw);
+    load_w_stage<CT, KS>(wf, W, make_woff<KS>(ldw, lane >> 4, wave * 16 * CT + CT * (lane & 15)));
+}
+
 // this wave's first-chunk weights of a one-stage product -> ring slot SLOT
 template <int CT, int KS, int SLOT>
 __device__ __forceinline__ void prefetch_one_stage(WRing<CT, KS>& w, const float* W, int ldw, int Np) {
@@ -555,10 +587,16 @@ struct RowScalars { const float* actions; const float* v0a; const float* v0b; co
 // mode 0: none ; 1 (policy): v0 = advs[src] (v0b null) or ((v0a - v0b) - stats[0]) / stats[1], v1 = old_neglogp
 // mode 2 (value) : v0 = returns, v1 = old_values
 
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_issue` runs right after this block's loads have been issued and before the first of them is consumed: loads the
+// caller issues there queue BEHIND the inputs (the inputs are needed first) but ahead of the wait, so they are in flight
+// during the staging round trip.
+template <class Hook = NoHook>
 __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const float* __restrict__ par_src, float* par, float* Xs, int ldx,
                                                    const float* __restrict__ obs, int row0, int nrows,
                                                    ObsNorm nz, float* __restrict__ obs_out, float* __restrict__ x0g, RowScalars rs,
-                                                   float* acts, float* rowv) {
+                                                   float* acts, float* rowv, Hook&& after_issue = Hook()) {
     const int tid = threadIdx.x;
     const int Kp0 = net.Kp0, O = net.O, A = net.A, Ap = net.Ap;
     constexpr int PK = 4, OK = 2, AK = 2;
@@ -598,6 +636,7 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
         r0 = rs.v0a[src]; r2 = rs.v1[src];
         if (rs.v0b) { r1 = rs.v0b[src]; s0 = rs.stats[0]; s1 = rs.stats[1]; }
     }
+    after_issue();
     // ---- consume ---------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < PK; ++k) { const int i = net.par_skip + tid + BLOCK_THREADS * k; if (i < net.par_total) par[i] = pv[k]; }
@@ -773,7 +812,12 @@ struct TrainArgs {
     unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS): [blocks][16] s_memtime stamps
 };
 
-template <int CT, int KS, int CTH, bool WIDE>
+// EARLY (18-obs / [256, 256-multiple] shape only: Kp0 == Ap == 16*KS, Hp[0] == Hp[L-1] == 256, L >= 2): the weights of the three
+// SMALL products -- first layer, policy head, policy head transposed, 32 registers each -- are requested at kernel entry
+// behind the input loads and stay in registers (the kernel runs one workgroup per CU: the whole 512-entry register file of
+// a SIMD belongs to one wave), and the second layer's first ring stages follow them.  The small phases then pay neither
+// their own weight round trip nor the burst that requests the next product's weights.
+template <int CT, int KS, int CTH, bool WIDE, bool EARLY = false>
 __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     warm_kernargs<sizeof(NetDev) + sizeof(TrainArgs)>();
@@ -793,26 +837,44 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     STAMP(0);
     WRing<CT, KS> wpre;
     HeadFrag<CTH> hpre;
-    dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
+    WFrag<CT, KS> wl0, whT;                              // EARLY: first-layer and transposed-head weights of this wave's 64 columns
+    if constexpr (!EARLY) dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][0], net.Hp[0], net.Hp[0], net.Kp0);
     float* par = lds + net.lds_par - net.par_skip;      // indexed with absolute mirror offsets
     ObsNorm nz = {nullptr, nullptr, 0.f, 0.f, 0};
     RowScalars rs;
     if (tower == 0) rs = RowScalars{a.actions, a.advs ? a.advs : a.returns, a.advs ? nullptr : a.old_values, a.old_neglogp, a.adv_stats, 1};
     else rs = RowScalars{nullptr, a.returns, nullptr, a.old_values, nullptr, 2};
     stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, row0, a.n, nz, nullptr,
-                       tower == 0 ? a.x0g : nullptr, rs, acts, rowv);
+                       tower == 0 ? a.x0g : nullptr, rs, acts, rowv, [&]() __attribute__((always_inline)) {
+                           if constexpr (EARLY) {
+                               load_frag<CT, KS>(wl0, a.theta + net.w_off[tower][0], net.Hp[0]);
+                               dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][1], net.Hp[1], net.Hp[1], net.Hp[0]);
+                               if (tower == 0) {
+                                   if constexpr (CTH > 0) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, net.Hp[net.L - 1]);
+                                   load_frag<CT, KS>(whT, a.thetaT + net.wmuT_off, net.Hp[net.L - 1]);
+                               }
+                           }
+                       });
     lds_barrier();
     STAMP(1);
     // ---- forward (G:6889-9187) -------------------------------------------------------------------------------
     int K = net.Kp0, ldx = ld0;
-    for (int l = 0; l < net.L; ++l) {
+    if constexpr (EARLY) {
+        const int Np = net.Hp[0], ldy = Np + LDS_PAD;
+        dense_tile_frag<CT, KS, EP_BIAS_TANH>(wl0, par + net.par_b[0], lds + net.lds_h[0], ld0, lds + net.lds_h[1], ldy, nullptr, 0, a.hg[tower][0], Np, row0, a.n);
+        lds_barrier();
+        STAMP(2);
+        K = Np; ldx = ldy;
+    }
+    for (int l = EARLY ? 1 : 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
         dense_tile<CT, KS, EP_BIAS_TANH>(wpre, a.theta + net.w_off[tower][l], Np, WIDE ? a.par + tower * net.par_total + net.par_b[l] : par + net.par_b[l], lds + net.lds_h[l], ldx, K,
                                          lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, a.hg[tower][l], Np, row0, a.n, [&]() __attribute__((always_inline)) {
                                              if (l + 1 < net.L) dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][l + 1], net.Hp[l + 1], net.Hp[l + 1], Np);
                                              else {
-                                                 if constexpr (CTH > 0) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, Np);
-                                                 if (tower == 1 && net.L > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[1][net.L - 1], net.Hp[net.L - 2], net.Hp[net.L - 2], Np);
+                                                 if constexpr (CTH > 0 && !EARLY) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, Np);
+                                                 // the backward pass's transposed second-layer weights: the ring is idle from here to the backward layer
+                                                 if ((tower == 1 || EARLY) && net.L > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[tower][net.L - 1], net.Hp[net.L - 2], net.Hp[net.L - 2], Np);
                                              }
                                          }
 #ifdef PPO_STAMPS
@@ -839,7 +901,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
         // pipeline stage deep (Ap == 16*KS) it goes to the last ring slot and the transposed weights of the layer
         // below take slots 0.. right away (see dense_tile_one_stage)
         constexpr bool ONE = CTH > 0 && CTH == KS;
-        if constexpr (ONE) {
+        if constexpr (EARLY) {
+            // nothing to request: the head's transposed weights have been in registers since kernel entry, the layer below's
+            // since the end of the last forward layer
+        } else if constexpr (ONE) {
             prefetch_one_stage<CT, KS, PPO_RING - 1>(wpre, a.thetaT + net.wmuT_off, HpL, HpL);
             if (net.L > 1) dense_prefetch<CT, KS>(wpre, a.thetaT + net.wT_off[0][net.L - 1], net.Hp[net.L - 2], net.Hp[net.L - 2], HpL);
         } else dense_prefetch<CT, KS>(wpre, a.thetaT + net.wmuT_off, HpL, HpL, net.Ap);
@@ -907,7 +972,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
         }
         STAMP(7);
         // dh_L = (dmu * W_mu^T) .* (1 - h_L^2): a dense product against the transposed head weights [Ap][HpL]
-        if constexpr (ONE)
+        if constexpr (EARLY)
+            dense_tile_frag<CT, KS, EP_TANHGRAD>(whT, nullptr, dcur, ldm, dnext, HpL + LDS_PAD, hL, ldhL, a.dyg[0][net.L - 1], HpL, row0, a.n);
+        else if constexpr (ONE)
             dense_tile_one_stage<CT, KS, EP_TANHGRAD, PPO_RING - 1>(wpre, a.thetaT + net.wmuT_off, HpL, nullptr, dcur, ldm, dnext, HpL + LDS_PAD, HpL, hL, ldhL,
                                                                     a.dyg[0][net.L - 1], HpL, row0, a.n);
         else
