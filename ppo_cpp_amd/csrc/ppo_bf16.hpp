@@ -49,6 +49,7 @@ struct GemmArgs {
     bf16_t* C[2]; int ldc;                    // out [I][J] bf16 (may be null)
     bf16_t* CT[2]; int ldct;                  // out [J][I] bf16 (may be null)
     float* F[2]; int ldf;                     // F32: out [I][J] fp32
+    float* bsum[2]; int bsum_ld;              // TANHGRAD: per row-tile column sums of the fp32 outputs, [tiles_i][bsum_ld] (bias gradients; may be null)
 };
 
 // 16-byte chunk c (0..7) of row r of a [rows][64 bf16] LDS tile lives at chunk c ^ (r & 7): a 16-lane group of a
@@ -147,6 +148,7 @@ __device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a
     const int g = lane >> 4, c = lane & 15;
     constexpr int BM = GB_BM(WM), TLD = BM + 8, NT = GB_THREADS(WM);
     bf16_t* tt = reinterpret_cast<bf16_t*>(lds);              // [128 cols j][TLD rows i]
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         const int j = wn + 16 * nb + c;
@@ -168,9 +170,32 @@ __device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (bf16_t)y[r];
             *reinterpret_cast<bf16x4*>(tt + j * TLD + i) = o;
+            if constexpr (EPI == GEPI_TANHGRAD) csum[nb] += (y[0] + y[1]) + (y[2] + y[3]);
+        }
+    }
+    // bias gradients ride along: db[j] = sum over rows of dY[:, j].  Each wave adds its 64 rows (16 values per lane, then the
+    // four lane groups), the WM waves that share the columns meet in LDS behind the parked image, and the tile's sums go
+    // to row `ti` of a small [row tiles][features] table the gradient assembly adds up in tile order (fixed order).
+    float* cs = reinterpret_cast<float*>(lds + GB_N * TLD * 2);           // [WM][128]
+    if constexpr (EPI == GEPI_TANHGRAD) {
+        if (a.bsum[tw]) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float v = csum[nb];
+                v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                if (g == 0) cs[(wave >> 1) * GB_N + wn + 16 * nb + c] = v;
+            }
         }
     }
     __syncthreads();
+    if constexpr (EPI == GEPI_TANHGRAD) {
+        if (a.bsum[tw] && tid < GB_N) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < WM; ++q) v += cs[q * GB_N + tid];
+            a.bsum[tw][(size_t)(i0 / BM) * a.bsum_ld + j0 + tid] = v;
+        }
+    }
     if (a.CT[tw]) {                                           // [J][I]: rows of the parked image, BM/8 chunks of 16 B per row
         constexpr int CH = BM / 8;
 #pragma unroll
@@ -220,8 +245,9 @@ __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_nt_bf16_kernel(GemmArgs a
 }
 
 // ---- weight gradients: every matrix of both towers in one grouped launch, split over the minibatch rows -------------
-struct DwTileB { const bf16_t* A; const bf16_t* B; int lda, ldb; int i0, j0; int out_off, ldo; };
-struct DwArgsB { const DwTileB* tiles; int nsplit; int rows_per_split; float* slabs; size_t slab_stride; };
+struct DwTileB { const bf16_t* A; const bf16_t* B; int lda, ldb; int i0, j0; int out_off, ldo; int is_x0; };
+struct DwArgsB { const DwTileB* tiles; int nsplit; int rows_per_split; float* slabs; size_t slab_stride;
+                 const bf16_t* x0T; int x0_ld; };     // epoch-staged transposed observations of this minibatch (null: the tiles' own x0T)
 
 template <int WM>
 __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_dw_bf16_kernel(DwArgsB a) {
@@ -229,7 +255,8 @@ __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_dw_bf16_kernel(DwArgsB a)
     const DwTileB t = a.tiles[blockIdx.x / a.nsplit];
     const int split = blockIdx.x % a.nsplit;                 // the splits of one tile sit on different XCDs; tiles of one split share X^T / dY^T panels
     GemmAcc acc;
-    gb_mainloop<WM>(acc, t.A, t.lda, t.i0, t.B, t.ldb, t.j0, split * a.rows_per_split, a.rows_per_split, gb_lds);
+    const bool ov = t.is_x0 && a.x0T;
+    gb_mainloop<WM>(acc, ov ? a.x0T : t.A, ov ? a.x0_ld : t.lda, t.i0, t.B, t.ldb, t.j0, split * a.rows_per_split, a.rows_per_split, gb_lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, g = lane >> 4, c = lane & 15;
     float* out = a.slabs + (size_t)split * a.slab_stride + t.out_off;
@@ -312,11 +339,12 @@ struct LossArgsB {
     float* slots[2]; int slot_w, slot_head, slot_aux, slot_loss;
 };
 
-__global__ __launch_bounds__(256) void bf16_loss_kernel(LossArgsB a) {
-    extern __shared__ __attribute__((aligned(16))) float ls[];      // [16][Ap] dmu | [16][Ap] dlogstd | [16][4] pi terms | [16][2] vf terms
-    float* dmu_s = ls; float* dls_s = ls + 16 * a.Ap; float* pt = dls_s + 16 * a.Ap; float* vt = pt + 64;
+#define BL_ROWS 32                 // rows per block of the loss kernel (16 lanes each): one slot row of partial sums per block
+__global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
+    extern __shared__ __attribute__((aligned(16))) float ls[];      // [R][Ap] dmu | [R][Ap] dlogstd | [R][4] pi terms | [R][2] vf terms
+    float* dmu_s = ls; float* dls_s = ls + BL_ROWS * a.Ap; float* pt = dls_s + BL_ROWS * a.Ap; float* vt = pt + 4 * BL_ROWS;
     const int tid = threadIdx.x, r = tid >> 4, part = tid & 15;
-    const int row = blockIdx.x * 16 + r;
+    const int row = blockIdx.x * BL_ROWS + r;
     const bool live = row < a.n;
     const float cr = a.hyper[1];
     const float g = a.inv_n;
@@ -361,7 +389,6 @@ __global__ __launch_bounds__(256) void bf16_loss_kernel(LossArgsB a) {
         }
         dmu_s[r * a.Ap + j] = dmu; dls_s[r * a.Ap + j] = dl;
         a.dhead[0][(size_t)row * a.Ap + j] = (bf16_t)dmu;
-        a.dheadT[0][(size_t)j * a.rows_pad + row] = (bf16_t)dmu;
     }
     // value tower (G:10213-10837, G:14975-19571)
     if (part == 0) {
@@ -385,16 +412,24 @@ __global__ __launch_bounds__(256) void bf16_loss_kernel(LossArgsB a) {
         a.dheadT[1][row] = (bf16_t)dv;
     }
     __syncthreads();
+    // the [features][rows] copy of d mu from the LDS tile: 8 consecutive rows of one feature = one 16-byte store
+    for (int i = tid; i < a.Ap * (BL_ROWS / 8); i += 16 * BL_ROWS) {
+        const int j = i / (BL_ROWS / 8), pr = i - j * (BL_ROWS / 8);
+        bf16x8 v;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (bf16_t)dmu_s[(8 * pr + q) * a.Ap + j];
+        *reinterpret_cast<bf16x8*>(a.dheadT[0] + (size_t)j * a.rows_pad + (size_t)blockIdx.x * BL_ROWS + 8 * pr) = v;
+    }
     float* s0 = a.slots[0] + (size_t)blockIdx.x * a.slot_w;
     float* s1 = a.slots[1] + (size_t)blockIdx.x * a.slot_w;
-    for (int j = tid; j < a.Ap; j += 256) {
+    for (int j = tid; j < a.Ap; j += 16 * BL_ROWS) {
         float sb = 0.f, sl = 0.f;
-        for (int q = 0; q < 16; ++q) { sb += dmu_s[q * a.Ap + j]; sl += dls_s[q * a.Ap + j]; }
+        for (int q = 0; q < BL_ROWS; ++q) { sb += dmu_s[q * a.Ap + j]; sl += dls_s[q * a.Ap + j]; }
         s0[a.slot_head + j] = sb;                              // db_mu  (fp32 sums of the fp32 values, not of their bf16 roundings)
         s0[a.slot_aux + j] = sl;                               // dlogstd
     }
-    if (tid < 4) { float s = 0.f; for (int q = 0; q < 16; ++q) s += pt[q * 4 + tid]; s0[a.slot_loss + tid] = s; }
-    if (tid == 4) { float sb = 0.f, sl = 0.f; for (int q = 0; q < 16; ++q) { sb += vt[q * 2]; sl += vt[q * 2 + 1]; } s1[a.slot_head] = sb; s1[a.slot_loss] = sl; }
+    if (tid >= 256 && tid < 260) { const int k = tid - 256; float s = 0.f; for (int q = 0; q < BL_ROWS; ++q) s += pt[q * 4 + k]; s0[a.slot_loss + k] = s; }
+    if (tid == 320) { float sb = 0.f, sl = 0.f; for (int q = 0; q < BL_ROWS; ++q) { sb += vt[q * 2]; sl += vt[q * 2 + 1]; } s1[a.slot_head] = sb; s1[a.slot_loss] = sl; }
 }
 
 // ---- bias gradients of the hidden layers: db[j] = sum over rows of dY, one wave per row of the [features][rows] copy ----
@@ -443,4 +478,56 @@ __global__ __launch_bounds__(256) void bf16_transpose_kernel(TrArgs a) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) a.dst[t.dst_off + (size_t)(c0 + y + 8 * k) * t.rows + r0 + x] = (bf16_t)tile[x][y + 8 * k];
+}
+
+// ---- gradient assembly for the bf16 path: one WAVE per 256-element chunk of the padded parameter vector, four consecutive
+// elements per lane (16-byte slab loads); the chunk's sum of squares is a wave reduction.  Same sources as grad_reduce_kernel
+// (kind 0 slabs, kind 1 per-block slots, kind 3 per-row-tile bias sums), same fixed summation orders. ---------------------
+__global__ __launch_bounds__(256) void bf16_grad_reduce_kernel(ReduceArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    // highest chunks first: the slot-summed vectors (head bias, logstd: hundreds of dependent-free but latency-bound loads per
+    // lane) sit at the END of the parameter vector and must not be the launch's tail
+    const int chunk = a.n_blocks - (int)(blockIdx.x * 4 + (tid >> 6));
+    if (chunk < 0) return;
+    if (chunk == a.n_blocks) {                              // loss tail: {pg, vf, ent, kl, cf, rows}
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {                       // lanes take the slot rows round robin, then meet in a fixed-shape tree
+            const int tower = (q == 1) ? 1 : 0, off = a.slot_loss + (q <= 1 ? 0 : q - 1);
+            float s = 0.f;
+            for (int b = lane; b < a.n_rowblocks; b += 64) s += a.slots[tower][(size_t)b * a.slot_w + off];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) a.grad[(size_t)a.n_blocks * 256 + q] = s;
+        }
+        if (lane == 5) a.grad[(size_t)a.n_blocks * 256 + 5] = a.n_local;
+        if (lane == 6) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }
+        return;
+    }
+    const GradSrc s = a.src[chunk];
+    const size_t idx = (size_t)chunk * 256 + 4 * lane;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s.kind == 0) {
+        for (int k = 0; k < a.nsplit; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)k * a.slab_stride + idx);
+            g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
+        }
+    } else if (s.kind == 1 || s.kind == 3) {
+        // rows of a small table, 16 bytes per lane and row, all loads independent (offsets are multiples of 4 floats on this path)
+        const int e0 = (int)(idx - (size_t)s.base);
+        const float* p = (s.kind == 1 ? a.slots[s.tower] : a.direct) + s.slot_off + e0;
+        const int rows = s.kind == 1 ? a.n_rowblocks : a.n_direct;
+        const size_t stride = s.kind == 1 ? (size_t)a.slot_w : (size_t)a.direct_stride;
+        if (e0 < s.count) {
+#pragma unroll 8
+            for (int b = 0; b < rows; ++b) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * stride);
+                g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (e0 + q >= s.count) g[q] = 0.f;
+        }
+    }
+    *reinterpret_cast<float4*>(a.grad + idx) = make_float4(g[0], g[1], g[2], g[3]);
+    float q = (g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]);
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) a.sumsq[chunk] = q;
 }

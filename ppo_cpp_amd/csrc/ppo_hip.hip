@@ -132,6 +132,8 @@ struct ppo_handle {
         int wt_off[2][PPO_MAX_LAYERS]{}; int whT_off[2]{}; int nT = 0;
         TrMat* d_trmats = nullptr; int n_trmats = 0, n_trtiles = 0;
         bf16_t *x0 = nullptr, *x0T = nullptr;
+        bf16_t *xe = nullptr, *xeT = nullptr; int xe_rows = 0; bool epoch_staged = false;   // observations of a whole epoch staged once (bf16, both layouts)
+        int db_tiles = 0;                               // row tiles the bias-gradient table is sized for
         bf16_t *hb[2][PPO_MAX_LAYERS]{}, *hT[2][PPO_MAX_LAYERS]{}, *dy[2][PPO_MAX_LAYERS]{}, *dyT[2][PPO_MAX_LAYERS]{};
         float* head_out[2]{};                           // [Rcap][Ap] fp32
         bf16_t *dhead[2]{}, *dheadT[2]{};
@@ -558,7 +560,7 @@ int bf16_refresh_mirrors(ppo_handle* h) {
 int bf16_create(ppo_handle* h) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
-    if (dev_alloc(h, &b.theta_bf, (size_t)h->P_pad) || dev_alloc(h, &b.thetaT_bf, (size_t)b.nT) || dev_alloc(h, &b.dbias, (size_t)b.n_dbias)) return -1;
+    if (dev_alloc(h, &b.theta_bf, (size_t)h->P_pad) || dev_alloc(h, &b.thetaT_bf, (size_t)b.nT)) return -1;
     std::vector<TrMat> mats;
     int tiles = 0;
     auto add = [&](int src_off, int dst_off, int rows, int cols) { mats.push_back(TrMat{src_off, dst_off, rows, cols, tiles}); tiles += (rows / 32) * (cols / 32); };
@@ -601,10 +603,12 @@ int bf16_ensure_ws(ppo_handle* h, int rows) {
         if (dev_alloc(h, &h->slots[t], (size_t)(R / 16) * n.slot_w)) return -1;
     }
     if (!h->slabs && dev_alloc(h, &h->slabs, (size_t)h->max_split * h->P_pad)) return -1;
+    b.db_tiles = R / 128;
+    if (dev_alloc(h, &b.dbias, (size_t)b.db_tiles * b.n_dbias)) return -1;
     // grouped weight-gradient tile table: dW = X^T dY for every layer and both heads, operands in the [features][rows] layout
     std::vector<DwTileB> tiles;
     auto add = [&](const bf16_t* A, const bf16_t* B, int Kp, int Np, int out_off) {
-        for (int i = 0; i < Kp; i += GB_BM(b.dw_wm)) for (int j = 0; j < Np; j += GB_N) tiles.push_back(DwTileB{A, B, R, R, i, j, out_off, Np});
+        for (int i = 0; i < Kp; i += GB_BM(b.dw_wm)) for (int j = 0; j < Np; j += GB_N) tiles.push_back(DwTileB{A, B, R, R, i, j, out_off, Np, A == b.x0T ? 1 : 0});
     };
     for (int t = 0; t < 2; ++t) {
         for (int l = 0; l < n.L; ++l) add(l ? b.hT[t][l - 1] : b.x0T, b.dyT[t][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l], n.w_off[t][l]);
@@ -633,14 +637,14 @@ int bf16_gemm(ppo_handle* h, const GemmArgs& a, int I, int J) {
 }
 
 // forward of both towers on `rows` staged rows: hidden layers (bias + tanh) and the padded heads (fp32 out)
-int bf16_forward(ppo_handle* h, int Rp, bool want_transposed) {
+int bf16_forward(ppo_handle* h, int Rp, bool want_transposed, const bf16_t* x0_override = nullptr) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
     for (int l = 0; l < n.L; ++l) {
         GemmArgs a{};
         const int Kp = l ? n.Hp[l - 1] : n.Kp0;
         for (int t = 0; t < 2; ++t) {
-            a.A[t] = l ? b.hb[t][l - 1] : b.x0; a.B[t] = b.thetaT_bf + b.wt_off[t][l]; a.bias[t] = h->theta + n.b_off[t][l];
+            a.A[t] = l ? b.hb[t][l - 1] : (x0_override ? x0_override : b.x0); a.B[t] = b.thetaT_bf + b.wt_off[t][l]; a.bias[t] = h->theta + n.b_off[t][l];
             a.C[t] = b.hb[t][l]; a.CT[t] = want_transposed ? b.hT[t][l] : nullptr;
         }
         a.lda = Kp; a.ldb = Kp; a.K = Kp; a.ldc = n.Hp[l]; a.ldct = b.Rcap;
@@ -680,16 +684,26 @@ int launch_step_bf16(ppo_handle* h, const StepArgs& a) {
     return 0;
 }
 
+// rows of the epoch-staged observations this minibatch starts at, or -1 when the step stages its own rows
+long bf16_epoch_row(ppo_handle* h, const TrainArgs& ta, int Rp) {
+    ppo_handle::Bf16& b = h->bf;
+    if (!b.epoch_staged || !h->mb_obs || ta.obs < h->mb_obs || Rp != ta.n) return -1;
+    const long r0 = (long)(ta.obs - h->mb_obs) / h->net.O;
+    return (r0 + ta.n <= b.xe_rows) ? r0 : -1;
+}
+
 int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
-    if (bf16_stage(h, ta.obs, ta.n, Rp, no_norm_fwd(), nullptr, true) || bf16_forward(h, Rp, true)) return -1;
+    const long er = bf16_epoch_row(h, ta, Rp);
+    if (er < 0 && bf16_stage(h, ta.obs, ta.n, Rp, no_norm_fwd(), nullptr, true)) return -1;
+    if (bf16_forward(h, Rp, true, er >= 0 ? b.xe + (size_t)er * n.Kp0 : nullptr)) return -1;
     LossArgsB la{};
     for (int t = 0; t < 2; ++t) { la.head[t] = b.head_out[t]; la.dhead[t] = b.dhead[t]; la.dheadT[t] = b.dheadT[t]; la.slots[t] = h->slots[t]; }
     la.ldh = n.Ap; la.logstd = h->theta + n.ls_off; la.actions = ta.actions; la.advs = ta.advs; la.returns = ta.returns; la.old_values = ta.old_values;
     la.old_neglogp = ta.old_neglogp; la.hyper = h->hyper; la.n = ta.n; la.A = n.A; la.Ap = n.Ap; la.rows_pad = b.Rcap; la.inv_n = ta.inv_n;
     la.ent_coef = n.ent_coef; la.vf_coef = n.vf_coef; la.slot_w = n.slot_w; la.slot_head = n.slot_head; la.slot_aux = n.slot_aux; la.slot_loss = n.slot_loss;
-    hipLaunchKernelGGL(bf16_loss_kernel, dim3(Rp / 16), dim3(256), (size_t)(2 * 16 * n.Ap + 64 + 32) * sizeof(float), h->stream, la);
+    hipLaunchKernelGGL(bf16_loss_kernel, dim3(Rp / BL_ROWS), dim3(16 * BL_ROWS), (size_t)(2 * BL_ROWS * n.Ap + 6 * BL_ROWS) * sizeof(float), h->stream, la);
     HIP_OK(h, hipGetLastError());
     // dY_{L-1} = (d head * W_head^T) .* (1 - h_L^2), then down the hidden layers
     const int HpL = n.Hp[n.L - 1];
@@ -699,32 +713,30 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
             a.A[t] = b.dhead[t]; a.B[t] = b.theta_bf + (t ? n.wv_off : n.wmu_off); a.HT[t] = b.hT[t][n.L - 1]; a.C[t] = b.dy[t][n.L - 1]; a.CT[t] = b.dyT[t][n.L - 1];
         }
         a.lda = n.Ap; a.ldb = n.Ap; a.K = n.Ap; a.ldht = b.Rcap; a.ldc = HpL; a.ldct = b.Rcap;
+        for (int t = 0; t < 2; ++t) a.bsum[t] = b.dbias + b.db_off[t][n.L - 1];
+        a.bsum_ld = b.n_dbias;
         if (bf16_gemm<GEPI_TANHGRAD>(h, a, Rp, HpL)) return -1;
     }
     for (int l = n.L - 1; l >= 1; --l) {
         GemmArgs a{};
         for (int t = 0; t < 2; ++t) {
-            a.A[t] = b.dy[t][l]; a.B[t] = b.theta_bf + n.w_off[t][l]; a.HT[t] = b.hT[t][l - 1]; a.C[t] = b.dy[t][l - 1]; a.CT[t] = b.dyT[t][l - 1];
+            // (the bottom layer's gradient is only ever an operand of its weight gradient: no [rows][features] copy)
+            a.A[t] = b.dy[t][l]; a.B[t] = b.theta_bf + n.w_off[t][l]; a.HT[t] = b.hT[t][l - 1]; a.C[t] = l > 1 ? b.dy[t][l - 1] : nullptr; a.CT[t] = b.dyT[t][l - 1];
         }
         a.lda = n.Hp[l]; a.ldb = n.Hp[l]; a.K = n.Hp[l]; a.ldht = b.Rcap; a.ldc = n.Hp[l - 1]; a.ldct = b.Rcap;
+        for (int t = 0; t < 2; ++t) a.bsum[t] = b.dbias + b.db_off[t][l - 1];
+        a.bsum_ld = b.n_dbias;
         if (bf16_gemm<GEPI_TANHGRAD>(h, a, Rp, n.Hp[l - 1])) return -1;
     }
     return 0;
 }
 
-int bf16_weight_grads(ppo_handle* h, int Rp, int nsplit) {
+int bf16_weight_grads(ppo_handle* h, const TrainArgs& ta, int Rp, int nsplit) {
     ppo_handle::Bf16& b = h->bf;
-    const NetDev& n = h->net;
-    DwArgsB da{b.dw_tiles, nsplit, Rp / nsplit, h->slabs, (size_t)h->P_pad};
+    const long er = bf16_epoch_row(h, ta, Rp);
+    DwArgsB da{b.dw_tiles, nsplit, Rp / nsplit, h->slabs, (size_t)h->P_pad, er >= 0 ? b.xeT + er : nullptr, b.xe_rows};
     if (b.dw_wm == 4) hipLaunchKernelGGL(gemm_dw_bf16_kernel<4>, dim3(b.n_dw_tiles * nsplit), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, da);
     else hipLaunchKernelGGL(gemm_dw_bf16_kernel<2>, dim3(b.n_dw_tiles * nsplit), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, da);
-    HIP_OK(h, hipGetLastError());
-    RowSumArgsB ra{};
-    int m = 0, first = 0;
-    for (int t = 0; t < 2; ++t)
-        for (int l = 0; l < n.L; ++l) { ra.src[m] = b.dyT[t][l]; ra.dst[m] = b.dbias + b.db_off[t][l]; ra.rows[m] = n.Hp[l]; ra.first[m] = first; first += n.Hp[l]; ++m; }
-    ra.first[m] = first; ra.n_mats = m; ra.ld = b.Rcap; ra.len = Rp;
-    hipLaunchKernelGGL(bf16_rowsum_kernel, dim3((first + 3) / 4), dim3(256), 0, h->stream, ra);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -834,14 +846,15 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
         int nsplit = 1;
         while (nsplit < h->max_split && h->bf.n_dw_tiles * nsplit < 512 && (Rp / (2 * nsplit)) % GB_K == 0 && Rp / (2 * nsplit) >= 256) nsplit *= 2;
         { ProfScope ps(h, PK_TRAIN_FB); if (bf16_train_fwd_bwd(h, ta, Rp)) return -1; }
-        { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, Rp, nsplit)) return -1; }
+        { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, ta, Rp, nsplit)) return -1; }
         {
             ProfScope ps(h, PK_REDUCE);
             ReduceArgs ra{};
             ra.src = h->grad_src; ra.n_blocks = h->n_blocks; ra.slabs = h->slabs; ra.slab_stride = (size_t)h->P_pad; ra.nsplit = nsplit;
-            ra.slots[0] = h->slots[0]; ra.slots[1] = h->slots[1]; ra.n_rowblocks = Rp / 16; ra.slot_w = n.slot_w; ra.slot_loss = n.slot_loss;
+            ra.slots[0] = h->slots[0]; ra.slots[1] = h->slots[1]; ra.n_rowblocks = Rp / BL_ROWS; ra.slot_w = n.slot_w; ra.slot_loss = n.slot_loss;
             ra.grad = h->grad; ra.sumsq = h->sumsq; ra.n_local = (float)ta.n; ra.beta_pow = h->beta_pow; ra.direct = h->bf.dbias;
-            hipLaunchKernelGGL(grad_reduce_kernel, dim3(h->n_blocks + 1), dim3(256), 0, h->stream, ra);
+            ra.n_direct = Rp / (Rp % 256 == 0 ? 256 : 128); ra.direct_stride = h->bf.n_dbias;
+            hipLaunchKernelGGL(bf16_grad_reduce_kernel, dim3((h->n_blocks + 1 + 3) / 4), dim3(256), 0, h->stream, ra);
             HIP_OK(h, hipGetLastError());
         }
         if (h->comm) {
@@ -1034,7 +1047,7 @@ void ppo_destroy(ppo_handle* h) {
     for (int i = 0; i < 6; ++i) if (h->st_vec[i]) (void)hipFree(h->st_vec[i]);
     {
         ppo_handle::Bf16& b = h->bf;
-        void* bp[] = {b.theta_bf, b.thetaT_bf, b.d_trmats, b.x0, b.x0T, b.head_out[0], b.head_out[1], b.dhead[0], b.dhead[1], b.dheadT[0], b.dheadT[1], b.dbias, b.dw_tiles};
+        void* bp[] = {b.theta_bf, b.thetaT_bf, b.d_trmats, b.x0, b.x0T, b.xe, b.xeT, b.head_out[0], b.head_out[1], b.dhead[0], b.dhead[1], b.dheadT[0], b.dheadT[1], b.dbias, b.dw_tiles};
         for (void* p : bp) if (p) (void)hipFree(p);
         for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) for (bf16_t* p : {b.hb[t][l], b.hT[t][l], b.dy[t][l], b.dyT[t][l]}) if (p) (void)hipFree(p);
     }
@@ -1203,6 +1216,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
                    const float* returns, const float* old_neglogp, const float* old_values, int32_t n, float losses[5]) {
     ENTER(h);
     if (n < 2) return fail(h, "ppo_train_step: n=%d (the reference asserts more than one row, ppo2.hpp:402)", n);
+    h->bf.epoch_staged = false;
     if (ensure_staging(h, n) || ensure_train_ws(h, n)) return -1;
     const NetDev& net = h->net;
     const size_t fb = sizeof(float);
@@ -1689,6 +1703,17 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
                           h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};
             hipLaunchKernelGGL(epoch_gather_kernel, dim3((B + 15) / 16), dim3(256), 0, h->stream, ga);
             HIP_OK(h, hipGetLastError());
+            if (h->bf.on) {
+                // bf16 path: the epoch's observations become bf16 once, in both layouts; a minibatch is then a row / column slice
+                ppo_handle::Bf16& bb = h->bf;
+                bb.epoch_staged = M % GB_PAD == 0 && bb.xe_rows >= B;
+                if (bb.epoch_staged) {
+                    StageArgsB sa{h->mb_obs, B, h->net.O, h->net.Kp0, B, no_norm(), nullptr, bb.xe, bb.xeT, bb.xe_rows};
+                    const size_t cnt = (size_t)B * h->net.Kp0;
+                    hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
+                    HIP_OK(h, hipGetLastError());
+                }
+            }
         }
         for (int k = 0; k < nmb; ++k) {
             TrainArgs ta{};
@@ -1725,6 +1750,10 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
             dev_alloc(h, &h->d_loss_mean, 8) || dev_alloc(h, &h->adv_xch, (size_t)2 * cs))
             return -1;
         h->upd_cap_rows = cr; h->upd_cap_steps = cs;
+        if (h->bf.on) {
+            if (dev_alloc(h, &h->bf.xe, (size_t)cr * h->net.Kp0) || dev_alloc(h, &h->bf.xeT, (size_t)cr * h->net.Kp0)) return -1;
+            h->bf.xe_rows = cr;
+        }
     }
     if (set_hyper(h, lr, cliprange)) return -1;
     const bool explicit_perms = perms != nullptr;

@@ -1388,7 +1388,8 @@ struct ReduceArgs {
     const float* slabs; size_t slab_stride; int nsplit;
     const float* slots[2]; int n_rowblocks; int slot_w;
     int slot_loss;
-    const float* direct;         // kind 3: finished sums (bias gradients of the bf16 path's row-sum kernel), indexed slot_off + e
+    const float* direct;         // kind 3: per-row-tile sums (bias gradients from the bf16 path's TanhGrad epilogues), [n_direct][direct_stride], indexed slot_off + e
+    int n_direct; int direct_stride;
     float* grad;                 // [P_pad]  (+ 8 tail floats: 5 loss sums, row count)
     float* sumsq;                // [n_blocks]
     float n_local;               // rows summed on this rank
@@ -1438,7 +1439,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
         }
     } else if (s.kind == 3) {
         const int e = (int)(idx - (size_t)s.base);
-        if (e < s.count) gsum = a.direct[s.slot_off + e];
+        if (e < s.count) for (int t = 0; t < a.n_direct; ++t) gsum += a.direct[(size_t)t * a.direct_stride + s.slot_off + e];
     }
     a.grad[idx] = gsum;
     float q = gsum * gsum;
