@@ -32,7 +32,7 @@ def build_hip(force=False, verbose=False):
     deps = _sources(csrc, (".hip", ".hpp", ".h")) + [os.path.join(ROOT, "include", "ppo_hip.h")]
     if force or _newer(HIP_SO, deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-               "-o", HIP_SO, os.path.join(csrc, "ppo_hip.hip"), "-ldl"]
+               "-o", HIP_SO, os.path.join(csrc, "ppo_hip.hip"), "-ldl"] + os.environ.get("PPO_HIP_EXTRA_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

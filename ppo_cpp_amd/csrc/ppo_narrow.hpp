@@ -18,7 +18,8 @@
 #include "ppo_kernels.hpp"
 
 #define NW_MAXL 4                  // hidden layers the narrow path accepts
-#define NW_PIPES 2                 // 16-row tiles per workgroup (4 waves each)
+#define NW_PIPES 2                 // 16-row tiles per workgroup (4 waves each); one pipe per workgroup (256 workgroups at M = 2048) measured
+                                   // slower: 7.5e6 against 7.9e6 env-steps/s at BASELINE configs[3] (twice the partial vectors to add up)
 #define NW_THREADS (256 * NW_PIPES)
 #define NW_ROWS (16 * NW_PIPES)
 #define NW_WPAD 16                 // LDS row padding of the weight images: B-operand reads of the 4 k-groups hit disjoint banks
@@ -114,7 +115,7 @@ __device__ __forceinline__ void nw_stage(const NetDev& net, const NwLayout& lay,
                                          const float* __restrict__ obs, int row0, int nrows, ObsNorm nz, float* __restrict__ obs_out, int tower,
                                          const float* __restrict__ actions, const float* __restrict__ v0, const float* __restrict__ v1, int mode) {
     const int tid = threadIdx.x;
-    constexpr int WV = 8;                                   // float4 loads per thread: 8 * 512 * 16 B = 64 KB covers the image
+    constexpr int WV = 16 / NW_PIPES;                       // float4 loads per thread: 64 KB in flight covers the image
     float4 wv[WV];
     const int n4 = n_img / 4;
 #pragma unroll
