@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank runs the config's n_envs; strong: the config's n_envs are divided over the ranks "
                          "(BASELINE configs[3] as written: 1024 envs in total over 8 GPUs)")
+    ap.add_argument("--collective", default="auto", choices=["auto", "peer", "rccl"],
+                    help="data-parallel exchange: one-shot peer all-reduce over IPC-mapped buffers (auto: when its probe passes on "
+                         "every rank) or ncclAllReduce; the other one is timed over a few steps as well and reported under `collectives`")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     from ppo_cpp_amd import dist as ppodist
@@ -252,6 +255,10 @@ def main():
     g.init_orthogonal(0)                                                   # same seed on every rank: replicated weights
     if world > 1:
         g.dist_init(world, rank, ppodist.broadcast_unique_id(dist, rank, ppo_cpp_amd.PPOHip.dist_unique_id))
+        if args.collective != "rccl" and world <= 8:
+            peer_ok = g.dist_peer_attach(ppodist.allgather_bytes(dist, g.dist_peer_export(), 64))
+            if args.collective == "peer" and not peer_ok:
+                sys.exit("--collective peer: the peer all-reduce probe failed")
     g.norm_init(E, GAMMA)
     g.rollout_alloc(E, T)
     env0 = ppodist.env_offset(E, rank)                                     # every rank owns its own E environments (global ids rank*E ..)
@@ -276,6 +283,29 @@ def main():
     barrier()
     if dist is not None:
         dt = ppodist.allreduce_max(dist, dt)
+    collectives = None
+    if dist is not None:
+        # the replicas must have stayed bit-identical (same reduced gradient in the same order on every rank), and the other
+        # exchange path is timed over a few steps so that one run of the scaling bench measures both
+        import hashlib
+        used = "peer" if g.dist_peer_active() else "rccl"
+        digests = ppodist.allgather_bytes(dist, hashlib.sha256(g.get_flat(0).tobytes()).digest(), 32)
+        collectives = {"used": used, "graph_captured": g.dist_graph_collectives(), "replicas_bit_identical": len(set(digests)) == 1,
+                       used: {"ms_per_step": 1e3 * dt / args.steps}}
+        if args.collective == "auto" and used == "peer":
+            g.dist_peer_enable(False)
+            k_other = max(1, min(args.steps, 3))
+            one_step(args.warmup + args.steps)                      # capture / warm the RCCL form
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(k_other):
+                one_step(args.warmup + args.steps + 1 + i)
+            g.sync()
+            dt_o = ppodist.allreduce_max(dist, time.perf_counter() - t1)
+            barrier()
+            collectives["rccl"] = {"ms_per_step": 1e3 * dt_o / k_other, "steps": k_other, "graph_captured": g.dist_graph_collectives()}
+            g.dist_peer_enable(True)
+            barrier()
 
     # per-kernel device time of the same workload, HIP events on the handle's stream, right after the timed region
     g.prof_enable(True)
@@ -339,6 +369,8 @@ def main():
         "kernels": kern,
         "losses": [float(x) for x in losses],
     }
+    if collectives is not None:
+        out["collectives"] = collectives
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg, args.config)
     # (skipped under rocprofv3: instantiating a second handle's hipGraph in one traced process crashes the profiler)

@@ -171,6 +171,23 @@ int ppo_dist_world(const ppo_handle* h);
 /* 1 when ppo_update replays the collectives from its hipGraph (the communicator's library passed the capture probe of
  * ppo_dist_init, or PPO_HIP_GRAPH_RCCL=1), 0 when they are issued eagerly between the launches */
 int ppo_dist_graph_collectives(const ppo_handle* h);
+/* One-shot all-reduce over peer-mapped buffers (xGMI is point-to-point: every rank pushes its vector into its slot of every
+ * peer's gather region, raises a flag there, and sums the slots of its own region in rank order -- one hop instead of a
+ * ring's 2(W-1), same summation order on every rank).  One node, world_size <= 8.
+ *   ppo_dist_peer_export: after ppo_dist_init; allocates this rank's gather region and returns its 64-byte IPC handle.
+ *   ppo_dist_peer_attach: COLLECTIVE; handles = world_size x 64 bytes in rank order (all-gathered by the launcher).  Maps the
+ *     peers' regions, runs a known-answer exchange and lets the ranks agree on the outcome over the communicator: every
+ *     collective of ppo_update / ppo_rollout_* / ppo_norm_* whose payload fits then uses the peer kernels (plain launches,
+ *     replayed from the update's hipGraph); if any rank fails to map a peer or fails the probe, all ranks stay on RCCL.
+ *     PPO_HIP_PEER_REDUCE=0 keeps RCCL; PPO_HIP_PEER_TIMEOUT_MS bounds the wait on a peer's flag (default 10 s), after which
+ *     the next ppo_update / ppo_rollout_finish / ppo_collect_synthetic returns an error instead of hanging the device.
+ *     The call ends with a collective over the communicator, so no rank returns before every rank has finished its probe.
+ *   ppo_dist_peer_active: 1 when the peer path is in use.   ppo_dist_peer_enable: switch between the two paths after a
+ *     successful attach (collectively, at the same point on every rank). */
+int ppo_dist_peer_export(ppo_handle* h, char handle[64]);
+int ppo_dist_peer_attach(ppo_handle* h, const char* handles);
+int ppo_dist_peer_active(const ppo_handle* h);
+int ppo_dist_peer_enable(ppo_handle* h, int on);
 
 /* ---- measurement hooks ----------------------------------------------------------------------------------
  * per-kernel device time (ms) accumulated with hipEvents on the handle's stream since the last reset;

@@ -274,6 +274,24 @@ class PPOHip:
     def dist_graph_collectives(self):
         return bool(self.lib.ppo_dist_graph_collectives(self.h))
 
+    def dist_peer_export(self):
+        """64-byte IPC handle of this rank's gather region (one-shot peer all-reduce); all-gather them and pass to dist_peer_attach"""
+        buf = C.create_string_buffer(64)
+        self._ck(self.lib.ppo_dist_peer_export(self.h, buf))
+        return buf.raw
+
+    def dist_peer_attach(self, handles):
+        """handles: world x 64 bytes in rank order.  Collective.  Returns True when the peer path is now in use."""
+        blob = b"".join(handles) if not isinstance(handles, (bytes, bytearray)) else bytes(handles)
+        self._ck(self.lib.ppo_dist_peer_attach(self.h, C.create_string_buffer(blob, len(blob))))
+        return self.dist_peer_active()
+
+    def dist_peer_active(self):
+        return bool(self.lib.ppo_dist_peer_active(self.h))
+
+    def dist_peer_enable(self, on=True):
+        self._ck(self.lib.ppo_dist_peer_enable(self.h, int(on)))
+
     def prof_enable(self, on=True):
         self._ck(self.lib.ppo_prof_enable(self.h, int(on)))
 

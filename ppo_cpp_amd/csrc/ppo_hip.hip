@@ -6,6 +6,7 @@
 #include "ppo_kernels.hpp"
 #include "ppo_bf16.hpp"
 #include "ppo_narrow.hpp"
+#include "ppo_peer.hpp"
 
 #include <dlfcn.h>
 
@@ -152,6 +153,16 @@ struct ppo_handle {
     void* comm = nullptr;
     int world = 1, rank = 0;
     bool graph_rccl = false;          // the collectives can be captured into the update's hipGraph (probed in ppo_dist_init)
+    // one-shot all-reduce over peer-mapped gather regions (ppo_peer.hpp; ppo_dist_peer_export / ppo_dist_peer_attach)
+    struct Peer {
+        bool on = false;                                // every collective that fits `cap` goes through the peer kernels
+        bool usable = false;                            // the probe passed on every rank (ppo_dist_peer_enable may switch `on`)
+        void* region = nullptr;                         // mine: [flag block | slots[2][world][cap]] (exported over IPC)
+        size_t cap = 0;                                 // floats per slot (multiple of PEER_CHUNK)
+        void* mapped[PEER_MAX_WORLD]{};                 // the other ranks' regions as this process sees them
+        unsigned* local = nullptr;                      // {seq, arrive, err}
+        PeerDev dev{};
+    } peer;
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
@@ -768,6 +779,42 @@ int launch_step(ppo_handle* h, const StepArgs& a) {
     return 0;
 }
 
+// ---- data-parallel collectives: one-shot peer exchange when attached and the payload fits, RCCL otherwise ------------------
+// sum-all-reduce of buf[0, count) in place; sumsq != null: also the per-256-element sums of squares of the first
+// sumsq_chunks chunks of the RESULT (what grad_sumsq_kernel would compute)
+int enqueue_allreduce(ppo_handle* h, float* buf, size_t count, float* sumsq = nullptr, int sumsq_chunks = 0) {
+    ProfScope ps(h, PK_COMM);
+    if (h->peer.on && count <= h->peer.cap) {
+        const unsigned grid = (unsigned)((count + PEER_CHUNK - 1) / PEER_CHUNK);
+        hipLaunchKernelGGL(peer_push_kernel, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, (const float*)buf, (unsigned long long)count);
+        hipLaunchKernelGGL(peer_sum_kernel, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, buf, (unsigned long long)count, sumsq, (unsigned)sumsq_chunks);
+        HIP_OK(h, hipGetLastError());
+        return 0;
+    }
+    const int rc = h->rccl.AllReduce(buf, buf, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
+    if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
+    if (sumsq) {
+        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(sumsq_chunks), dim3(256), 0, h->stream, buf, sumsq);
+        HIP_OK(h, hipGetLastError());
+    }
+    return 0;
+}
+
+// the padded gradient + loss sums + row count of one minibatch, then the sums of squares of the reduced gradient
+int enqueue_grad_allreduce(ppo_handle* h) { return enqueue_allreduce(h, h->grad, (size_t)h->P_pad + 8, h->sumsq, h->n_blocks); }
+
+// after a stream synchronisation: did a peer wait time out since the last check?
+int peer_check(ppo_handle* h) {
+    if (!h->peer.on) return 0;
+    unsigned e = 0;
+    HIP_OK(h, hipMemcpy(&e, h->peer.dev.err, sizeof e, hipMemcpyDeviceToHost));
+    if (e) {
+        (void)hipMemset(h->peer.dev.err, 0, sizeof e);
+        return fail(h, "peer all-reduce: rank %d gave up waiting for rank %u's flag (dead or diverged peer)", h->rank, e - 1);
+    }
+    return 0;
+}
+
 int pick_split(ppo_handle* h, int n) {
     int s = h->max_split;
     while (s > 1 && (n % (16 * s) != 0)) s >>= 1;
@@ -829,12 +876,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
             HIP_OK(h, hipGetLastError());
         }
         if (h->comm) {
-            ProfScope ps(h, PK_COMM);
-            const size_t cnt = (size_t)h->P_pad + 8;
-            const int rc = h->rccl.AllReduce(h->grad, h->grad, cnt, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
-            if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
-            hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
-            HIP_OK(h, hipGetLastError());
+            if (enqueue_grad_allreduce(h)) return -1;
             return enqueue_adam(h, loss_row);
         }
         return enqueue_adam(h, loss_row, n_chunks);
@@ -857,14 +899,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
             hipLaunchKernelGGL(bf16_grad_reduce_kernel, dim3((h->n_blocks + 1 + 3) / 4), dim3(256), 0, h->stream, ra);
             HIP_OK(h, hipGetLastError());
         }
-        if (h->comm) {
-            ProfScope ps(h, PK_COMM);
-            const size_t cnt = (size_t)h->P_pad + 8;
-            const int rc = h->rccl.AllReduce(h->grad, h->grad, cnt, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
-            if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
-            hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
-            HIP_OK(h, hipGetLastError());
-        }
+        if (h->comm && enqueue_grad_allreduce(h)) return -1;
         if (enqueue_adam(h, loss_row)) return -1;
         ProfScope ps(h, PK_ADAM);
         return bf16_refresh_transposes(h);                 // (adam_kernel itself keeps the straight bf16 copy current)
@@ -907,14 +942,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(h->n_blocks + 1), dim3(256), 0, h->stream, ra);
         HIP_OK(h, hipGetLastError());
     }
-    if (h->comm) {                                       // also with a 1-rank communicator: same code path as N ranks
-        ProfScope ps(h, PK_COMM);
-        const size_t cnt = (size_t)h->P_pad + 8;
-        const int rc = h->rccl.AllReduce(h->grad, h->grad, cnt, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
-        if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
-        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
-        HIP_OK(h, hipGetLastError());
-    }
+    if (h->comm && enqueue_grad_allreduce(h)) return -1;         // also with a 1-rank communicator: same code path as N ranks
     return enqueue_adam(h, loss_row);
 }
 
@@ -1033,6 +1061,9 @@ void ppo_destroy(ppo_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->upd_graph) (void)hipGraphExecDestroy(h->upd_graph);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    for (void* m : h->peer.mapped) if (m) (void)hipIpcCloseMemHandle(m);
+    if (h->peer.region) (void)hipFree(h->peer.region);
+    if (h->peer.local) (void)hipFree(h->peer.local);
     if (h->nw_partials) (void)hipFree(h->nw_partials);
     if (h->nw_img) (void)hipFree(h->nw_img);
     if (h->nw_alt) (void)hipFree(h->nw_alt);
@@ -1326,12 +1357,7 @@ int ppo_norm_reset_returns(ppo_handle* h) {
 }
 
 // device-side pieces shared by the host-pointer API and the rollout loop
-static int allreduce_f32(ppo_handle* h, float* buf, size_t count) {
-    ProfScope ps(h, PK_COMM);
-    const int rc = h->rccl.AllReduce(buf, buf, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
-    if (rc != 0) return fail(h, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
-    return 0;
-}
+static int allreduce_f32(ppo_handle* h, float* buf, size_t count) { return enqueue_allreduce(h, buf, count); }
 
 // EnvNormalize::step's statistics + reward branch for one batch of envs: one multi-block launch; with a communicator
 // the ranks' batch moments are exchanged with ONE all-reduce (slot table = all-gather) and a one-block finish, so the
@@ -1556,7 +1582,7 @@ int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
     if (enqueue_finish(h, gamma, lam)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    return 0;
+    return peer_check(h);
 }
 
 int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t step0, int first, const float* noise, float gamma, float lam) {
@@ -1629,7 +1655,7 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
     if (enqueue_finish(h, gamma, lam)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    return 0;
+    return peer_check(h);
 }
 
 static float* rollout_field(ppo_handle* h, int field, size_t* count) {
@@ -1788,7 +1814,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     // hipGraph replay of the whole update; RCCL calls and event-bracketed profiling run eagerly
     // With a communicator the sequence runs eagerly by default (the host enqueues a step faster than the GPU runs it);
     // PPO_HIP_GRAPH_RCCL=1 opts into capturing the ncclAllReduce calls as well.
-    const bool graph_ok = h->use_graph && !h->prof && (!h->comm || h->graph_rccl);
+    const bool graph_ok = h->use_graph && !h->prof && (!h->comm || h->graph_rccl || h->peer.on);
     if (graph_ok) {
         const bool same = h->upd_graph && h->g_epochs == epochs && h->g_nmb == nmb && h->g_E == h->E && h->g_T == h->T &&
                           h->g_explicit == (int)explicit_perms && h->g_world == h->world;
@@ -1821,7 +1847,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    return 0;
+    return peer_check(h);
 }
 
 // ---- data parallel -------------------------------------------------------------------------------------------------------
@@ -1905,7 +1931,126 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
 }
 
 int ppo_dist_world(const ppo_handle* h) { return h->world; }
-int ppo_dist_graph_collectives(const ppo_handle* h) { return h->comm && h->graph_rccl && h->use_graph ? 1 : 0; }
+int ppo_dist_graph_collectives(const ppo_handle* h) { return h->comm && (h->graph_rccl || h->peer.on) && h->use_graph ? 1 : 0; }
+
+// ---- one-shot peer all-reduce (ppo_peer.hpp) ---------------------------------------------------------------------------------
+// Region = [4 KB flag block | slots[2][world][cap]]; allocated uncached / fine-grained where the runtime offers it (the flags
+// and slots are written by other devices), plain device memory otherwise (the kernels' system-scope fences do not depend on it).
+static const size_t kPeerFlagBytes = 4096;
+
+int ppo_dist_peer_export(ppo_handle* h, char handle[64]) {
+    ENTER(h);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!h->comm) return fail(h, "ppo_dist_peer_export: call ppo_dist_init first");
+    if (h->world > PEER_MAX_WORLD) return fail(h, "ppo_dist_peer_export: world %d > %d (one node)", h->world, PEER_MAX_WORLD);
+    ppo_handle::Peer& P = h->peer;
+    if (!P.region) {
+        P.cap = (size_t)ru(std::max(h->P_pad + 8, 4096), PEER_CHUNK);
+        const size_t bytes = kPeerFlagBytes + (size_t)2 * h->world * P.cap * sizeof(float);
+        hipError_t e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocFinegrained); }
+        if (e != hipSuccess) { (void)hipGetLastError(); P.region = nullptr; HIP_OK(h, hipMalloc(&P.region, bytes)); }
+        HIP_OK(h, hipMemset(P.region, 0, bytes));
+        HIP_OK(h, hipMalloc((void**)&P.local, 64));
+        HIP_OK(h, hipMemset(P.local, 0, 64));
+        HIP_OK(h, hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t ipc;
+    HIP_OK(h, hipIpcGetMemHandle(&ipc, P.region));
+    memcpy(handle, &ipc, 64);
+    return 0;
+}
+
+// One peer all-reduce of a known pattern per parity; true when every element came back as the sum over the ranks
+static bool peer_probe(ppo_handle* h) {
+    ppo_handle::Peer& P = h->peer;
+    const int n = 3000;                                            // not a multiple of the chunk: the tail path runs too
+    std::vector<float> host(n), want(n);
+    float* buf = nullptr;
+    if (hipMalloc((void**)&buf, n * sizeof(float)) != hipSuccess) return false;
+    bool ok = true;
+    const PeerDev saved = P.dev;
+    P.dev.spin_limit = 400000;                                     // a fraction of a second: a rank whose mapping failed never pushes
+    P.on = true;
+    for (int round = 0; round < 2 && ok; ++round) {
+        for (int i = 0; i < n; ++i) {
+            host[i] = (float)((h->rank + 1) * (i % 7 + 1 + round));
+            want[i] = (float)((h->world * (h->world + 1) / 2) * (i % 7 + 1 + round));
+        }
+        ok = hipMemcpy(buf, host.data(), n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && enqueue_allreduce(h, buf, n) == 0 &&
+             hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(host.data(), buf, n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int i = 0; i < n && ok; ++i) ok = host[i] == want[i];
+    }
+    unsigned e = 0;
+    if (hipMemcpy(&e, P.dev.err, sizeof e, hipMemcpyDeviceToHost) != hipSuccess || e) ok = false;
+    (void)hipMemset(P.dev.err, 0, sizeof e);
+    P.on = false;
+    P.dev.spin_limit = saved.spin_limit;
+    (void)hipFree(buf);
+    (void)hipGetLastError();
+    return ok;
+}
+
+int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
+    ENTER(h);
+    ppo_handle::Peer& P = h->peer;
+    if (!h->comm || !P.region) return fail(h, "ppo_dist_peer_attach: call ppo_dist_init and ppo_dist_peer_export first");
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    P.on = false;
+    bool mapped = true;
+    for (int r = 0; r < h->world; ++r) {
+        if (r == h->rank) continue;
+        if (P.mapped[r]) { (void)hipIpcCloseMemHandle(P.mapped[r]); P.mapped[r] = nullptr; }
+        hipIpcMemHandle_t ipc;
+        memcpy(&ipc, handles + (size_t)r * 64, 64);
+        if (hipIpcOpenMemHandle(&P.mapped[r], ipc, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); P.mapped[r] = nullptr; mapped = false; }
+    }
+    PeerDev d{};
+    for (int r = 0; r < h->world; ++r) {
+        char* base = (char*)(r == h->rank ? P.region : P.mapped[r]);
+        if (!base) base = (char*)P.region;                         // unmapped peer: the probe fails, nothing is ever sent there afterwards
+        d.flags[r] = (unsigned*)base;
+        d.slots[r] = (float*)(base + kPeerFlagBytes);
+    }
+    d.seq = P.local; d.arrive = P.local + 1; d.err = P.local + 2;
+    d.cap = P.cap; d.world = h->world; d.rank = h->rank;
+    const char* tm = getenv("PPO_HIP_PEER_TIMEOUT_MS");
+    const double ms = tm ? atof(tm) : 10000.0;
+    d.spin_limit = (unsigned)std::min(4.0e9, std::max(1000.0, ms * 2000.0));       // ~0.5 us per wait iteration
+    P.dev = d;
+    const char* en = getenv("PPO_HIP_PEER_REDUCE");
+    const bool wanted = !(en && en[0] == '0');
+    // the verdict must be COMMON: a rank that could not map a peer, or whose probe failed, takes everybody back to RCCL
+    bool ok = wanted && mapped;
+    if (wanted) ok = peer_probe(h) && ok;
+    float* flag = nullptr;
+    HIP_OK(h, hipMalloc((void**)&flag, sizeof(float)));
+    const float mine = ok ? 1.f : 0.f;
+    HIP_OK(h, hipMemcpy(flag, &mine, sizeof mine, hipMemcpyHostToDevice));
+    const int rc = h->rccl.AllReduce(flag, flag, 1, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
+    float got = 0.f;
+    const bool agreed = rc == 0 && hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(&got, flag, sizeof got, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(flag);
+    if (!agreed) return fail(h, "ppo_dist_peer_attach: the ranks could not agree on the probe result");
+    P.on = got == (float)h->world;
+    P.usable = P.on;
+    // No reset of seq / flags here: after a probe that passed everywhere every rank stands at the same sequence number, and a
+    // rank zeroing its flags now could erase the first flag of a peer that has already left this call.
+    if (wanted && !P.on) fprintf(stderr, "libppo_hip: peer all-reduce probe failed on some rank (this rank: %s); using RCCL\n", ok ? "ok" : "failed");
+    return 0;
+}
+
+int ppo_dist_peer_active(const ppo_handle* h) { return h->peer.on ? 1 : 0; }
+
+int ppo_dist_peer_enable(ppo_handle* h, int on) {
+    ENTER(h);
+    if (on && !h->peer.usable) return fail(h, "ppo_dist_peer_enable: not attached, or the probe failed");
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    h->peer.on = on != 0;
+    return 0;
+}
 
 // ---- measurement ----------------------------------------------------------------------------------------------------------
 int ppo_prof_enable(ppo_handle* h, int on) {

@@ -38,3 +38,13 @@ def allreduce_max(dist, value):
     t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def allgather_bytes(dist, blob, n):
+    """Every rank contributes n bytes; returns the list of all ranks' blobs in rank order (IPC handles, digests)."""
+    import torch
+    assert len(blob) == n
+    mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).clone()
+    out = [torch.zeros(n, dtype=torch.uint8) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [bytes(t.numpy().tobytes()) for t in out]

@@ -20,6 +20,26 @@ def main():
     g = ppo_cpp_amd.PPOHip(18, 18, hidden, device=0)
     g.set_flat(d["theta"])
     g.dist_init(world, rank, d["uid"].tobytes())
+    if os.environ.get("PPO_TEST_PEER") == "1":
+        # one-shot peer all-reduce: the 64-byte IPC handles travel through files next to the inputs (the launcher's control
+        # plane in bench.py is gloo); ppo_dist_peer_attach itself ends with a collective, so nobody runs ahead
+        import time
+        base = os.path.dirname(os.path.abspath(fout))
+        with open(os.path.join(base, "peer%d.tmp" % rank), "wb") as f:
+            f.write(g.dist_peer_export())
+        os.replace(os.path.join(base, "peer%d.tmp" % rank), os.path.join(base, "peer%d.bin" % rank))
+        handles = []
+        for r in range(world):
+            fn = os.path.join(base, "peer%d.bin" % r)
+            t0 = time.time()
+            while not os.path.exists(fn):
+                if time.time() - t0 > 120:
+                    raise RuntimeError("no IPC handle from rank %d" % r)
+                time.sleep(0.01)
+            handles.append(open(fn, "rb").read())
+        if not g.dist_peer_attach(handles):
+            raise RuntimeError("peer all-reduce probe failed (rank %d)" % rank)
+        assert g.dist_graph_collectives()
     g.norm_init(El, float(d["gamma"]))
     g.rollout_alloc(El, T)
     g.collect_synthetic(int(d["seed"]), float(d["gamma"]), float(d["lam"]), d["noise"][:, sl], env0=rank * El, step0=0, first=True)

@@ -46,6 +46,19 @@ def _worker(rank, world, port, out):
         uid = ppodist.broadcast_unique_id(dist, rank, lambda: bytes(range(128)))
         assert uid == bytes(range(128))
         assert ppodist.allreduce_max(dist, 1.0 + rank) == float(world)
+        assert ppodist.allgather_bytes(dist, bytes([rank]) * 64, 64) == [bytes([r]) * 64 for r in range(world)]   # IPC-handle exchange
+        # the one-shot peer all-reduce's arithmetic: every rank adds the W gathered vectors in RANK order (not "mine first"),
+        # so all replicas get the same bits even where fp32 addition does not commute across three or more terms
+        rngp = np.random.RandomState(100 + rank)
+        mine = (rngp.normal(size=4096) * 10.0 ** rngp.uniform(-6, 6, 4096)).astype(np.float32)
+        slots = [torch.zeros(4096) for _ in range(world)]
+        dist.all_gather(slots, torch.from_numpy(mine))
+        acc = slots[0].numpy().copy()
+        for r in range(1, world):
+            acc = (acc + slots[r].numpy()).astype(np.float32)
+        sums = [torch.zeros(4096) for _ in range(world)]
+        dist.all_gather(sums, torch.from_numpy(acc))
+        assert all(torch.equal(sums[0], t) for t in sums)
         # weak-scaling env shards tile the global env set of the seeded synthetic env
         E = 8
         mine, _, _ = o.seeded_env_step(1234, ppodist.env_offset(E, rank), E, 3, 18)

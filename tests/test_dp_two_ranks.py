@@ -34,7 +34,11 @@ def build_fake_rccl(tmp):
                                                    # BASELINE configs[3] at its per-rank workload (1024 envs over 8 GPUs = 128 envs x 64 steps
                                                    # per rank, MLP [64,64], 32 minibatches of 256 rows per rank)
                                                    ((64, 64), 256, 64, 32, 1)])
-def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden, E, T, nmb, epochs):
+@pytest.mark.parametrize("peer", [False, True])
+def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden, E, T, nmb, epochs, peer):
+    """peer = True: every collective goes through the one-shot peer all-reduce (ppo_peer.hpp) -- the two processes map each
+    other's gather region over hipIpc (same mechanism as two GPUs of a node; here both regions live on the one test GPU) and
+    the whole update, collectives included, replays from the hipGraph."""
     world = 2
     tmp = str(tmp_path)
     fake = build_fake_rccl(tmp)
@@ -58,7 +62,7 @@ def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden
     fin = os.path.join(tmp, "in.npz")
     np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
              noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
-    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="1" if peer else "0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), fin, os.path.join(tmp, "out%d.npz" % r)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []

@@ -306,6 +306,44 @@ def test_rccl_plumbing_single_rank_communicator():
     close(g2.get_flat(0), orc2.theta, rtol=2e-4, atol=5e-6)
 
 
+@pytest.mark.parametrize("hidden", [(64, 64), (256, 256)])
+def test_peer_allreduce_single_rank_is_bitwise_the_rccl_path(hidden):
+    """The one-shot peer all-reduce (push into the gather slot, flag, rank-ordered sum + sums of squares) with a one-rank
+    communicator: the region is this process's own, so the kernels, the sequence / parity protocol, the probe of
+    ppo_dist_peer_attach and the hipGraph capture of the peer kernels all run -- and, one slot being added to nothing, the
+    rollout and the update must be BIT-identical to the same run over ncclAllReduce."""
+    import ppo_cpp_amd
+    E, T, nmb, epochs = 16, 16, 4, 2
+    outs = []
+    for peer in (False, True):
+        orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 31)
+        g.dist_init(1, 0, ppo_cpp_amd.PPOHip.dist_unique_id())
+        if peer:
+            assert g.dist_peer_attach([g.dist_peer_export()]), "probe of the peer path failed"
+            assert g.dist_graph_collectives()
+        else:
+            assert not g.dist_peer_active()
+        g.collect_synthetic(1234, GAMMA, LAM, noise)
+        got = {f: g.rollout_get(f) for f in ("obs", "values", "returns")}
+        got["obs_mean"], got["obs_var"], _ = g.norm_stats(0)
+        for f in ("obs", "actions", "values", "neglogp", "returns"):
+            g.rollout_set(f, ro[f])
+        rng = np.random.RandomState(5)
+        perms = np.stack([rng.permutation(E * T).astype(np.int32) for _ in range(epochs)])
+        for it in range(2):                                  # second update: graph replay, both parities several times over
+            got["rows%d" % it], _ = g.update(LR, CR, epochs, nmb, perms)
+        got["theta"], got["m"], got["v"] = g.get_flat(0), g.get_flat(1), g.get_flat(2)
+        if peer:
+            g.dist_peer_enable(False); assert not g.dist_peer_active()
+            g.dist_peer_enable(True)
+            got["rows2"], _ = g.update(LR, CR, epochs, nmb, perms)
+        outs.append(got)
+        g.close()
+    assert np.abs(outs[0]["rows0"]).max() > 0
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+
+
 @pytest.mark.parametrize("hidden,O,A,n", [((512, 512), 18, 18, 64), ((1024, 1024, 1024), 256, 64, 48), ((1024,), 256, 64, 40), ((1100,), 18, 18, 20),
                                           # regular layout, 64-column wave tiles, widths that are not multiples of 256
                                           # (generic policy head instead of the split-K one), wide obs/action vectors
