@@ -147,6 +147,11 @@ struct ppo_handle {
     bool nw_static = false;
     float* nw_img = nullptr;          // [2][w_total] packed weight images (kept current by adam_kernel / transpose_refresh_kernel)
     float* nw_partials = nullptr; int nw_groups_cap = 0; int nw_stride = 0;
+    // deferred Adam inside ppo_update (reference shape): second parameter / moment set and the step whose clip + Adam is pending
+    float *nw_theta1 = nullptr, *nw_m1 = nullptr, *nw_v1 = nullptr;
+    bool nw_lazy = false;             // the path is available (static shape, PPO_HIP_NO_LAZY_ADAM unset)
+    int nw_cur = 0;                   // parameter set holding the current weights (0 outside ppo_update)
+    bool nw_pending = false; float* nw_pending_loss = nullptr; int nw_pending_parts = 0;
     float* nw_alt = nullptr; double* nw_alt_counts = nullptr; int nw_alt_envs = 0;   // second env/normaliser state set of the fused collect step
     // dist
     Rccl rccl;
@@ -833,14 +838,17 @@ int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0) {      // n_su
     }
     AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
                 h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out, parts, n_parts,
-                h->bf.on ? h->bf.theta_bf : nullptr, h->narrow ? h->nw_img : nullptr};
+                h->bf.on ? h->bf.theta_bf : nullptr, h->narrow ? h->nw_img : nullptr, nullptr, nullptr, nullptr};
+    if (h->nw_cur == 1) { aa.theta_in = h->nw_theta1; aa.m_in = h->nw_m1; aa.v_in = h->nw_v1; h->nw_cur = 0; }   // (always writes set 0)
     hipLaunchKernelGGL(adam_kernel, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
 
 // the per-minibatch launch sequence: fwd+loss+bwd -> weight grads -> reduce [-> all-reduce] -> clip+Adam
-int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
+// defer (narrow reference shape, inside ppo_update only): leave this step's clip + Adam to the next train kernel's prologue
+// (flush_pending_adam after the last step)
+int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = false) {
     const NetDev& n = h->net;
     const int n_rb = (ta.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     ta.theta = h->theta; ta.thetaT = h->thetaT; ta.par = h->par; ta.hyper = h->hyper;
@@ -864,8 +872,18 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
             na.stamps = g_stamps;
 #endif
             const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
-            if (h->nw_static) hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na);
-            else hipLaunchKernelGGL((narrow_train_kernel<0, 0, 0, 0>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na);
+            NwLazyArgs z{};
+            if (h->nw_pending) {
+                // the previous step's clip + Adam rides in this launch: read set nw_cur, write the other one
+                float* set[2][3] = {{h->theta, h->adam_m, h->adam_v}, {h->nw_theta1, h->nw_m1, h->nw_v1}};
+                const int ci = h->nw_cur, co = ci ^ 1;
+                z = NwLazyArgs{h->grad, h->sumsq, h->nw_pending_parts, set[ci][0], set[ci][1], set[ci][2], set[co][0], set[co][1], set[co][2], h->beta_pow,
+                               h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, h->nw_pending_loss, h->norm_out};
+                hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
+                h->nw_cur = co; h->nw_pending = false;
+            }
+            else if (h->nw_static) hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
+            else hipLaunchKernelGGL((narrow_train_kernel<0, 0, 0, 0>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
             HIP_OK(h, hipGetLastError());
         }
         const int n_chunks = h->P_pad / 64;
@@ -875,11 +893,10 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
             hipLaunchKernelGGL(narrow_reduce_kernel, dim3(n_chunks + 1), dim3(256), 0, h->stream, ra);
             HIP_OK(h, hipGetLastError());
         }
-        if (h->comm) {
-            if (enqueue_grad_allreduce(h)) return -1;
-            return enqueue_adam(h, loss_row);
-        }
-        return enqueue_adam(h, loss_row, n_chunks);
+        if (h->comm && enqueue_grad_allreduce(h)) return -1;
+        const int n_parts = h->comm ? 0 : n_chunks;               // after an all-reduce: one partial per 256-element chunk (grad_sumsq_kernel's)
+        if (defer && h->nw_lazy) { h->nw_pending = true; h->nw_pending_loss = loss_row; h->nw_pending_parts = n_parts ? n_parts : h->n_blocks; return 0; }
+        return enqueue_adam(h, loss_row, n_parts);
     }
     if (h->bf.on) {
         const int Rp = ru(ta.n, GB_PAD);
@@ -944,6 +961,14 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row) {
     }
     if (h->comm && enqueue_grad_allreduce(h)) return -1;         // also with a 1-rank communicator: same code path as N ranks
     return enqueue_adam(h, loss_row);
+}
+
+// the clip + Adam of the last deferred step, as a launch of its own (also brings the weights home to set 0 and refreshes the
+// packed image / mirrors that only adam_kernel writes)
+int flush_pending_adam(ppo_handle* h) {
+    if (!h->nw_pending) return 0;
+    h->nw_pending = false;
+    return enqueue_adam(h, h->nw_pending_loss, h->nw_pending_parts == h->n_blocks ? 0 : h->nw_pending_parts);
 }
 
 int set_hyper(ppo_handle* h, float lr, float cr) {
@@ -1042,11 +1067,18 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     if (h->narrow) {
         attr_ok = hipFuncSetAttribute((const void*)narrow_train_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_train_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_train_kernel<32, 64, 32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
+        const char* nl = getenv("PPO_HIP_NO_LAZY_ADAM");
+        if (h->nw_static && !(nl && nl[0] == '1')) {
+            // second parameter / moment set of the deferred Adam (zero-filled: the padding elements are never written and must read 0)
+            if (dev_alloc(h, &h->nw_theta1, P) || dev_alloc(h, &h->nw_m1, P) || dev_alloc(h, &h->nw_v1, P)) return bail(0);
+            h->nw_lazy = true;
+        }
         if (dev_alloc(h, &h->nw_img, (size_t)2 * h->nw.w_total)) return bail(0);
     }
     const float pw[2] = {cfg->adam_beta1, cfg->adam_beta2};
@@ -1064,6 +1096,7 @@ void ppo_destroy(ppo_handle* h) {
     for (void* m : h->peer.mapped) if (m) (void)hipIpcCloseMemHandle(m);
     if (h->peer.region) (void)hipFree(h->peer.region);
     if (h->peer.local) (void)hipFree(h->peer.local);
+    for (float* p : {h->nw_theta1, h->nw_m1, h->nw_v1}) if (p) (void)hipFree(p);
     if (h->nw_partials) (void)hipFree(h->nw_partials);
     if (h->nw_img) (void)hipFree(h->nw_img);
     if (h->nw_alt) (void)hipFree(h->nw_alt);
@@ -1695,6 +1728,7 @@ int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count
 // ---- update -----------------------------------------------------------------------------------------------------------
 static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perms) {
     const int B = h->E * h->T, M = B / nmb;
+    h->nw_pending = false; h->nw_cur = 0;                      // outside an update the weights always live in set 0
     uint32_t bits = 1;
     while ((1u << bits) < (uint32_t)B) ++bits;
     for (int ep = 0; ep < epochs; ++ep) {
@@ -1747,9 +1781,10 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             ta.obs = h->mb_obs + r0 * h->net.O; ta.actions = h->mb_act + r0 * h->net.A; ta.returns = h->mb_ret + r0; ta.old_values = h->mb_val + r0;
             ta.old_neglogp = h->mb_nlp + r0; ta.advs = h->mb_adv + r0; ta.adv_stats = nullptr; ta.n = M;
             ta.inv_n = 1.0f / (float)((int64_t)M * h->world);
-            if (enqueue_train(h, ta, h->d_loss_rows + (size_t)(ep * nmb + k) * 5)) return -1;
+            if (enqueue_train(h, ta, h->d_loss_rows + (size_t)(ep * nmb + k) * 5, /*defer*/ true)) return -1;
         }
     }
+    if (flush_pending_adam(h)) return -1;
     hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(320), 0, h->stream, h->d_loss_rows, epochs * nmb, h->d_loss_mean);
     HIP_OK(h, hipGetLastError());
     return 0;

@@ -1496,6 +1496,7 @@ struct AdamArgs {
     const float* norm_parts; int n_parts;   // what the norm is summed from: sumsq itself, or its 1024-wide folds for very large nets
     __bf16* theta_bf;            // bf16 path: straight bf16 copy of theta kept current here (null otherwise)
     float* img;                  // narrow path: packed LDS images kept current here (null otherwise)
+    const float* theta_in; const float* m_in; const float* v_in;   // read from another parameter set (narrow path's deferred Adam); null = in place
 };
 
 // second-level partial sums of the per-chunk sums of squares: with millions of parameters every Adam block re-reading
@@ -1527,9 +1528,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     gs.t_off = -1; gs.p_off = -1;
     if (live) {
         g4 = *reinterpret_cast<const float4*>(a.grad + idx);
-        m4 = *reinterpret_cast<const float4*>(a.m + idx);
-        v4 = *reinterpret_cast<const float4*>(a.v + idx);
-        t4 = *reinterpret_cast<const float4*>(a.theta + idx);
+        m4 = *reinterpret_cast<const float4*>((a.m_in ? a.m_in : a.m) + idx);
+        v4 = *reinterpret_cast<const float4*>((a.v_in ? a.v_in : a.v) + idx);
+        t4 = *reinterpret_cast<const float4*>((a.theta_in ? a.theta_in : a.theta) + idx);
         gs = a.src[chunk];
     }
     const float b1p = a.beta_pow[0], b2p = a.beta_pow[1], lr = a.hyper[0];

@@ -219,6 +219,38 @@ def test_update_phase_matches_oracle(hidden, E, T, nmb, epochs):
     close(rows2, ref_rows2, rtol=3e-4, atol=3e-6, msg="second update")
 
 
+@pytest.mark.parametrize("E,T,nmb,epochs", [(16, 16, 4, 3), (64, 64, 32, 1), (3, 100, 4, 2), (16, 16, 1, 1)])
+def test_deferred_adam_is_bitwise_the_adam_launch(E, T, nmb, epochs, monkeypatch):
+    """Reference shape ([64,64]): inside ppo_update the clip + Adam of step k is applied by the prologue of step k+1's train
+    kernel (ping-pong parameter sets, weights written straight into the LDS image).  Same expression, same norm order: loss
+    rows, weights, both moments, beta powers, the reported norm and the act model after the update must equal the run with
+    an adam_kernel launch per step (PPO_HIP_NO_LAZY_ADAM=1) bit for bit -- including a one-step update (nothing to defer to),
+    ragged minibatches, and a second update replayed from the graph."""
+    outs = []
+    for lazy in (True, False):
+        monkeypatch.setenv("PPO_HIP_NO_LAZY_ADAM", "0" if lazy else "1")
+        orc, g, nz, ro, noise = _rollout_pair((64, 64), E, T, 23)
+        for f in ("obs", "actions", "values", "neglogp", "returns"):
+            g.rollout_set(f, ro[f])
+        rng = np.random.RandomState(99)
+        perms = np.stack([rng.permutation(E * T).astype(np.int32) for _ in range(epochs)])
+        got = {}
+        for it in range(2):
+            got["rows%d" % it], got["mean%d" % it] = g.update(LR, CR, epochs, nmb, perms)
+        got["theta"], got["m"], got["v"], got["pow"] = g.get_flat(0), g.get_flat(1), g.get_flat(2), g.beta_powers()
+        got["norm"] = np.float32(g.last_grad()[1])
+        obs = np.random.RandomState(3).uniform(-2, 2, (40, 18)).astype(np.float32)
+        got["value"] = g.value(obs); got["mu"] = g.act_deterministic(obs)       # the packed image the act kernels read
+        mb = H.synth_minibatch(orc, 64, seed=9)                                  # a plain train step afterwards: set 0 holds the weights
+        got["step"] = g.train_step(LR, CR, mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+        got["theta2"] = g.get_flat(0)
+        outs.append(got)
+        g.close()
+    assert np.abs(outs[0]["rows0"]).max() > 0 and np.isfinite(outs[0]["theta"]).all()
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+
+
 def test_update_with_device_permutation_is_a_valid_shuffle():
     """perms=NULL: the keyed bijection must visit every row exactly once per epoch (sum of per-minibatch means of a
     permutation-invariant quantity) and runs must be reproducible for a fixed seed."""
