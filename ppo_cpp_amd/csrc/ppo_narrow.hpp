@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
     NSTAMP(0);
     if constexpr (LAZY) {
         static_assert(KP0 == 32 && HP == 64 && AP == 32 && LL == 2, "deferred Adam: reference shape only");
-        __shared__ float lazy_red[4];
+        float* lazy_red = lds + lay.w_total + lay.misc;      // 4 floats of pipe 0's loss scratch (no static LDS: the launch may ask for all 160 KB)
         NwLazyRegs R;
         nw_lazy_issue(net, z, tower, R);
         nw_stage<S>(net, lay, nullptr, 0, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
