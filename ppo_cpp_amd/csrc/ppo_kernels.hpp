@@ -1514,6 +1514,19 @@ __global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* sumsq, int
     if (tid == 0) parts[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// TF-1.14 ApplyAdam on one element (G:30430-31383): m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); theta -= alpha m / (sqrt(v) + eps),
+// g already scaled by the clip factor.  The quotient uses the hardware's 1-ulp square root and reciprocal (v_sqrt_f32, v_rcp_f32)
+// instead of the correctly rounded sequences (~25 instructions each): the update term is ~1e-3 of the weight, so a 3-ulp error
+// in it is 4e-10 absolute -- a twentieth of the weight's own ulp -- and this expression runs redundantly in every workgroup of
+// the narrow path's deferred Adam (ppo_narrow.hpp), where the exact sequences cost 2.2 k cycles of a 25 k-cycle kernel.  (A
+// denormal v gives sqrt = 0: invisible behind eps.)  One function for every path, so all paths agree bit for bit.
+__device__ __forceinline__ void adam_element(float gscaled, float m, float v, float t, float one_m_b1, float one_m_b2, float alpha, float eps,
+                                             float& mo, float& vo, float& to) {
+    mo = m + (gscaled - m) * one_m_b1;
+    vo = v + (gscaled * gscaled - v) * one_m_b2;
+    to = t - (mo * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vo) + eps);
+}
+
 // One block = 1024 consecutive parameters (4 per thread, 16-byte accesses); n_blocks counts the 256-element chunks the
 // gradient-source table and the partial sums of squares are indexed by.
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
@@ -1548,12 +1561,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
         float mo[4], vo[4], to[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float g = gv[k] * scale;
-            mo[k] = mv[k] + (g - mv[k]) * (1.0f - a.beta1);
-            vo[k] = vv[k] + (g * g - vv[k]) * (1.0f - a.beta2);
-            to[k] = tv[k] - (mo[k] * alpha) / (sqrtf(vo[k]) + a.eps);
-        }
+        for (int k = 0; k < 4; ++k) adam_element(gv[k] * scale, mv[k], vv[k], tv[k], 1.0f - a.beta1, 1.0f - a.beta2, alpha, a.eps, mo[k], vo[k], to[k]);
         *reinterpret_cast<float4*>(a.m + idx) = make_float4(mo[0], mo[1], mo[2], mo[3]);
         *reinterpret_cast<float4*>(a.v + idx) = make_float4(vo[0], vo[1], vo[2], vo[3]);
         *reinterpret_cast<float4*>(a.theta + idx) = make_float4(to[0], to[1], to[2], to[3]);

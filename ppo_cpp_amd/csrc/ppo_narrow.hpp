@@ -208,31 +208,44 @@ struct NwLazyArgs {
     float* loss_row; float* norm_out;
 };
 
-struct NwLazyRegs { float4 g[5], m[5], v[5], t[5]; float part; };
+struct NwLazyRegs { float4 g[5], m[5], v[5], t[5]; float part, b1p, b2p, lr; };
 
-// piece k of thread tid: 0,1 = second-layer matrix (float4 index tid + 512 k), 2 = first-layer matrix, 3 = policy head matrix,
-// 4 = one float4 of a vector (tid < 49); returns the element offset in the padded parameter vector or -1
-__device__ __forceinline__ int nw_lazy_piece(const NetDev& net, int tower, int k, int tid) {
-    if (k < 2) return net.w_off[tower][1] + 4 * (tid + 512 * k);
-    if (k == 2) return net.w_off[tower][0] + 4 * tid;
-    if (k == 3) return tower == 0 ? net.wmu_off + 4 * tid : -1;
-    if (tid < 16) return net.b_off[tower][0] + 4 * tid;
-    if (tid < 32) return net.b_off[tower][1] + 4 * (tid - 16);
-    if (tower == 0) {
-        if (tid < 40) return net.bmu_off + 4 * (tid - 32);
-        if (tid < 48) return net.ls_off + 4 * (tid - 40);
-        return -1;
+// Thread -> 16-byte piece.  Pieces 0,1 = second-layer matrix [64][64], 2 = first-layer matrix [32][64], 3 = policy head matrix
+// [64][32], 4 = one float4 of a vector (threads 0..48).  Matrix pieces in memory order (fully coalesced loads: the prologue is
+// bound by the bytes it pulls through the L1, 160 KB per workgroup; a row-spread dealing that would make the transposed LDS
+// copy conflict-free costs more in the loads than it saves in LDS).  The transposed copy (element (r, c) -> [c][r], row pitch
+// = 16 mod 64 banks) is written with lane-rotated elements -- the j-th write of a lane stores its element (j + c4) & 3 -- which
+// brings the bank conflicts from 16-way to 4-way.
+struct NwPiece { int off; int r, c; };       // element offset in the padded parameter vector (-1: none); row / first column of the float4
+
+__device__ __forceinline__ NwPiece nw_lazy_piece(const NetDev& net, int tower, int k, int tid) {
+    NwPiece p{-1, 0, 0};
+    if (k < 3) {
+        const int idx = k < 2 ? tid + 512 * k : tid;              // W1: 1024 float4 (16 per row) ; W0: 512 float4 (16 per row)
+        const int c4 = idx & 15, r = idx >> 4 & 63;
+        if (k < 2) { p.r = r; p.c = 4 * c4; p.off = net.w_off[tower][1] + 64 * r + 4 * c4; }
+        else { p.r = idx >> 4; p.c = 4 * (idx & 15); p.off = net.w_off[tower][0] + 4 * idx; }
+        return p;
     }
-    if (tid < 48) return net.wv_off + 4 * (tid - 32);
-    if (tid == 48) return net.bv_off;
-    return -1;
+    if (k == 3) {
+        if (tower != 0) return p;
+        p.r = tid >> 3; p.c = 4 * (tid & 7); p.off = net.wmu_off + 4 * tid;    // [64][32]: 8 float4 per row
+        return p;
+    }
+    if (tid < 16) p.off = net.b_off[tower][0] + 4 * tid;
+    else if (tid < 32) p.off = net.b_off[tower][1] + 4 * (tid - 16);
+    else if (tower == 0) { if (tid < 40) p.off = net.bmu_off + 4 * (tid - 32); else if (tid < 48) p.off = net.ls_off + 4 * (tid - 40); }
+    else if (tid < 48) p.off = net.wv_off + 4 * (tid - 32);
+    else if (tid == 48) p.off = net.bv_off;
+    return p;
 }
 
-__device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArgs& z, int tower, NwLazyRegs& R) {
+__device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArgs& z, const float* hyper, int tower, NwLazyRegs& R) {
     const int tid = threadIdx.x;
+    R.b1p = z.beta_pow[0]; R.b2p = z.beta_pow[1]; R.lr = hyper[0];             // requested with everything else: one round trip
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const int off = nw_lazy_piece(net, tower, k, tid);
+        const int off = nw_lazy_piece(net, tower, k, tid).off;
         R.g[k] = R.m[k] = R.v[k] = R.t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (off >= 0) {
             R.g[k] = *reinterpret_cast<const float4*>(z.grad + off);
@@ -241,17 +254,23 @@ __device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArg
             R.t[k] = *reinterpret_cast<const float4*>(z.th_in + off);
         }
     }
-    float s = 0.f;
-    if (tid < 256) for (int i = tid; i < z.n_parts; i += 256) s += z.parts[i];        // adam_kernel's order
-    R.part = s;
+    // the norm partials: adam_kernel's order (thread t adds parts[t], parts[t + 256], ...); the first one is only REQUESTED here
+    // (an addition would wait for it: a whole memory round trip before the rows are even asked for)
+    R.part = (tid < 256 && tid < z.n_parts) ? z.parts[tid] : 0.f;
 }
 
 // `red`: 4 floats of LDS scratch.  Ends with the image complete in LDS (caller synchronises).
-__device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout& lay, const NwLazyArgs& z, const float* hyper, int tower, int grp, int n_groups,
-                                              NwLazyRegs& R, float* lds, float* red) {
+__device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout& lay, const NwLazyArgs& z, int tower, int grp, int n_groups,
+                                              NwLazyRegs& R, float* lds, float* red, unsigned long long* st = nullptr) {
     const int tid = threadIdx.x;
-    const float b1p = z.beta_pow[0], b2p = z.beta_pow[1], lr = hyper[0];
-    float s = R.part;
+#ifdef PPO_STAMPS
+#define LSTAMP(i) do { if (st && tid == 0) st[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#endif
+    const float b1p = R.b1p, b2p = R.b2p, lr = R.lr;
+    float s = 0.f + R.part;
+    if (tid < 256) for (int i = tid + 256; i < z.n_parts; i += 256) s += z.parts[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (tid < 256 && (tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
@@ -259,39 +278,43 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
     float scale = z.max_norm * tf_min(1.0f / norm, 1.0f / z.max_norm);          // G:24289-24472
     if (!isfinite(norm)) scale = __builtin_nanf("");                            // G:24493-24543
     const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    LSTAMP(20);
     float* par = lds + lay.par;
+    // write-back ownership: workgroup g of the tower stores the pieces [g * per, (g + 1) * per) of each 512-piece block (one
+    // wave-uniform division per kernel; a per-piece modulo by the runtime group count is ~40 vector instructions each)
+    const int per = (512 + n_groups - 1) / n_groups, own_lo = grp * per, own_hi = own_lo + per;
+    const bool own = tid >= own_lo && tid < own_hi;
+    // transposed copy of one float4: the j-th write stores element (j + rot) & 3, rot = the lane's float4 column (see above)
+    auto put_t = [&](float* base, int ld, int r, int c, const float (&to)[4], int rot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = (j + rot) & 3;
+            const float x = i == 0 ? to[0] : i == 1 ? to[1] : i == 2 ? to[2] : to[3];
+            base[(c + i) * ld + r] = x;
+        }
+    };
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const int off = nw_lazy_piece(net, tower, k, tid);
-        if (off < 0) continue;
+        const NwPiece pc = nw_lazy_piece(net, tower, k, tid);
+        if (pc.off < 0) continue;
         const float gv[4] = {R.g[k].x, R.g[k].y, R.g[k].z, R.g[k].w}, mv[4] = {R.m[k].x, R.m[k].y, R.m[k].z, R.m[k].w};
         const float vv[4] = {R.v[k].x, R.v[k].y, R.v[k].z, R.v[k].w}, tv[4] = {R.t[k].x, R.t[k].y, R.t[k].z, R.t[k].w};
         float mo[4], vo[4], to[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                                           // adam_kernel's expression, operation for operation
-            const float g = gv[i] * scale;
-            mo[i] = mv[i] + (g - mv[i]) * (1.0f - z.beta1);
-            vo[i] = vv[i] + (g * g - vv[i]) * (1.0f - z.beta2);
-            to[i] = tv[i] - (mo[i] * alpha) / (sqrtf(vo[i]) + z.eps);
-        }
+        for (int i = 0; i < 4; ++i) adam_element(gv[i] * scale, mv[i], vv[i], tv[i], 1.0f - z.beta1, 1.0f - z.beta2, alpha, z.eps, mo[i], vo[i], to[i]);
         const float4 t4 = make_float4(to[0], to[1], to[2], to[3]);
         bool mine;                                                              // who writes this piece back
         if (k < 2) {                                                            // W1 [64][64]: forward + transposed copies
-            const int f = tid + 512 * k, e = 4 * f, r = e >> 6, c = e & 63;
-            *reinterpret_cast<float4*>(lds + lay.wf[1] + r * lay.wf_ld[1] + c) = t4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lds[lay.wt[1] + (c + i) * lay.wt_ld[1] + r] = to[i];
-            mine = (f % n_groups) == grp;
+            *reinterpret_cast<float4*>(lds + lay.wf[1] + pc.r * lay.wf_ld[1] + pc.c) = t4;
+            put_t(lds + lay.wt[1], lay.wt_ld[1], pc.r, pc.c, to, tid & 3);
+            mine = own;
         } else if (k == 2) {                                                    // W0 [32][64]
-            const int e = 4 * tid, r = e >> 6, c = e & 63;
-            *reinterpret_cast<float4*>(lds + lay.wf[0] + r * lay.wf_ld[0] + c) = t4;
-            mine = (tid % n_groups) == grp;
+            *reinterpret_cast<float4*>(lds + lay.wf[0] + pc.r * lay.wf_ld[0] + pc.c) = t4;
+            mine = own;
         } else if (k == 3) {                                                    // W_mu [64][32]
-            const int e = 4 * tid, r = e >> 5, c = e & 31;
-            *reinterpret_cast<float4*>(lds + lay.wh + r * lay.wh_ld + c) = t4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lds[lay.wht + (c + i) * lay.wht_ld + r] = to[i];
-            mine = (tid % n_groups) == grp;
+            *reinterpret_cast<float4*>(lds + lay.wh + pc.r * lay.wh_ld + pc.c) = t4;
+            put_t(lds + lay.wht, lay.wht_ld, pc.r, pc.c, to, tid & 3);
+            mine = own;
         } else {
             int po;
             if (tid < 16) po = net.par_b[0] + 4 * tid;
@@ -302,11 +325,12 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
             mine = grp == 0;
         }
         if (mine) {
-            *reinterpret_cast<float4*>(z.th_out + off) = t4;
-            *reinterpret_cast<float4*>(z.m_out + off) = make_float4(mo[0], mo[1], mo[2], mo[3]);
-            *reinterpret_cast<float4*>(z.v_out + off) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+            *reinterpret_cast<float4*>(z.th_out + pc.off) = t4;
+            *reinterpret_cast<float4*>(z.m_out + pc.off) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+            *reinterpret_cast<float4*>(z.v_out + pc.off) = make_float4(vo[0], vo[1], vo[2], vo[3]);
         }
     }
+    LSTAMP(21);
     if (tower == 0 && grp == 0) {                                               // adam_kernel's block 0
         if (tid == 0) {
             z.beta_pow[2] = b1p * z.beta1;                                      // G:31217-31342
@@ -340,10 +364,17 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
         static_assert(KP0 == 32 && HP == 64 && AP == 32 && LL == 2, "deferred Adam: reference shape only");
         float* lazy_red = lds + lay.w_total + lay.misc;      // 4 floats of pipe 0's loss scratch (no static LDS: the launch may ask for all 160 KB)
         NwLazyRegs R;
-        nw_lazy_issue(net, z, tower, R);
+        nw_lazy_issue(net, z, a.hyper, tower, R);
+        NSTAMP(12);
         nw_stage<S>(net, lay, nullptr, 0, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
                     a.actions, tower == 0 ? a.advs : a.returns, tower == 0 ? a.old_neglogp : a.old_values, tower == 0 ? 1 : 2);
-        nw_lazy_apply(net, lay, z, a.hyper, tower, grp, (int)gridDim.x, R, lds, lazy_red);
+        NSTAMP(13);
+        nw_lazy_apply(net, lay, z, tower, grp, (int)gridDim.x, R, lds, lazy_red
+#ifdef PPO_STAMPS
+                      , a.stamps ? a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr
+#endif
+                      );
+        NSTAMP(14);
     } else {
         nw_stage<S>(net, lay, a.img + (size_t)tower * lay.w_total, lay.w_total, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
                     a.actions, tower == 0 ? a.advs : a.returns, tower == 0 ? a.old_neglogp : a.old_values, tower == 0 ? 1 : 2);
