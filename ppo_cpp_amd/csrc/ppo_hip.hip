@@ -1072,6 +1072,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         const char* nl = getenv("PPO_HIP_NO_LAZY_ADAM");
         if (h->nw_static && !(nl && nl[0] == '1')) {
@@ -1637,7 +1639,34 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
     // small environment counts on the narrow path: one fused launch per env step (policy step + env + EnvNormalize bookkeeping)
     static const bool no_fused = [] { const char* e = getenv("PPO_HIP_NO_FUSED_COLLECT"); return e && e[0] == '1'; }();
     const bool fused = h->narrow && !h->comm && !no_fused && E <= NW_ROWS && n.O <= 64;
-    if (fused) {
+    // ... and on top of that the whole rollout in ONE launch of one persistent workgroup (narrow_rollout_kernel): state in LDS,
+    // only stores leave the CU; the value tower runs afterwards, batched over the T x E normalised rows
+    const char* npe = getenv("PPO_HIP_NO_PERSISTENT_COLLECT");
+    const bool no_persist = npe && npe[0] == '1';
+    const size_t ro_lds = ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float);
+    const bool persistent = fused && !no_persist && ro_lds <= 160 * 1024 && n.A <= 64;
+    if (persistent) {
+        NwRolloutArgs q{};
+        q.img = h->nw_img;
+        q.st = NwEnvState{h->raw_obs, h->obs_rms.mean, h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->cur_done};
+        q.noise = noise ? h->ro_noise : nullptr;
+        q.ro_obs = h->ro_obs; q.ro_act = h->ro_act; q.ro_nlp = h->ro_nlp; q.ro_rew = h->ro_rew; q.ro_done = h->ro_done;
+        q.E = E; q.T = T; q.seed = seed; q.step0 = step0; q.env0 = env0;
+        q.gamma = h->nz_gamma; q.clip_rew = h->nz_clip_rew; q.clip_obs = h->nz_clip_obs; q.eps = h->nz_eps; q.norm_obs = h->norm_obs_flag; q.norm_rew = h->norm_rew_flag;
+#ifdef PPO_STAMPS
+        if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+        q.stamps = g_stamps;
+#endif
+        { ProfScope ps(h, PK_STEP);
+          if (h->nw_static) hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2>), dim3(1), dim3(NW_THREADS), ro_lds, h->stream, n, h->nw, q);
+          else hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0>), dim3(1), dim3(NW_THREADS), ro_lds, h->stream, n, h->nw, q);
+          HIP_OK(h, hipGetLastError()); }
+        StepArgs va{};                                         // values of all T x E rows: the rows are already normalised
+        va.obs = h->ro_obs; va.value = h->ro_val; va.n = E * T; va.nz = no_norm();
+        if (launch_step(h, va)) return -1;
+        h->done_staged = -1;
+    }
+    if (fused && !persistent) {
         if (h->nw_alt_envs != E) {
             HIP_OK(h, hipStreamSynchronize(h->stream));
             if (dev_alloc(h, &h->nw_alt, (size_t)E * n.O + 2 * n.O + 2 + 2 * (size_t)E) || dev_alloc(h, &h->nw_alt_counts, 2)) return -1;

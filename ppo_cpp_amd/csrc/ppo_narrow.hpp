@@ -830,3 +830,211 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_collect_kernel(NetDev net, 
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Persistent rollout for small environment counts (n_envs <= 32) against the on-device seeded env: ALL T env steps of a
+// rollout in ONE launch of ONE workgroup.  The policy tower's forward image is copied into LDS once; the raw observations,
+// the running statistics (EnvNormalize: obs_rms, ret_rms, the discounted returns, the done flags) live in LDS / registers
+// for the whole rollout; per env step the workgroup normalises, runs the forward pass, samples, steps the env and merges the
+// statistics -- the arithmetic of narrow_collect_kernel, statement for statement -- and only STORES leave the CU (the rollout
+// rows).  Nothing of a step waits on memory or on a launch: 7.5 us per env step (one launch each) becomes ~2.5 us.
+// The value tower is not needed inside the loop (values are consumed by the GAE scan only): the host runs it afterwards as
+// one batched launch of narrow_step_kernel over the T x E normalised rows this kernel stored.
+// Replaces, for this case, the loop of runner.hpp:75-127 over policies.hpp:33-46 + env_normalize.hpp:64-116.
+// ------------------------------------------------------------------------------------------------------------------------
+struct NwRolloutArgs {
+    const float* img;            // policy tower's packed image
+    NwEnvState st;               // read at entry, written back at exit
+    const float* noise;          // [T][E][A] or null -> counter RNG
+    float* ro_obs; float* ro_act; float* ro_nlp; float* ro_rew; float* ro_done;
+    int E, T;
+    uint32_t seed, step0; int env0;
+    float gamma, clip_rew, clip_obs, eps; int norm_obs, norm_rew;
+    unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS)
+};
+#define NW_RO_XS (NW_ROWS * 64)                    // floats of LDS behind the regular layout: raw observations
+#define NW_RO_EXTRA (NW_RO_XS + 64 + 64 + 3 * NW_ROWS + 8 + 64 + 16 * 64)
+
+template <int KP0, int HP, int AP, int LL>
+__global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
+    typedef NwShape<KP0, HP, AP, LL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwRolloutArgs)>();
+    const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
+    const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
+    const int E = q.E, O = net.O, A = net.A;
+    float* xs = lds + lay.lds_total;                        // [E][O] raw observations of the current state
+    float* s_mean = xs + NW_RO_XS; float* s_var = s_mean + 64;
+    float* rs = s_var + 64;                                 // [32] rewards | [32] dones | [32] returns
+    float* s_retstat = rs + 3 * NW_ROWS;                    // ret_rms mean, var
+    float* s_istd = s_retstat + 8;                          // 1 / sqrt(var + eps) per column: the expression of the per-step kernels, evaluated once per statistics update
+    // ---- entry: image + state, one round trip ----------------------------------------------------------------------------
+    {
+        const int n4 = lay.w_fwd / 4;
+        for (int e = tid; e < n4; e += NW_THREADS) reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(q.img)[e];
+        for (int i = tid; i < E * O; i += NW_THREADS) xs[i] = q.st.raw_obs[i];
+        if (tid < O) { s_mean[tid] = q.st.obs_mean[tid]; const float v0 = q.st.obs_var[tid]; s_var[tid] = v0; s_istd[tid] = 1.0f / sqrtf(v0 + q.eps); }
+        if (tid < E) { rs[NW_ROWS + tid] = q.st.done[tid]; rs[2 * NW_ROWS + tid] = q.st.ret[tid]; }
+        if (tid == 0) { s_retstat[0] = *q.st.ret_mean; s_retstat[1] = *q.st.ret_var; }
+    }
+    double obs_cnt = *q.st.obs_count, ret_cnt = *q.st.ret_count;          // replicated: every thread that merges holds the count
+    __syncthreads();
+    float* P = lds + lay.w_total + pipe * lay.pipe_total;
+    const float* par = lds + lay.par;
+    const int r = ptid >> 4, part = ptid & 15;
+    const int row = 16 * pipe + r;
+    const bool live_pipe = 16 * pipe < E;
+    const bool have_helper = NW_PIPES == 2 && E <= 16, helper = have_helper && pipe == 1;
+    float* s_eps = s_istd + 64;                             // [16][A] counter-RNG draws of the current step (written by the helper pipe)                   // a pipe without environments skips the matrix work (it shares the SIMDs' matrix pipes with the live one)
+    auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
+        const double nb = (double)nbf, tot = cnt + nb;
+        const float bvar = bM2 / (float)nb;                                        // running_statistics.hpp:51-54
+        const float delta = bmean - mean0;                                         // :90
+        mean1 = mean0 + (delta * (float)nb) / (float)tot;                          // :94
+        const float m_a = var0 * (float)cnt, m_b = bvar * (float)nb;               // :97-98
+        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;   // :100
+        var1 = M2 / (float)tot;                                                    // :101
+    };
+#ifdef PPO_STAMPS
+#define RSTAMP(i) do { if (q.stamps && tid == 0 && t == q.T - 1) q.stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RSTAMP(i) do { } while (0)
+#endif
+    for (int t = 0; t < q.T; ++t) {
+        RSTAMP(0);
+        // explicit noise of this step: requested now, consumed after the forward pass
+        float nz_eps[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q.noise) {
+            if (row < E) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) nz_eps[k] = q.noise[((size_t)t * E + row) * A + j]; }
+            }
+        } else if (helper) {
+            // counter RNG (two 64-bit hashes, log, cos, sqrt per draw): with <= 16 environments the second pipe has no rows and
+            // draws the first pipe's noise into LDS while that one runs the forward pass
+            if (r < E) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) s_eps[r * A + j] = ctr_normal(q.seed, (uint32_t)q.env0 + r, q.step0 + (uint32_t)t, j); }
+            }
+        } else if (!have_helper && row < E) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) nz_eps[k] = ctr_normal(q.seed, (uint32_t)q.env0 + row, q.step0 + (uint32_t)t, j); }
+        }
+        // ---- normalise the current observations (env_normalize.hpp:99-104) -> input tile + rollout row t --------------------
+        for (int i = tid; i < NW_ROWS * Kp0; i += NW_THREADS) {
+            const int rr = i / Kp0, j = i - rr * Kp0;
+            float x = 0.f;
+            if (rr < E && j < O) {
+                x = xs[rr * O + j];
+                if (q.norm_obs) {
+                    x = (x - s_mean[j]) * s_istd[j];
+                    x = tf_min(tf_max(x, -q.clip_obs), q.clip_obs);
+                }
+                q.ro_obs[((size_t)t * E + rr) * O + j] = x;
+            }
+            lds[lay.w_total + (rr >> 4) * lay.pipe_total + lay.x[0] + (rr & 15) * lay.ldx[0] + j] = x;
+        }
+        if (tid < E) q.ro_done[(size_t)t * E + tid] = rs[NW_ROWS + tid];            // the flags that arrived with obs_t
+        lds_barrier();
+        RSTAMP(1);
+        // ---- forward + head (narrow_step_kernel's code) ---------------------------------------------------------------------
+        for (int l = 0; l < L; ++l) {
+            const float* bias = par + net.par_b[l];
+            float* Ys = P + lay.x[l + 1]; const int ldy = lay.ldx[l + 1];
+            auto ep = [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+                const float b = bias[col];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) Ys[(4 * g + rr) * ldy + col] = fast_tanh(acc[rr] + b);
+            };
+            if (live_pipe) {
+                if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
+                else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+            }
+            lds_barrier();
+            RSTAMP(2 + l);
+        }
+        const float* hL = P + lay.x[L]; const int ldh = lay.ldx[L]; const int HpL = S::Hp(net, L - 1);
+        float* mus = P + lay.mu; const int ldm = lay.ldm;
+        if (live_pipe) nw_dense<HP>(hL, ldh, HpL, lds + lay.wh, lay.wh_ld, Ap, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+            const float b = par[net.par_bmu + col];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mus[(4 * g + k) * ldm + col] = acc[k] + b;
+        });
+        lds_barrier();
+        RSTAMP(6);
+        // ---- sample + neglogp (G:5894-6672) ------------------------------------------------------------------------------------
+        if (live_pipe) {
+            float ssq = 0.f, slog = 0.f;
+            int k = 0;
+            for (int j = part; j < A; j += 16, ++k) {
+                const float mu = mus[r * ldm + j];
+                const float logstd = mu * 0.0f + par[net.par_ls + j];
+                const float sigma = expf(logstd);
+                float eps = 0.f;
+                if (row < E) eps = (q.noise || !have_helper) ? nz_eps[k & 3] : s_eps[row * A + j];        // (A <= 64: k < 4)
+                const float act = mu + sigma * eps;
+                const float z = (act - mu) / sigma;
+                ssq += z * z; slog += logstd;
+                if (row < E) q.ro_act[((size_t)t * E + row) * A + j] = act;
+            }
+            ssq = group16_sum(ssq); slog = group16_sum(slog);
+            if (part == 0 && row < E) q.ro_nlp[(size_t)t * E + row] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
+        }
+        RSTAMP(7);
+        // ---- env transition (counter hash) -> new raw observations, rewards, dones -------------------------------------------
+        const uint32_t env_step = q.step0 + (uint32_t)t + 1u;
+        for (int i = tid; i < E * (O + 2); i += NW_THREADS) {
+            const int e = i / (O + 2), j = i - e * (O + 2);
+            const uint32_t hsh = ctr_hash(q.seed, (uint32_t)(q.env0 + e), env_step, (uint32_t)j);
+            if (j < O) xs[e * O + j] = u32_to_sym_unit(hsh);
+            else if (j == O) rs[e] = u32_to_sym_unit(hsh);
+            else rs[NW_ROWS + e] = (hsh % 300u == 0u) ? 1.0f : 0.0f;
+        }
+        lds_barrier();
+        RSTAMP(8);
+        // ---- EnvNormalize::step bookkeeping (env_normalize.hpp:64-116, running_statistics.hpp:26-104) --------------------------
+        if (tid < O) {
+            if (q.norm_obs) {
+                float sum = 0.f;
+                for (int e = 0; e < E; ++e) sum += xs[e * O + tid];
+                const float bmean = sum / (float)E;                                    // colwise().mean()
+                float m2 = 0.f;
+                for (int e = 0; e < E; ++e) { const float d = xs[e * O + tid] - bmean; m2 += d * d; }
+                float m1, v1;
+                merge(s_mean[tid], s_var[tid], obs_cnt, bmean, m2, (float)E, m1, v1);
+                s_mean[tid] = m1; s_var[tid] = v1; s_istd[tid] = 1.0f / sqrtf(v1 + q.eps);
+                obs_cnt = (double)(float)E + obs_cnt;                                   // :103
+            }
+        }
+        if (tid == 64) {                                        // (a different wave than the observation columns)
+            float* ret = rs + 2 * NW_ROWS;
+            float sum = 0.f;
+            for (int e = 0; e < E; ++e) { ret[e] = ret[e] * q.gamma + rs[e]; sum += ret[e]; }            // env_normalize.hpp:66
+            float m1 = s_retstat[0], v1 = s_retstat[1];
+            if (q.norm_rew) {                                                                              // :75-77 (training)
+                const float bmean = sum / (float)E;
+                float m2 = 0.f;
+                for (int e = 0; e < E; ++e) { const float d = ret[e] - bmean; m2 += d * d; }
+                merge(s_retstat[0], s_retstat[1], ret_cnt, bmean, m2, (float)E, m1, v1);
+                ret_cnt = (double)(float)E + ret_cnt;
+            }
+            s_retstat[0] = m1; s_retstat[1] = v1;
+            const float inv = 1.0f / sqrtf(v1 + q.eps);                                                    // :79
+            for (int e = 0; e < E; ++e) {
+                float y = rs[e];
+                if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
+                q.ro_rew[(size_t)t * E + e] = y;
+                ret[e] = ret[e] * (1.0f - rs[NW_ROWS + e]);                                                // :88-91
+            }
+        }
+        RSTAMP(9);
+        lds_barrier();
+        RSTAMP(10);
+    }
+    // ---- exit: the state goes home ----------------------------------------------------------------------------------------------
+    for (int i = tid; i < E * O; i += NW_THREADS) q.st.raw_obs[i] = xs[i];
+    if (tid < O) { q.st.obs_mean[tid] = s_mean[tid]; q.st.obs_var[tid] = s_var[tid]; }
+    if (tid < E) { q.st.done[tid] = rs[NW_ROWS + tid]; q.st.ret[tid] = rs[2 * NW_ROWS + tid]; }
+    if (tid == 0) *q.st.obs_count = obs_cnt;
+    if (tid == 64) { *q.st.ret_mean = s_retstat[0]; *q.st.ret_var = s_retstat[1]; *q.st.ret_count = ret_cnt; }
+}

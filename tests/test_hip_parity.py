@@ -219,6 +219,33 @@ def test_update_phase_matches_oracle(hidden, E, T, nmb, epochs):
     close(rows2, ref_rows2, rtol=3e-4, atol=3e-6, msg="second update")
 
 
+@pytest.mark.parametrize("hidden,E,T,explicit_noise", [((64, 64), 1, 64, True), ((64, 64), 1, 33, False), ((64, 64), 7, 16, True), ((64, 64), 32, 9, False),
+                                                      ((4, 5), 1, 40, True), ((16, 8, 8), 5, 12, False)])
+def test_persistent_rollout_is_bitwise_the_per_step_launches(hidden, E, T, explicit_noise, monkeypatch):
+    """n_envs <= 32 on the device env: the whole rollout runs in ONE launch of one persistent workgroup (state in LDS, value
+    tower batched afterwards).  Same statements as the one-launch-per-env-step kernel: every rollout field, the running
+    statistics and the state carried into the NEXT rollout must be bit-identical, with explicit noise and with the counter RNG."""
+    outs = []
+    for persistent in (True, False):
+        monkeypatch.setenv("PPO_HIP_NO_PERSISTENT_COLLECT", "0" if persistent else "1")
+        orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 27)
+        got = {}
+        for it in range(2):                                  # the second rollout continues from the state the first one left
+            g.collect_synthetic(1234, GAMMA, LAM, noise if explicit_noise else None, step0=it * T, first=(it == 0))
+            for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones"):
+                got["%s%d" % (f, it)] = g.rollout_get(f)
+            for which, nm in ((0, "obs"), (1, "ret")):
+                m, v, c = g.norm_stats(which)
+                got["%s_mean%d" % (nm, it)], got["%s_var%d" % (nm, it)], got["%s_cnt%d" % (nm, it)] = m, v, np.float64(c)
+        if explicit_noise:                                   # and against the oracle's rollout
+            for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+                close(got[f + "0"], ro[f], rtol=2e-4, atol=2e-5, msg=f)
+        outs.append(got)
+        g.close()
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+
+
 @pytest.mark.parametrize("E,T,nmb,epochs", [(16, 16, 4, 3), (64, 64, 32, 1), (3, 100, 4, 2), (16, 16, 1, 1)])
 def test_deferred_adam_is_bitwise_the_adam_launch(E, T, nmb, epochs, monkeypatch):
     """Reference shape ([64,64]): inside ppo_update the clip + Adam of step k is applied by the prologue of step k+1's train
