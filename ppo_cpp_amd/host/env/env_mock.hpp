@@ -47,15 +47,15 @@ inline uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-inline uint32_t ctr_hash(uint32_t seed, uint32_t env, uint32_t step, uint32_t lane) {
-    return (uint32_t)(splitmix64(splitmix64(((uint64_t)seed << 32) | env) ^ (((uint64_t)step << 32) | lane)) >> 32);
-}
+inline uint64_t ctr_key(uint32_t seed, uint32_t env) { return splitmix64(((uint64_t)seed << 32) | env); }      // the (seed, env) half of the hash
+inline uint32_t ctr_hash_keyed(uint64_t key, uint32_t step, uint32_t lane) { return (uint32_t)(splitmix64(key ^ (((uint64_t)step << 32) | lane)) >> 32); }
+inline uint32_t ctr_hash(uint32_t seed, uint32_t env, uint32_t step, uint32_t lane) { return ctr_hash_keyed(ctr_key(seed, env), step, lane); }
 inline float sym_unit(uint32_t h) { return (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f; }
 }  // namespace ppo_detail
 
 class SeededEnvMock : public Env {
 public:
-    SeededEnvMock(uint32_t seed, uint32_t env_id) : seed_(seed), id_(env_id), step_(0), last_rew_(0.f) {}
+    SeededEnvMock(uint32_t seed, uint32_t env_id) : seed_(seed), id_(env_id), step_(0), last_rew_(0.f), key_(ppo_detail::ctr_key(seed, env_id)) {}
     std::string get_action_space() override { return Env::SPACE_CONTINOUS; }
     std::string get_observation_space() override { return Env::SPACE_CONTINOUS; }
     int get_action_space_size() override { return kDim; }
@@ -64,10 +64,13 @@ public:
     std::vector<Mat> step(const Mat& /*actions*/) override {
         ++step_;
         Mat rew(1, 1), done(1, 1);
-        last_rew_ = ppo_detail::sym_unit(ppo_detail::ctr_hash(seed_, id_, step_, kDim));
+        last_rew_ = ppo_detail::sym_unit(ppo_detail::ctr_hash_keyed(key_, step_, kDim));
         rew(0, 0) = last_rew_;
-        done(0, 0) = (ppo_detail::ctr_hash(seed_, id_, step_, kDim + 1) % 300u == 0u) ? 1.f : 0.f;
-        return {obs_at(step_), rew, done};
+        done(0, 0) = (ppo_detail::ctr_hash_keyed(key_, step_, kDim + 1) % 300u == 0u) ? 1.f : 0.f;
+        std::vector<Mat> out;             // (a braced list would COPY the three matrices into the vector: three more allocations per env step)
+        out.reserve(3);
+        out.push_back(obs_at(step_)); out.push_back(std::move(rew)); out.push_back(std::move(done));
+        return out;
     }
     Mat get_original_obs() override { return obs_at(step_); }
     Mat get_original_rew() override { Mat r(1, 1); r(0, 0) = last_rew_; return r; }
@@ -78,7 +81,8 @@ public:
 
 private:
     static constexpr int kDim = 18;
-    Mat obs_at(uint32_t step) const { Mat m(1, kDim); for (int j = 0; j < kDim; ++j) m(0, j) = ppo_detail::sym_unit(ppo_detail::ctr_hash(seed_, id_, step, (uint32_t)j)); return m; }
+    Mat obs_at(uint32_t step) const { Mat m(1, kDim); for (int j = 0; j < kDim; ++j) m(0, j) = ppo_detail::sym_unit(ppo_detail::ctr_hash_keyed(key_, step, (uint32_t)j)); return m; }
     uint32_t seed_, id_, step_;
     float last_rew_;
+    uint64_t key_;                  // splitmix64(seed, env id): the step-independent half of the counter hash
 };

@@ -132,6 +132,7 @@ private:
     void worker(int begin, int end) {
         for (int i = begin; i < end; ++i) envs_[i]->reset();
         unsigned long seen = 0;
+        Mat a(1, 1);
         finish_one();
         for (;;) {
             {
@@ -141,8 +142,8 @@ private:
                 if (terminate_) return;
             }
             const int acols = static_cast<int>(actions_->cols());
+            if (a.cols() != acols) a = Mat(1, acols);               // one action row per worker, reused (not one allocation per env step)
             for (int i = begin; i < end; ++i) {
-                Mat a(1, acols);
                 mat_set_row(a, 0, mat_row_ptr(*actions_, i));
                 const std::vector<Mat> res = envs_[i]->step(a);
                 mat_set_row(observations_, i, res[0].data());
