@@ -6,12 +6,12 @@ python bench.py --steps 5 --warmup 2 > $out/bench_cfg3.json 2> $out/bench_cfg3.e
 for cfg in cfg3 cfg2 cfg4 cfg5; do
   [ $cfg != cfg3 ] && python bench.py --config $cfg --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $out/bench_$cfg.json 2> $out/bench_$cfg.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$cfg -- python3 bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $out/bench_prof_$cfg.json 2> $out/prof_$cfg.err
-  cp $(find $out/prof_$cfg -name "*kernel_stats.csv" | head -1) $out/kernel_stats_$cfg.csv
+  cp $(find $out/prof_$cfg -name "*kernel_stats.csv" | head -1) $out/kernel_stats_$cfg.csv; rm -rf $out/prof_$cfg
 done
 pmc() { # name config counters...
   n=$1; cfg=$2; shift 2
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/pmc_$n -- python3 bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-extra > $out/pmc_$n.json 2> $out/pmc_$n.err || tail -3 $out/pmc_$n.err
-  cp $(find $out/pmc_$n -name "*counter_collection.csv" | head -1) $out/pmc_$n.csv
+  cp $(find $out/pmc_$n -name "*counter_collection.csv" | head -1) $out/pmc_$n.csv; rm -rf $out/pmc_$n
 }
 pmc fetch_cfg3 cfg3 FETCH_SIZE
 pmc write_cfg3 cfg3 WRITE_SIZE
