@@ -790,9 +790,15 @@ int launch_step(ppo_handle* h, const StepArgs& a) {
 int enqueue_allreduce(ppo_handle* h, float* buf, size_t count, float* sumsq = nullptr, int sumsq_chunks = 0) {
     ProfScope ps(h, PK_COMM);
     if (h->peer.on && count <= h->peer.cap) {
-        const unsigned grid = (unsigned)((count + PEER_CHUNK - 1) / PEER_CHUNK);
-        hipLaunchKernelGGL(peer_push_kernel, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, (const float*)buf, (unsigned long long)count);
-        hipLaunchKernelGGL(peer_sum_kernel, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, buf, (unsigned long long)count, sumsq, (unsigned)sumsq_chunks);
+        if (count > 32768) {
+            const unsigned grid = (unsigned)((count + 4095) / 4096);
+            hipLaunchKernelGGL(peer_push_kernel<4>, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, (const float*)buf, (unsigned long long)count);
+            hipLaunchKernelGGL(peer_sum_kernel<4>, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, buf, (unsigned long long)count, sumsq, (unsigned)sumsq_chunks);
+        } else {
+            const unsigned grid = (unsigned)((count + 1023) / 1024);
+            hipLaunchKernelGGL(peer_push_kernel<1>, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, (const float*)buf, (unsigned long long)count);
+            hipLaunchKernelGGL(peer_sum_kernel<1>, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, buf, (unsigned long long)count, sumsq, (unsigned)sumsq_chunks);
+        }
         HIP_OK(h, hipGetLastError());
         return 0;
     }
@@ -2009,10 +2015,16 @@ int ppo_dist_peer_export(ppo_handle* h, char handle[64]) {
     if (h->world > PEER_MAX_WORLD) return fail(h, "ppo_dist_peer_export: world %d > %d (one node)", h->world, PEER_MAX_WORLD);
     ppo_handle::Peer& P = h->peer;
     if (!P.region) {
-        P.cap = (size_t)ru(std::max(h->P_pad + 8, 4096), PEER_CHUNK);
+        P.cap = (size_t)ru(std::max(h->P_pad + 8, 4096), PEER_CHUNK_MAX);
         const size_t bytes = kPeerFlagBytes + (size_t)2 * h->world * P.cap * sizeof(float);
-        hipError_t e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocUncached);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocFinegrained); }
+        // memory kind of the region (other devices write into it): fine-grained = coherent at system scope with the kernels'
+        // fences, cached in L2; uncached = every access goes to memory (slowest, needs no fence to be seen); coarse = plain
+        // hipMalloc (fastest; coherent across devices only at kernel boundaries by the letter of the memory model)
+        const char* mk = getenv("PPO_HIP_PEER_MEM");
+        const int kind = !mk ? 0 : mk[0] == 'u' ? 1 : mk[0] == 'c' ? 2 : 0;
+        hipError_t e = hipErrorUnknown;
+        if (kind == 0) e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocFinegrained);
+        if (kind == 1 || (kind == 0 && e != hipSuccess)) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocUncached); }
         if (e != hipSuccess) { (void)hipGetLastError(); P.region = nullptr; HIP_OK(h, hipMalloc(&P.region, bytes)); }
         HIP_OK(h, hipMemset(P.region, 0, bytes));
         HIP_OK(h, hipMalloc((void**)&P.local, 64));

@@ -38,32 +38,42 @@ __device__ __forceinline__ unsigned peer_ld_sys(const unsigned* p) { return __hi
 __device__ __forceinline__ void peer_st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 #define PEER_THREADS 256
-#define PEER_CHUNK 1024                // floats per workgroup (one float4 per thread)
+// V = float4 per thread of the push kernel = 1024-float pieces per workgroup: fewer, larger workgroups pay fewer system-scope
+// fences per exchange (0.6 MB: 62 us per train step at V = 4 against 69 at V = 1, one rank), small payloads want the
+// parallelism (52 KB: 30 against 35 us).  The host picks per call; `cap` is a multiple of the largest chunk.
+#define PEER_CHUNK_MAX 4096
 
-// grid = ceil(count / PEER_CHUNK); src must be 16-byte aligned, slots are
+// grid = ceil(count / (1024 V)); src must be 16-byte aligned, slots are
+template <int PEER_V>
 __global__ __launch_bounds__(PEER_THREADS) void peer_push_kernel(PeerDev p, const float* __restrict__ src, unsigned long long count) {
     __shared__ unsigned s_seq, s_last;
     if (threadIdx.x == 0) s_seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     __syncthreads();
+    constexpr int PEER_CHUNK = 1024 * PEER_V;
     const unsigned s = s_seq, par = s & 1u;
-    const unsigned long long i0 = (unsigned long long)blockIdx.x * PEER_CHUNK + 4ull * threadIdx.x;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i0 + 3 < count) v = *reinterpret_cast<const float4*>(src + i0);
-    else {
-        if (i0 < count) v.x = src[i0];
-        if (i0 + 1 < count) v.y = src[i0 + 1];
-        if (i0 + 2 < count) v.z = src[i0 + 2];
-    }
-    if (i0 < count) {
-        const unsigned long long off = ((unsigned long long)par * p.world + p.rank) * p.cap + i0;      // cap is a multiple of 4
-#pragma unroll 1
-        for (int k = 0; k < p.world; ++k) {
-            const int r = (p.rank + k) % p.world;               // every rank starts at a different peer: the links share the load
-            *reinterpret_cast<float4*>(p.slots[r] + off) = v;
+    float4 v[PEER_V];
+#pragma unroll
+    for (int q = 0; q < PEER_V; ++q) {
+        const unsigned long long i0 = (unsigned long long)blockIdx.x * PEER_CHUNK + 1024ull * q + 4ull * threadIdx.x;
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + 3 < count) v[q] = *reinterpret_cast<const float4*>(src + i0);
+        else {
+            if (i0 < count) v[q].x = src[i0];
+            if (i0 + 1 < count) v[q].y = src[i0 + 1];
+            if (i0 + 2 < count) v[q].z = src[i0 + 2];
         }
     }
-    __atomic_thread_fence(__ATOMIC_RELEASE);                    // system scope (HIP's default for __atomic_thread_fence): my writes have landed
-    __threadfence_system();
+#pragma unroll 1
+    for (int k = 0; k < p.world; ++k) {
+        const int r = (p.rank + k) % p.world;                   // every rank starts at a different peer: the links share the load
+        float* dst = p.slots[r] + ((unsigned long long)par * p.world + p.rank) * p.cap;      // cap is a multiple of PEER_CHUNK
+#pragma unroll
+        for (int q = 0; q < PEER_V; ++q) {
+            const unsigned long long i0 = (unsigned long long)blockIdx.x * PEER_CHUNK + 1024ull * q + 4ull * threadIdx.x;
+            if (i0 < count) *reinterpret_cast<float4*>(dst + i0) = v[q];
+        }
+    }
+    __threadfence_system();                                     // my writes have landed (system scope release)
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned old = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -71,7 +81,6 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_push_kernel(PeerDev p, cons
     }
     __syncthreads();
     if (s_last) {
-        __threadfence_system();
         if (threadIdx.x < (unsigned)p.world)
             peer_st_sys(p.flags[threadIdx.x] + ((size_t)par * PEER_MAX_WORLD + p.rank) * PEER_FLAG_STRIDE, s);
         if (threadIdx.x == 0) {
@@ -81,13 +90,15 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_push_kernel(PeerDev p, cons
     }
 }
 
-// grid = ceil(count / PEER_CHUNK); dst[i] = sum_r slot[r][i] in rank order.  Thread t owns elements t, t+256, t+512, t+768 of
-// the workgroup's 1024, so every 256-element chunk is laid over the 256 threads exactly as in grad_reduce_kernel /
+// grid = ceil(count / (1024 V)); dst[i] = sum_r slot[r][i] in rank order.  Thread t owns elements t, t+256, t+512, ... of
+// the workgroup's chunk, so every 256-element chunk is laid over the 256 threads exactly as in grad_reduce_kernel /
 // grad_sumsq_kernel and its sum of squares is formed by the same tree (bit-identical to what those kernels would write).
 // sumsq (may be null): one partial per 256-element chunk; chunks at or beyond `sumsq_chunks` are not written (the loss sums
 // ride behind the gradient in the same payload and must not enter the norm).
+template <int PEER_V>
 __global__ __launch_bounds__(PEER_THREADS) void peer_sum_kernel(PeerDev p, float* __restrict__ dst, unsigned long long count, float* __restrict__ sumsq,
                                                                unsigned sumsq_chunks) {
+    constexpr int PEER_CHUNK = 1024 * PEER_V;
     __shared__ unsigned s_seq;
     __shared__ float s_part[PEER_CHUNK / 256][PEER_THREADS / 64];
     if (threadIdx.x == 0) s_seq = __hip_atomic_load(p.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
