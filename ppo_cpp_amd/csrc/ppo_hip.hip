@@ -122,6 +122,10 @@ struct ppo_handle {
     float* pin_in = nullptr;          // pinned host mirror of env_in (hipHostMalloc, owned by the handle)
     float* pin_out = nullptr;         // pinned host landing buffer for the actions of one env step [E*A]
     size_t pin_in_n = 0, pin_out_n = 0;
+    // fused host-Env step for <= 32 environments (narrow_host_step_kernel): the kernel reads pin_in / writes pin_out itself
+    unsigned* pin_flag = nullptr;     // pinned host word the step kernel raises when the actions are in pin_out
+    unsigned act_seq = 0;
+    bool host_pending = false; int host_pending_t = 0;   // a transition sits in pin_in, its bookkeeping rides in the next launch
     bool pin_in_busy = false;         // an H2D copy out of pin_in may still be in flight (cleared by every stream synchronisation of the rollout calls)
     int upd_cap_epochs = 0;
     // bf16 matrix-core path (ppo_config::compute_dtype == PPO_BF16; kernels in ppo_bf16.hpp)
@@ -1080,6 +1084,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_host_step_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_host_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         const char* nl = getenv("PPO_HIP_NO_LAZY_ADAM");
         if (h->nw_static && !(nl && nl[0] == '1')) {
@@ -1125,6 +1131,7 @@ void ppo_destroy(ppo_handle* h) {
     }
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->pin_flag) (void)hipHostFree(h->pin_flag);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1379,6 +1386,8 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
     if (h->pin_out) { (void)hipHostFree(h->pin_out); h->pin_out = nullptr; }
     HIP_OK(h, hipHostMalloc((void**)&h->pin_in, in_n * sizeof(float), hipHostMallocDefault));
     HIP_OK(h, hipHostMalloc((void**)&h->pin_out, (size_t)n_envs * h->net.A * sizeof(float), hipHostMallocDefault));
+    if (!h->pin_flag) { HIP_OK(h, hipHostMalloc((void**)&h->pin_flag, 64, hipHostMallocDefault)); memset(h->pin_flag, 0, 64); h->act_seq = 0; }
+    h->host_pending = false;
     h->pin_in_n = in_n; h->pin_out_n = (size_t)n_envs * h->net.A;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -1561,12 +1570,49 @@ static int enqueue_finish(ppo_handle* h, float gamma, float lam) {
     return 0;
 }
 
+// fused host-Env step available for this handle / rollout shape?
+static bool host_fused(const ppo_handle* h) {
+    const char* e = getenv("PPO_HIP_NO_HOST_FUSED");
+    if (e && e[0] == '1') return false;
+    const NetDev& n = h->net;
+    return h->narrow && !h->comm && !h->bf.on && h->E <= NW_ROWS && n.O <= 64 && n.A <= 64 && h->pin_flag &&
+           ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float) <= 160 * 1024;
+}
+
+// one launch of narrow_host_step_kernel: the pending transition's bookkeeping (if any) and, with act, the policy step of row t
+static int enqueue_host_step(ppo_handle* h, int t, bool act, const float* noise_dev, uint32_t rng_step) {
+    const NetDev& n = h->net;
+    const size_t E = h->E;
+    NwHostStepArgs q{};
+    q.img = h->nw_img;
+    q.st = NwEnvState{h->raw_obs, h->obs_rms.mean, h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->cur_done};
+    void* din = nullptr; void* dact = nullptr; void* dflag = nullptr;
+    HIP_OK(h, hipHostGetDevicePointer(&din, h->pin_in, 0));
+    HIP_OK(h, hipHostGetDevicePointer(&dact, h->pin_out, 0));
+    HIP_OK(h, hipHostGetDevicePointer(&dflag, h->pin_flag, 0));
+    q.host_in = (const float*)din; q.host_act = (float*)dact; q.host_flag = (unsigned*)dflag; q.flag_value = act ? ++h->act_seq : 0u;
+    q.noise = noise_dev;
+    if (act) { q.ro_obs = h->ro_obs + t * E * n.O; q.ro_act = h->ro_act + t * E * n.A; q.ro_nlp = h->ro_nlp + t * E; q.ro_done = h->ro_done + t * E; }
+    q.has_transition = h->host_pending ? 1 : 0;
+    q.ro_rew_prev = h->host_pending ? h->ro_rew + (size_t)h->host_pending_t * E : nullptr;
+    q.E = (int)E; q.act = act ? 1 : 0;
+    q.seed = h->rng_seed; q.rng_step = rng_step; q.row_base = (uint32_t)(h->rank * h->E);
+    q.gamma = h->nz_gamma; q.clip_rew = h->nz_clip_rew; q.clip_obs = h->nz_clip_obs; q.eps = h->nz_eps; q.norm_obs = h->norm_obs_flag; q.norm_rew = h->norm_rew_flag;
+    const size_t lds = ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float);
+    ProfScope ps(h, PK_STEP);
+    if (h->nw_static) hipLaunchKernelGGL((narrow_host_step_kernel<32, 64, 32, 2>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+    else hipLaunchKernelGGL((narrow_host_step_kernel<0, 0, 0, 0>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+    HIP_OK(h, hipGetLastError());
+    h->host_pending = false;
+    return 0;
+}
+
 int ppo_rollout_reset(ppo_handle* h, const float* raw_obs) {
     if (!h->E) return fail(h, "ppo_rollout_reset: call ppo_rollout_alloc first");
     ENTER(h);
     const size_t on = (size_t)h->E * h->net.O;
     if (h->pin_in_busy) HIP_OK(h, hipStreamSynchronize(h->stream));
-    h->pin_in_busy = false;
+    h->pin_in_busy = false; h->host_pending = false;
     memcpy(h->pin_in, raw_obs, on * sizeof(float));
     HIP_OK(h, hipMemcpyAsync(h->raw_obs, h->pin_in, on * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)h->E * sizeof(float), h->stream));          // env_normalize.hpp:114
@@ -1584,6 +1630,23 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
     const size_t cnt = (size_t)h->E * n.A;
     float* nd = nullptr;
     if (noise) { nd = h->ro_noise; HIP_OK(h, hipMemcpyAsync(nd, noise, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream)); }
+    if (host_fused(h)) {
+        // <= 32 environments on the narrow path: ONE launch does the pending transition's EnvNormalize bookkeeping (read from the
+        // pinned block), the policy tower and the action store into pinned memory; the host spins on the completion word
+        if (enqueue_host_step(h, t, true, nd, h->rng_calls++)) return -1;
+        const unsigned want = h->act_seq;
+        unsigned long spins = 0;
+        while (__atomic_load_n(h->pin_flag, __ATOMIC_ACQUIRE) != want) {
+            if ((++spins & 0x3ffff) == 0) {                     // every ~quarter million polls: is the stream still alive?
+                const hipError_t qe = hipStreamQuery(h->stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) return fail(h, "ppo_rollout_act: %s", hipGetErrorString(qe));
+                if (qe == hipSuccess && __atomic_load_n(h->pin_flag, __ATOMIC_ACQUIRE) != want) return fail(h, "ppo_rollout_act: the step kernel finished without publishing");
+            }
+        }
+        h->pin_in_busy = false; h->done_staged = -1;
+        memcpy(actions_out, h->pin_out, cnt * sizeof(float));
+        return 0;
+    }
     if (enqueue_rollout_act(h, t, nd, h->rng_seed, h->rng_calls++, (uint32_t)(h->rank * h->E))) return -1;
     // one D2H into the handle's pinned landing buffer and the ONLY stream synchronisation of an env step: the statistics
     // kernel of the previous ppo_rollout_observe, this policy step and the copy drain together
@@ -1611,6 +1674,7 @@ int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const fl
     memcpy(h->pin_in, raw_obs, on * sizeof(float));
     memcpy(h->pin_in + on, raw_rew, E * sizeof(float));
     memcpy(h->pin_in + on + E, dones, E * sizeof(float));
+    if (host_fused(h)) { h->host_pending = true; h->host_pending_t = t; return 0; }      // the next launch reads the block in place
     HIP_OK(h, hipMemcpyAsync(h->env_in, h->pin_in, (on + 2 * E) * sizeof(float), hipMemcpyHostToDevice, h->stream));
     h->pin_in_busy = true;
     if (enqueue_observe(h, t)) return -1;
@@ -1620,6 +1684,12 @@ int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const fl
 int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
     ENTER(h);
     if (!h->E) return fail(h, "ppo_rollout_finish: call ppo_rollout_alloc first");
+    if (host_fused(h)) {
+        if (h->host_pending && enqueue_host_step(h, 0, false, nullptr, 0)) return -1;      // the last transition's bookkeeping
+        StepArgs va{};                                                                     // values of all T x E normalised rows, batched
+        va.obs = h->ro_obs; va.value = h->ro_val; va.n = h->E * h->T; va.nz = no_norm();
+        if (launch_step(h, va)) return -1;
+    }
     if (enqueue_finish(h, gamma, lam)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);

@@ -1038,3 +1038,174 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     if (tid == 0) *q.st.obs_count = obs_cnt;
     if (tid == 64) { *q.st.ret_mean = s_retstat[0]; *q.st.ret_var = s_retstat[1]; *q.st.ret_count = ret_cnt; }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Host-Env rollout step for small environment counts (n_envs <= 32; BASELINE configs[1]: ONE environment stepped on the
+// host): one launch per env step instead of {H2D copy, statistics kernel, policy step of both towers, D2H copy}.
+// The kernel reads the transition the host's Env::step produced STRAIGHT from the handle's pinned host block (zero-copy over
+// PCIe: 80 bytes at one environment), does EnvNormalize::step's bookkeeping for it (env_normalize.hpp:64-116, the statements
+// of narrow_collect_kernel), then normalises the new observations, runs the policy tower, samples, stores the actions
+// STRAIGHT into pinned host memory and raises a completion word there; the host spins on that word.  No copy-engine
+// operation and no stream query sits between the host's env step and the next action (34.6 -> ~16 us per env step at one
+// environment).  The value tower is not needed per step: one batched launch at ppo_rollout_finish.
+// ------------------------------------------------------------------------------------------------------------------------
+struct NwHostStepArgs {
+    const float* img;            // policy tower's packed image
+    NwEnvState st;               // device-resident state (read and written: one workgroup, no race)
+    const float* host_in;        // pinned host block [E*O obs | E rewards | E dones]: the transition that followed the previous action
+    float* host_act;             // pinned host [E*A]
+    unsigned* host_flag; unsigned flag_value;
+    const float* noise;          // device [E][A] or null -> counter RNG
+    float* ro_obs; float* ro_act; float* ro_nlp; float* ro_done;     // rollout row t (act != 0)
+    float* ro_rew_prev;          // rollout rewards row t-1 (has_transition != 0)
+    int E; int has_transition; int act;
+    uint32_t seed, rng_step, row_base;
+    float gamma, clip_rew, clip_obs, eps; int norm_obs, norm_rew;
+};
+
+template <int KP0, int HP, int AP, int LL>
+__global__ __launch_bounds__(NW_THREADS) void narrow_host_step_kernel(NetDev net, NwLayout lay, NwHostStepArgs q) {
+    typedef NwShape<KP0, HP, AP, LL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwHostStepArgs)>();
+    const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
+    const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
+    const int E = q.E, O = net.O, A = net.A;
+    float* xs = lds + lay.lds_total;                        // [E][O] raw observations
+    float* s_mean = xs + NW_RO_XS; float* s_var = s_mean + 64;
+    float* rs = s_var + 64;                                 // [32] rewards | [32] dones | [32] returns
+    // ---- everything this launch reads, requested together: image, transition (host memory) or current observations, state ----
+    {
+        const int n4 = q.act ? lay.w_fwd / 4 : 0;
+        for (int e = tid; e < n4; e += NW_THREADS) reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(q.img)[e];
+        const float* src = q.has_transition ? q.host_in : q.st.raw_obs;
+        for (int i = tid; i < E * O; i += NW_THREADS) xs[i] = src[i];
+        if (tid < O) { s_mean[tid] = q.st.obs_mean[tid]; s_var[tid] = q.st.obs_var[tid]; }
+        if (tid < E) {
+            rs[2 * NW_ROWS + tid] = q.st.ret[tid];
+            if (q.has_transition) { rs[tid] = q.host_in[(size_t)E * O + tid]; rs[NW_ROWS + tid] = q.host_in[(size_t)E * O + E + tid]; }
+            else rs[NW_ROWS + tid] = q.st.done[tid];
+        }
+    }
+    float nz_eps[4] = {0.f, 0.f, 0.f, 0.f};
+    const int r = ptid >> 4, part = ptid & 15;
+    const int row = 16 * pipe + r;
+    if (q.act && q.noise && row < E) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) nz_eps[k] = q.noise[(size_t)row * A + j]; }
+    }
+    __syncthreads();
+    // ---- EnvNormalize::step bookkeeping for the transition that arrived (env_normalize.hpp:64-116) ------------------------------
+    if (q.has_transition) {
+        auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
+            const double nb = (double)nbf, tot = cnt + nb;
+            const float bvar = bM2 / (float)nb;                                        // running_statistics.hpp:51-54
+            const float delta = bmean - mean0;                                         // :90
+            mean1 = mean0 + (delta * (float)nb) / (float)tot;                          // :94
+            const float m_a = var0 * (float)cnt, m_b = bvar * (float)nb;               // :97-98
+            const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;   // :100
+            var1 = M2 / (float)tot;                                                    // :101
+        };
+        if (tid < O && q.norm_obs) {
+            const double cnt = *q.st.obs_count;
+            float sum = 0.f;
+            for (int e = 0; e < E; ++e) sum += xs[e * O + tid];
+            const float bmean = sum / (float)E;
+            float m2 = 0.f;
+            for (int e = 0; e < E; ++e) { const float d = xs[e * O + tid] - bmean; m2 += d * d; }
+            float m1, v1;
+            merge(s_mean[tid], s_var[tid], cnt, bmean, m2, (float)E, m1, v1);
+            s_mean[tid] = m1; s_var[tid] = v1;
+            q.st.obs_mean[tid] = m1; q.st.obs_var[tid] = v1;
+        }
+        if (tid == 64) {
+            float* ret = rs + 2 * NW_ROWS;
+            float sum = 0.f;
+            for (int e = 0; e < E; ++e) { ret[e] = ret[e] * q.gamma + rs[e]; sum += ret[e]; }            // :66
+            float m1 = *q.st.ret_mean, v1 = *q.st.ret_var;
+            if (q.norm_rew) {
+                const double cnt = *q.st.ret_count;
+                const float bmean = sum / (float)E;
+                float m2 = 0.f;
+                for (int e = 0; e < E; ++e) { const float d = ret[e] - bmean; m2 += d * d; }
+                merge(*q.st.ret_mean, *q.st.ret_var, cnt, bmean, m2, (float)E, m1, v1);
+                *q.st.ret_mean = m1; *q.st.ret_var = v1; *q.st.ret_count = (double)(float)E + cnt;
+            }
+            const float inv = 1.0f / sqrtf(v1 + q.eps);                                                    // :79
+            for (int e = 0; e < E; ++e) {
+                float y = rs[e];
+                if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
+                q.ro_rew_prev[e] = y;
+                q.st.ret[e] = ret[e] * (1.0f - rs[NW_ROWS + e]);                                           // :88-91
+                q.st.done[e] = rs[NW_ROWS + e];
+            }
+        }
+        for (int i = tid; i < E * O; i += NW_THREADS) q.st.raw_obs[i] = xs[i];       // the device copy ppo_rollout_finish bootstraps from
+        __syncthreads();
+        // (the count is bumped after every column has read it)
+        if (tid == 0 && q.norm_obs) *q.st.obs_count = (double)(float)E + *q.st.obs_count;              // :103
+    }
+    if (!q.act) return;
+    // ---- normalise (env_normalize.hpp:99-104) -> input tile + rollout row -----------------------------------------------------------
+    for (int i = tid; i < NW_ROWS * Kp0; i += NW_THREADS) {
+        const int rr = i / Kp0, j = i - rr * Kp0;
+        float x = 0.f;
+        if (rr < E && j < O) {
+            x = xs[rr * O + j];
+            if (q.norm_obs) {
+                x = (x - s_mean[j]) * (1.0f / sqrtf(s_var[j] + q.eps));
+                x = tf_min(tf_max(x, -q.clip_obs), q.clip_obs);
+            }
+            q.ro_obs[(size_t)rr * O + j] = x;
+        }
+        lds[lay.w_total + (rr >> 4) * lay.pipe_total + lay.x[0] + (rr & 15) * lay.ldx[0] + j] = x;
+    }
+    if (tid < E) q.ro_done[tid] = rs[NW_ROWS + tid];
+    lds_barrier();
+    float* P = lds + lay.w_total + pipe * lay.pipe_total;
+    const float* par = lds + lay.par;
+    const bool live_pipe = 16 * pipe < E;
+    for (int l = 0; l < L; ++l) {
+        const float* bias = par + net.par_b[l];
+        float* Ys = P + lay.x[l + 1]; const int ldy = lay.ldx[l + 1];
+        auto ep = [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+            const float b = bias[col];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) Ys[(4 * g + rr) * ldy + col] = fast_tanh(acc[rr] + b);
+        };
+        if (live_pipe) {
+            if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
+            else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+        }
+        lds_barrier();
+    }
+    const float* hL = P + lay.x[L]; const int ldh = lay.ldx[L]; const int HpL = S::Hp(net, L - 1);
+    float* mus = P + lay.mu; const int ldm = lay.ldm;
+    if (live_pipe) nw_dense<HP>(hL, ldh, HpL, lds + lay.wh, lay.wh_ld, Ap, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+        const float b = par[net.par_bmu + col];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mus[(4 * g + k) * ldm + col] = acc[k] + b;
+    });
+    lds_barrier();
+    if (live_pipe) {
+        float ssq = 0.f, slog = 0.f;
+        int k = 0;
+        for (int j = part; j < A; j += 16, ++k) {
+            const float mu = mus[r * ldm + j];
+            const float logstd = mu * 0.0f + par[net.par_ls + j];
+            const float sigma = expf(logstd);
+            float eps = 0.f;
+            if (row < E) eps = q.noise ? nz_eps[k & 3] : ctr_normal(q.seed, q.row_base + row, q.rng_step, j);
+            const float act = mu + sigma * eps;
+            const float z = (act - mu) / sigma;
+            ssq += z * z; slog += logstd;
+            if (row < E) { q.ro_act[(size_t)row * A + j] = act; q.host_act[(size_t)row * A + j] = act; }
+        }
+        ssq = group16_sum(ssq); slog = group16_sum(slog);
+        if (part == 0 && row < E) q.ro_nlp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
+    }
+    // ---- publish: the host's actions have landed, then the completion word ------------------------------------------------------------
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(q.host_flag, q.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
