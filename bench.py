@@ -395,6 +395,18 @@ def main():
                                                       "ms_per_step": 1e3 * dt2, "steps": 3, "warmup": 1}}
         g2.close()
         g = None
+        try:
+            # ... and the same configuration as the reference actually runs it: the ONE environment stepped on the HOST (Env::step
+            # behind VecEnv / EnvNormalize, PPO2::learn), every env step a PCIe round trip
+            from ppo_cpp_amd import hostapi
+            r2 = hostapi.learn(c2["n_envs"], c2["n_steps"], c2["hidden"], n_updates=5, nminibatches=c2["nminibatches"], noptepochs=c2["noptepochs"],
+                               lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM)
+            out["also"]["BASELINE configs[1] (cfg2), Env on the host"] = {
+                "value": r2["env_steps_per_s"], "unit": "env-steps/s", "collect_ms": r2["collect_ms"], "update_ms": r2["update_ms"],
+                "us_per_env_step": 1e3 * r2["collect_ms"] / c2["n_steps"],
+                "note": "SeededEnvMock on the host; resident rollout kernel, actions / transitions through pinned memory"}
+        except Exception as e:
+            out["also"]["BASELINE configs[1] (cfg2), Env on the host"] = {"error": repr(e)}
     # PCIe-inclusive leg: on by default in the plain single-GPU run (same guard as above), or forced with --host-env
     if world == 1 and (args.host_env or (args.config == "cfg3" and not args.no_extra and not profiled)):
         # PCIe-inclusive: the reference's own stack (N x mock Env -> VecEnv -> EnvNormalize -> PPO2::learn) on the host,

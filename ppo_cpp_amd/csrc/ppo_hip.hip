@@ -126,6 +126,10 @@ struct ppo_handle {
     unsigned* pin_flag = nullptr;     // pinned host word the step kernel raises when the actions are in pin_out
     unsigned act_seq = 0;
     bool host_pending = false; int host_pending_t = 0;   // a transition sits in pin_in, its bookkeeping rides in the next launch
+    // ... and the RESIDENT form (narrow_rollout_kernel in host mode): one launch serves many env steps, host and kernel talk
+    // through sequence words in pinned memory (pin_flag[PCTL_*])
+    bool hp_active = false;           // a resident kernel may be running
+    int hp_posted = 0;                // transitions posted in this rollout
     bool pin_in_busy = false;         // an H2D copy out of pin_in may still be in flight (cleared by every stream synchronisation of the rollout calls)
     int upd_cap_epochs = 0;
     // bf16 matrix-core path (ppo_config::compute_dtype == PPO_BF16; kernels in ppo_bf16.hpp)
@@ -1104,6 +1108,7 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
 void ppo_destroy(ppo_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->hp_active && h->pin_flag) __atomic_store_n(h->pin_flag + 64 + PCTL_STOP, 1u, __ATOMIC_RELEASE);    // a resident rollout kernel: ask it to leave
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->upd_graph) (void)hipGraphExecDestroy(h->upd_graph);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
@@ -1386,7 +1391,7 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
     if (h->pin_out) { (void)hipHostFree(h->pin_out); h->pin_out = nullptr; }
     HIP_OK(h, hipHostMalloc((void**)&h->pin_in, in_n * sizeof(float), hipHostMallocDefault));
     HIP_OK(h, hipHostMalloc((void**)&h->pin_out, (size_t)n_envs * h->net.A * sizeof(float), hipHostMallocDefault));
-    if (!h->pin_flag) { HIP_OK(h, hipHostMalloc((void**)&h->pin_flag, 64, hipHostMallocDefault)); memset(h->pin_flag, 0, 64); h->act_seq = 0; }
+    if (!h->pin_flag) { HIP_OK(h, hipHostMalloc((void**)&h->pin_flag, 1024, hipHostMallocDefault)); memset(h->pin_flag, 0, 1024); h->act_seq = 0; }
     h->host_pending = false;
     h->pin_in_n = in_n; h->pin_out_n = (size_t)n_envs * h->net.A;
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -1607,12 +1612,61 @@ static int enqueue_host_step(ppo_handle* h, int t, bool act, const float* noise_
     return 0;
 }
 
+// ---- resident host-Env rollout kernel (see NwRolloutArgs) -----------------------------------------------------------------------
+// control words live at pin_flag + 64 (the first line is the per-launch completion word of narrow_host_step_kernel)
+static unsigned* hp_ctl(ppo_handle* h) { return h->pin_flag + 64; }
+static bool host_resident(const ppo_handle* h) {
+    const char* e = getenv("PPO_HIP_NO_HOST_RESIDENT");
+    return host_fused(h) && !(e && e[0] == '1');
+}
+static int hp_launch(ppo_handle* h, int t0, uint32_t rng_step_t0) {
+    const NetDev& n = h->net;
+    NwRolloutArgs q{};
+    q.img = h->nw_img;
+    q.st = NwEnvState{h->raw_obs, h->obs_rms.mean, h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->cur_done};
+    q.ro_obs = h->ro_obs; q.ro_act = h->ro_act; q.ro_nlp = h->ro_nlp; q.ro_rew = h->ro_rew; q.ro_done = h->ro_done;
+    q.E = h->E; q.T = h->T; q.seed = h->rng_seed; q.step0 = rng_step_t0 - (uint32_t)t0; q.env0 = h->rank * h->E;
+    q.gamma = h->nz_gamma; q.clip_rew = h->nz_clip_rew; q.clip_obs = h->nz_clip_obs; q.eps = h->nz_eps; q.norm_obs = h->norm_obs_flag; q.norm_rew = h->norm_rew_flag;
+    q.host_mode = 1; q.t0 = t0; q.pending = h->host_pending ? 1 : 0;
+    void* din = nullptr; void* dact = nullptr; void* dctl = nullptr;
+    HIP_OK(h, hipHostGetDevicePointer(&din, h->pin_in, 0));
+    HIP_OK(h, hipHostGetDevicePointer(&dact, h->pin_out, 0));
+    HIP_OK(h, hipHostGetDevicePointer(&dctl, hp_ctl(h), 0));
+    q.host_in = (const float*)din; q.host_act = (float*)dact; q.ctl = (unsigned*)dctl;
+    const char* pc = getenv("PPO_HIP_HOST_POLLS");
+    q.poll_cap = pc ? (unsigned)atol(pc) : 150000u;                 // ~2 us per poll over PCIe: a fraction of a second, then the kernel parks itself
+    __atomic_store_n(hp_ctl(h) + PCTL_EXIT, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(hp_ctl(h) + PCTL_STOP, 0u, __ATOMIC_RELEASE);
+    const size_t lds = ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float);
+    if (h->nw_static) hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+    else hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+    HIP_OK(h, hipGetLastError());
+    h->hp_active = true; h->host_pending = false;
+    return 0;
+}
+// the resident kernel has left (or is asked to and waited for): fold its report into the host's bookkeeping
+static int hp_retire(ppo_handle* h, bool ask) {
+    if (!h->hp_active) return 0;
+    unsigned* ctl = hp_ctl(h);
+    if (ask) __atomic_store_n(ctl + PCTL_STOP, 1u, __ATOMIC_RELEASE);
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    const unsigned ex = __atomic_load_n(ctl + PCTL_EXIT, __ATOMIC_ACQUIRE);
+    h->hp_active = false;
+    if (!ex) return fail(h, "host-Env rollout: the resident kernel ended without its exit report");
+    const int booked = (int)ex - 1;
+    h->host_pending = booked < h->hp_posted;                       // a posted transition the kernel did not get to: the next launch books it
+    h->host_pending_t = h->hp_posted - 1;
+    return 0;
+}
+
 int ppo_rollout_reset(ppo_handle* h, const float* raw_obs) {
     if (!h->E) return fail(h, "ppo_rollout_reset: call ppo_rollout_alloc first");
     ENTER(h);
     const size_t on = (size_t)h->E * h->net.O;
+    if (hp_retire(h, true)) return -1;
     if (h->pin_in_busy) HIP_OK(h, hipStreamSynchronize(h->stream));
-    h->pin_in_busy = false; h->host_pending = false;
+    h->pin_in_busy = false; h->host_pending = false; h->hp_posted = 0;
+    if (h->pin_flag) { __atomic_store_n(hp_ctl(h) + PCTL_H2D, 0u, __ATOMIC_RELEASE); __atomic_store_n(hp_ctl(h) + PCTL_D2H, 0u, __ATOMIC_RELEASE); }
     memcpy(h->pin_in, raw_obs, on * sizeof(float));
     HIP_OK(h, hipMemcpyAsync(h->raw_obs, h->pin_in, on * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)h->E * sizeof(float), h->stream));          // env_normalize.hpp:114
@@ -1630,7 +1684,28 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
     const size_t cnt = (size_t)h->E * n.A;
     float* nd = nullptr;
     if (noise) { nd = h->ro_noise; HIP_OK(h, hipMemcpyAsync(nd, noise, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream)); }
+    if (host_resident(h) && !noise) {
+        // the kernel stays resident over the rollout: actions and transitions travel through the pinned blocks, sequence words
+        // order them; (re)launched here when it is not running (first step, or it parked itself after a long host pause)
+        unsigned* ctl = hp_ctl(h);
+        const uint32_t rng_step = h->rng_calls++;
+        if (t == 0) { h->hp_posted = 0; }
+        for (int attempt = 0; ; ++attempt) {
+            if (!h->hp_active) { if (attempt > 3) return fail(h, "ppo_rollout_act: the resident kernel keeps leaving before step %d", t); if (hp_launch(h, t, rng_step)) return -1; }
+            bool have = false;
+            for (;;) {
+                if (__atomic_load_n(ctl + PCTL_D2H, __ATOMIC_ACQUIRE) >= (unsigned)(t + 1)) { have = true; break; }
+                if (__atomic_load_n(ctl + PCTL_EXIT, __ATOMIC_ACQUIRE)) { have = __atomic_load_n(ctl + PCTL_D2H, __ATOMIC_ACQUIRE) >= (unsigned)(t + 1); break; }
+            }
+            if (have) break;
+            if (hp_retire(h, false)) return -1;                     // it parked itself before producing row t: relaunch from here
+        }
+        h->pin_in_busy = false; h->done_staged = -1;
+        memcpy(actions_out, h->pin_out, cnt * sizeof(float));
+        return 0;
+    }
     if (host_fused(h)) {
+        if (hp_retire(h, true)) return -1;
         // <= 32 environments on the narrow path: ONE launch does the pending transition's EnvNormalize bookkeeping (read from the
         // pinned block), the policy tower and the action store into pinned memory; the host spins on the completion word
         if (enqueue_host_step(h, t, true, nd, h->rng_calls++)) return -1;
@@ -1674,7 +1749,11 @@ int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const fl
     memcpy(h->pin_in, raw_obs, on * sizeof(float));
     memcpy(h->pin_in + on, raw_rew, E * sizeof(float));
     memcpy(h->pin_in + on + E, dones, E * sizeof(float));
-    if (host_fused(h)) { h->host_pending = true; h->host_pending_t = t; return 0; }      // the next launch reads the block in place
+    if (host_fused(h)) {                                        // the (next or resident) launch reads the block in place
+        h->host_pending = true; h->host_pending_t = t; h->hp_posted = t + 1;
+        __atomic_store_n(hp_ctl(h) + PCTL_H2D, (unsigned)(t + 1), __ATOMIC_RELEASE);
+        return 0;
+    }
     HIP_OK(h, hipMemcpyAsync(h->env_in, h->pin_in, (on + 2 * E) * sizeof(float), hipMemcpyHostToDevice, h->stream));
     h->pin_in_busy = true;
     if (enqueue_observe(h, t)) return -1;
@@ -1685,6 +1764,12 @@ int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
     ENTER(h);
     if (!h->E) return fail(h, "ppo_rollout_finish: call ppo_rollout_alloc first");
     if (host_fused(h)) {
+        if (h->hp_active) {
+            // after its last row the resident kernel waits for the last transition, books it and leaves by itself; if the host
+            // stopped early it is asked to leave
+            if (hp_retire(h, h->hp_posted < h->T)) return -1;
+        }
+        if (h->pin_flag) { __atomic_store_n(hp_ctl(h) + PCTL_H2D, 0u, __ATOMIC_RELEASE); __atomic_store_n(hp_ctl(h) + PCTL_D2H, 0u, __ATOMIC_RELEASE); }
         if (h->host_pending && enqueue_host_step(h, 0, false, nullptr, 0)) return -1;      // the last transition's bookkeeping
         StepArgs va{};                                                                     // values of all T x E normalised rows, batched
         va.obs = h->ro_obs; va.value = h->ro_val; va.n = h->E * h->T; va.nz = no_norm();

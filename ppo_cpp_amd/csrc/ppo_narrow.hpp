@@ -16,6 +16,7 @@
 #pragma once
 
 #include "ppo_kernels.hpp"
+#include "ppo_peer.hpp"      // system-scope word load / store helpers
 
 #define NW_MAXL 4                  // hidden layers the narrow path accepts
 #define NW_PIPES 2                 // 16-row tiles per workgroup (4 waves each); one pipe per workgroup (256 workgroups at M = 2048) measured
@@ -851,7 +852,19 @@ struct NwRolloutArgs {
     uint32_t seed, step0; int env0;
     float gamma, clip_rew, clip_obs, eps; int norm_obs, norm_rew;
     unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS)
+    // HOST mode (host_mode != 0): the env lives on the host.  The kernel stays resident across env steps: it publishes the actions
+    // of step t into pinned host memory (host_act, then ctl[PCTL_D2H] = t + 1), waits until the host has posted the transition
+    // (ctl[PCTL_H2D] >= t + 1, data in host_in = [E*O obs | E rewards | E dones]) and goes on -- no launch, no copy, no image
+    // reload per env step.  A wait is BOUNDED (poll_cap polls, or the host's stop word): the kernel then saves its state, reports
+    // how many transitions it has booked (ctl[PCTL_EXIT] = 1 + count) and exits; the host relaunches it at its next action
+    // (t0, pending = a posted transition is still unbooked).  step0 is then the counter-RNG step of row t0 minus t0.
+    int host_mode, t0, pending;
+    const float* host_in; float* host_act; unsigned* ctl; unsigned poll_cap;
 };
+#define PCTL_H2D 0
+#define PCTL_D2H 16
+#define PCTL_EXIT 32
+#define PCTL_STOP 48
 #define NW_RO_XS (NW_ROWS * 64)                    // floats of LDS behind the regular layout: raw observations
 #define NW_RO_EXTRA (NW_RO_XS + 64 + 64 + 3 * NW_ROWS + 8 + 64 + 16 * 64)
 
@@ -900,7 +913,59 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
 #else
 #define RSTAMP(i) do { } while (0)
 #endif
-    for (int t = 0; t < q.T; ++t) {
+    int* s_ok = reinterpret_cast<int*>(s_retstat + 4);
+    // host transition -> xs / rs (zero-copy reads of the pinned block)
+    auto read_host = [&]() __attribute__((always_inline)) {
+        for (int i = tid; i < E * O; i += NW_THREADS) xs[i] = q.host_in[i];
+        if (tid < E) { rs[tid] = q.host_in[(size_t)E * O + tid]; rs[NW_ROWS + tid] = q.host_in[(size_t)E * O + E + tid]; }
+    };
+    // EnvNormalize::step bookkeeping of the transition in xs / rs (env_normalize.hpp:64-116, running_statistics.hpp:26-104); rewards -> row tr
+    auto bookkeeping = [&](int tr) __attribute__((always_inline)) {
+        if (tid < O) {
+            if (q.norm_obs) {
+                float sum = 0.f;
+                for (int e = 0; e < E; ++e) sum += xs[e * O + tid];
+                const float bmean = sum / (float)E;                                    // colwise().mean()
+                float m2 = 0.f;
+                for (int e = 0; e < E; ++e) { const float d = xs[e * O + tid] - bmean; m2 += d * d; }
+                float m1, v1;
+                merge(s_mean[tid], s_var[tid], obs_cnt, bmean, m2, (float)E, m1, v1);
+                s_mean[tid] = m1; s_var[tid] = v1; s_istd[tid] = 1.0f / sqrtf(v1 + q.eps);
+                obs_cnt = (double)(float)E + obs_cnt;                                   // :103
+            }
+        }
+        if (tid == 64) {                                        // (a different wave than the observation columns)
+            float* ret = rs + 2 * NW_ROWS;
+            float sum = 0.f;
+            for (int e = 0; e < E; ++e) { ret[e] = ret[e] * q.gamma + rs[e]; sum += ret[e]; }            // env_normalize.hpp:66
+            float m1 = s_retstat[0], v1 = s_retstat[1];
+            if (q.norm_rew) {                                                                              // :75-77 (training)
+                const float bmean = sum / (float)E;
+                float m2 = 0.f;
+                for (int e = 0; e < E; ++e) { const float d = ret[e] - bmean; m2 += d * d; }
+                merge(s_retstat[0], s_retstat[1], ret_cnt, bmean, m2, (float)E, m1, v1);
+                ret_cnt = (double)(float)E + ret_cnt;
+            }
+            s_retstat[0] = m1; s_retstat[1] = v1;
+            const float inv = 1.0f / sqrtf(v1 + q.eps);                                                    // :79
+            for (int e = 0; e < E; ++e) {
+                float y = rs[e];
+                if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
+                q.ro_rew[(size_t)tr * E + e] = y;
+                ret[e] = ret[e] * (1.0f - rs[NW_ROWS + e]);                                                // :88-91
+            }
+        }
+    };
+    int booked = q.t0;                                          // transitions whose bookkeeping is done (host mode's exit report)
+    if (q.host_mode && q.pending) {                             // a transition posted before this launch: rewards row t0 - 1
+        booked = q.t0 - 1;
+        read_host();
+        lds_barrier();
+        bookkeeping(q.t0 - 1);
+        lds_barrier();
+        booked = q.t0;
+    }
+    for (int t = q.t0; t < q.T; ++t) {
         RSTAMP(0);
         // explicit noise of this step: requested now, consumed after the forward pass
         float nz_eps[4] = {0.f, 0.f, 0.f, 0.f};
@@ -975,58 +1040,44 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
                 const float act = mu + sigma * eps;
                 const float z = (act - mu) / sigma;
                 ssq += z * z; slog += logstd;
-                if (row < E) q.ro_act[((size_t)t * E + row) * A + j] = act;
+                if (row < E) { q.ro_act[((size_t)t * E + row) * A + j] = act; if (q.host_mode) q.host_act[(size_t)row * A + j] = act; }
             }
             ssq = group16_sum(ssq); slog = group16_sum(slog);
             if (part == 0 && row < E) q.ro_nlp[(size_t)t * E + row] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
         }
         RSTAMP(7);
-        // ---- env transition (counter hash) -> new raw observations, rewards, dones -------------------------------------------
-        const uint32_t env_step = q.step0 + (uint32_t)t + 1u;
-        for (int i = tid; i < E * (O + 2); i += NW_THREADS) {
-            const int e = i / (O + 2), j = i - e * (O + 2);
-            const uint32_t hsh = ctr_hash(q.seed, (uint32_t)(q.env0 + e), env_step, (uint32_t)j);
-            if (j < O) xs[e * O + j] = u32_to_sym_unit(hsh);
-            else if (j == O) rs[e] = u32_to_sym_unit(hsh);
-            else rs[NW_ROWS + e] = (hsh % 300u == 0u) ? 1.0f : 0.0f;
+        if (q.host_mode) {
+            // ---- publish the actions, wait for the host's transition ---------------------------------------------------------------
+            __threadfence_system();                             // every thread's stores into host_act have landed
+            __syncthreads();
+            if (tid == 0) {
+                peer_st_sys(q.ctl + PCTL_D2H, (unsigned)(t + 1));
+                unsigned n = 0; int ok = 1;
+                while (peer_ld_sys(q.ctl + PCTL_H2D) < (unsigned)(t + 1)) {
+                    if (++n > q.poll_cap || peer_ld_sys(q.ctl + PCTL_STOP)) { ok = 0; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                *s_ok = ok;
+            }
+            __syncthreads();
+            if (!*s_ok) break;                                  // bounded wait over (or stop requested): save the state and leave
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);            // system scope: the transition's bytes are read after its sequence word
+            read_host();
+        } else {
+            // ---- env transition (counter hash) -> new raw observations, rewards, dones -------------------------------------------
+            const uint32_t env_step = q.step0 + (uint32_t)t + 1u;
+            for (int i = tid; i < E * (O + 2); i += NW_THREADS) {
+                const int e = i / (O + 2), j = i - e * (O + 2);
+                const uint32_t hsh = ctr_hash(q.seed, (uint32_t)(q.env0 + e), env_step, (uint32_t)j);
+                if (j < O) xs[e * O + j] = u32_to_sym_unit(hsh);
+                else if (j == O) rs[e] = u32_to_sym_unit(hsh);
+                else rs[NW_ROWS + e] = (hsh % 300u == 0u) ? 1.0f : 0.0f;
+            }
         }
         lds_barrier();
         RSTAMP(8);
-        // ---- EnvNormalize::step bookkeeping (env_normalize.hpp:64-116, running_statistics.hpp:26-104) --------------------------
-        if (tid < O) {
-            if (q.norm_obs) {
-                float sum = 0.f;
-                for (int e = 0; e < E; ++e) sum += xs[e * O + tid];
-                const float bmean = sum / (float)E;                                    // colwise().mean()
-                float m2 = 0.f;
-                for (int e = 0; e < E; ++e) { const float d = xs[e * O + tid] - bmean; m2 += d * d; }
-                float m1, v1;
-                merge(s_mean[tid], s_var[tid], obs_cnt, bmean, m2, (float)E, m1, v1);
-                s_mean[tid] = m1; s_var[tid] = v1; s_istd[tid] = 1.0f / sqrtf(v1 + q.eps);
-                obs_cnt = (double)(float)E + obs_cnt;                                   // :103
-            }
-        }
-        if (tid == 64) {                                        // (a different wave than the observation columns)
-            float* ret = rs + 2 * NW_ROWS;
-            float sum = 0.f;
-            for (int e = 0; e < E; ++e) { ret[e] = ret[e] * q.gamma + rs[e]; sum += ret[e]; }            // env_normalize.hpp:66
-            float m1 = s_retstat[0], v1 = s_retstat[1];
-            if (q.norm_rew) {                                                                              // :75-77 (training)
-                const float bmean = sum / (float)E;
-                float m2 = 0.f;
-                for (int e = 0; e < E; ++e) { const float d = ret[e] - bmean; m2 += d * d; }
-                merge(s_retstat[0], s_retstat[1], ret_cnt, bmean, m2, (float)E, m1, v1);
-                ret_cnt = (double)(float)E + ret_cnt;
-            }
-            s_retstat[0] = m1; s_retstat[1] = v1;
-            const float inv = 1.0f / sqrtf(v1 + q.eps);                                                    // :79
-            for (int e = 0; e < E; ++e) {
-                float y = rs[e];
-                if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
-                q.ro_rew[(size_t)t * E + e] = y;
-                ret[e] = ret[e] * (1.0f - rs[NW_ROWS + e]);                                                // :88-91
-            }
-        }
+        bookkeeping(t);
+        booked = t + 1;
         RSTAMP(9);
         lds_barrier();
         RSTAMP(10);
@@ -1037,6 +1088,11 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     if (tid < E) { q.st.done[tid] = rs[NW_ROWS + tid]; q.st.ret[tid] = rs[2 * NW_ROWS + tid]; }
     if (tid == 0) *q.st.obs_count = obs_cnt;
     if (tid == 64) { *q.st.ret_mean = s_retstat[0]; *q.st.ret_var = s_retstat[1]; *q.st.ret_count = ret_cnt; }
+    if (q.host_mode) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) peer_st_sys(q.ctl + PCTL_EXIT, 1u + (unsigned)booked);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

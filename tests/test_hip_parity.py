@@ -195,6 +195,48 @@ def test_host_env_rollout_api_matches_device_env_path():
         close(g.rollout_get(f), ro[f], rtol=2e-4, atol=2e-5, msg=f)
 
 
+@pytest.mark.parametrize("hidden,E,T", [((64, 64), 1, 40), ((64, 64), 5, 12), ((64, 64), 32, 7), ((4, 5), 1, 30), ((16, 8, 8), 3, 9)])
+def test_host_env_small_batches_three_forms_agree(hidden, E, T, monkeypatch):
+    """Env on the host, <= 32 environments (the reference's own setting is ONE): (a) the resident kernel that serves the whole
+    rollout from one launch, talking to the host through sequence words in pinned memory, (b) one fused launch per env step,
+    (c) the general path (copy, statistics kernel, both towers, copy back).  (a) and (b) run the same statements: every rollout
+    field and the statistics must be bit-identical, over two rollouts (state carried over); (c) agrees to rounding.  A host that
+    pauses longer than the kernel is willing to poll makes it park itself and be relaunched mid-rollout: same bits."""
+    import time
+    rng = np.random.RandomState(7)
+    trans = [(rng.uniform(-1, 1, (E, 18)).astype(np.float32), rng.uniform(-1, 1, E).astype(np.float32), (rng.uniform(size=E) < 0.1).astype(np.float32))
+             for _ in range(2 * T + 1)]
+    outs = {}
+    for form in ("resident", "resident_parking", "fused", "general"):
+        monkeypatch.setenv("PPO_HIP_NO_HOST_RESIDENT", "0" if form.startswith("resident") else "1")
+        monkeypatch.setenv("PPO_HIP_NO_HOST_FUSED", "1" if form == "general" else "0")
+        monkeypatch.setenv("PPO_HIP_HOST_POLLS", "300" if form == "resident_parking" else "150000")
+        orc, g = pair(hidden)
+        g.norm_init(E); g.rollout_alloc(E, T); g.seed(99)
+        got = {}
+        g.rollout_reset(trans[0][0])
+        k = 1
+        for it in range(2):
+            for t in range(T):
+                got["act%d_%d" % (it, t)] = g.rollout_act(t, None)
+                if form == "resident_parking" and t % 3 == 1:
+                    time.sleep(0.02)                                   # longer than 300 polls: the kernel parks, the next act relaunches it
+                g.rollout_observe(t, *trans[k]); k += 1
+            g.rollout_finish(GAMMA, LAM)
+            for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones"):
+                got["%s%d" % (f, it)] = g.rollout_get(f)
+            for which, nm in ((0, "obs"), (1, "ret")):
+                m, v, c = g.norm_stats(which)
+                got["%s_mean%d" % (nm, it)], got["%s_var%d" % (nm, it)], got["%s_cnt%d" % (nm, it)] = m, v, np.float64(c)
+        outs[form] = got
+        g.close()
+    assert np.abs(outs["fused"]["actions1"]).max() > 0
+    for key in outs["fused"]:
+        np.testing.assert_array_equal(outs["resident"][key], outs["fused"][key], err_msg="resident vs fused: " + key)
+        np.testing.assert_array_equal(outs["resident_parking"][key], outs["fused"][key], err_msg="parking vs fused: " + key)
+        close(outs["general"][key], outs["fused"][key], rtol=2e-4, atol=2e-5, msg="general vs fused: " + key)
+
+
 @pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((4, 5), 1, 256, 4, 2), ((64, 64), 16, 16, 4, 3), ((256, 256), 64, 16, 4, 2),
                                                    ((64, 64), 3, 100, 4, 2)])        # M = 75 rows: ragged minibatches
 def test_update_phase_matches_oracle(hidden, E, T, nmb, epochs):
