@@ -801,7 +801,8 @@ int enqueue_allreduce(ppo_handle* h, float* buf, size_t count, float* sumsq = nu
         if (count > 32768) {
             const unsigned grid = (unsigned)((count + 4095) / 4096);
             hipLaunchKernelGGL(peer_push_kernel<4>, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, (const float*)buf, (unsigned long long)count);
-            hipLaunchKernelGGL(peer_sum_kernel<4>, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, buf, (unsigned long long)count, sumsq, (unsigned)sumsq_chunks);
+            // (the sum wants parallelism, not few fences: 4096-float pieces took 9.9 us here)
+            hipLaunchKernelGGL(peer_sum_kernel<1>, dim3((unsigned)((count + 1023) / 1024)), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, buf, (unsigned long long)count, sumsq, (unsigned)sumsq_chunks);
         } else {
             const unsigned grid = (unsigned)((count + 1023) / 1024);
             hipLaunchKernelGGL(peer_push_kernel<1>, dim3(grid), dim3(PEER_THREADS), 0, h->stream, h->peer.dev, (const float*)buf, (unsigned long long)count);

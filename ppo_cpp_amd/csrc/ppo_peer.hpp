@@ -73,10 +73,13 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_push_kernel(PeerDev p, cons
             if (i0 < count) *reinterpret_cast<float4*>(dst + i0) = v[q];
         }
     }
-    __threadfence_system();                                     // my writes have landed (system scope release)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                // system-scope RELEASE only (write-back + wait): __threadfence_system() would also invalidate the L2
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // relaxed: every workgroup's slot writes were written back and waited for by the release fence above, BEFORE its
+        // arrival; the last arriver reads nothing of theirs, it only must not raise the flags earlier (an acq_rel atomic here
+        // would be one more L2 write-back + invalidate per workgroup)
+        const unsigned old = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (old == gridDim.x - 1) ? 1u : 0u;
     }
     __syncthreads();
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_push_kernel(PeerDev p, cons
             peer_st_sys(p.flags[threadIdx.x] + ((size_t)par * PEER_MAX_WORLD + p.rank) * PEER_FLAG_STRIDE, s);
         if (threadIdx.x == 0) {
             __hip_atomic_store(p.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.seq, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.seq, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read by the NEXT kernel (sum): the kernel boundary orders it
         }
     }
 }
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_sum_kernel(PeerDev p, float
     constexpr int PEER_CHUNK = 1024 * PEER_V;
     __shared__ unsigned s_seq;
     __shared__ float s_part[PEER_CHUNK / 256][PEER_THREADS / 64];
-    if (threadIdx.x == 0) s_seq = __hip_atomic_load(p.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const unsigned s = s_seq, par = s & 1u;
     if (threadIdx.x < (unsigned)p.world) {
@@ -113,7 +116,8 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_sum_kernel(PeerDev p, float
         }
     }
     __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);                    // system scope: nothing below is served from a stale cache line
+    // The slots are read with SYSTEM-scope loads (sc0 sc1: served by memory, never by a stale cache line), issued after the
+    // flags were seen.  An acquire fence instead would invalidate the whole L2 once per workgroup (590 of them at 0.6 MB).
     const float* mine = p.slots[p.rank] + (unsigned long long)par * p.world * p.cap;
     // every load of the workgroup is issued before the first addition (one round trip, not one per rank); the additions run
     // in rank order, skipped -- not fed with zeros -- for ranks that do not exist (-0 + 0 would flip a sign bit)
@@ -122,7 +126,8 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_sum_kernel(PeerDev p, float
     for (int k = 0; k < PEER_CHUNK / 256; ++k) {
         const unsigned long long i = (unsigned long long)blockIdx.x * PEER_CHUNK + 256 * k + threadIdx.x;
 #pragma unroll
-        for (int r = 0; r < PEER_MAX_WORLD; ++r) v[k][r] = (r < p.world && i < count) ? mine[(unsigned long long)r * p.cap + i] : 0.f;
+        for (int r = 0; r < PEER_MAX_WORLD; ++r)
+            v[k][r] = (r < p.world && i < count) ? __hip_atomic_load(mine + (unsigned long long)r * p.cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
     }
     float acc[PEER_CHUNK / 256];
 #pragma unroll
