@@ -2019,13 +2019,15 @@ __global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a)
     }
     // last-block-done, one counter per job: release our partials, count, and let the final arrival acquire everyone's.
     // The two jobs finish independently (two workgroups run the two tails side by side).
-    __threadfence();
+    // (release only before the arrival, acquire only in the last arriver: __threadfence() is both -- a write-back AND an
+    // invalidate of the whole L2 -- in every workgroup)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     const unsigned total = which == 0 ? (unsigned)a.g_obs : (unsigned)a.g_rew;
-    if (tid == 0) is_last = (atomicAdd(a.counter + which, 1u) == total - 1u) ? 1 : 0;
+    if (tid == 0) is_last = (__hip_atomic_fetch_add(a.counter + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) ? 1 : 0;
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     float* publish = a.xch ? a.xch + (size_t)a.rank * (so + 3) + (which ? so : 0) : nullptr;
     if (which == 0) norm_finish(a, 0, a.part, a.g_obs, so, publish, sh);
     else norm_finish(a, 1, part_rew, a.g_rew, 3, publish, sh);
