@@ -128,6 +128,7 @@ struct ppo_handle {
     bool host_pending = false; int host_pending_t = 0;   // a transition sits in pin_in, its bookkeeping rides in the next launch
     // ... and the RESIDENT form (narrow_rollout_kernel in host mode): one launch serves many env steps, host and kernel talk
     // through sequence words in pinned memory (pin_flag[PCTL_*])
+    bool host_proto = false;          // the last ppo_rollout_act used the resident / fused form: observe only posts the transition
     bool hp_active = false;           // a resident kernel may be running
     int hp_posted = 0;                // transitions posted in this rollout
     bool pin_in_busy = false;         // an H2D copy out of pin_in may still be in flight (cleared by every stream synchronisation of the rollout calls)
@@ -1576,14 +1577,18 @@ static int enqueue_finish(ppo_handle* h, float gamma, float lam) {
     return 0;
 }
 
-// fused host-Env step available for this handle / rollout shape?
-static bool host_fused(const ppo_handle* h) {
+// Small host-Env rollouts (narrow path, one rank): up to NW_RO_MAX_E environments are served by the resident kernel
+// (narrow_rollout_kernel in host mode), up to NW_ROWS also by one fused launch per env step (narrow_host_step_kernel).  While
+// either is in use ("protocol" mode) ppo_rollout_observe only fills the pinned block: the transition is booked by the next
+// launch / the resident kernel.
+static bool host_small(const ppo_handle* h) {
     const char* e = getenv("PPO_HIP_NO_HOST_FUSED");
     if (e && e[0] == '1') return false;
     const NetDev& n = h->net;
-    return h->narrow && !h->comm && !h->bf.on && h->E <= NW_ROWS && n.O <= 64 && n.A <= 64 && h->pin_flag &&
-           ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float) <= 160 * 1024;
+    return h->narrow && !h->comm && !h->bf.on && h->E <= NW_RO_MAX_E && n.O <= 64 && n.A <= 64 && h->pin_flag &&
+           ((size_t)h->nw.lds_total + std::max(nw_ro_extra(h->E, n.O), NW_RO_EXTRA)) * sizeof(float) <= 160 * 1024;
 }
+static bool host_fused(const ppo_handle* h) { return host_small(h) && h->E <= NW_ROWS; }
 
 // one launch of narrow_host_step_kernel: the pending transition's bookkeeping (if any) and, with act, the policy step of row t
 static int enqueue_host_step(ppo_handle* h, int t, bool act, const float* noise_dev, uint32_t rng_step) {
@@ -1618,7 +1623,7 @@ static int enqueue_host_step(ppo_handle* h, int t, bool act, const float* noise_
 static unsigned* hp_ctl(ppo_handle* h) { return h->pin_flag + 64; }
 static bool host_resident(const ppo_handle* h) {
     const char* e = getenv("PPO_HIP_NO_HOST_RESIDENT");
-    return host_fused(h) && !(e && e[0] == '1');
+    return host_small(h) && !(e && e[0] == '1');
 }
 static int hp_launch(ppo_handle* h, int t0, uint32_t rng_step_t0) {
     const NetDev& n = h->net;
@@ -1638,7 +1643,7 @@ static int hp_launch(ppo_handle* h, int t0, uint32_t rng_step_t0) {
     q.poll_cap = pc ? (unsigned)atol(pc) : 150000u;                 // ~2 us per poll over PCIe: a fraction of a second, then the kernel parks itself
     __atomic_store_n(hp_ctl(h) + PCTL_EXIT, 0u, __ATOMIC_RELEASE);
     __atomic_store_n(hp_ctl(h) + PCTL_STOP, 0u, __ATOMIC_RELEASE);
-    const size_t lds = ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float);
+    const size_t lds = ((size_t)h->nw.lds_total + nw_ro_extra(h->E, n.O)) * sizeof(float);
     if (h->nw_static) hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
     else hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
     HIP_OK(h, hipGetLastError());
@@ -1658,6 +1663,17 @@ static int hp_retire(ppo_handle* h, bool ask) {
     h->host_pending = booked < h->hp_posted;                       // a posted transition the kernel did not get to: the next launch books it
     h->host_pending_t = h->hp_posted - 1;
     return 0;
+}
+
+// a posted transition that no kernel has booked yet, booked now (outside the resident kernel)
+static int host_flush_pending(ppo_handle* h) {
+    if (!h->host_pending) return 0;
+    if (h->E <= NW_ROWS) return enqueue_host_step(h, 0, false, nullptr, 0);
+    const size_t E = h->E, on = E * h->net.O;                       // more than one row group: the general path's copy + statistics kernel
+    HIP_OK(h, hipMemcpyAsync(h->env_in, h->pin_in, (on + 2 * E) * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->pin_in_busy = true;
+    h->host_pending = false;
+    return enqueue_observe(h, h->host_pending_t);
 }
 
 int ppo_rollout_reset(ppo_handle* h, const float* raw_obs) {
@@ -1701,12 +1717,13 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
             if (have) break;
             if (hp_retire(h, false)) return -1;                     // it parked itself before producing row t: relaunch from here
         }
-        h->pin_in_busy = false; h->done_staged = -1;
+        h->pin_in_busy = false; h->done_staged = -1; h->host_proto = true;
         memcpy(actions_out, h->pin_out, cnt * sizeof(float));
         return 0;
     }
+    if (host_small(h)) { if (hp_retire(h, true)) return -1; if (!host_fused(h) && host_flush_pending(h)) return -1; }
+    h->host_proto = host_fused(h);
     if (host_fused(h)) {
-        if (hp_retire(h, true)) return -1;
         // <= 32 environments on the narrow path: ONE launch does the pending transition's EnvNormalize bookkeeping (read from the
         // pinned block), the policy tower and the action store into pinned memory; the host spins on the completion word
         if (enqueue_host_step(h, t, true, nd, h->rng_calls++)) return -1;
@@ -1750,7 +1767,7 @@ int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const fl
     memcpy(h->pin_in, raw_obs, on * sizeof(float));
     memcpy(h->pin_in + on, raw_rew, E * sizeof(float));
     memcpy(h->pin_in + on + E, dones, E * sizeof(float));
-    if (host_fused(h)) {                                        // the (next or resident) launch reads the block in place
+    if (host_small(h) && h->host_proto) {                       // the (next or resident) launch reads the block in place
         h->host_pending = true; h->host_pending_t = t; h->hp_posted = t + 1;
         __atomic_store_n(hp_ctl(h) + PCTL_H2D, (unsigned)(t + 1), __ATOMIC_RELEASE);
         return 0;
@@ -1764,14 +1781,14 @@ int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const fl
 int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
     ENTER(h);
     if (!h->E) return fail(h, "ppo_rollout_finish: call ppo_rollout_alloc first");
-    if (host_fused(h)) {
+    if (host_small(h)) {
         if (h->hp_active) {
             // after its last row the resident kernel waits for the last transition, books it and leaves by itself; if the host
             // stopped early it is asked to leave
             if (hp_retire(h, h->hp_posted < h->T)) return -1;
         }
         if (h->pin_flag) { __atomic_store_n(hp_ctl(h) + PCTL_H2D, 0u, __ATOMIC_RELEASE); __atomic_store_n(hp_ctl(h) + PCTL_D2H, 0u, __ATOMIC_RELEASE); }
-        if (h->host_pending && enqueue_host_step(h, 0, false, nullptr, 0)) return -1;      // the last transition's bookkeeping
+        if (host_flush_pending(h)) return -1;                                              // the last transition's bookkeeping
         StepArgs va{};                                                                     // values of all T x E normalised rows, batched
         va.obs = h->ro_obs; va.value = h->ro_val; va.n = h->E * h->T; va.nz = no_norm();
         if (launch_step(h, va)) return -1;
@@ -1805,8 +1822,9 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
     // only stores leave the CU; the value tower runs afterwards, batched over the T x E normalised rows
     const char* npe = getenv("PPO_HIP_NO_PERSISTENT_COLLECT");
     const bool no_persist = npe && npe[0] == '1';
-    const size_t ro_lds = ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float);
-    const bool persistent = fused && !no_persist && ro_lds <= 160 * 1024 && n.A <= 64;
+    // (up to NW_RO_MAX_E environments: the one workgroup walks them in groups of 32 rows)
+    const size_t ro_lds = ((size_t)h->nw.lds_total + nw_ro_extra(E, n.O)) * sizeof(float);
+    const bool persistent = h->narrow && !h->comm && !no_fused && !no_persist && E <= NW_RO_MAX_E && n.O <= 64 && n.A <= 64 && ro_lds <= 160 * 1024;
     if (persistent) {
         NwRolloutArgs q{};
         q.img = h->nw_img;
@@ -1869,7 +1887,7 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
         }
         h->done_staged = -1;
     }
-    for (int t = 0; t < T && !fused; ++t) {
+    for (int t = 0; t < T && !fused && !persistent; ++t) {
         if (enqueue_rollout_act(h, t, noise ? h->ro_noise + (size_t)t * E * n.A : nullptr, seed, step0 + t, (uint32_t)env0)) return -1;
         { ProfScope ps(h, PK_ENV);
           hipLaunchKernelGGL(seeded_env_kernel, dim3((envW + 255) / 256), dim3(256), 0, h->stream, seed, env0, E, step0 + (uint32_t)t + 1u, n.O, h->raw_obs, h->raw_rew, h->cur_done);

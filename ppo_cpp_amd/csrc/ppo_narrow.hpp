@@ -865,8 +865,13 @@ struct NwRolloutArgs {
 #define PCTL_D2H 16
 #define PCTL_EXIT 32
 #define PCTL_STOP 48
-#define NW_RO_XS (NW_ROWS * 64)                    // floats of LDS behind the regular layout: raw observations
+#define NW_RO_XS (NW_ROWS * 64)                    // (narrow_host_step_kernel, <= 32 environments) raw observations
 #define NW_RO_EXTRA (NW_RO_XS + 64 + 64 + 3 * NW_ROWS + 8 + 64 + 16 * 64)
+#define NW_RO_MAX_E 64                             // environments ONE resident workgroup serves: groups of 32 rows, one after the other.
+                                                   // Measured behind a host Env (us per env step, resident | general path): 1 env 18 | 37,
+                                                   // 32: 25 | 38, 64: 35 | 38, 128: 50 | 39, 256: 82 | 49 -- beyond two groups the whole GPU wins
+// floats of LDS behind the regular layout for E environments of O observations (E rounded up to whole row groups)
+__host__ __device__ inline int nw_ro_extra(int E, int O) { const int Er = (E + NW_ROWS - 1) / NW_ROWS * NW_ROWS; return Er * O + 64 + 64 + 3 * Er + 8 + 64 + 16 * 64; }
 
 template <int KP0, int HP, int AP, int LL>
 __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
@@ -876,10 +881,11 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
     const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
     const int E = q.E, O = net.O, A = net.A;
+    const int ES = (E + NW_ROWS - 1) / NW_ROWS * NW_ROWS;   // environments rounded up to whole row groups: stride of the per-environment vectors
     float* xs = lds + lay.lds_total;                        // [E][O] raw observations of the current state
-    float* s_mean = xs + NW_RO_XS; float* s_var = s_mean + 64;
-    float* rs = s_var + 64;                                 // [32] rewards | [32] dones | [32] returns
-    float* s_retstat = rs + 3 * NW_ROWS;                    // ret_rms mean, var
+    float* s_mean = xs + ES * O; float* s_var = s_mean + 64;
+    float* rs = s_var + 64;                                 // [ES] rewards | [ES] dones | [ES] returns
+    float* s_retstat = rs + 3 * ES;                         // ret_rms mean, var
     float* s_istd = s_retstat + 8;                          // 1 / sqrt(var + eps) per column: the expression of the per-step kernels, evaluated once per statistics update
     // ---- entry: image + state, one round trip ----------------------------------------------------------------------------
     {
@@ -887,7 +893,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
         for (int e = tid; e < n4; e += NW_THREADS) reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(q.img)[e];
         for (int i = tid; i < E * O; i += NW_THREADS) xs[i] = q.st.raw_obs[i];
         if (tid < O) { s_mean[tid] = q.st.obs_mean[tid]; const float v0 = q.st.obs_var[tid]; s_var[tid] = v0; s_istd[tid] = 1.0f / sqrtf(v0 + q.eps); }
-        if (tid < E) { rs[NW_ROWS + tid] = q.st.done[tid]; rs[2 * NW_ROWS + tid] = q.st.ret[tid]; }
+        if (tid < E) { rs[ES + tid] = q.st.done[tid]; rs[2 * ES + tid] = q.st.ret[tid]; }
         if (tid == 0) { s_retstat[0] = *q.st.ret_mean; s_retstat[1] = *q.st.ret_var; }
     }
     double obs_cnt = *q.st.obs_count, ret_cnt = *q.st.ret_count;          // replicated: every thread that merges holds the count
@@ -896,7 +902,6 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     const float* par = lds + lay.par;
     const int r = ptid >> 4, part = ptid & 15;
     const int row = 16 * pipe + r;
-    const bool live_pipe = 16 * pipe < E;
     const bool have_helper = NW_PIPES == 2 && E <= 16, helper = have_helper && pipe == 1;
     float* s_eps = s_istd + 64;                             // [16][A] counter-RNG draws of the current step (written by the helper pipe)                   // a pipe without environments skips the matrix work (it shares the SIMDs' matrix pipes with the live one)
     auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     // host transition -> xs / rs (zero-copy reads of the pinned block)
     auto read_host = [&]() __attribute__((always_inline)) {
         for (int i = tid; i < E * O; i += NW_THREADS) xs[i] = q.host_in[i];
-        if (tid < E) { rs[tid] = q.host_in[(size_t)E * O + tid]; rs[NW_ROWS + tid] = q.host_in[(size_t)E * O + E + tid]; }
+        if (tid < E) { rs[tid] = q.host_in[(size_t)E * O + tid]; rs[ES + tid] = q.host_in[(size_t)E * O + E + tid]; }
     };
     // EnvNormalize::step bookkeeping of the transition in xs / rs (env_normalize.hpp:64-116, running_statistics.hpp:26-104); rewards -> row tr
     auto bookkeeping = [&](int tr) __attribute__((always_inline)) {
@@ -935,7 +940,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
             }
         }
         if (tid == 64) {                                        // (a different wave than the observation columns)
-            float* ret = rs + 2 * NW_ROWS;
+            float* ret = rs + 2 * ES;
             float sum = 0.f;
             for (int e = 0; e < E; ++e) { ret[e] = ret[e] * q.gamma + rs[e]; sum += ret[e]; }            // env_normalize.hpp:66
             float m1 = s_retstat[0], v1 = s_retstat[1];
@@ -952,7 +957,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
                 float y = rs[e];
                 if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
                 q.ro_rew[(size_t)tr * E + e] = y;
-                ret[e] = ret[e] * (1.0f - rs[NW_ROWS + e]);                                                // :88-91
+                ret[e] = ret[e] * (1.0f - rs[ES + e]);                                                // :88-91
             }
         }
     };
@@ -967,83 +972,88 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     }
     for (int t = q.t0; t < q.T; ++t) {
         RSTAMP(0);
-        // explicit noise of this step: requested now, consumed after the forward pass
-        float nz_eps[4] = {0.f, 0.f, 0.f, 0.f};
-        if (q.noise) {
-            if (row < E) {
+        if (tid < E) q.ro_done[(size_t)t * E + tid] = rs[ES + tid];                  // the flags that arrived with obs_t
+        // the environments go through the two 16-row pipes in groups of 32 (one group at <= 32 environments)
+        for (int g0 = 0; g0 < E; g0 += NW_ROWS) {
+            const int grow = g0 + row;                          // this thread's environment in the sampling phase
+            const bool live_pipe = g0 + 16 * pipe < E;          // a pipe without environments skips the matrix work (it shares the SIMDs' matrix pipes with the live one)
+            // explicit noise of this step: requested now, consumed after the forward pass
+            float nz_eps[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q.noise) {
+                if (grow < E) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) nz_eps[k] = q.noise[((size_t)t * E + row) * A + j]; }
-            }
-        } else if (helper) {
-            // counter RNG (two 64-bit hashes, log, cos, sqrt per draw): with <= 16 environments the second pipe has no rows and
-            // draws the first pipe's noise into LDS while that one runs the forward pass
-            if (r < E) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) s_eps[r * A + j] = ctr_normal(q.seed, (uint32_t)q.env0 + r, q.step0 + (uint32_t)t, j); }
-            }
-        } else if (!have_helper && row < E) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) nz_eps[k] = ctr_normal(q.seed, (uint32_t)q.env0 + row, q.step0 + (uint32_t)t, j); }
-        }
-        // ---- normalise the current observations (env_normalize.hpp:99-104) -> input tile + rollout row t --------------------
-        for (int i = tid; i < NW_ROWS * Kp0; i += NW_THREADS) {
-            const int rr = i / Kp0, j = i - rr * Kp0;
-            float x = 0.f;
-            if (rr < E && j < O) {
-                x = xs[rr * O + j];
-                if (q.norm_obs) {
-                    x = (x - s_mean[j]) * s_istd[j];
-                    x = tf_min(tf_max(x, -q.clip_obs), q.clip_obs);
+                    for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) nz_eps[k] = q.noise[((size_t)t * E + grow) * A + j]; }
                 }
-                q.ro_obs[((size_t)t * E + rr) * O + j] = x;
-            }
-            lds[lay.w_total + (rr >> 4) * lay.pipe_total + lay.x[0] + (rr & 15) * lay.ldx[0] + j] = x;
-        }
-        if (tid < E) q.ro_done[(size_t)t * E + tid] = rs[NW_ROWS + tid];            // the flags that arrived with obs_t
-        lds_barrier();
-        RSTAMP(1);
-        // ---- forward + head (narrow_step_kernel's code) ---------------------------------------------------------------------
-        for (int l = 0; l < L; ++l) {
-            const float* bias = par + net.par_b[l];
-            float* Ys = P + lay.x[l + 1]; const int ldy = lay.ldx[l + 1];
-            auto ep = [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
-                const float b = bias[col];
+            } else if (helper) {
+                // counter RNG (two 64-bit hashes, log, cos, sqrt per draw): with <= 16 environments the second pipe has no rows and
+                // draws the first pipe's noise into LDS while that one runs the forward pass
+                if (r < E) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) Ys[(4 * g + rr) * ldy + col] = fast_tanh(acc[rr] + b);
-            };
-            if (live_pipe) {
-                if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
-                else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+                    for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) s_eps[r * A + j] = ctr_normal(q.seed, (uint32_t)q.env0 + r, q.step0 + (uint32_t)t, j); }
+                }
+            } else if (!have_helper && grow < E) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int j = part + 16 * k; if (j < A) nz_eps[k] = ctr_normal(q.seed, (uint32_t)q.env0 + grow, q.step0 + (uint32_t)t, j); }
+            }
+            // ---- normalise the group's observations (env_normalize.hpp:99-104) -> input tiles + rollout row t ----------------
+            for (int i = tid; i < NW_ROWS * Kp0; i += NW_THREADS) {
+                const int rr = i / Kp0, j = i - rr * Kp0, ge = g0 + rr;
+                float x = 0.f;
+                if (ge < E && j < O) {
+                    x = xs[ge * O + j];
+                    if (q.norm_obs) {
+                        x = (x - s_mean[j]) * s_istd[j];
+                        x = tf_min(tf_max(x, -q.clip_obs), q.clip_obs);
+                    }
+                    q.ro_obs[((size_t)t * E + ge) * O + j] = x;
+                }
+                lds[lay.w_total + (rr >> 4) * lay.pipe_total + lay.x[0] + (rr & 15) * lay.ldx[0] + j] = x;
             }
             lds_barrier();
-            RSTAMP(2 + l);
-        }
-        const float* hL = P + lay.x[L]; const int ldh = lay.ldx[L]; const int HpL = S::Hp(net, L - 1);
-        float* mus = P + lay.mu; const int ldm = lay.ldm;
-        if (live_pipe) nw_dense<HP>(hL, ldh, HpL, lds + lay.wh, lay.wh_ld, Ap, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
-            const float b = par[net.par_bmu + col];
+            RSTAMP(1);
+            // ---- forward + head (narrow_step_kernel's code) -----------------------------------------------------------------
+            for (int l = 0; l < L; ++l) {
+                const float* bias = par + net.par_b[l];
+                float* Ys = P + lay.x[l + 1]; const int ldy = lay.ldx[l + 1];
+                auto ep = [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+                    const float b = bias[col];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) mus[(4 * g + k) * ldm + col] = acc[k] + b;
-        });
-        lds_barrier();
-        RSTAMP(6);
-        // ---- sample + neglogp (G:5894-6672) ------------------------------------------------------------------------------------
-        if (live_pipe) {
-            float ssq = 0.f, slog = 0.f;
-            int k = 0;
-            for (int j = part; j < A; j += 16, ++k) {
-                const float mu = mus[r * ldm + j];
-                const float logstd = mu * 0.0f + par[net.par_ls + j];
-                const float sigma = expf(logstd);
-                float eps = 0.f;
-                if (row < E) eps = (q.noise || !have_helper) ? nz_eps[k & 3] : s_eps[row * A + j];        // (A <= 64: k < 4)
-                const float act = mu + sigma * eps;
-                const float z = (act - mu) / sigma;
-                ssq += z * z; slog += logstd;
-                if (row < E) { q.ro_act[((size_t)t * E + row) * A + j] = act; if (q.host_mode) q.host_act[(size_t)row * A + j] = act; }
+                    for (int rr = 0; rr < 4; ++rr) Ys[(4 * g + rr) * ldy + col] = fast_tanh(acc[rr] + b);
+                };
+                if (live_pipe) {
+                    if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
+                    else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+                }
+                lds_barrier();
+                RSTAMP(2 + l);
             }
-            ssq = group16_sum(ssq); slog = group16_sum(slog);
-            if (part == 0 && row < E) q.ro_nlp[(size_t)t * E + row] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
+            const float* hL = P + lay.x[L]; const int ldh = lay.ldx[L]; const int HpL = S::Hp(net, L - 1);
+            float* mus = P + lay.mu; const int ldm = lay.ldm;
+            if (live_pipe) nw_dense<HP>(hL, ldh, HpL, lds + lay.wh, lay.wh_ld, Ap, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+                const float b = par[net.par_bmu + col];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mus[(4 * g + k) * ldm + col] = acc[k] + b;
+            });
+            lds_barrier();
+            RSTAMP(6);
+            // ---- sample + neglogp (G:5894-6672) --------------------------------------------------------------------------------
+            if (live_pipe) {
+                float ssq = 0.f, slog = 0.f;
+                int k = 0;
+                for (int j = part; j < A; j += 16, ++k) {
+                    const float mu = mus[r * ldm + j];
+                    const float logstd = mu * 0.0f + par[net.par_ls + j];
+                    const float sigma = expf(logstd);
+                    float eps = 0.f;
+                    if (grow < E) eps = (q.noise || !have_helper) ? nz_eps[k & 3] : s_eps[grow * A + j];      // (A <= 64: k < 4)
+                    const float act = mu + sigma * eps;
+                    const float z = (act - mu) / sigma;
+                    ssq += z * z; slog += logstd;
+                    if (grow < E) { q.ro_act[((size_t)t * E + grow) * A + j] = act; if (q.host_mode) q.host_act[(size_t)grow * A + j] = act; }
+                }
+                ssq = group16_sum(ssq); slog = group16_sum(slog);
+                if (part == 0 && grow < E) q.ro_nlp[(size_t)t * E + grow] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
+            }
         }
         RSTAMP(7);
         if (q.host_mode) {
@@ -1071,7 +1081,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
                 const uint32_t hsh = ctr_hash(q.seed, (uint32_t)(q.env0 + e), env_step, (uint32_t)j);
                 if (j < O) xs[e * O + j] = u32_to_sym_unit(hsh);
                 else if (j == O) rs[e] = u32_to_sym_unit(hsh);
-                else rs[NW_ROWS + e] = (hsh % 300u == 0u) ? 1.0f : 0.0f;
+                else rs[ES + e] = (hsh % 300u == 0u) ? 1.0f : 0.0f;
             }
         }
         lds_barrier();
@@ -1085,7 +1095,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     // ---- exit: the state goes home ----------------------------------------------------------------------------------------------
     for (int i = tid; i < E * O; i += NW_THREADS) q.st.raw_obs[i] = xs[i];
     if (tid < O) { q.st.obs_mean[tid] = s_mean[tid]; q.st.obs_var[tid] = s_var[tid]; }
-    if (tid < E) { q.st.done[tid] = rs[NW_ROWS + tid]; q.st.ret[tid] = rs[2 * NW_ROWS + tid]; }
+    if (tid < E) { q.st.done[tid] = rs[ES + tid]; q.st.ret[tid] = rs[2 * ES + tid]; }
     if (tid == 0) *q.st.obs_count = obs_cnt;
     if (tid == 64) { *q.st.ret_mean = s_retstat[0]; *q.st.ret_var = s_retstat[1]; *q.st.ret_count = ret_cnt; }
     if (q.host_mode) {

@@ -195,6 +195,50 @@ def test_host_env_rollout_api_matches_device_env_path():
         close(g.rollout_get(f), ro[f], rtol=2e-4, atol=2e-5, msg=f)
 
 
+@pytest.mark.parametrize("hidden,E,T", [((64, 64), 40, 6), ((64, 64), 64, 5), ((16, 8, 8), 50, 5), ((64, 64), 100, 4)])
+def test_resident_workgroup_serves_several_row_groups(hidden, E, T, monkeypatch):
+    """33..64 environments (100: past the limit, the general path on both sides): the one resident workgroup walks them in groups of 32 rows, on the device env (against the
+    oracle's rollout and against the three-kernel path) and behind a host Env (against the general path: copy, statistics
+    kernel, both towers, copy back); the statistics are summed in a different order there, so agreement is to rounding."""
+    orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 29)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    dev = {f: g.rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones")}
+    dev["obs_mean"], dev["obs_var"], _ = g.norm_stats(0)
+    for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+        close(dev[f], ro[f], rtol=2e-4, atol=2e-5, msg="device env vs oracle: " + f)
+    np.testing.assert_array_equal(dev["dones"], ro["dones"])
+    g.close()
+    monkeypatch.setenv("PPO_HIP_NO_PERSISTENT_COLLECT", "1")
+    orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 29)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+        close(g.rollout_get(f), dev[f], rtol=2e-4, atol=2e-5, msg="three-kernel path vs resident: " + f)
+    g.close()
+    # host Env: counter RNG (the resident form), same transitions for both forms
+    rng = np.random.RandomState(11)
+    trans = [(rng.uniform(-1, 1, (E, 18)).astype(np.float32), rng.uniform(-1, 1, E).astype(np.float32), (rng.uniform(size=E) < 0.1).astype(np.float32))
+             for _ in range(2 * T + 1)]
+    outs = {}
+    for form in ("resident", "general"):
+        monkeypatch.setenv("PPO_HIP_NO_HOST_FUSED", "1" if form == "general" else "0")
+        orc, g = pair(hidden)
+        g.norm_init(E); g.rollout_alloc(E, T); g.seed(5)
+        g.rollout_reset(trans[0][0])
+        got = {}; k = 1
+        for it in range(2):
+            for t in range(T):
+                got["act%d_%d" % (it, t)] = g.rollout_act(t, None)
+                g.rollout_observe(t, *trans[k]); k += 1
+            g.rollout_finish(GAMMA, LAM)
+            for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones"):
+                got["%s%d" % (f, it)] = g.rollout_get(f)
+            got["obs_mean%d" % it], got["obs_var%d" % it], _ = g.norm_stats(0)
+        outs[form] = got
+        g.close()
+    for key in outs["general"]:
+        close(outs["resident"][key], outs["general"][key], rtol=2e-4, atol=2e-5, msg="host Env, resident vs general: " + key)
+
+
 @pytest.mark.parametrize("hidden,E,T", [((64, 64), 1, 40), ((64, 64), 5, 12), ((64, 64), 32, 7), ((4, 5), 1, 30), ((16, 8, 8), 3, 9)])
 def test_host_env_small_batches_three_forms_agree(hidden, E, T, monkeypatch):
     """Env on the host, <= 32 environments (the reference's own setting is ONE): (a) the resident kernel that serves the whole
