@@ -161,6 +161,7 @@ struct ppo_handle {
     bool nw_lazy = false;             // the path is available (static shape, PPO_HIP_NO_LAZY_ADAM unset)
     int nw_cur = 0;                   // parameter set holding the current weights (0 outside ppo_update)
     bool nw_pending = false; float* nw_pending_loss = nullptr; int nw_pending_parts = 0;
+    float* nw_coop = nullptr; int nw_coop_G = 0;      // cooperative persistent rollout: [2][G][NW_COOP_PW] chunk moments, then {arrive, err}
     float* nw_alt = nullptr; double* nw_alt_counts = nullptr; int nw_alt_envs = 0;   // second env/normaliser state set of the fused collect step
     // dist
     Rccl rccl;
@@ -1090,6 +1091,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_coop_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_coop_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_host_step_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_host_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
@@ -1121,6 +1124,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->nw_partials) (void)hipFree(h->nw_partials);
     if (h->nw_img) (void)hipFree(h->nw_img);
     if (h->nw_alt) (void)hipFree(h->nw_alt);
+    if (h->nw_coop) (void)hipFree(h->nw_coop);
     if (h->nw_alt_counts) (void)hipFree(h->nw_alt_counts);
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->sumsq2, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
@@ -1846,6 +1850,38 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
         if (launch_step(h, va)) return -1;
         h->done_staged = -1;
     }
+    // 65..2048 environments: G = ceil(E / 32) resident workgroups, one per CU, meeting once per env step for the statistics
+    const int coopG = (E + NW_ROWS - 1) / NW_ROWS;
+    const bool coop = !persistent && h->narrow && !h->comm && !no_fused && !no_persist && E > NW_RO_MAX_E && coopG <= NW_COOP_MAX_G && n.O <= 64 && n.A <= 64 &&
+                      ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float) <= 160 * 1024 &&
+                      coopG * (2 * n.O + 3) <= h->nw.w_total - h->nw.w_fwd;             // the chunks of a step are staged in the image's unused backward half
+    if (coop) {
+        const size_t pf = (size_t)2 * coopG * NW_COOP_PW;
+        if (h->nw_coop_G != coopG) {
+            HIP_OK(h, hipStreamSynchronize(h->stream));
+            if (dev_alloc(h, &h->nw_coop, pf + 16 * (size_t)(coopG + 1))) return -1;
+            h->nw_coop_G = coopG;
+        }
+        unsigned* ctl = reinterpret_cast<unsigned*>(h->nw_coop + pf);       // [G][16] step words, then the error word
+        HIP_OK(h, hipMemsetAsync(ctl, 0, 16 * (size_t)(coopG + 1) * sizeof(unsigned), h->stream));
+        NwCoopArgs q{};
+        q.img = h->nw_img;
+        q.st = NwEnvState{h->raw_obs, h->obs_rms.mean, h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->cur_done};
+        q.noise = noise ? h->ro_noise : nullptr;
+        q.ro_obs = h->ro_obs; q.ro_act = h->ro_act; q.ro_nlp = h->ro_nlp; q.ro_rew = h->ro_rew; q.ro_done = h->ro_done;
+        q.E = E; q.T = T; q.G = coopG; q.seed = seed; q.step0 = step0; q.env0 = env0;
+        q.gamma = h->nz_gamma; q.clip_rew = h->nz_clip_rew; q.clip_obs = h->nz_clip_obs; q.eps = h->nz_eps; q.norm_obs = h->norm_obs_flag; q.norm_rew = h->norm_rew_flag;
+        q.part = h->nw_coop; q.arrive = ctl; q.err = ctl + 16 * (size_t)coopG; q.spin_limit = 4000000u;
+        const size_t lds = ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float);
+        { ProfScope ps(h, PK_STEP);
+          if (h->nw_static) hipLaunchKernelGGL((narrow_rollout_coop_kernel<32, 64, 32, 2>), dim3(coopG), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+          else hipLaunchKernelGGL((narrow_rollout_coop_kernel<0, 0, 0, 0>), dim3(coopG), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+          HIP_OK(h, hipGetLastError()); }
+        StepArgs va{};
+        va.obs = h->ro_obs; va.value = h->ro_val; va.n = E * T; va.nz = no_norm();
+        if (launch_step(h, va)) return -1;
+        h->done_staged = -1;
+    }
     if (fused && !persistent) {
         if (h->nw_alt_envs != E) {
             HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -1887,7 +1923,7 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
         }
         h->done_staged = -1;
     }
-    for (int t = 0; t < T && !fused && !persistent; ++t) {
+    for (int t = 0; t < T && !fused && !persistent && !coop; ++t) {
         if (enqueue_rollout_act(h, t, noise ? h->ro_noise + (size_t)t * E * n.A : nullptr, seed, step0 + t, (uint32_t)env0)) return -1;
         { ProfScope ps(h, PK_ENV);
           hipLaunchKernelGGL(seeded_env_kernel, dim3((envW + 255) / 256), dim3(256), 0, h->stream, seed, env0, E, step0 + (uint32_t)t + 1u, n.O, h->raw_obs, h->raw_rew, h->cur_done);
@@ -1897,6 +1933,11 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
     if (enqueue_finish(h, gamma, lam)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
+    if (coop) {
+        unsigned e = 0;
+        HIP_OK(h, hipMemcpy(&e, reinterpret_cast<unsigned*>(h->nw_coop + (size_t)2 * coopG * NW_COOP_PW) + 16 * (size_t)coopG, sizeof e, hipMemcpyDeviceToHost));
+        if (e) return fail(h, "ppo_collect_synthetic: workgroup %u of the cooperative rollout gave up waiting for the others", e - 1);
+    }
     return peer_check(h);
 }
 

@@ -1275,3 +1275,231 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_host_step_kernel(NetDev net
     __syncthreads();
     if (tid == 0) __hip_atomic_store(q.host_flag, q.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Cooperative persistent rollout for 65..2048 environments on the device env (BASELINE configs[3]: 1024): G = ceil(E / 32)
+// workgroups, each resident on its own CU for the whole rollout and owning 32 environments (image, raw observations, returns
+// and done flags in LDS).  The only coupling between them is EnvNormalize's running statistics: per env step every workgroup
+// reduces its 32 rows to chunk moments (n, mean, M2 per column, the reference's two passes), publishes them, all workgroups
+// meet at a flat arrival counter, and each one combines the G chunks in index order (mean = sum n_k mean_k / n, M2 = sum M2_k
+// + n_k (mean_k - mean)^2: norm_batch_kernel's combine) before RunningStatistics::update's merge -- every workgroup holds the
+// same statistics, bit for bit.  One launch instead of 3 T (policy step, env, statistics kernel per env step): 21 -> ~9 us per
+// env step at 1024 environments.  The waits are bounded (a workgroup that never arrives sets `err` instead of hanging the GPU).
+// ------------------------------------------------------------------------------------------------------------------------
+struct NwCoopArgs {
+    const float* img;
+    NwEnvState st;               // read at entry; workgroup 0 writes the statistics back, every workgroup its environments' rows
+    const float* noise;          // [T][E][A] or null
+    float* ro_obs; float* ro_act; float* ro_nlp; float* ro_rew; float* ro_done;
+    int E, T, G;
+    uint32_t seed, step0; int env0;
+    float gamma, clip_rew, clip_obs, eps; int norm_obs, norm_rew;
+    float* part;                 // [2 parities][G][NW_COOP_PW] chunk moments
+    unsigned* arrive;            // [G][16] step words, one 64-byte line per workgroup (zeroed by the host before every launch)
+    unsigned* err; unsigned spin_limit;
+};
+#define NW_COOP_PW 132           // upper bound of the floats one workgroup publishes per step (2 O + 3 at O <= 64)
+#define NW_COOP_MAX_G 64
+
+template <int KP0, int HP, int AP, int LL>
+__global__ __launch_bounds__(NW_THREADS) void narrow_rollout_coop_kernel(NetDev net, NwLayout lay, NwCoopArgs q) {
+    typedef NwShape<KP0, HP, AP, LL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwCoopArgs)>();
+    const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
+    const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
+    const int wg = blockIdx.x, G = q.G, O = net.O, A = net.A;
+    const int e0 = wg * NW_ROWS, El = min(NW_ROWS, q.E - e0);      // this workgroup's environments [e0, e0 + El)
+    float* xs = lds + lay.lds_total;                        // [El][O] raw observations
+    float* s_mean = xs + NW_RO_XS; float* s_var = s_mean + 64;
+    float* rs = s_var + 64;                                 // [32] rewards | [32] dones | [32] returns
+    float* s_retstat = rs + 3 * NW_ROWS;                    // ret_rms mean, var | [4..7] scratch
+    float* s_istd = s_retstat + 8;
+    {
+        const int n4 = lay.w_fwd / 4;
+        for (int e = tid; e < n4; e += NW_THREADS) reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(q.img)[e];
+        for (int i = tid; i < El * O; i += NW_THREADS) xs[i] = q.st.raw_obs[(size_t)e0 * O + i];
+        if (tid < O) { s_mean[tid] = q.st.obs_mean[tid]; const float v0 = q.st.obs_var[tid]; s_var[tid] = v0; s_istd[tid] = 1.0f / sqrtf(v0 + q.eps); }
+        if (tid < El) { rs[NW_ROWS + tid] = q.st.done[e0 + tid]; rs[2 * NW_ROWS + tid] = q.st.ret[e0 + tid]; }
+        if (tid == 0) { s_retstat[0] = *q.st.ret_mean; s_retstat[1] = *q.st.ret_var; }
+    }
+    double obs_cnt = *q.st.obs_count, ret_cnt = *q.st.ret_count;
+    __syncthreads();
+    float* P = lds + lay.w_total + pipe * lay.pipe_total;
+    const float* par = lds + lay.par;
+    const int r = ptid >> 4, part_ = ptid & 15;
+    const int row = 16 * pipe + r;                          // local environment of this thread in the sampling phase
+    const bool live_pipe = 16 * pipe < El;
+    int* s_ok = reinterpret_cast<int*>(s_retstat + 4);
+    const int pw = 2 * O + 3;                               // published chunk: n | mean[O] | M2[O] | ret mean | ret M2
+    float* lp = lds + lay.w_fwd;                            // all G chunks of a step, staged in LDS (the image's backward half is unused here)
+    auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
+        const double nb = (double)nbf, tot = cnt + nb;
+        const float bvar = bM2 / (float)nb;                                        // running_statistics.hpp:51-54
+        const float delta = bmean - mean0;                                         // :90
+        mean1 = mean0 + (delta * (float)nb) / (float)tot;                          // :94
+        const float m_a = var0 * (float)cnt, m_b = bvar * (float)nb;               // :97-98
+        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;   // :100
+        var1 = M2 / (float)tot;                                                    // :101
+    };
+    bool dead = false;
+    for (int t = 0; t < q.T && !dead; ++t) {
+        float nz_eps[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < El) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = part_ + 16 * k;
+                if (j < A) nz_eps[k] = q.noise ? q.noise[((size_t)t * q.E + e0 + row) * A + j] : ctr_normal(q.seed, (uint32_t)(q.env0 + e0 + row), q.step0 + (uint32_t)t, j);
+            }
+        }
+        // ---- normalise (env_normalize.hpp:99-104) -> input tiles + rollout row t ----------------------------------------------------
+        for (int i = tid; i < NW_ROWS * Kp0; i += NW_THREADS) {
+            const int rr = i / Kp0, j = i - rr * Kp0;
+            float x = 0.f;
+            if (rr < El && j < O) {
+                x = xs[rr * O + j];
+                if (q.norm_obs) {
+                    x = (x - s_mean[j]) * s_istd[j];
+                    x = tf_min(tf_max(x, -q.clip_obs), q.clip_obs);
+                }
+                q.ro_obs[((size_t)t * q.E + e0 + rr) * O + j] = x;
+            }
+            lds[lay.w_total + (rr >> 4) * lay.pipe_total + lay.x[0] + (rr & 15) * lay.ldx[0] + j] = x;
+        }
+        if (tid < El) q.ro_done[(size_t)t * q.E + e0 + tid] = rs[NW_ROWS + tid];
+        lds_barrier();
+        for (int l = 0; l < L; ++l) {
+            const float* bias = par + net.par_b[l];
+            float* Ys = P + lay.x[l + 1]; const int ldy = lay.ldx[l + 1];
+            auto ep = [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+                const float b = bias[col];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) Ys[(4 * g + rr) * ldy + col] = fast_tanh(acc[rr] + b);
+            };
+            if (live_pipe) {
+                if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
+                else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+            }
+            lds_barrier();
+        }
+        const float* hL = P + lay.x[L]; const int ldh = lay.ldx[L]; const int HpL = S::Hp(net, L - 1);
+        float* mus = P + lay.mu; const int ldm = lay.ldm;
+        if (live_pipe) nw_dense<HP>(hL, ldh, HpL, lds + lay.wh, lay.wh_ld, Ap, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
+            const float b = par[net.par_bmu + col];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mus[(4 * g + k) * ldm + col] = acc[k] + b;
+        });
+        lds_barrier();
+        if (live_pipe) {
+            float ssq = 0.f, slog = 0.f;
+            int k = 0;
+            for (int j = part_; j < A; j += 16, ++k) {
+                const float mu = mus[r * ldm + j];
+                const float logstd = mu * 0.0f + par[net.par_ls + j];
+                const float sigma = expf(logstd);
+                const float eps = row < El ? nz_eps[k & 3] : 0.f;
+                const float act = mu + sigma * eps;
+                const float z = (act - mu) / sigma;
+                ssq += z * z; slog += logstd;
+                if (row < El) q.ro_act[((size_t)t * q.E + e0 + row) * A + j] = act;
+            }
+            ssq = group16_sum(ssq); slog = group16_sum(slog);
+            if (part_ == 0 && row < El) q.ro_nlp[(size_t)t * q.E + e0 + row] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
+        }
+        // ---- env transition (counter hash) of this workgroup's environments ---------------------------------------------------------
+        const uint32_t env_step = q.step0 + (uint32_t)t + 1u;
+        for (int i = tid; i < El * (O + 2); i += NW_THREADS) {
+            const int e = i / (O + 2), j = i - e * (O + 2);
+            const uint32_t hsh = ctr_hash(q.seed, (uint32_t)(q.env0 + e0 + e), env_step, (uint32_t)j);
+            if (j < O) xs[e * O + j] = u32_to_sym_unit(hsh);
+            else if (j == O) rs[e] = u32_to_sym_unit(hsh);
+            else rs[NW_ROWS + e] = (hsh % 300u == 0u) ? 1.0f : 0.0f;
+        }
+        lds_barrier();
+        // ---- chunk moments of my rows -> published (agent-scope stores: visible to the other XCDs without a cache-wide fence) ------
+        float* mine = q.part + ((size_t)(t & 1) * G + wg) * pw;
+        if (tid < O) {
+            float sum = 0.f;
+            for (int e = 0; e < El; ++e) sum += xs[e * O + tid];
+            const float bmean = sum / (float)El;
+            float m2 = 0.f;
+            for (int e = 0; e < El; ++e) { const float d = xs[e * O + tid] - bmean; m2 += d * d; }
+            __hip_atomic_store(mine + 1 + tid, bmean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1 + O + tid, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(mine, (float)El, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 64) {
+            float* ret = rs + 2 * NW_ROWS;
+            float sum = 0.f;
+            for (int e = 0; e < El; ++e) { ret[e] = ret[e] * q.gamma + rs[e]; sum += ret[e]; }            // env_normalize.hpp:66
+            const float bmean = sum / (float)El;
+            float m2 = 0.f;
+            for (int e = 0; e < El; ++e) { const float d = ret[e] - bmean; m2 += d * d; }
+            __hip_atomic_store(mine + 1 + 2 * O, bmean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 2 + 2 * O, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- all workgroups meet.  No read-modify-write on a shared word (same-address atomics serialise at the memory side): every
+        // workgroup raises ITS OWN step word once its chunk's stores have been performed, and G lanes of every workgroup watch the G
+        // words in parallel (bounded: a workgroup that never shows up sets `err` instead of hanging the device).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) { *s_ok = 1; __hip_atomic_store(q.arrive + (size_t)wg * 16, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __syncthreads();
+        if (tid < G) {
+            unsigned n = 0;
+            while (__hip_atomic_load(q.arrive + (size_t)tid * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(t + 1)) {
+                if (++n > q.spin_limit) { *s_ok = 0; __hip_atomic_store(q.err, 1u + (unsigned)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (!*s_ok) { dead = true; }
+        // every chunk of the step into LDS: all loads of the workgroup in one round trip (agent-scope loads: past any stale line)
+        {
+            const float* all = q.part + (size_t)(t & 1) * G * pw;
+            for (int i = tid; i < G * pw; i += NW_THREADS) lp[i] = __hip_atomic_load(all + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_barrier();
+        if (tid < O && q.norm_obs) {
+            float ntot = 0.f, acc = 0.f;
+            for (int k = 0; k < G; ++k) { const float nk = lp[k * pw]; ntot += nk; acc += nk * lp[k * pw + 1 + tid]; }
+            const float bmean = acc / ntot;
+            float m2 = 0.f;
+            for (int k = 0; k < G; ++k) { const float nk = lp[k * pw], d = lp[k * pw + 1 + tid] - bmean; m2 += lp[k * pw + 1 + O + tid] + nk * (d * d); }
+            float m1, v1;
+            merge(s_mean[tid], s_var[tid], obs_cnt, bmean, m2, ntot, m1, v1);
+            s_mean[tid] = m1; s_var[tid] = v1; s_istd[tid] = 1.0f / sqrtf(v1 + q.eps);
+            obs_cnt = (double)ntot + obs_cnt;                                       // :103
+        }
+        if (tid == 64) {
+            float* ret = rs + 2 * NW_ROWS;
+            float m1 = s_retstat[0], v1 = s_retstat[1];
+            if (q.norm_rew) {
+                float ntot = 0.f, acc = 0.f;
+                for (int k = 0; k < G; ++k) { const float nk = lp[k * pw]; ntot += nk; acc += nk * lp[k * pw + 1 + 2 * O]; }
+                const float bmean = acc / ntot;
+                float m2 = 0.f;
+                for (int k = 0; k < G; ++k) { const float nk = lp[k * pw], d = lp[k * pw + 1 + 2 * O] - bmean; m2 += lp[k * pw + 2 + 2 * O] + nk * (d * d); }
+                merge(s_retstat[0], s_retstat[1], ret_cnt, bmean, m2, ntot, m1, v1);
+                ret_cnt = (double)ntot + ret_cnt;
+            }
+            s_retstat[0] = m1; s_retstat[1] = v1;
+            const float inv = 1.0f / sqrtf(v1 + q.eps);                                                    // :79
+            for (int e = 0; e < El; ++e) {
+                float y = rs[e];
+                if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
+                q.ro_rew[(size_t)t * q.E + e0 + e] = y;
+                ret[e] = ret[e] * (1.0f - rs[NW_ROWS + e]);                                                // :88-91
+            }
+        }
+        lds_barrier();
+    }
+    // ---- exit: my environments' state goes home; workgroup 0 also writes the (common) statistics ------------------------------------
+    for (int i = tid; i < El * O; i += NW_THREADS) q.st.raw_obs[(size_t)e0 * O + i] = xs[i];
+    if (tid < El) { q.st.done[e0 + tid] = rs[NW_ROWS + tid]; q.st.ret[e0 + tid] = rs[2 * NW_ROWS + tid]; }
+    if (wg == 0) {
+        if (tid < O) { q.st.obs_mean[tid] = s_mean[tid]; q.st.obs_var[tid] = s_var[tid]; }
+        if (tid == 0) *q.st.obs_count = obs_cnt;
+        if (tid == 64) { *q.st.ret_mean = s_retstat[0]; *q.st.ret_var = s_retstat[1]; *q.st.ret_count = ret_cnt; }
+    }
+}

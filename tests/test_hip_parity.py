@@ -239,6 +239,45 @@ def test_resident_workgroup_serves_several_row_groups(hidden, E, T, monkeypatch)
         close(outs["resident"][key], outs["general"][key], rtol=2e-4, atol=2e-5, msg="host Env, resident vs general: " + key)
 
 
+@pytest.mark.parametrize("hidden,E,T", [((64, 64), 100, 6), ((64, 64), 1024, 8), ((64, 64), 2048, 4), ((16, 8, 8), 333, 5)])
+def test_cooperative_persistent_rollout(hidden, E, T, monkeypatch):
+    """65..2048 environments on the device env: ceil(E / 32) resident workgroups, one launch per rollout, meeting once per env
+    step to combine their chunk moments into the common running statistics.  Against the oracle's rollout (explicit noise),
+    against the three-kernel path (to rounding: the statistics are summed in a different chunking), two rollouts in a row,
+    and twice with the counter RNG: bit-identical (the combine order is fixed, not arrival order)."""
+    orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 31)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    got = {f: g.rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones")}
+    for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+        close(got[f], ro[f], rtol=2e-4, atol=2e-5, msg="vs oracle: " + f)
+    np.testing.assert_array_equal(got["dones"], ro["dones"])
+    m, v, c = g.norm_stats(0)
+    close(m, nz.obs_rms.mean, rtol=1e-5, atol=1e-6); close(v, nz.obs_rms.var, rtol=1e-5); assert c == nz.obs_rms.count
+    m, v, c = g.norm_stats(1)
+    close(v, nz.ret_rms.var, rtol=1e-5); assert c == nz.ret_rms.count
+    g.collect_synthetic(1234, GAMMA, LAM, None, step0=T, first=False)          # second rollout, counter RNG
+    second = {f: g.rollout_get(f) for f in ("obs", "actions", "values", "rewards", "returns")}
+    second["mean"], second["var"], _ = g.norm_stats(0)
+    g.close()
+    # the same two rollouts again: same bits
+    orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 31)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    g.collect_synthetic(1234, GAMMA, LAM, None, step0=T, first=False)
+    again = {f: g.rollout_get(f) for f in ("obs", "actions", "values", "rewards", "returns")}
+    again["mean"], again["var"], _ = g.norm_stats(0)
+    g.close()
+    for k in second:
+        np.testing.assert_array_equal(second[k], again[k], err_msg=k)
+    # and the one-launch-per-kernel path
+    monkeypatch.setenv("PPO_HIP_NO_PERSISTENT_COLLECT", "1")
+    orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 31)
+    g.collect_synthetic(1234, GAMMA, LAM, noise)
+    g.collect_synthetic(1234, GAMMA, LAM, None, step0=T, first=False)
+    for f in ("obs", "actions", "values", "rewards", "returns"):
+        close(g.rollout_get(f), second[f], rtol=3e-4, atol=3e-5, msg="three-kernel path vs cooperative: " + f)
+    g.close()
+
+
 @pytest.mark.parametrize("hidden,E,T", [((64, 64), 1, 40), ((64, 64), 5, 12), ((64, 64), 32, 7), ((4, 5), 1, 30), ((16, 8, 8), 3, 9)])
 def test_host_env_small_batches_three_forms_agree(hidden, E, T, monkeypatch):
     """Env on the host, <= 32 environments (the reference's own setting is ONE): (a) the resident kernel that serves the whole
