@@ -128,6 +128,8 @@ struct ppo_handle {
     bool host_pending = false; int host_pending_t = 0;   // a transition sits in pin_in, its bookkeeping rides in the next launch
     // ... and the RESIDENT form (narrow_rollout_kernel in host mode): one launch serves many env steps, host and kernel talk
     // through sequence words in pinned memory (pin_flag[PCTL_*])
+    bool opt_no_host_fused = false, opt_no_host_resident = false;     // PPO_HIP_NO_HOST_FUSED / _RESIDENT, read once in ppo_create
+    float* pin_in_dev = nullptr; float* pin_out_dev = nullptr; unsigned* pin_flag_dev = nullptr;   // the pinned blocks as the device sees them
     bool host_proto = false;          // the last ppo_rollout_act used the resident / fused form: observe only posts the transition
     bool hp_active = false;           // a resident kernel may be running
     int hp_posted = 0;                // transitions posted in this rollout
@@ -1089,13 +1091,17 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<32, 64, 32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<0, 0, 0, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<32, 64, 32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<0, 0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_coop_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_coop_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_host_step_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         attr_ok &= hipFuncSetAttribute((const void*)narrow_host_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
+        { const char* e1 = getenv("PPO_HIP_NO_HOST_FUSED"); const char* e2 = getenv("PPO_HIP_NO_HOST_RESIDENT");
+          h->opt_no_host_fused = e1 && e1[0] == '1'; h->opt_no_host_resident = e2 && e2[0] == '1'; }
         const char* nl = getenv("PPO_HIP_NO_LAZY_ADAM");
         if (h->nw_static && !(nl && nl[0] == '1')) {
             // second parameter / moment set of the deferred Adam (zero-filled: the padding elements are never written and must read 0)
@@ -1398,6 +1404,12 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
     HIP_OK(h, hipHostMalloc((void**)&h->pin_in, in_n * sizeof(float), hipHostMallocDefault));
     HIP_OK(h, hipHostMalloc((void**)&h->pin_out, (size_t)n_envs * h->net.A * sizeof(float), hipHostMallocDefault));
     if (!h->pin_flag) { HIP_OK(h, hipHostMalloc((void**)&h->pin_flag, 1024, hipHostMallocDefault)); memset(h->pin_flag, 0, 1024); h->act_seq = 0; }
+    {
+        void* d = nullptr;
+        HIP_OK(h, hipHostGetDevicePointer(&d, h->pin_in, 0)); h->pin_in_dev = (float*)d;
+        HIP_OK(h, hipHostGetDevicePointer(&d, h->pin_out, 0)); h->pin_out_dev = (float*)d;
+        HIP_OK(h, hipHostGetDevicePointer(&d, h->pin_flag, 0)); h->pin_flag_dev = (unsigned*)d;
+    }
     h->host_pending = false;
     h->pin_in_n = in_n; h->pin_out_n = (size_t)n_envs * h->net.A;
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -1586,8 +1598,7 @@ static int enqueue_finish(ppo_handle* h, float gamma, float lam) {
 // either is in use ("protocol" mode) ppo_rollout_observe only fills the pinned block: the transition is booked by the next
 // launch / the resident kernel.
 static bool host_small(const ppo_handle* h) {
-    const char* e = getenv("PPO_HIP_NO_HOST_FUSED");
-    if (e && e[0] == '1') return false;
+    if (h->opt_no_host_fused) return false;
     const NetDev& n = h->net;
     return h->narrow && !h->comm && !h->bf.on && h->E <= NW_RO_MAX_E && n.O <= 64 && n.A <= 64 && h->pin_flag &&
            ((size_t)h->nw.lds_total + std::max(nw_ro_extra(h->E, n.O), NW_RO_EXTRA)) * sizeof(float) <= 160 * 1024;
@@ -1601,11 +1612,7 @@ static int enqueue_host_step(ppo_handle* h, int t, bool act, const float* noise_
     NwHostStepArgs q{};
     q.img = h->nw_img;
     q.st = NwEnvState{h->raw_obs, h->obs_rms.mean, h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->cur_done};
-    void* din = nullptr; void* dact = nullptr; void* dflag = nullptr;
-    HIP_OK(h, hipHostGetDevicePointer(&din, h->pin_in, 0));
-    HIP_OK(h, hipHostGetDevicePointer(&dact, h->pin_out, 0));
-    HIP_OK(h, hipHostGetDevicePointer(&dflag, h->pin_flag, 0));
-    q.host_in = (const float*)din; q.host_act = (float*)dact; q.host_flag = (unsigned*)dflag; q.flag_value = act ? ++h->act_seq : 0u;
+    q.host_in = h->pin_in_dev; q.host_act = h->pin_out_dev; q.host_flag = h->pin_flag_dev; q.flag_value = act ? ++h->act_seq : 0u;
     q.noise = noise_dev;
     if (act) { q.ro_obs = h->ro_obs + t * E * n.O; q.ro_act = h->ro_act + t * E * n.A; q.ro_nlp = h->ro_nlp + t * E; q.ro_done = h->ro_done + t * E; }
     q.has_transition = h->host_pending ? 1 : 0;
@@ -1622,13 +1629,22 @@ static int enqueue_host_step(ppo_handle* h, int t, bool act, const float* noise_
     return 0;
 }
 
+static void launch_rollout_kernel(ppo_handle* h, const NwRolloutArgs& q, size_t lds) {
+    const NetDev& n = h->net;
+    const bool multi = q.E > NW_ROWS;
+    if (h->nw_static) {
+        if (multi) hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2, true>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+        else hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2, false>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+    } else {
+        if (multi) hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0, true>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+        else hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0, false>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+    }
+}
+
 // ---- resident host-Env rollout kernel (see NwRolloutArgs) -----------------------------------------------------------------------
 // control words live at pin_flag + 64 (the first line is the per-launch completion word of narrow_host_step_kernel)
 static unsigned* hp_ctl(ppo_handle* h) { return h->pin_flag + 64; }
-static bool host_resident(const ppo_handle* h) {
-    const char* e = getenv("PPO_HIP_NO_HOST_RESIDENT");
-    return host_small(h) && !(e && e[0] == '1');
-}
+static bool host_resident(const ppo_handle* h) { return host_small(h) && !h->opt_no_host_resident; }
 static int hp_launch(ppo_handle* h, int t0, uint32_t rng_step_t0) {
     const NetDev& n = h->net;
     NwRolloutArgs q{};
@@ -1638,18 +1654,13 @@ static int hp_launch(ppo_handle* h, int t0, uint32_t rng_step_t0) {
     q.E = h->E; q.T = h->T; q.seed = h->rng_seed; q.step0 = rng_step_t0 - (uint32_t)t0; q.env0 = h->rank * h->E;
     q.gamma = h->nz_gamma; q.clip_rew = h->nz_clip_rew; q.clip_obs = h->nz_clip_obs; q.eps = h->nz_eps; q.norm_obs = h->norm_obs_flag; q.norm_rew = h->norm_rew_flag;
     q.host_mode = 1; q.t0 = t0; q.pending = h->host_pending ? 1 : 0;
-    void* din = nullptr; void* dact = nullptr; void* dctl = nullptr;
-    HIP_OK(h, hipHostGetDevicePointer(&din, h->pin_in, 0));
-    HIP_OK(h, hipHostGetDevicePointer(&dact, h->pin_out, 0));
-    HIP_OK(h, hipHostGetDevicePointer(&dctl, hp_ctl(h), 0));
-    q.host_in = (const float*)din; q.host_act = (float*)dact; q.ctl = (unsigned*)dctl;
+    q.host_in = h->pin_in_dev; q.host_act = h->pin_out_dev; q.ctl = h->pin_flag_dev + 64;
     const char* pc = getenv("PPO_HIP_HOST_POLLS");
     q.poll_cap = pc ? (unsigned)atol(pc) : 150000u;                 // ~2 us per poll over PCIe: a fraction of a second, then the kernel parks itself
     __atomic_store_n(hp_ctl(h) + PCTL_EXIT, 0u, __ATOMIC_RELEASE);
     __atomic_store_n(hp_ctl(h) + PCTL_STOP, 0u, __ATOMIC_RELEASE);
-    const size_t lds = ((size_t)h->nw.lds_total + nw_ro_extra(h->E, n.O)) * sizeof(float);
-    if (h->nw_static) hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
-    else hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+    const size_t lds = ((size_t)h->nw.lds_total + (h->E > NW_ROWS ? nw_ro_extra(h->E, n.O) : NW_RO_EXTRA)) * sizeof(float);
+    launch_rollout_kernel(h, q, lds);
     HIP_OK(h, hipGetLastError());
     h->hp_active = true; h->host_pending = false;
     return 0;
@@ -1827,7 +1838,7 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
     const char* npe = getenv("PPO_HIP_NO_PERSISTENT_COLLECT");
     const bool no_persist = npe && npe[0] == '1';
     // (up to NW_RO_MAX_E environments: the one workgroup walks them in groups of 32 rows)
-    const size_t ro_lds = ((size_t)h->nw.lds_total + nw_ro_extra(E, n.O)) * sizeof(float);
+    const size_t ro_lds = ((size_t)h->nw.lds_total + (E > NW_ROWS ? nw_ro_extra(E, n.O) : NW_RO_EXTRA)) * sizeof(float);
     const bool persistent = h->narrow && !h->comm && !no_fused && !no_persist && E <= NW_RO_MAX_E && n.O <= 64 && n.A <= 64 && ro_lds <= 160 * 1024;
     if (persistent) {
         NwRolloutArgs q{};
@@ -1842,8 +1853,7 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
         q.stamps = g_stamps;
 #endif
         { ProfScope ps(h, PK_STEP);
-          if (h->nw_static) hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2>), dim3(1), dim3(NW_THREADS), ro_lds, h->stream, n, h->nw, q);
-          else hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0>), dim3(1), dim3(NW_THREADS), ro_lds, h->stream, n, h->nw, q);
+          launch_rollout_kernel(h, q, ro_lds);
           HIP_OK(h, hipGetLastError()); }
         StepArgs va{};                                         // values of all T x E rows: the rows are already normalised
         va.obs = h->ro_obs; va.value = h->ro_val; va.n = E * T; va.nz = no_norm();

@@ -873,7 +873,9 @@ struct NwRolloutArgs {
 // floats of LDS behind the regular layout for E environments of O observations (E rounded up to whole row groups)
 __host__ __device__ inline int nw_ro_extra(int E, int O) { const int Er = (E + NW_ROWS - 1) / NW_ROWS * NW_ROWS; return Er * O + 64 + 64 + 3 * Er + 8 + 64 + 16 * 64; }
 
-template <int KP0, int HP, int AP, int LL>
+// MULTI = more than one group of 32 rows (33..NW_RO_MAX_E environments); the single-group instantiation keeps the straight-line
+// step (the runtime group loop costs the <= 32-environment case ~2.5 k cycles per env step in scheduling freedom)
+template <int KP0, int HP, int AP, int LL, bool MULTI = false>
 __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
     typedef NwShape<KP0, HP, AP, LL> S;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -881,9 +883,10 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
     const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
     const int E = q.E, O = net.O, A = net.A;
-    const int ES = (E + NW_ROWS - 1) / NW_ROWS * NW_ROWS;   // environments rounded up to whole row groups: stride of the per-environment vectors
+    // stride of the per-environment vectors / size of the observation block: compile-time for the single-group instantiation
+    const int ES = MULTI ? (E + NW_ROWS - 1) / NW_ROWS * NW_ROWS : NW_ROWS;
     float* xs = lds + lay.lds_total;                        // [E][O] raw observations of the current state
-    float* s_mean = xs + ES * O; float* s_var = s_mean + 64;
+    float* s_mean = xs + (MULTI ? ES * O : NW_RO_XS); float* s_var = s_mean + 64;
     float* rs = s_var + 64;                                 // [ES] rewards | [ES] dones | [ES] returns
     float* s_retstat = rs + 3 * ES;                         // ret_rms mean, var
     float* s_istd = s_retstat + 8;                          // 1 / sqrt(var + eps) per column: the expression of the per-step kernels, evaluated once per statistics update
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
         RSTAMP(0);
         if (tid < E) q.ro_done[(size_t)t * E + tid] = rs[ES + tid];                  // the flags that arrived with obs_t
         // the environments go through the two 16-row pipes in groups of 32 (one group at <= 32 environments)
-        for (int g0 = 0; g0 < E; g0 += NW_ROWS) {
+        for (int g0 = 0; g0 < (MULTI ? E : 1); g0 += NW_ROWS) {
             const int grow = g0 + row;                          // this thread's environment in the sampling phase
             const bool live_pipe = g0 + 16 * pipe < E;          // a pipe without environments skips the matrix work (it shares the SIMDs' matrix pipes with the live one)
             // explicit noise of this step: requested now, consumed after the forward pass
