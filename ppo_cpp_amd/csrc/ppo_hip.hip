@@ -1725,9 +1725,15 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
         for (int attempt = 0; ; ++attempt) {
             if (!h->hp_active) { if (attempt > 3) return fail(h, "ppo_rollout_act: the resident kernel keeps leaving before step %d", t); if (hp_launch(h, t, rng_step)) return -1; }
             bool have = false;
-            for (;;) {
+            for (unsigned long spins = 1; ; ++spins) {
                 if (__atomic_load_n(ctl + PCTL_D2H, __ATOMIC_ACQUIRE) >= (unsigned)(t + 1)) { have = true; break; }
                 if (__atomic_load_n(ctl + PCTL_EXIT, __ATOMIC_ACQUIRE)) { have = __atomic_load_n(ctl + PCTL_D2H, __ATOMIC_ACQUIRE) >= (unsigned)(t + 1); break; }
+                if ((spins & 0xfffff) == 0) {                       // every million polls: is the stream still alive?
+                    const hipError_t qe = hipStreamQuery(h->stream);
+                    if (qe != hipSuccess && qe != hipErrorNotReady) return fail(h, "ppo_rollout_act: %s", hipGetErrorString(qe));
+                    if (qe == hipSuccess && !__atomic_load_n(ctl + PCTL_EXIT, __ATOMIC_ACQUIRE) && __atomic_load_n(ctl + PCTL_D2H, __ATOMIC_ACQUIRE) < (unsigned)(t + 1))
+                        return fail(h, "ppo_rollout_act: the resident kernel is gone without a report");
+                }
             }
             if (have) break;
             if (hp_retire(h, false)) return -1;                     // it parked itself before producing row t: relaunch from here
@@ -2328,10 +2334,10 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
     float* flag = nullptr;
     HIP_OK(h, hipMalloc((void**)&flag, sizeof(float)));
     const float mine = ok ? 1.f : 0.f;
-    HIP_OK(h, hipMemcpy(flag, &mine, sizeof mine, hipMemcpyHostToDevice));
-    const int rc = h->rccl.AllReduce(flag, flag, 1, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream);
     float got = 0.f;
-    const bool agreed = rc == 0 && hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(&got, flag, sizeof got, hipMemcpyDeviceToHost) == hipSuccess;
+    const bool agreed = hipMemcpy(flag, &mine, sizeof mine, hipMemcpyHostToDevice) == hipSuccess &&
+                        h->rccl.AllReduce(flag, flag, 1, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream) == 0 &&
+                        hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(&got, flag, sizeof got, hipMemcpyDeviceToHost) == hipSuccess;
     (void)hipFree(flag);
     if (!agreed) return fail(h, "ppo_dist_peer_attach: the ranks could not agree on the probe result");
     P.on = got == (float)h->world;
