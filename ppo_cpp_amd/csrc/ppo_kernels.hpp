@@ -116,6 +116,29 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // stores (which only the next kernel reads).  LDS traffic is ordered by lgkmcnt alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Write-through (agent scope, sc1) stores for data that only the NEXT kernel reads: as ordinary stores they would sit dirty
+// in this XCD's L2 until the end-of-kernel write-back, which then delays the kernel boundary; written through they drain
+// while the kernel computes.  It pays where a workgroup's output is a trickle beside its compute (the fused train kernels'
+// workspaces: -3 us for 17 MB; the narrow path's partial vectors: -1 us) and COSTS where storing is most of the kernel: the
+// slab stores of the weight-gradient kernel (+0.4 us), Adam's parameter / moment stores (+2.2 us), the bf16 GEMM's epilogue
+// (+8 us per GEMM).  Selected per kernel below.
+template <bool WT> __device__ __forceinline__ void st_wt(float* p, float v) {
+    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool WT> __device__ __forceinline__ void st_wt4(float* p, float4 v) {
+    if constexpr (WT) { const f32x4 x = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory"); }
+    else *reinterpret_cast<float4*>(p) = v;
+}
+#ifndef PPO_WT_B
+#define PPO_WT_B 0
+#endif
+#ifndef PPO_WT_C1
+#define PPO_WT_C1 1                 // measured at config 3 (us per train step): none 45.67, B 46.05, C1 45.49, C2 47.86
+#endif
+#ifndef PPO_WT_C2
+#define PPO_WT_C2 0
+#endif
+
 // Kernel arguments live in memory and the compiler fetches them on demand: a kernel with ~1 KB of by-value arguments
 // (NetDev + the args struct) otherwise starts with 5-7 DEPENDENT scalar-load round trips (~700 cycles each, cold) before
 // its first vector load goes out.  Touching one dword of every 64-byte line of the kernarg segment in one batch costs
@@ -1164,7 +1187,7 @@ __device__ __forceinline__ void dw_tile_body(const DwTile& t, int n, int nsplit,
     for (int i = threadIdx.x; i < TH * TW; i += BLOCK_THREADS) {
         const float s = ((lds[i] + lds[TH * TW + i]) + lds[2 * TH * TW + i]) + lds[3 * TH * TW + i];
         const int orow = i / TW, ocol = i - orow * TW;
-        out[(size_t)(t.i0 + orow) * t.ldo + t.j0 + ocol] = s;
+        st_wt<PPO_WT_B>(out + (size_t)(t.i0 + orow) * t.ldo + t.j0 + ocol, s);
     }
     DSTAMP(4);
 }
@@ -1300,20 +1323,20 @@ __device__ __forceinline__ void dw_main_with_strips(const DwWork& w, int n, int 
         const float4 p2 = *reinterpret_cast<const float4*>(lds + 2 * WSZ + i), p3 = *reinterpret_cast<const float4*>(lds + 3 * WSZ + i);
         const float4 s_ = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
                                       ((p0.w + p1.w) + p2.w) + p3.w);
-        *reinterpret_cast<float4*>(slab + t.out_off + (size_t)(t.i0 + (i >> 6)) * t.ldo + t.j0 + (i & 63)) = s_;
+        st_wt4<PPO_WT_B>(slab + t.out_off + (size_t)(t.i0 + (i >> 6)) * t.ldo + t.j0 + (i & 63), s_);
     }
     if constexpr (NE >= 1) {
         for (int i = threadIdx.x; i < 512; i += BLOCK_THREADS) {
             const int j = 4096 + i;
             const float s_ = ((lds[j] + lds[WSZ + j]) + lds[2 * WSZ + j]) + lds[3 * WSZ + j];
-            slab[e0.out_off + (size_t)(e0.i0 + (i >> 4)) * e0.ldo + e0.j0 + (i & 15)] = s_;
+            st_wt<PPO_WT_B>(slab + e0.out_off + (size_t)(e0.i0 + (i >> 4)) * e0.ldo + e0.j0 + (i & 15), s_);
         }
     }
     if constexpr (NE >= 2) {
         for (int i = threadIdx.x; i < 512; i += BLOCK_THREADS) {
             const int j = 4608 + i;
             const float s_ = ((lds[j] + lds[WSZ + j]) + lds[2 * WSZ + j]) + lds[3 * WSZ + j];
-            slab[e1.out_off + (size_t)(e1.i0 + (i >> 5)) * e1.ldo + e1.j0 + (i & 31)] = s_;
+            st_wt<PPO_WT_B>(slab + e1.out_off + (size_t)(e1.i0 + (i >> 5)) * e1.ldo + e1.j0 + (i & 31), s_);
         }
     }
 }
@@ -1441,12 +1464,12 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
         const int e = (int)(idx - (size_t)s.base);
         if (e < s.count) for (int t = 0; t < a.n_direct; ++t) gsum += a.direct[(size_t)t * a.direct_stride + s.slot_off + e];
     }
-    a.grad[idx] = gsum;
+    st_wt<PPO_WT_C1>(a.grad + idx, gsum);
     float q = gsum * gsum;
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     if ((tid & 63) == 0) red[tid >> 6] = q;
     __syncthreads();
-    if (tid == 0) a.sumsq[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) st_wt<PPO_WT_C1>(a.sumsq + blk, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // rebuild every transposed copy from theta (after parameters were written from the host)
@@ -1562,9 +1585,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         float mo[4], vo[4], to[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) adam_element(gv[k] * scale, mv[k], vv[k], tv[k], 1.0f - a.beta1, 1.0f - a.beta2, alpha, a.eps, mo[k], vo[k], to[k]);
-        *reinterpret_cast<float4*>(a.m + idx) = make_float4(mo[0], mo[1], mo[2], mo[3]);
-        *reinterpret_cast<float4*>(a.v + idx) = make_float4(vo[0], vo[1], vo[2], vo[3]);
-        *reinterpret_cast<float4*>(a.theta + idx) = make_float4(to[0], to[1], to[2], to[3]);
+        st_wt4<PPO_WT_C2>(a.m + idx, make_float4(mo[0], mo[1], mo[2], mo[3]));
+        st_wt4<PPO_WT_C2>(a.v + idx, make_float4(vo[0], vo[1], vo[2], vo[3]));
+        st_wt4<PPO_WT_C2>(a.theta + idx, make_float4(to[0], to[1], to[2], to[3]));
         if (a.theta_bf) {
             typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
             bf16x4_t o4; o4[0] = (__bf16)to[0]; o4[1] = (__bf16)to[1]; o4[2] = (__bf16)to[2]; o4[3] = (__bf16)to[3];
@@ -1575,7 +1598,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int e = e0 + k;
-                if (e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; a.thetaT[gs.t_off + c * gs.prow + r] = to[k]; }
+                if (e < gs.prow * gs.pcol) { const int r = e / gs.pcol, c = e - r * gs.pcol; st_wt<PPO_WT_C2>(a.thetaT + gs.t_off + c * gs.prow + r, to[k]); }
             }
         }
         if (gs.p_off >= 0) {
