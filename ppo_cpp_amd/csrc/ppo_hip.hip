@@ -1288,7 +1288,9 @@ static int step_common(ppo_handle* h, const float* obs, int n, const float* nois
     a.value = value ? h->st_vec[0] : nullptr;
     a.neglogp = neglogp ? h->st_vec[1] : nullptr;
     a.obs_out = nullptr; a.nz = no_norm(); a.n = n;
-    a.seed = h->rng_seed; a.rng_step = h->rng_calls++; a.row_base = (uint32_t)h->rank * (uint32_t)(h->nz_envs > 0 ? h->nz_envs : n);
+    // (only a call that actually draws from the counter RNG advances it: ppo_value / ppo_act_deterministic in the middle of a
+    // rollout must not shift the rollout's noise)
+    a.seed = h->rng_seed; a.rng_step = (sample && action && !noise) ? h->rng_calls++ : h->rng_calls; a.row_base = (uint32_t)h->rank * (uint32_t)(h->nz_envs > 0 ? h->nz_envs : n);
     if (launch_step(h, a)) return -1;
     if (action || det_action) HIP_OK(h, hipMemcpyAsync(action ? action : det_action, h->st_act, (size_t)n * net.A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (value) HIP_OK(h, hipMemcpyAsync(value, h->st_vec[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1386,6 +1388,10 @@ static int norm_alloc_stats(ppo_handle* h, NormDev& s, int dim) {
     return 0;
 }
 
+// (defined with the host-Env rollout forms below) the normaliser's state as a caller expects to see it: no resident rollout
+// kernel holding it in LDS, every posted transition booked
+static int host_quiesce(ppo_handle* h);
+
 int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, float clip_rew, float epsilon) {
     ENTER(h);
     if (n_envs < 1) return fail(h, "ppo_norm_init: n_envs must be positive");
@@ -1425,6 +1431,7 @@ int ppo_norm_set_flags(ppo_handle* h, int norm_obs, int norm_reward) {
 int ppo_norm_reset_returns(ppo_handle* h) {
     ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_reset_returns: call ppo_norm_init first");
+    if (host_quiesce(h)) return -1;
     HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)h->nz_envs * sizeof(float), h->stream));      // env_normalize.hpp:114
     return 0;
 }
@@ -1483,6 +1490,7 @@ static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, con
 int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int training, float* out) {
     ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_obs: call ppo_norm_init first");
+    if (host_quiesce(h)) return -1;
     if (n_envs != h->nz_envs) return fail(h, "ppo_norm_obs: n_envs %d != %d", n_envs, h->nz_envs);
     const size_t cnt = (size_t)n_envs * h->net.O;
     if (ensure_staging(h, n_envs)) return -1;
@@ -1503,6 +1511,7 @@ int ppo_norm_obs(ppo_handle* h, const float* raw_obs, int32_t n_envs, int traini
 int ppo_norm_reward(ppo_handle* h, const float* raw_rew, const float* dones, int32_t n_envs, int training, float* out) {
     ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_reward: call ppo_norm_init first");
+    if (host_quiesce(h)) return -1;
     if (n_envs != h->nz_envs) return fail(h, "ppo_norm_reward: n_envs %d != %d", n_envs, h->nz_envs);
     if (ensure_staging(h, n_envs)) return -1;
     HIP_OK(h, hipMemcpyAsync(h->raw_rew, raw_rew, (size_t)n_envs * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -1516,6 +1525,7 @@ int ppo_norm_reward(ppo_handle* h, const float* raw_rew, const float* dones, int
 int ppo_norm_get_stats(ppo_handle* h, int which, float* mean, float* var, double* count) {
     ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_get_stats: call ppo_norm_init first");
+    if (host_quiesce(h)) return -1;
     NormDev& s = which == 0 ? h->obs_rms : h->ret_rms;
     const int dim = which == 0 ? h->net.O : 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -1528,6 +1538,7 @@ int ppo_norm_get_stats(ppo_handle* h, int which, float* mean, float* var, double
 int ppo_norm_set_stats(ppo_handle* h, int which, const float* mean, const float* var, double count) {
     ENTER(h);
     if (!h->nz_envs) return fail(h, "ppo_norm_set_stats: call ppo_norm_init first");
+    if (host_quiesce(h)) return -1;
     NormDev& s = which == 0 ? h->obs_rms : h->ret_rms;
     const int dim = which == 0 ? h->net.O : 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -1543,6 +1554,7 @@ int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
     if (E < 1 || T < 1) return fail(h, "ppo_rollout_alloc: bad shape");
     if (!h->nz_envs && ppo_norm_init(h, E, 0.99f, 10.f, 10.f, 1e-8f)) return -1;
     if (h->nz_envs != E) return fail(h, "ppo_rollout_alloc: n_envs %d != normaliser's %d", E, h->nz_envs);
+    if (host_quiesce(h)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
     const NetDev& n = h->net;
@@ -1683,7 +1695,11 @@ static int hp_retire(ppo_handle* h, bool ask) {
 // a posted transition that no kernel has booked yet, booked now (outside the resident kernel)
 static int host_flush_pending(ppo_handle* h) {
     if (!h->host_pending) return 0;
-    if (h->E <= NW_ROWS) return enqueue_host_step(h, 0, false, nullptr, 0);
+    if (h->E <= NW_ROWS) {
+        if (enqueue_host_step(h, 0, false, nullptr, 0)) return -1;
+        h->pin_in_busy = true;                                      // that launch reads the pinned block in place: nobody rewrites it before a synchronisation
+        return 0;
+    }
     const size_t E = h->E, on = E * h->net.O;                       // more than one row group: the general path's copy + statistics kernel
     HIP_OK(h, hipMemcpyAsync(h->env_in, h->pin_in, (on + 2 * E) * sizeof(float), hipMemcpyHostToDevice, h->stream));
     h->pin_in_busy = true;
@@ -1691,11 +1707,17 @@ static int host_flush_pending(ppo_handle* h) {
     return enqueue_observe(h, h->host_pending_t);
 }
 
+static int host_quiesce(ppo_handle* h) {
+    if (!h->hp_active && !h->host_pending) return 0;
+    if (hp_retire(h, true)) return -1;
+    return host_flush_pending(h);
+}
+
 int ppo_rollout_reset(ppo_handle* h, const float* raw_obs) {
     if (!h->E) return fail(h, "ppo_rollout_reset: call ppo_rollout_alloc first");
     ENTER(h);
     const size_t on = (size_t)h->E * h->net.O;
-    if (hp_retire(h, true)) return -1;
+    if (host_quiesce(h)) return -1;                             // (a transition observed before the reset is still booked, as on the general path)
     if (h->pin_in_busy) HIP_OK(h, hipStreamSynchronize(h->stream));
     h->pin_in_busy = false; h->host_pending = false; h->hp_posted = 0;
     if (h->pin_flag) { __atomic_store_n(hp_ctl(h) + PCTL_H2D, 0u, __ATOMIC_RELEASE); __atomic_store_n(hp_ctl(h) + PCTL_D2H, 0u, __ATOMIC_RELEASE); }

@@ -239,6 +239,51 @@ def test_resident_workgroup_serves_several_row_groups(hidden, E, T, monkeypatch)
         close(outs["resident"][key], outs["general"][key], rtol=2e-4, atol=2e-5, msg="host Env, resident vs general: " + key)
 
 
+def test_resident_host_kernel_survives_an_unruly_host(monkeypatch):
+    """While the resident rollout kernel waits for the host: another entry point that synchronises the stream (the kernel
+    parks itself after its bounded wait, the call goes through, the next act relaunches it), a rollout abandoned half way and
+    restarted with ppo_rollout_reset, and a ppo_rollout_finish that comes early.  Same bits as one fused launch per env step
+    driven the same way; nothing hangs."""
+    E, T = 3, 10
+    rng = np.random.RandomState(3)
+    trans = [(rng.uniform(-1, 1, (E, 18)).astype(np.float32), rng.uniform(-1, 1, E).astype(np.float32), (rng.uniform(size=E) < 0.2).astype(np.float32))
+             for _ in range(40)]
+    outs = []
+    for resident in (True, False):
+        monkeypatch.setenv("PPO_HIP_NO_HOST_RESIDENT", "0" if resident else "1")
+        monkeypatch.setenv("PPO_HIP_HOST_POLLS", "2000")                 # park after a few milliseconds
+        orc, g = pair((64, 64))
+        g.norm_init(E); g.rollout_alloc(E, T); g.seed(7)
+        got = {}
+        g.rollout_reset(trans[0][0]); k = 1
+        for t in range(4):                                               # an abandoned rollout
+            got["a%d" % t] = g.rollout_act(t, None)
+            g.rollout_observe(t, *trans[k]); k += 1
+            if t == 1:
+                got["stats_mid"] = g.norm_stats(0)[0]                    # synchronises the stream while the kernel waits for the host
+                got["theta_mid"] = g.get_flat(0)
+        g.rollout_reset(trans[k][0]); k += 1                             # start over
+        for t in range(T):
+            got["b%d" % t] = g.rollout_act(t, None)
+            g.rollout_observe(t, *trans[k]); k += 1
+            if t == 6:
+                got["value_mid"] = g.value(trans[0][0])                  # a policy evaluation in between (its own launches)
+        g.rollout_finish(GAMMA, LAM)
+        for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones"):
+            got[f] = g.rollout_get(f)
+        got["mean"], got["var"], cnt = g.norm_stats(0); got["cnt"] = np.float64(cnt)
+        for t in range(3):                                               # a rollout that is finished early
+            got["c%d" % t] = g.rollout_act(t, None)
+            g.rollout_observe(t, *trans[k]); k += 1
+        g.rollout_finish(GAMMA, LAM)
+        got["mean2"], got["var2"], cnt = g.norm_stats(0); got["cnt2"] = np.float64(cnt)
+        got["rew_early"] = g.rollout_get("rewards")[:3]
+        outs.append(got)
+        g.close()
+    for key in outs[0]:
+        np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=key)
+
+
 @pytest.mark.parametrize("hidden,E,T", [((64, 64), 100, 6), ((64, 64), 1024, 8), ((64, 64), 2048, 4), ((16, 8, 8), 333, 5)])
 def test_cooperative_persistent_rollout(hidden, E, T, monkeypatch):
     """65..2048 environments on the device env: ceil(E / 32) resident workgroups, one launch per rollout, meeting once per env
