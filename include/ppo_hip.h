@@ -137,7 +137,12 @@ int ppo_rollout_alloc(ppo_handle* h, int32_t n_envs, int32_t n_steps);
 /* host-Env path (an Env behind env/env.hpp steps on the host):
  *   reset   : EnvNormalize::reset + Runner ctor (runner.hpp:48-50): normalise raw obs, dones = 0
  *   act     : policy step on the current obs -> rollout[t]; actions copied back for Env::step (runner.hpp:75-116)
- *   observe : EnvNormalize::step on the raw step result; stores reward[t]; becomes the current obs/dones */
+ *   observe : EnvNormalize::step on the raw step result; stores reward[t]; becomes the current obs/dones
+ * Call pattern per rollout: act(0), observe(0), act(1), ... observe(T-1), finish.  With <= 64 environments on the narrow path
+ * (the reference's setting is ONE) and no explicit noise, the library serves the whole rollout from one resident kernel: act /
+ * observe then only exchange the actions and the transition through pinned memory.  That is invisible to the caller: any other
+ * entry point called in between sees the state the step-by-step path would show (the kernel is retired and relaunched as
+ * needed), values[t] are available after ppo_rollout_finish, and a host that pauses only costs the kernel a bounded wait. */
 int ppo_rollout_reset(ppo_handle* h, const float* raw_obs);
 int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions_out);
 int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const float* raw_rew, const float* dones);
