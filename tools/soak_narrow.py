@@ -1,0 +1,44 @@
+"""Soak: many collect + update iterations on the narrow path (cooperative rollout, deferred Adam) -- hipGraph replay against
+eager launches, bitwise; then many host-Env rollouts through the resident kernel against one fused launch per env step, bitwise.
+usage: python tools/soak_narrow.py [iterations]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ppo_cpp_amd
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+def run(E, T, nmb, eager):
+    if eager: os.environ["PPO_HIP_NO_GRAPH"] = "1"
+    else: os.environ.pop("PPO_HIP_NO_GRAPH", None)
+    g = ppo_cpp_amd.PPOHip(18, 18, [64, 64]); g.init_orthogonal(0); g.norm_init(E, 0.99); g.rollout_alloc(E, T)
+    means = []
+    for i in range(N):
+        g.collect_synthetic(1234, 0.99, 0.95, None, env0=0, step0=i * T, first=(i == 0))
+        means.append(g.update(3.93141e-4, 0.161023, 4, nmb, None, seed=1000 + i, want_rows=False)[1].copy())
+    th = g.get_flat(0); st = g.norm_stats(0); g.close()
+    return th, np.array(means), st
+for E, T, nmb in ((1024, 64, 32), (1, 512, 8), (48, 32, 4)):
+    t0 = time.time(); a = run(E, T, nmb, False); b = run(E, T, nmb, True)
+    ok = np.isfinite(a[0]).all() and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2][0], b[2][0]) and a[2][2] == b[2][2]
+    print("E %4d T %3d: %d iterations graph vs eager bitwise equal: %s (%.1f s)" % (E, T, N, ok, time.time() - t0), flush=True)
+    assert ok
+def host(E, T, resident):
+    os.environ["PPO_HIP_NO_HOST_RESIDENT"] = "0" if resident else "1"
+    g = ppo_cpp_amd.PPOHip(18, 18, [64, 64]); g.init_orthogonal(0); g.norm_init(E, 0.99); g.rollout_alloc(E, T); g.seed(3)
+    rng = np.random.RandomState(0)
+    g.rollout_reset(rng.uniform(-1, 1, (E, 18)).astype(np.float32))
+    acc = []
+    for it in range(N // 4):
+        for t in range(T):
+            a = g.rollout_act(t, None)
+            g.rollout_observe(t, np.tanh(a).astype(np.float32), a[:, 0].copy(), (rng.uniform(size=E) < 0.05).astype(np.float32))   # the env reacts to the actions
+        g.rollout_finish(0.99, 0.95)
+        acc.append(g.rollout_get("returns").copy())
+        g.update(3.93141e-4, 0.161023, 2, 4, None, seed=it, want_rows=False)
+    th = g.get_flat(0); st = g.norm_stats(0); g.close()
+    return th, np.array(acc), st
+for E, T in ((1, 64), (20, 32), (64, 16)):
+    t0 = time.time(); a = host(E, T, True); b = host(E, T, False)
+    ok = np.isfinite(a[0]).all() and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2][0], b[2][0])
+    print("host Env E %3d T %3d: %d rollouts + updates, resident vs %s: bitwise equal: %s (%.1f s)" % (E, T, N // 4, "fused launches" if E <= 32 else "general path (rounding only)", ok, time.time() - t0), flush=True)
+    if E <= 32: assert ok
+    else: np.testing.assert_allclose(a[1], b[1], rtol=5e-3, atol=5e-3)
