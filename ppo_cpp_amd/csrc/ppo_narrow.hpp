@@ -842,7 +842,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_collect_kernel(NetDev net, 
 // the running statistics (EnvNormalize: obs_rms, ret_rms, the discounted returns, the done flags) live in LDS / registers
 // for the whole rollout; per env step the workgroup normalises, runs the forward pass, samples, steps the env and merges the
 // statistics -- the arithmetic of narrow_collect_kernel, statement for statement -- and only STORES leave the CU (the rollout
-// rows).  Nothing of a step waits on memory or on a launch: 7.5 us per env step (one launch each) becomes ~2.5 us.
+// rows).  Nothing of a step waits on memory or on a launch: 7.5 us per env step (one launch each) becomes 4.4 us.
 // The value tower is not needed inside the loop (values are consumed by the GAE scan only): the host runs it afterwards as
 // one batched launch of narrow_step_kernel over the T x E normalised rows this kernel stored.
 // Replaces, for this case, the loop of runner.hpp:75-127 over policies.hpp:33-46 + env_normalize.hpp:64-116.
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_rollout_kernel(NetDev net, 
     const int r = ptid >> 4, part = ptid & 15;
     const int row = 16 * pipe + r;
     const bool have_helper = NW_PIPES == 2 && E <= 16, helper = have_helper && pipe == 1;
-    float* s_eps = s_istd + 64;                             // [16][A] counter-RNG draws of the current step (written by the helper pipe)                   // a pipe without environments skips the matrix work (it shares the SIMDs' matrix pipes with the live one)
+    float* s_eps = s_istd + 64;                             // [16][A] counter-RNG draws of the current step (written by the helper pipe)
     auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
         const double nb = (double)nbf, tot = cnt + nb;
         const float bvar = bM2 / (float)nb;                                        // running_statistics.hpp:51-54
@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_host_step_kernel(NetDev net
 // reduces its 32 rows to chunk moments (n, mean, M2 per column, the reference's two passes), publishes them, all workgroups
 // meet at a flat arrival counter, and each one combines the G chunks in index order (mean = sum n_k mean_k / n, M2 = sum M2_k
 // + n_k (mean_k - mean)^2: norm_batch_kernel's combine) before RunningStatistics::update's merge -- every workgroup holds the
-// same statistics, bit for bit.  One launch instead of 3 T (policy step, env, statistics kernel per env step): 21 -> ~9 us per
+// same statistics, bit for bit.  One launch instead of 3 T (policy step, env, statistics kernel per env step): 21 -> 14 us per
 // env step at 1024 environments.  The waits are bounded (a workgroup that never arrives sets `err` instead of hanging the GPU).
 // ------------------------------------------------------------------------------------------------------------------------
 struct NwCoopArgs {
@@ -1301,7 +1301,7 @@ struct NwCoopArgs {
     int E, T, G;
     uint32_t seed, step0; int env0;
     float gamma, clip_rew, clip_obs, eps; int norm_obs, norm_rew;
-    float* part;                 // [2 parities][G][NW_COOP_PW] chunk moments
+    float* part;                 // [2 parities][G][2 O + 3] chunk moments (allocated for NW_COOP_PW floats per workgroup)
     unsigned* arrive;            // [G][16] step words, one 64-byte line per workgroup (zeroed by the host before every launch)
     unsigned* err; unsigned spin_limit;
 };
