@@ -2032,13 +2032,13 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             ea.xch = h->adv_xch; ea.n_global = (float)((int64_t)M * h->world);
             if (!h->comm) {
                 ea.phase = 0;
-                hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(256), 0, h->stream, ea);
+                hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(EP_THREADS), 0, h->stream, ea);
                 HIP_OK(h, hipGetLastError());
             } else {
                 // the advantage statistics are over the whole (all-rank) minibatch (ppo2.hpp:401-406)
                 for (int phase = 1; phase <= 3; ++phase) {
                     ea.phase = phase;
-                    hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(256), 0, h->stream, ea);
+                    hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(EP_THREADS), 0, h->stream, ea);
                     HIP_OK(h, hipGetLastError());
                     if (phase == 1 && allreduce_f32(h, h->adv_xch, (size_t)nmb)) return -1;
                     if (phase == 2 && allreduce_f32(h, h->adv_xch + nmb, (size_t)nmb)) return -1;
