@@ -1,0 +1,289 @@
+// ppo_dw2.hpp -- weight gradients AND gradient assembly of one train step in ONE launch, for the 18-obs / [256,256] shape
+// (BASELINE configs[2]; SURVEY 8a rows a13 / a14's inputs: G's .../MatMul_grad/MatMul_1, .../Add_grad/Sum_1 and loss Mean nodes).
+//
+// What it replaces: weight_grad_kernel (8 row splits, 64x64 tiles, a table of tiles in memory) followed by grad_reduce_kernel
+// (a launch whose only job was to add 8 slabs and 128 per-row-block slots: 4.7 us at its launch + round-trip floor).  Here
+//   * the tile a workgroup owns follows from blockIdx alone (no table read in front of the first operand load);
+//   * 4 row splits x 64 tiles of [64 x 32] (+ one thin strip of the first-layer / policy-head gradient each) = 256 workgroups of
+//     8 waves; a wave's whole share of the rows (64 at M = 2048) is requested before its first matrix instruction and the two
+//     waves of a SIMD cover each other's waits;
+//   * the split that finishes a tile LAST adds the 4 slabs in split order (bitwise reproducible whoever is last), writes the
+//     finished gradient tile and its sum of squares: the hand-off is the guide's counter form -- slabs stored write-through
+//     (sc1), every wave drains its stores, a workgroup barrier, ONE agent-scope arrival; the last arriver reads with sc1 loads;
+//   * the per-row-block slots of the train kernel (bias / logstd / value-head gradients, loss sums) are spread over the 256
+//     workgroups, requested at kernel entry and finished after the matrix work.
+// clip + Adam (adam_kernel) then reads `grad` and the 64 + 256 partial sums of squares; nothing else changes.
+#pragma once
+#include "ppo_kernels.hpp"
+
+#define DW2_THREADS 512
+#define DW2_SPLITS 4
+#define DW2_TILES 64                        // 2 towers x (4 x 8) tiles of 64 x 32 of the [256 x 256] second-layer gradient
+#define DW2_GRID (DW2_TILES * DW2_SPLITS)
+#define DW2_CH 128                          // minibatch rows per LDS chunk
+// one chunk in LDS (floats): X [128][64] | Y [128][32] | U [128][32] | W [128][16]; two chunks (double buffer) + 64 words of flags / scratch
+#define DW2_OX 0
+#define DW2_OY (DW2_CH * 64)
+#define DW2_OU (DW2_OY + DW2_CH * 32)
+#define DW2_OW (DW2_OU + DW2_CH * 32)
+#define DW2_BUF (DW2_OW + DW2_CH * 16)
+#define DW2_LDS_FLOATS (2 * DW2_BUF + 64)   // 148 KB: one workgroup per CU (the hand-off's measured form)
+#ifdef PPO_STAMPS
+#define DW2_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = (i) == 15 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
+#else
+#define DW2_STAMP(i) do { } while (0)
+#endif
+#define DW2_SLOTK 8                         // row blocks per lane of a slot job: up to 256 row blocks (4096 minibatch rows)
+
+struct SlotJob { int tower; int slot_off; int dst; int in_norm; };
+
+struct Dw2Args {
+    const float* x0g;            // [n][32]  layer-0 input (written by the policy tower's workgroups)
+    const float* h1[2];          // [n][256] layer-1 input per tower
+    const float* h2pi;           // [n][256] policy head input
+    const float* dy0[2];         // [n][256] dLoss/d(pre-activation of layer 0)
+    const float* dy1[2];         // [n][256] ... of layer 1
+    const float* dmug;           // [n][32]
+    int n;                       // minibatch rows: a multiple of 512
+    float* slabs; unsigned long long slab_stride;      // [4][P_pad]
+    unsigned* counters;          // [DW2_TILES] arrivals; zero between launches (the last arriver resets its word)
+    float* grad;                 // [P_pad + 8]
+    float* parts;                // [DW2_TILES + DW2_GRID] partial sums of squares for the global norm
+    int w0_off[2], w1_off[2], wmu_off;
+    const SlotJob* jobs; int n_jobs, jobs_per_wg;
+    const float* slots[2]; int n_rowblocks, slot_w;
+    float n_local; float* beta_pow; int tail_off;
+    unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS): [grid][16]
+};
+
+// write-through (sc1) 16-byte load for bytes another workgroup stored write-through in this launch.  Inline asm: the compiler
+// does not count it, so the caller waits with dw2_wait4() (which names every destination) before the first use.
+__device__ __forceinline__ f32x4 dw2_ld_sc1(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void dw2_wait4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
+}
+
+// One 1 KB piece (64 lanes x 16 bytes) global -> LDS without a register stop; dst is wave-uniform, src per lane.
+__device__ __forceinline__ void dw2_dma(const float* src_base, unsigned lane_off, float* dst) {
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(src_base) + lane_off), (lptr)dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(Dw2Args)>();
+    DW2_STAMP(15); DW2_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    // workgroups are dealt round-robin over the 8 XCDs: XCD x takes row split x >> 1 of tower x & 1, so the rows x 2 operands
+    // of that split (1 MB at M = 2048) are fetched from the fabric once per XCD and shared by its 32 tiles through the L2, and
+    // they are exactly the rows the train kernel's workgroups on XCD x wrote (its xcd_map 1).  Speed only.
+    const int b = blockIdx.x;
+    const int split = (b >> 1) & 3, tower = b & 1, tile = b >> 3;
+    const int gtile = tower * 32 + tile;
+    const int i0 = (tile >> 3) * 64, j0 = (tile & 7) * 32;
+    // strip: kind 0 = [32 x 16] of the first-layer gradient (both towers, tiles 0..15), kind 1 = [16 x 32] of the policy-head
+    // gradient (policy tower, tiles 16..31), kind 2 = none.  Either way a 32-column operand U (layer-0 input / d mu) and 16
+    // columns [16 s, 16 s + 16) of a 256-column operand W (layer-0 dY / policy-head input).
+#ifdef DW2_NOSTRIP
+    const int kind = 2;          // timing experiment only: results are wrong
+#else
+    const int kind = uni(tile < 16 ? 0 : (tower == 0 ? 1 : 2));
+#endif
+    const int sidx = tile & 15;
+    // the slot-job descriptor of this half-wave: requested first, needed after the first chunk is on its way
+    const int jl = tid >> 5, jb = b * a.jobs_per_wg + jl;
+    const bool has_job = jl < a.jobs_per_wg && jb < a.n_jobs;
+    const int4 jraw = reinterpret_cast<const int4*>(a.jobs)[has_job ? jb : 0];     // unconditional: the wait sits at the first use, not here
+    // ---- operand staging: LDS-DMA, 1 KB pieces; the image of a chunk is [row][cols]; in the 64-column X image the two 32-column
+    // halves of odd rows are swapped (on the SOURCE address: the destination of a piece is lane-linear), so that the 8-byte
+    // fragment reads of rows R and R + 1 (one 32-lane group) cover all 64 banks; 32- and 16-column rows alternate bank halves
+    // by themselves
+    const int rows_split = a.n >> 2, nch = rows_split / DW2_CH;
+    const size_t r0 = (size_t)split * rows_split;
+    const float* Xg = uni(a.h1[tower]) + r0 * 256;
+    const float* Yg = uni(a.dy1[tower]) + r0 * 256;
+    const float* Ug = uni(kind == 1 ? a.dmug : a.x0g) + r0 * 32;
+    const float* Wg = uni(kind == 1 ? a.h2pi : a.dy0[tower]) + r0 * 256;
+    const unsigned lx = (unsigned)(((lane >> 4) * 256 + i0 + 4 * ((lane & 15) ^ (((lane >> 4) & 1) << 3))) * 4);
+    const unsigned ly = (unsigned)(((lane >> 3) * 256 + j0 + 4 * (lane & 7)) * 4);
+    const unsigned lu = (unsigned)(((lane >> 3) * 32 + 4 * (lane & 7)) * 4);
+    const unsigned lw = (unsigned)(((lane >> 2) * 256 + 16 * sidx + 4 * (lane & 3)) * 4);
+    auto stage = [&](int ch, float* buf) __attribute__((always_inline)) {
+        const size_t rb = (size_t)ch * DW2_CH;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = 4 * wave + k; dw2_dma(Xg + (rb + 4 * j) * 256, lx, buf + DW2_OX + j * 256); }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { const int j = 2 * wave + k; dw2_dma(Yg + (rb + 8 * j) * 256, ly, buf + DW2_OY + j * 256); }
+        if (kind != 2) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int j = 2 * wave + k; dw2_dma(Ug + (rb + 8 * j) * 32, lu, buf + DW2_OU + j * 256); }
+            dw2_dma(Wg + (rb + 16 * wave) * 256, lw, buf + DW2_OW + wave * 256);
+        }
+    };
+    stage(0, lds);
+    DW2_STAMP(1);
+    // ---- slot jobs: 32 lanes per element, loads issued now, finished after the matrix work ------------------------------------
+    float sj[DW2_SLOTK];
+    {
+        const int ln = tid & 31;
+        const float* p = (jraw.x ? a.slots[1] : a.slots[0]) + jraw.y;
+#pragma unroll
+        for (int k = 0; k < DW2_SLOTK; ++k) { const int rb = ln + 32 * k; sj[k] = (has_job && rb < a.n_rowblocks) ? p[(size_t)rb * a.slot_w] : 0.f; }
+    }
+    // ---- matrix work: wave w = (X half t = w & 1, K quarter kq = w >> 1) computes the [32 x 32] tile t of the [64 x 32] tile from
+    // rows 32 kq .. 32 kq + 31 of every chunk as 2 x 2 matrix instructions per k-step fed by TWO 8-byte LDS reads (tiles interleaved:
+    // instruction (i, j) covers gradient rows i0 + 32 t + 2 m + i, columns j0 + 2 n + j); the four K quarters meet in LDS at the
+    // end.  Strip: k-steps 4w .. 4w+3 of every chunk, summed over the 8 waves at the end.
+    const int tx = wave & 1, kq = wave >> 1;
+    const int ax = (32 * kq + g) * 64 + ((32 * tx + 2 * c) ^ ((g & 1) << 5)), by = (32 * kq + g) * 32 + 2 * c;
+    const int suo = (16 * wave + g) * 32 + 2 * c, swo = (16 * wave + g) * 16 + c;
+    f32x4 acc[2][2], sacc[2];
+    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = sacc[0] = sacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DW2_STAMP(2);
+    for (int ch = 0; ch < nch; ++ch) {
+        float* buf = lds + (ch & 1) * DW2_BUF;
+#ifndef DW2_NODMA
+        if (ch + 1 < nch) stage(ch + 1, lds + ((ch + 1) & 1) * DW2_BUF);
+#endif
+        const float* Xs = buf + DW2_OX + ax;
+        const float* Ys = buf + DW2_OY + by;
+        float2 xa[8], yb[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { xa[ks] = *reinterpret_cast<const float2*>(Xs + ks * 256); yb[ks] = *reinterpret_cast<const float2*>(Ys + ks * 128); }
+        float2 uu[4]; float ww[4];
+        if (kind != 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { uu[ks] = *reinterpret_cast<const float2*>(buf + DW2_OU + suo + ks * 128); ww[ks] = buf[DW2_OW + swo + ks * 64]; }
+        }
+#ifdef DW2_NOMFMA
+        if (a.n < 0)
+#endif
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks].x, yb[ks].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks].x, yb[ks].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks].y, yb[ks].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks].y, yb[ks].y, acc[1][1], 0, 0, 0);
+        }
+        if (kind == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[ks].x, ww[ks], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[ks].y, ww[ks], sacc[1], 0, 0, 0);
+            }
+        } else if (kind == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[ks], uu[ks].x, sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[ks], uu[ks].y, sacc[1], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next chunk has landed (this wave's pieces) ...
+        __syncthreads();                                            // ... everybody's, and everybody is done reading this one
+    }
+    DW2_STAMP(3);
+    // ---- park: main partials [4 K quarters][64][32], strip partials [8 waves][512]; slot jobs finish here too ----------------------
+    float* park = lds;
+    float* spark = lds + 4 * 2048;
+    float* red2 = lds + 2 * DW2_BUF + 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float2*>(park + kq * 2048 + (32 * tx + 2 * (4 * g + r) + i) * 32 + 2 * c) = make_float2(acc[i][0][r], acc[i][1][r]);
+    if (kind == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) spark[wave * 512 + (2 * (4 * g + r) + t) * 16 + c] = sacc[t][r];                                   // [32 x 16]
+    } else if (kind == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(spark + wave * 512 + (4 * g + r) * 32 + 2 * c) = make_float2(sacc[0][r], sacc[1][r]);   // [16 x 32]
+    }
+    {
+        float s = ((sj[0] + sj[1]) + (sj[2] + sj[3])) + ((sj[4] + sj[5]) + (sj[6] + sj[7]));
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);                                       // within the 32 lanes of the job
+        if ((tid & 31) == 0) {
+            if (has_job) a.grad[jraw.z] = s;
+            red2[tid >> 5] = (has_job && jraw.w) ? s * s : 0.f;
+        }
+    }
+    __syncthreads();
+    float4 m4 = *reinterpret_cast<const float4*>(park + 4 * tid);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) { const float4 p = *reinterpret_cast<const float4*>(park + q * 2048 + 4 * tid); m4.x += p.x; m4.y += p.y; m4.z += p.z; m4.w += p.w; }
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool strip_thread = kind != 2 && tid < 128;
+    if (strip_thread) {
+        sv = *reinterpret_cast<const float4*>(spark + 4 * tid);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { const float4 p = *reinterpret_cast<const float4*>(spark + w * 512 + 4 * tid); sv.x += p.x; sv.y += p.y; sv.z += p.z; sv.w += p.w; }
+    }
+    // element offsets inside the padded parameter vector
+    const unsigned moff = (unsigned)(a.w1_off[tower] + (i0 + (tid >> 3)) * 256 + j0 + 4 * (tid & 7));
+    unsigned soff = 0;
+    if (kind == 0) soff = (unsigned)(a.w0_off[tower] + (tid >> 2) * 256 + 16 * sidx + 4 * (tid & 3));
+    else if (kind == 1) soff = (unsigned)(a.wmu_off + (16 * sidx + (tid >> 3)) * 32 + 4 * (tid & 7));
+    float* slab = a.slabs + (size_t)split * a.slab_stride;
+    st_wt4<true>(slab + moff, m4);
+    if (strip_thread) st_wt4<true>(slab + soff, sv);
+    if (tid == 0) {
+        float q = 0.f;
+        for (int j = 0; j < 16; ++j) q += red2[j];
+        a.parts[DW2_TILES + b] = q;
+    }
+    if (b == 0 && tid == 64) a.grad[a.tail_off + 5] = a.n_local;
+    if (b == 0 && tid == 65) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }    // cur <- next (adam writes next)
+    DW2_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                                // ... before the one arrival that signals for all of them
+    DW2_STAMP(5);
+    int* flag = reinterpret_cast<int*>(lds + 2 * DW2_BUF);
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = (old == DW2_SPLITS - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    DW2_STAMP(6);
+    if (flag[0]) {
+        // last arriver: the four slabs in split order (its own included: same bits whoever is last), all loads first
+        f32x4 p[DW2_SPLITS], q[DW2_SPLITS];
+#pragma unroll
+        for (int s = 0; s < DW2_SPLITS; ++s) {
+            p[s] = dw2_ld_sc1(a.slabs + (size_t)s * a.slab_stride + moff);
+            q[s] = dw2_ld_sc1(a.slabs + (size_t)s * a.slab_stride + (strip_thread ? soff : moff));
+        }
+        dw2_wait4(p[0], p[1], p[2], p[3]);
+        dw2_wait4(q[0], q[1], q[2], q[3]);
+        f32x4 t4 = p[0], u4 = q[0];
+#pragma unroll
+        for (int s = 1; s < DW2_SPLITS; ++s) { t4 += p[s]; u4 += q[s]; }
+        *reinterpret_cast<float4*>(a.grad + moff) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        float sq = (t4[0] * t4[0] + t4[1] * t4[1]) + (t4[2] * t4[2] + t4[3] * t4[3]);
+        if (strip_thread) {
+            *reinterpret_cast<float4*>(a.grad + soff) = make_float4(u4[0], u4[1], u4[2], u4[3]);
+            sq += (u4[0] * u4[0] + u4[1] * u4[1]) + (u4[2] * u4[2] + u4[3] * u4[3]);
+        }
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        float* red = lds + 2 * DW2_BUF + 16;
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += red[w];
+            a.parts[gtile] = s;
+            __hip_atomic_store(a.counters + gtile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+        }
+        __syncthreads();
+    }
+    DW2_STAMP(7);
+}

@@ -7,6 +7,7 @@
 #include "ppo_bf16.hpp"
 #include "ppo_narrow.hpp"
 #include "ppo_peer.hpp"
+#include "ppo_dw2.hpp"
 
 #include <dlfcn.h>
 
@@ -86,6 +87,9 @@ struct ppo_handle {
     DwWork* dw_tiles = nullptr;
     int n_dw_tiles = 0;
     bool dw_has_big = false;
+    // weight gradients + gradient assembly in one launch (ppo_dw2.hpp; 18-obs / [256,256] shape)
+    bool dw2 = false;
+    unsigned* dw2_counters = nullptr; float* dw2_parts = nullptr; SlotJob* dw2_jobs = nullptr; int dw2_n_jobs = 0, dw2_jpw = 0;
     // staging for host-pointer calls
     int st_rows = 0;
     float *st_obs = nullptr, *st_act = nullptr, *st_noise = nullptr, *st_vec[6]{};
@@ -846,9 +850,9 @@ int pick_split(ppo_handle* h, int n) {
 }
 
 // clip + Adam on the assembled gradient (after the optional all-reduce)
-int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0) {      // n_sumsq: entries of h->sumsq (0 = one per 256-element chunk)
+int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* parts_from = nullptr) {      // n_sumsq: entries of h->sumsq / parts_from (0 = one per 256-element chunk)
     ProfScope ps(h, PK_ADAM);
-    const float* parts = h->sumsq; int n_parts = n_sumsq ? n_sumsq : h->n_blocks;
+    const float* parts = parts_from ? parts_from : h->sumsq; int n_parts = n_sumsq ? n_sumsq : h->n_blocks;
     if (!n_sumsq && h->n_blocks > 2048) {                  // very large nets: fold the per-chunk partials first
         n_parts = (h->n_blocks + 1023) / 1024;
         hipLaunchKernelGGL(sumsq_fold_kernel, dim3(n_parts), dim3(256), 0, h->stream, h->sumsq, h->n_blocks, h->sumsq2);
@@ -940,6 +944,9 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
         ProfScope ps(h, PK_ADAM);
         return bf16_refresh_transposes(h);                 // (adam_kernel itself keeps the straight bf16 copy current)
     }
+    const int n_pad = ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
+    const bool use_dw2 = h->dw2 && n_pad % 512 == 0 && n_rb <= 32 * DW2_SLOTK;
+    ta.xcd_map = use_dw2 ? 1 : 0;
     {
         ProfScope ps(h, PK_TRAIN_FB);
         dim3 grid(n_rb, 2);
@@ -955,7 +962,25 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
         else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
         HIP_OK(h, hipGetLastError());
     }
-    const int n_pad = ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
+    if (use_dw2) {
+        // weight gradients + slab / slot sums + partial sums of squares in ONE launch (ppo_dw2.hpp): no grad_reduce_kernel
+        {
+            ProfScope ps(h, PK_DW);
+            Dw2Args da{};
+            da.x0g = h->x0g; da.h2pi = h->hg[0][1]; da.dmug = h->dmug;
+            for (int t = 0; t < 2; ++t) { da.h1[t] = h->hg[t][0]; da.dy0[t] = h->dyg[t][0]; da.dy1[t] = h->dyg[t][1]; da.w0_off[t] = n.w_off[t][0]; da.w1_off[t] = n.w_off[t][1]; da.slots[t] = h->slots[t]; }
+            da.wmu_off = n.wmu_off; da.n = n_pad; da.slabs = h->slabs; da.slab_stride = (unsigned long long)h->P_pad; da.counters = h->dw2_counters;
+            da.grad = h->grad; da.parts = h->dw2_parts; da.jobs = h->dw2_jobs; da.n_jobs = h->dw2_n_jobs; da.jobs_per_wg = h->dw2_jpw;
+#ifdef PPO_STAMPS
+            da.stamps = g_stamps + 4096 * 16;
+#endif
+            da.n_rowblocks = n_rb; da.slot_w = n.slot_w; da.n_local = (float)ta.n; da.beta_pow = h->beta_pow; da.tail_off = h->P_pad;
+            hipLaunchKernelGGL(weight_grad_assemble_kernel, dim3(DW2_GRID), dim3(DW2_THREADS), (size_t)DW2_LDS_FLOATS * sizeof(float), h->stream, da);
+            HIP_OK(h, hipGetLastError());
+        }
+        if (h->comm) { if (enqueue_grad_allreduce(h)) return -1; return enqueue_adam(h, loss_row); }
+        return enqueue_adam(h, loss_row, DW2_TILES + DW2_GRID, h->dw2_parts);
+    }
     const int split = pick_split(h, n_pad);
     {
         ProfScope ps(h, PK_DW);
@@ -1082,6 +1107,36 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         return bail(0);
     build_narrow_layout(h);
     if (upload_grad_src(h)) return bail(0);
+    { const char* e = getenv("PPO_HIP_NO_DW2"); const NetDev& nn = h->net;
+      h->dw2 = !(e && e[0] == '1') && h->early && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256; }
+    if (h->dw2) {
+        if (hipFuncSetAttribute((const void*)weight_grad_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS_FLOATS * 4) != hipSuccess) { fail(h, "hipFuncSetAttribute failed for weight_grad_assemble_kernel"); return bail(0); }
+        // slot jobs: every element the train kernel leaves as per-row-block partial sums (bias / logstd / value-head gradients), then the loss sums
+        const NetDev& nn = h->net;
+        std::vector<SlotJob> jobs;
+        for (const Tensor& t : h->tensors) {
+            const std::string nm = t.name;
+            const int tower = nm[0] == 'v' ? 1 : 0;
+            int l = -1;
+            if (nm.find("_fc") != std::string::npos) l = atoi(nm.c_str() + 5);
+            int so = -1, cnt = 0;
+            if (l >= 0 && nm.substr(nm.size() - 2) == "/b") { so = nn.slot_db[l]; cnt = nn.Hp[l]; }
+            else if (nm == "vf/w") { so = nn.slot_head; cnt = nn.Hp[nn.L - 1]; }
+            else if (nm == "vf/b") { so = nn.slot_aux; cnt = 1; }
+            else if (nm == "pi/b") { so = nn.slot_head; cnt = nn.Ap; }
+            else if (nm == "pi/logstd") { so = nn.slot_aux; cnt = nn.Ap; }
+            for (int e2 = 0; e2 < cnt; ++e2) jobs.push_back(SlotJob{tower, so + e2, t.off_pad + e2, 1});
+        }
+        for (int q = 0; q < 5; ++q) jobs.push_back(SlotJob{q == 1 ? 1 : 0, nn.slot_loss + (q <= 1 ? 0 : q - 1), h->P_pad + q, 0});   // {pg, vf, ent, kl, cf} sums
+        h->dw2_n_jobs = (int)jobs.size();
+        h->dw2_jpw = (h->dw2_n_jobs + DW2_GRID - 1) / DW2_GRID;
+        if (h->dw2_jpw > DW2_THREADS / 32) h->dw2 = false;
+        else {
+            if (dev_alloc(h, &h->dw2_jobs, jobs.size()) || dev_alloc(h, &h->dw2_counters, (size_t)DW2_TILES) || dev_alloc(h, &h->dw2_parts, (size_t)DW2_TILES + DW2_GRID)) return bail(0);
+            HIP_OK(h, hipMemcpyAsync(h->dw2_jobs, jobs.data(), jobs.size() * sizeof(SlotJob), hipMemcpyHostToDevice, h->stream));
+            HIP_OK(h, hipStreamSynchronize(h->stream));
+        }
+    }
     if (h->bf.on && bf16_create(h)) return bail(0);
     if (h->narrow) {
         attr_ok = hipFuncSetAttribute((const void*)narrow_train_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
@@ -1132,6 +1187,9 @@ void ppo_destroy(ppo_handle* h) {
     if (h->nw_alt) (void)hipFree(h->nw_alt);
     if (h->nw_coop) (void)hipFree(h->nw_coop);
     if (h->nw_alt_counts) (void)hipFree(h->nw_alt_counts);
+    if (h->dw2_jobs) (void)hipFree(h->dw2_jobs);
+    if (h->dw2_counters) (void)hipFree(h->dw2_counters);
+    if (h->dw2_parts) (void)hipFree(h->dw2_parts);
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->sumsq2, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
                     h->obs_rms.var, h->obs_rms.count, h->ret_rms.mean, h->ret_rms.var, h->ret_rms.count, h->nz_ret, h->stats_xch, h->stats_part, h->stats_counter, h->adv_xch, h->ro_obs, h->ro_act,

@@ -126,7 +126,7 @@ template <bool WT> __device__ __forceinline__ void st_wt(float* p, float v) {
     if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
 }
 template <bool WT> __device__ __forceinline__ void st_wt4(float* p, float4 v) {
-    if constexpr (WT) { const f32x4 x = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory"); }
+    if constexpr (WT) { const f32x4 x = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory"); }   // (s_nop: the data registers stay untouched until the store has read them)
     else *reinterpret_cast<float4*>(p) = v;
 }
 #ifndef PPO_WT_B
@@ -709,7 +709,7 @@ __device__ __forceinline__ void stage_block_inputs(const NetDev& net, const floa
 
 #ifdef PPO_STAMPS
 #define STAMP(i)                                                                                        \
-    do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+    do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)(tower * gridDim.x + rb) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -833,6 +833,7 @@ struct TrainArgs {
     float* dmug;                 // [n][Ap]
     float* slots[2];             // [tower][n_blocks][slot_w]
     unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS): [blocks][16] s_memtime stamps
+    int xcd_map;                 // workgroup -> (tower, row tile) placement, see the kernel (speed only)
 };
 
 // EARLY (18-obs / [256, 256-multiple] shape only: Kp0 == Ap == 16*KS, Hp[0] == Hp[L-1] == 256, L >= 2): the weights of the three
@@ -844,11 +845,18 @@ template <int CT, int KS, int CTH, bool WIDE, bool EARLY = false>
 __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     warm_kernargs<sizeof(NetDev) + sizeof(TrainArgs)>();
-    const int tower = blockIdx.y;
     // XCD-aware row mapping: workgroups are dealt round-robin over the 8 XCDs; giving XCD x the CONTIGUOUS row tiles
     // [x*G/8, (x+1)*G/8) makes the activations / gradients this kernel leaves in that XCD's L2 exactly the rows the
-    // weight-gradient kernel's row split x (also on XCD x) streams next.
-    const int rb = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+    // weight-gradient kernel's row split x (also on XCD x) streams next.  xcd_map 1 (weight_grad_assemble_kernel follows, 4 row
+    // splits): XCD x takes tower x & 1 and the row tiles of split x >> 1 -- what that kernel's workgroups on XCD x read, and
+    // nobody else's (write-through stores to lines another XCD's L2 has read since cost this kernel 2 us).  Speed only.
+    int tower = blockIdx.y;
+    int rb = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+    if (a.xcd_map == 1 && gridDim.x % 4 == 0) {
+        const int lid = (int)(blockIdx.x + gridDim.x * blockIdx.y), x = lid & 7, q = lid >> 3;
+        tower = x & 1;
+        rb = (x >> 1) * (int)(gridDim.x / 4) + q;
+    }
     const int row0 = rb * ROWS_PER_BLOCK;
     const int tid = threadIdx.x;
     const int ld0 = net.Kp0 + LDS_PAD;
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
                                              }
                                          }
 #ifdef PPO_STAMPS
-                                         , a.stamps ? (l == PPO_STAMP_LAYER ? a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 : nullptr) : nullptr
+                                         , a.stamps ? (l == PPO_STAMP_LAYER ? a.stamps + (size_t)(tower * gridDim.x + rb) * 32 + 16 : nullptr) : nullptr
 #endif
                                          );
         lds_barrier();
