@@ -20,14 +20,15 @@
 #define DW2_SPLITS 4
 #define DW2_TILES 64                        // 2 towers x (4 x 8) tiles of 64 x 32 of the [256 x 256] second-layer gradient
 #define DW2_GRID (DW2_TILES * DW2_SPLITS)
-#define DW2_CH 128                          // minibatch rows per LDS chunk
-// one chunk in LDS (floats): X [128][64] | Y [128][32] | U [128][32] | W [128][16]; two chunks (double buffer) + 64 words of flags / scratch
+#define DW2_CH 64                           // minibatch rows per LDS chunk
+// one chunk in LDS (floats): X [64][64] | Y [64][32] | U [64][32] | W [64][16]; a ring of three chunks + 64 words of flags / scratch
 #define DW2_OX 0
 #define DW2_OY (DW2_CH * 64)
 #define DW2_OU (DW2_OY + DW2_CH * 32)
 #define DW2_OW (DW2_OU + DW2_CH * 32)
 #define DW2_BUF (DW2_OW + DW2_CH * 16)
-#define DW2_LDS_FLOATS (2 * DW2_BUF + 64)   // 148 KB: one workgroup per CU (the hand-off's measured form)
+#define DW2_NBUF 3
+#define DW2_LDS_FLOATS (DW2_NBUF * DW2_BUF + 64)   // 108 KB: one workgroup per CU (the hand-off's measured form)
 #ifdef PPO_STAMPS
 #define DW2_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = (i) == 15 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
 #else
@@ -67,11 +68,15 @@ __device__ __forceinline__ void dw2_wait4(f32x4& a, f32x4& b, f32x4& c, f32x4& d
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
 }
 
-// One 1 KB piece (64 lanes x 16 bytes) global -> LDS without a register stop; dst is wave-uniform, src per lane.
+// One 1 KB piece (64 lanes x 16 bytes) global -> LDS without a register stop; dst is wave-uniform, src per lane.  Inline asm on
+// purpose: hipcc treats the builtin form as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front of every later ds_read,
+// which drains the pieces this kernel keeps in flight across two iterations; its own counted waits (wait_keep_one) order them.
+// M0 carries the LDS byte address and is restored in the same statement (the compiler owns M0).
 __device__ __forceinline__ void dw2_dma(const float* src_base, unsigned lane_off, float* dst) {
-    typedef const __attribute__((address_space(1))) void* gptr;
-    typedef __attribute__((address_space(3))) void* lptr;
-    __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(src_base) + lane_off), (lptr)dst, 16, 0, 0);
+    const char* src = reinterpret_cast<const char*>(src_base) + lane_off;
+    const unsigned lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)dst));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
 }
 
 __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Args a) {
@@ -114,20 +119,83 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     const unsigned ly = (unsigned)(((lane >> 3) * 256 + j0 + 4 * (lane & 7)) * 4);
     const unsigned lu = (unsigned)(((lane >> 3) * 32 + 4 * (lane & 7)) * 4);
     const unsigned lw = (unsigned)(((lane >> 2) * 256 + 16 * sidx + 4 * (lane & 3)) * 4);
-    auto stage = [&](int ch, float* buf) __attribute__((always_inline)) {
+    // pieces of one 64-row chunk: X 16 (4 rows each), Y 8, U 8 (8 rows each), W 4 (16 rows each); wave w requests X 2w, 2w+1, Y w, U w
+    // and (w < 4) W w: NP pieces per chunk, the count the in-loop waits leave in flight
+    auto stage = [&](int ch) __attribute__((always_inline)) {
+        float* buf = lds + (ch % DW2_NBUF) * DW2_BUF;
         const size_t rb = (size_t)ch * DW2_CH;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int j = 4 * wave + k; dw2_dma(Xg + (rb + 4 * j) * 256, lx, buf + DW2_OX + j * 256); }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { const int j = 2 * wave + k; dw2_dma(Yg + (rb + 8 * j) * 256, ly, buf + DW2_OY + j * 256); }
+        for (int k = 0; k < 2; ++k) { const int j = 2 * wave + k; dw2_dma(Xg + (rb + 4 * j) * 256, lx, buf + DW2_OX + j * 256); }
+        dw2_dma(Yg + (rb + 8 * wave) * 256, ly, buf + DW2_OY + wave * 256);
         if (kind != 2) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) { const int j = 2 * wave + k; dw2_dma(Ug + (rb + 8 * j) * 32, lu, buf + DW2_OU + j * 256); }
-            dw2_dma(Wg + (rb + 16 * wave) * 256, lw, buf + DW2_OW + wave * 256);
+            dw2_dma(Ug + (rb + 8 * wave) * 32, lu, buf + DW2_OU + wave * 256);
+            if (wave < 4) dw2_dma(Wg + (rb + 16 * wave) * 256, lw, buf + DW2_OW + wave * 256);
         }
     };
-    stage(0, lds);
+    // wait until at most ONE chunk's pieces of this wave are still in flight (vector-memory operations complete in order)
+    auto wait_keep_one = [&]() __attribute__((always_inline)) {
+        if (kind == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+    stage(0);
+    if (nch > 1) stage(1);
+    if (nch > 2) stage(2);
     DW2_STAMP(1);
+    // ---- matrix work: wave w = (X half t = w & 1, K quarter kq = w >> 1) computes the [32 x 32] tile t of the [64 x 32] tile from
+    // rows 16 kq .. 16 kq + 15 of every chunk as 2 x 2 matrix instructions per k-step fed by TWO 8-byte LDS reads (tiles interleaved:
+    // instruction (i, j) covers gradient rows i0 + 32 t + 2 m + i, columns j0 + 2 n + j); the four K quarters meet in LDS at the
+    // end.  Strip: k-steps 2w, 2w+1 of every chunk, summed over the 8 waves at the end.  The fragments of chunk i+1 are read
+    // while the matrix instructions of chunk i run from registers; chunk i+3 is requested at the top of iteration i, chunk i+2
+    // must have landed at its bottom: two iterations of lead for every piece.
+    const int tx = wave & 1, kq = wave >> 1;
+    const int ax = (16 * kq + g) * 64 + ((32 * tx + 2 * c) ^ ((g & 1) << 5)), by = (16 * kq + g) * 32 + 2 * c;
+    const int suo = (8 * wave + g) * 32 + 2 * c, swo = (8 * wave + g) * 16 + c;
+    struct Frags { float2 xa[4], yb[4], uu[2]; float ww[2]; };
+    auto read_frags = [&](Frags& f, int ch) __attribute__((always_inline)) {
+        const float* buf = lds + (ch % DW2_NBUF) * DW2_BUF;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f.xa[ks] = *reinterpret_cast<const float2*>(buf + DW2_OX + ax + ks * 256);
+            f.yb[ks] = *reinterpret_cast<const float2*>(buf + DW2_OY + by + ks * 128);
+        }
+        if (kind != 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { f.uu[ks] = *reinterpret_cast<const float2*>(buf + DW2_OU + suo + ks * 128); f.ww[ks] = buf[DW2_OW + swo + ks * 64]; }
+        }
+    };
+    f32x4 acc[2][2], sacc[2];
+    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = sacc[0] = sacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+#ifdef DW2_NOMFMA
+        if (a.n < 0)
+#endif
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].x, f.yb[ks].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].x, f.yb[ks].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].y, f.yb[ks].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].y, f.yb[ks].y, acc[1][1], 0, 0, 0);
+        }
+        if (kind == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.uu[ks].x, f.ww[ks], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.uu[ks].y, f.ww[ks], sacc[1], 0, 0, 0);
+            }
+        } else if (kind == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ww[ks], f.uu[ks].x, sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ww[ks], f.uu[ks].y, sacc[1], 0, 0, 0);
+            }
+        }
+    };
+    // chunks 0 and 1 (and the job descriptor) have landed once at most the pieces of chunk 2 are in flight
+    if (nch > 2) wait_keep_one(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags fa, fb;
+    read_frags(fa, 0);
     // ---- slot jobs: 32 lanes per element, loads issued now, finished after the matrix work ------------------------------------
     float sj[DW2_SLOTK];
     {
@@ -136,64 +204,26 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
 #pragma unroll
         for (int k = 0; k < DW2_SLOTK; ++k) { const int rb = ln + 32 * k; sj[k] = (has_job && rb < a.n_rowblocks) ? p[(size_t)rb * a.slot_w] : 0.f; }
     }
-    // ---- matrix work: wave w = (X half t = w & 1, K quarter kq = w >> 1) computes the [32 x 32] tile t of the [64 x 32] tile from
-    // rows 32 kq .. 32 kq + 31 of every chunk as 2 x 2 matrix instructions per k-step fed by TWO 8-byte LDS reads (tiles interleaved:
-    // instruction (i, j) covers gradient rows i0 + 32 t + 2 m + i, columns j0 + 2 n + j); the four K quarters meet in LDS at the
-    // end.  Strip: k-steps 4w .. 4w+3 of every chunk, summed over the 8 waves at the end.
-    const int tx = wave & 1, kq = wave >> 1;
-    const int ax = (32 * kq + g) * 64 + ((32 * tx + 2 * c) ^ ((g & 1) << 5)), by = (32 * kq + g) * 32 + 2 * c;
-    const int suo = (16 * wave + g) * 32 + 2 * c, swo = (16 * wave + g) * 16 + c;
-    f32x4 acc[2][2], sacc[2];
-    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = sacc[0] = sacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     DW2_STAMP(2);
-    for (int ch = 0; ch < nch; ++ch) {
-        float* buf = lds + (ch & 1) * DW2_BUF;
+    auto iteration = [&](int i, Frags& cur, Frags& nxt) __attribute__((always_inline)) {
 #ifndef DW2_NODMA
-        if (ch + 1 < nch) stage(ch + 1, lds + ((ch + 1) & 1) * DW2_BUF);
+        if (i + 3 < nch) stage(i + 3);                 // into the buffer of chunk i: every wave read its fragments of it before the last barrier
 #endif
-        const float* Xs = buf + DW2_OX + ax;
-        const float* Ys = buf + DW2_OY + by;
-        float2 xa[8], yb[8];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) { xa[ks] = *reinterpret_cast<const float2*>(Xs + ks * 256); yb[ks] = *reinterpret_cast<const float2*>(Ys + ks * 128); }
-        float2 uu[4]; float ww[4];
-        if (kind != 2) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { uu[ks] = *reinterpret_cast<const float2*>(buf + DW2_OU + suo + ks * 128); ww[ks] = buf[DW2_OW + swo + ks * 64]; }
-        }
-#ifdef DW2_NOMFMA
-        if (a.n < 0)
-#endif
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks].x, yb[ks].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks].x, yb[ks].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks].y, yb[ks].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks].y, yb[ks].y, acc[1][1], 0, 0, 0);
-        }
-        if (kind == 0) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[ks].x, ww[ks], sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[ks].y, ww[ks], sacc[1], 0, 0, 0);
-            }
-        } else if (kind == 1) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[ks], uu[ks].x, sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[ks], uu[ks].y, sacc[1], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next chunk has landed (this wave's pieces) ...
-        __syncthreads();                                            // ... everybody's, and everybody is done reading this one
+        if (i + 1 < nch) read_frags(nxt, i + 1);
+        mma(cur);
+        if (i + 3 < nch) wait_keep_one(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk i+2 has landed (this wave's pieces)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          // this wave's reads of chunk i+1 are done
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int i = 0; i < nch; i += 2) {
+        iteration(i, fa, fb);
+        if (i + 1 < nch) iteration(i + 1, fb, fa);
     }
     DW2_STAMP(3);
     // ---- park: main partials [4 K quarters][64][32], strip partials [8 waves][512]; slot jobs finish here too ----------------------
     float* park = lds;
     float* spark = lds + 4 * 2048;
-    float* red2 = lds + 2 * DW2_BUF + 32;
+    float* red2 = lds + DW2_NBUF * DW2_BUF + 32;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                                // ... before the one arrival that signals for all of them
     DW2_STAMP(5);
-    int* flag = reinterpret_cast<int*>(lds + 2 * DW2_BUF);
+    int* flag = reinterpret_cast<int*>(lds + DW2_NBUF * DW2_BUF);
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag[0] = (old == DW2_SPLITS - 1) ? 1 : 0;
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
             sq += (u4[0] * u4[0] + u4[1] * u4[1]) + (u4[2] * u4[2] + u4[3] * u4[3]);
         }
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-        float* red = lds + 2 * DW2_BUF + 16;
+        float* red = lds + DW2_NBUF * DW2_BUF + 16;
         if (lane == 0) red[wave] = sq;
         __syncthreads();
         if (tid == 0) {
