@@ -38,6 +38,10 @@ public:
     std::vector<std::pair<int, float>>& episode_rewards() { return episodes_; }
     bool quiet = false;
     unsigned long long seed = 0;
+    // parity runs (tests): explicit exploration noise [n_updates][n_steps][n_envs][A] and epoch permutations
+    // [n_updates][noptepochs][n_batch] (out.row(perm[i]) = in.row(i), ppo2.hpp:291-296) replace the generators of both loops
+    const float* explicit_noise = nullptr;
+    const int32_t* explicit_perms = nullptr;
     // host-Env collect split, summed over the updates after the second (the first pays allocation + graph capture, the first
     // env step after that capture a one-off runtime hiccup)
     double phase_env_ms = 0, phase_act_ms = 0, phase_observe_ms = 0;
@@ -113,7 +117,10 @@ public:
     void learn(int total_timesteps, int num_saves = 0, const std::string& save_path = "") {
         num_timesteps_ = 0;
         updates_this_learn_ = 0;
-        check(ppo_seed(h_, seed));                                 // exploration noise follows PPO2::seed / --seed
+        if (!seeded_ || seeded_with_ != seed) {                    // exploration noise follows PPO2::seed / --seed; a repeated learn() with the
+            check(ppo_seed(h_, seed));                             // same seed continues the generator instead of replaying its draws
+            seeded_ = true; seeded_with_ = seed;
+        }
         const int n_updates = total_timesteps / n_batch_;
         save_interval_ = num_saves > 0 ? static_cast<int>(std::ceil(static_cast<float>(n_updates) / static_cast<float>(num_saves))) : -1;
         save_path_ = save_path;
@@ -151,7 +158,8 @@ private:
             for (int t = 0; t < T; ++t) {
                 for (int e = 0; e < E; ++e) done_view(e, t) = dones(e, 0);
                 const auto p0 = clk::now();
-                check(ppo_rollout_act(h_, t, nullptr, actions.data()));
+                const float* eps = explicit_noise ? explicit_noise + ((size_t)(update - 1) * T + t) * E * actions.cols() : nullptr;
+                check(ppo_rollout_act(h_, t, eps, actions.data()));
                 const auto p1 = clk::now();
                 const std::vector<Mat> r = raw.step(actions);
                 const auto p2 = clk::now();
@@ -166,7 +174,8 @@ private:
             const auto t1 = clk::now();
             num_timesteps_ += n_batch_;
             UpdateLog log{};
-            check(ppo_update(h_, learning_rate_, cliprange_, noptepochs_, nminibatches_, nullptr, seed + (unsigned long long)update, nullptr,
+            const int32_t* perms = explicit_perms ? explicit_perms + (size_t)(update - 1) * noptepochs_ * n_batch_ : nullptr;
+            check(ppo_update(h_, learning_rate_, cliprange_, noptepochs_, nminibatches_, perms, seed + (unsigned long long)update, nullptr,
                              log.losses));
             const auto t2 = clk::now();
             finish_update(log, t0, t1, t2, rew_view, done_view);
@@ -179,6 +188,7 @@ private:
         const int batch_size = n_batch_ / nminibatches_;
         for (int update = 1; update <= n_updates; ++update) {
             const auto t0 = clk::now();
+            runner.noise = explicit_noise ? explicit_noise + (size_t)(update - 1) * n_batch_ * env_.get_action_space_size() : nullptr;
             const MiniBatch mb = runner.run();
             const auto t1 = clk::now();
             const auto all = mb.get_train_input();
@@ -187,7 +197,8 @@ private:
             num_timesteps_ += n_batch_;
             double acc[5] = {0, 0, 0, 0, 0};
             for (int epoch = 0; epoch < noptepochs_; ++epoch) {
-                std::shuffle(perm.begin(), perm.end(), rng);                 // cumulative, like ppo2.hpp:288
+                if (explicit_perms) std::memcpy(perm.data(), explicit_perms + ((size_t)(update - 1) * noptepochs_ + epoch) * n_batch_, sizeof(int) * (size_t)n_batch_);
+                else std::shuffle(perm.begin(), perm.end(), rng);            // cumulative, like ppo2.hpp:288
                 std::vector<Mat> shuffled;
                 for (const auto& v : all) {                                  // out.row(perm[i]) = in.row(i)  (ppo2.hpp:291-296)
                     Mat o(v->rows(), v->cols());
@@ -247,6 +258,7 @@ private:
     Mat episode_reward_;
     int save_interval_ = -1;
     int updates_this_learn_ = 0;
+    bool seeded_ = false; unsigned long long seeded_with_ = 0;
     std::string save_path_;
     ckpt::Bundle extra_tensors_;      // q/w, q/b carried through load -> save
     std::vector<UpdateLog> history_;

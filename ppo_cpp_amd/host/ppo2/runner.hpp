@@ -29,7 +29,9 @@ public:
         Mat values(T, E), neglogp(T, E), dones(T, E), rewards(T, E), raw_rewards(T, E);
         for (int t = 0; t < T; ++t) {
             std::memcpy(&obs[(size_t)t * E * O], obs_.data(), sizeof(float) * (size_t)E * O);
-            const std::vector<Mat> s = model_.step(obs_);
+            Mat eps;                                                       // explicit exploration noise of this env step [E, A], if any
+            if (noise) { eps = Mat(E, A); std::memcpy(eps.data(), noise + (size_t)t * E * A, sizeof(float) * (size_t)E * A); }
+            const std::vector<Mat> s = model_.step(obs_, noise ? &eps : nullptr);
             assert(s[0].rows() == E && s[0].cols() == A && s[1].rows() == E && s[2].rows() == E);
             std::memcpy(&act[(size_t)t * E * A], s[0].data(), sizeof(float) * (size_t)E * A);
             mat_set_row(values, t, s[1].data());
@@ -57,6 +59,10 @@ public:
         mb.unnormalized_rewards = flatten(raw_rewards.data(), T, E, 1);
         return mb;
     }
+
+    // parity runs: [n_steps, n_envs, A] standard-normal draws used instead of the on-device generator (the reference draws from
+    // TF's RandomStandardNormal with seed 0, G:5894, i.e. it is not reproducible; SURVEY 7 "noise is an explicit input")
+    const float* noise = nullptr;
 
     const Mat& current_obs() const { return obs_; }
     const Mat& current_dones() const { return dones_; }

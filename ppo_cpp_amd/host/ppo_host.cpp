@@ -181,7 +181,18 @@ struct ppo_host_result {
     double phase_env_ms, phase_act_ms, phase_observe_ms;   // host-Env collect split per update: Env::step | ppo_rollout_act (kernel + D2H + sync) | ppo_rollout_observe (pack + H2D enqueue)
 };
 
-int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
+// explicit inputs / extra outputs of a parity run (all optional)
+struct ppo_host_explicit {
+    const float* theta_in;       // [P] dense initial weights (null: ppo_init_orthogonal(0))
+    const float* noise;          // [n_updates][n_steps][n_envs][A]
+    const int32_t* perms;        // [n_updates][noptepochs][n_batch]
+    float* losses_out;           // [n_updates][5] mean losses of every update (ppo2.hpp:335)
+    float* theta_out;            // [P]
+    float* obs_mean; float* obs_var; double* obs_count;      // obs_rms [18], [18], [1]
+    float* ret_mean; float* ret_var; double* ret_count;      // ret_rms [1], [1], [1]
+};
+
+static int run_learn(const ppo_host_args* a, ppo_host_result* out, const ppo_host_explicit* x) {
     std::memset(out, 0, sizeof *out);
     ppo_handle* h = nullptr;
     try {
@@ -190,6 +201,7 @@ int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
         cfg.device = a->device;
         if (ppo_create(&cfg, &h) != 0) throw std::runtime_error(ppo_last_error(nullptr));
         if (ppo_init_orthogonal(h, 0) != 0) throw std::runtime_error(ppo_last_error(h));
+        if (x && x->theta_in && ppo_set_flat(h, 0, x->theta_in, ppo_num_params(h)) != 0) throw std::runtime_error(ppo_last_error(h));
         std::vector<std::shared_ptr<Env>> envs;
         for (int i = 0; i < a->n_envs; ++i) {
             if (a->seeded_env) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i));
@@ -222,6 +234,7 @@ int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
             literal.quiet = true;
             PPO2& algo = a->reference_loop ? literal : algorithm;
             algo.seed = a->seed;
+            if (x) { algo.explicit_noise = x->noise; algo.explicit_perms = x->perms; }
             const auto t0 = std::chrono::steady_clock::now();
             algo.learn(a->n_updates * a->n_envs * a->n_steps);
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -243,6 +256,12 @@ int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
             env.serialize(j);
             out->obs_count = j["obs_rms"]["count"].get<double>(); out->ret_count = j["ret_rms"]["count"].get<double>();
             env.deserialize(j);
+            if (x) {
+                if (x->losses_out) for (size_t i = 0; i < hist.size(); ++i) std::memcpy(x->losses_out + 5 * i, hist[i].losses, sizeof(float) * 5);
+                if (x->theta_out && ppo_get_flat(h, 0, x->theta_out, ppo_num_params(h)) != 0) throw std::runtime_error(ppo_last_error(h));
+                if (x->obs_mean && ppo_norm_get_stats(h, 0, x->obs_mean, x->obs_var, x->obs_count) != 0) throw std::runtime_error(ppo_last_error(h));
+                if (x->ret_mean && ppo_norm_get_stats(h, 1, x->ret_mean, x->ret_var, x->ret_count) != 0) throw std::runtime_error(ppo_last_error(h));
+            }
         }
         ppo_destroy(h);
         return 0;
@@ -252,5 +271,12 @@ int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) {
         return -1;
     }
 }
+
+int ppo_host_learn(const ppo_host_args* a, ppo_host_result* out) { return run_learn(a, out, nullptr); }
+
+// PPO2::learn with EXPLICIT exploration noise and epoch permutations on the reference's stack (SeededEnvMock x N -> VecEnv ->
+// EnvNormalize -> PPO2; ppo2.cpp:188-250), through the HBM-resident loop or (reference_loop) the literal one: what
+// tests/test_host_layer.py holds against oracle.collect + oracle.update update by update (ppo2.hpp:264-349).
+int ppo_host_learn_explicit(const ppo_host_args* a, const ppo_host_explicit* x, ppo_host_result* out) { return run_learn(a, out, x); }
 
 }  // extern "C"

@@ -51,3 +51,38 @@ def learn(n_envs, n_steps, hidden, n_updates, nminibatches=32, noptepochs=10, lr
     return {"env_steps_per_s": r.env_steps_per_s, "collect_ms": r.collect_ms, "update_ms": r.update_ms,
             "losses": [float(x) for x in r.losses], "fps_last": r.fps_last, "obs_count": r.obs_count, "ret_count": r.ret_count,
             "phase_ms": {"env_step": r.phase_env_ms, "act_kernel_d2h_sync": r.phase_act_ms, "observe_pack_h2d_enqueue": r.phase_observe_ms}}
+
+
+class HostExplicit(C.Structure):
+    _fields_ = [("theta_in", C.c_void_p), ("noise", C.c_void_p), ("perms", C.c_void_p), ("losses_out", C.c_void_p), ("theta_out", C.c_void_p),
+                ("obs_mean", C.c_void_p), ("obs_var", C.c_void_p), ("obs_count", C.c_void_p),
+                ("ret_mean", C.c_void_p), ("ret_var", C.c_void_p), ("ret_count", C.c_void_p)]
+
+
+def learn_explicit(n_envs, n_steps, hidden, theta, noise, perms, nminibatches, lr=3.93141e-4, cliprange=0.161023, gamma=0.99, lam=0.95,
+                   reference_loop=False, device=-1):
+    """PPO2::learn for perms.shape[0] updates with explicit weights, exploration noise [U,T,E,A] and epoch permutations [U,epochs,B]
+    on SeededEnvMock x n_envs behind VecEnv + EnvNormalize.  Returns per-update mean losses [U,5], final weights, obs_rms, ret_rms."""
+    import numpy as np
+    lib = load_host_library()
+    U, epochs, B = perms.shape
+    assert noise.shape[:3] == (U, n_steps, n_envs) and B == n_envs * n_steps
+    theta = np.ascontiguousarray(theta, np.float32); noise = np.ascontiguousarray(noise, np.float32); perms = np.ascontiguousarray(perms, np.int32)
+    a = HostArgs()
+    a.n_envs, a.n_steps, a.n_hidden = n_envs, n_steps, len(hidden)
+    for i, h in enumerate(hidden):
+        a.hidden[i] = h
+    a.nminibatches, a.noptepochs, a.n_updates = nminibatches, epochs, U
+    a.lr, a.cliprange, a.gamma, a.lam = lr, cliprange, gamma, lam
+    a.seeded_env, a.device, a.max_workers, a.reference_loop = 1, device, 0, int(reference_loop)
+    a.norm_obs, a.norm_reward, a.seed = 1, 1, 0
+    out = {"losses": np.zeros((U, 5), np.float32), "theta": np.zeros(theta.size, np.float32),
+           "obs_mean": np.zeros(18, np.float32), "obs_var": np.zeros(18, np.float32), "obs_count": np.zeros(1, np.float64),
+           "ret_mean": np.zeros(1, np.float32), "ret_var": np.zeros(1, np.float32), "ret_count": np.zeros(1, np.float64)}
+    x = HostExplicit(theta.ctypes.data, noise.ctypes.data, perms.ctypes.data, out["losses"].ctypes.data, out["theta"].ctypes.data,
+                     out["obs_mean"].ctypes.data, out["obs_var"].ctypes.data, out["obs_count"].ctypes.data,
+                     out["ret_mean"].ctypes.data, out["ret_var"].ctypes.data, out["ret_count"].ctypes.data)
+    r = HostResult()
+    if lib.ppo_host_learn_explicit(C.byref(a), C.byref(x), C.byref(r)) != 0:
+        raise RuntimeError(r.error.decode())
+    return out

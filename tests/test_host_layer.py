@@ -20,15 +20,50 @@ def test_host_utilities():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("reference_loop", [False, True])
+@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((64, 64), 8, 32, 4, 2), ((256, 256), 8, 16, 4, 2)])
+def test_learn_matches_the_oracle_update_by_update(hidden, E, T, nmb, epochs, reference_loop):
+    """PPO2::learn end to end against the oracle (reference ppo2/ppo2.hpp:264-349 driving ppo2/runner.hpp:56-191): SeededEnvMock x 8
+    behind VecEnv + EnvNormalize, two updates with EXPLICIT exploration noise and epoch permutations, through the HBM-resident
+    loop and through the literal reference loop (Runner::run, host-side row permutation and slicing, _train_step per minibatch).
+    Every update's five mean losses, the final weights and both running statistics must match oracle.collect + oracle.update at
+    the fp32 tolerances of test_update_phase_matches_oracle: the done-view bookkeeping, the carry of observations / dones /
+    discounted returns from one rollout into the next, the env-major flatten and the per-update permutation are all on this path."""
+    from oracle import oracle as o
+    LR, CR, GAMMA, LAM = 0.000393141177482903, 0.16102319955825806, 0.99, 0.95
+    U, B = 2, E * T
+    orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(3)
+    orc.tensor("pi/logstd")[:] = np.random.RandomState(4).uniform(-1.0, 0.2, (1, 18))
+    theta0 = orc.theta.copy()
+    rng = np.random.RandomState(77)
+    noise = rng.normal(size=(U, T, E, 18)).astype(np.float32)
+    perms = np.empty((U, epochs, B), np.int32)
+    for u in range(U):
+        perm = np.arange(B, dtype=np.int32)                        # identity per update, shuffled cumulatively per epoch (ppo2.hpp:274-288)
+        for e in range(epochs):
+            rng.shuffle(perm); perms[u, e] = perm
+    got = hostapi.learn_explicit(E, T, list(hidden), theta0, noise, perms, nmb, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM, reference_loop=reference_loop)
+    nz = o.Normalizer(E, 18, gamma=GAMMA)
+    state = None
+    for u in range(U):
+        ro, state, _ = o.collect(orc, nz, 1234, T, noise[u], GAMMA, LAM, step0=u * T, state=state)
+        _, mean = orc.update(ro, perms[u], nmb, LR, CR)
+        np.testing.assert_allclose(got["losses"][u][:4], mean[:4], rtol=3e-4, atol=3e-6, err_msg="mean losses of update %d" % u)
+        assert abs(float(got["losses"][u][4]) - float(mean[4])) <= 1.01 / (B // nmb), "clipfrac of update %d" % u
+    np.testing.assert_allclose(got["theta"], orc.theta, rtol=2e-4, atol=5e-6, err_msg="weights after %d updates" % U)
+    np.testing.assert_allclose(got["obs_mean"], nz.obs_rms.mean, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(got["obs_var"], nz.obs_rms.var, rtol=1e-5)
+    np.testing.assert_allclose(got["ret_mean"], nz.ret_rms.mean, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(got["ret_var"], nz.ret_rms.var, rtol=1e-5)
+    assert got["obs_count"][0] == nz.obs_rms.count and got["ret_count"][0] == nz.ret_rms.count
+
+
+@pytest.mark.gpu
 def test_learn_resident_and_reference_loop_agree_on_first_update():
-    """Same env stack (SeededEnvMock x 8 -> VecEnv -> EnvNormalize), same weights: the HBM-resident learn() and the
-    literal reference loop differ only in the shuffle, so their first-update mean losses agree loosely and the entropy
-    (shuffle independent to first order) tightly."""
+    """Same env stack, same weights, own generators (on-device noise and shuffle vs host shuffle): the two loops differ only in the
+    draws, so the entropy (draw independent to first order) agrees tightly.  (The oracle comparison is the test above.)"""
     a = hostapi.learn(8, 32, [64, 64], n_updates=1, nminibatches=4, noptepochs=2)
     b = hostapi.learn(8, 32, [64, 64], n_updates=1, nminibatches=4, noptepochs=2, reference_loop=True)
     assert np.isfinite(a["losses"]).all() and np.isfinite(b["losses"]).all()
     assert a["losses"][2] == pytest.approx(b["losses"][2], rel=1e-3)
-    assert a["losses"][1] == pytest.approx(b["losses"][1], rel=0.2)
     assert a["fps_last"] > 0 and b["fps_last"] > 0
 
 
