@@ -199,10 +199,20 @@ def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
         vect = cpu_baseline_vectorised(cfg)
     except Exception as e:
         vect = {"error": repr(e)}
-    return {"all_cores": all_cores, "vectorised": vect, "value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d policy steps at %d rows + %d train steps at %d rows of the oracle's C restatement, extrapolated to "
-                      "%d steps + %d train steps per update" % (n_step, Es, n_tr, Ms, T, ep * nmb) + ("" if (Es, Ms) == (E, M) else " (rows scaled to %d / %d)" % (E, M)),
-            "update_samples_per_s": ep * B / (ep * nmb * t_train)}
+    scalar = {"value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port (oracle's C restatement: scalar loops, double accumulators)",
+              "sample": "%d policy steps at %d rows + %d train steps at %d rows, extrapolated to %d steps + %d train steps per update"
+                        % (n_step, Es, n_tr, Ms, T, ep * nmb) + ("" if (Es, Ms) == (E, M) else " (rows scaled to %d / %d)" % (E, M)),
+              "update_samples_per_s": ep * B / (ep * nmb * t_train)}
+    # the stated baseline is the FASTER of the two single-thread legs; the other one stays on record beside it
+    best, other, other_key = scalar, vect, "vectorised"
+    if isinstance(vect, dict) and vect.get("value", 0.0) > scalar["value"]:
+        best, other, other_key = dict(vect), scalar, "scalar_port"
+    out = dict(best)
+    out["kind"] = "port" if best is scalar else "port (vectorised: NumPy/BLAS sgemm, 1 thread, dense products + tanh only)"
+    out["kind_detail"] = best["kind"]
+    out[other_key] = other
+    out["all_cores"] = all_cores
+    return out
 
 
 def main():
@@ -221,9 +231,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank runs the config's n_envs; strong: the config's n_envs are divided over the ranks "
                          "(BASELINE configs[3] as written: 1024 envs in total over 8 GPUs)")
-    ap.add_argument("--collective", default="auto", choices=["auto", "peer", "rccl"],
-                    help="data-parallel exchange: one-shot peer all-reduce over IPC-mapped buffers (auto: when its probe passes on "
-                         "every rank) or ncclAllReduce; the other one is timed over a few steps as well and reported under `collectives`")
+    ap.add_argument("--collective", default="rccl", choices=["auto", "peer", "rccl"],
+                    help="data-parallel exchange: ncclAllReduce (default: the only form that has run across physical devices), the "
+                         "one-shot peer all-reduce over IPC-mapped buffers, or auto = when the peer probe passes on every rank, TIME both over "
+                         "a few steps and keep the faster one for the timed region (both timings go into `collectives`)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     from ppo_cpp_amd import dist as ppodist
@@ -258,7 +269,7 @@ def main():
         if args.collective != "rccl" and world <= 8:
             peer_ok = g.dist_peer_attach(ppodist.allgather_bytes(dist, g.dist_peer_export(), 64))
             if args.collective == "peer" and not peer_ok:
-                sys.exit("--collective peer: the peer all-reduce probe failed")
+                sys.exit("--collective peer: the peer all-reduce probe failed (or its region is not fine-grained memory)")
     g.norm_init(E, GAMMA)
     g.rollout_alloc(E, T)
     env0 = ppodist.env_offset(E, rank)                                     # every rank owns its own E environments (global ids rank*E ..)
@@ -272,8 +283,24 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    probe = None
+    if dist is not None and args.collective == "auto" and g.dist_peer_active():
+        # both exchange paths over a few steps each (first one warm / captured), the faster one runs the timed region
+        probe = {}
+        one_step(0, first=True)
+        for mode in ("peer", "rccl"):
+            g.dist_peer_enable(mode == "peer")
+            one_step(1)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(2):
+                one_step(2 + i)
+            g.sync()
+            probe[mode] = 1e3 * ppodist.allreduce_max(dist, time.perf_counter() - t1) / 2
+            barrier()
+        g.dist_peer_enable(probe["peer"] < probe["rccl"])
     for i in range(max(args.warmup, 1)):
-        losses = one_step(i, first=(i == 0))
+        losses = one_step(i, first=(i == 0 and probe is None))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -285,27 +312,19 @@ def main():
         dt = ppodist.allreduce_max(dist, dt)
     collectives = None
     if dist is not None:
-        # the replicas must have stayed bit-identical (same reduced gradient in the same order on every rank), and the other
-        # exchange path is timed over a few steps so that one run of the scaling bench measures both
+        # the replicas must have stayed bit-identical (same reduced gradient in the same order on every rank): checked, and fatal
         import hashlib
         used = "peer" if g.dist_peer_active() else "rccl"
         digests = ppodist.allgather_bytes(dist, hashlib.sha256(g.get_flat(0).tobytes()).digest(), 32)
         collectives = {"used": used, "graph_captured": g.dist_graph_collectives(), "replicas_bit_identical": len(set(digests)) == 1,
                        used: {"ms_per_step": 1e3 * dt / args.steps}}
-        if args.collective == "auto" and used == "peer":
-            g.dist_peer_enable(False)
-            k_other = max(1, min(args.steps, 3))
-            one_step(args.warmup + args.steps)                      # capture / warm the RCCL form
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(k_other):
-                one_step(args.warmup + args.steps + 1 + i)
-            g.sync()
-            dt_o = ppodist.allreduce_max(dist, time.perf_counter() - t1)
-            barrier()
-            collectives["rccl"] = {"ms_per_step": 1e3 * dt_o / k_other, "steps": k_other, "graph_captured": g.dist_graph_collectives()}
-            g.dist_peer_enable(True)
-            barrier()
+        if probe is not None:
+            collectives["auto_probe_ms_per_step"] = probe
+        if not collectives["replicas_bit_identical"]:
+            if rank == 0:
+                print(json.dumps({"error": "replicas diverged: the weights are not bit-identical across the ranks", "collectives": collectives}), flush=True)
+            g.close()
+            sys.exit(3)
 
     # per-kernel device time of the same workload, HIP events on the handle's stream, right after the timed region
     g.prof_enable(True)
@@ -338,14 +357,26 @@ def main():
     kern = {k: {"avg_us": 1e3 * ms / n, "launches": n} for k, (ms, n) in prof.items() if n}
     dom = max((k for k in kern if k in kflops), key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
     ach = kflops[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if args.config == "cfg3" and os.path.exists(tpath):          # PMC passes cannot run inside the timed process: measured offline
-        t = json.load(open(tpath))["kernels"].get(dom)
-        if t:
-            traffic = (2.0 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024.0
+    # PMC passes and the profiler's kernel trace cannot run inside the timed process: both come from the committed files that
+    # profiles/current.json names (written with the round's profiles), and the JSON line says so
+    traffic = traffic_source = rocprof_avg_us = rocprof_source = None
+    kname = {"train_fwd_bwd": "train_fwd_bwd_kernel", "weight_grad": "weight_grad", "policy_step": "policy_step_kernel"}[dom]
+    try:
+        idx = json.load(open(os.path.join(ROOT, "profiles", "current.json"))).get(args.config, {})
+        if idx.get("hbm_traffic"):
+            t = [v for k, v in json.load(open(os.path.join(ROOT, "profiles", idx["hbm_traffic"])))["kernels"].items() if kname in k]
+            if t:
+                traffic = (2.0 * t[0]["FETCH_SIZE"] + t[0]["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in t[0] else (2.0 * t[0]["FETCH_SIZE_KB"] + t[0]["WRITE_SIZE_KB"]) * 1024.0
+                traffic_source = "profiles/%s (offline rocprofv3 --pmc passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % idx["hbm_traffic"]
+        if idx.get("kernel_stats"):
+            import csv
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", idx["kernel_stats"]))):
+                if kname in r["Name"]:
+                    rocprof_avg_us = float(r["AverageNs"]) / 1e3
+                    rocprof_source = "profiles/%s (rocprofv3 --kernel-trace --stats of this command)" % idx["kernel_stats"]
+                    break
+    except Exception as e:
+        traffic_source = "unavailable: %r" % (e,)
     step_flops = (f_fwd + f_dx + f_dw) * M
     step_us = sum(kern[k]["avg_us"] for k in ("train_fwd_bwd", "weight_grad", "grad_reduce", "adam") if k in kern)
     out = {
@@ -358,7 +389,8 @@ def main():
         "update_samples_per_s": world * ep * B / (t_c - t_b),
         "phase_ms": {"collect": 1e3 * (t_b - t_a), "update": 1e3 * (t_c - t_b)},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                     "frac": ach / peak, "traffic": traffic,
+                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
+                     "rocprof_avg_us": rocprof_avg_us, "rocprof_source": rocprof_source,
                      "flop_per_launch": kflops[dom], "avg_us": kern[dom]["avg_us"],
                      "timing": "HIP events on the handle's stream around every launch of an eager pass right after the timed region: "
                                "an UPPER bound on kernel time (launch gaps included); the rocprofv3 kernel-trace of the same command is in profiles/",

@@ -165,6 +165,7 @@ struct ppo_handle {
     // deferred Adam inside ppo_update (reference shape): second parameter / moment set and the step whose clip + Adam is pending
     float *nw_theta1 = nullptr, *nw_m1 = nullptr, *nw_v1 = nullptr;
     bool nw_lazy = false;             // the path is available (static shape, PPO_HIP_NO_LAZY_ADAM unset)
+    bool adam_fast = false;           // adam_kernel uses the 1-ulp quotient of the deferred form (nw_lazy, or PPO_HIP_ADAM_FAST=1 for the bitwise test)
     int nw_cur = 0;                   // parameter set holding the current weights (0 outside ppo_update)
     bool nw_pending = false; float* nw_pending_loss = nullptr; int nw_pending_parts = 0;
     float* nw_coop = nullptr; int nw_coop_G = 0;      // cooperative persistent rollout: [2][G][NW_COOP_PW] chunk moments, then {arrive, err}
@@ -178,6 +179,7 @@ struct ppo_handle {
     struct Peer {
         bool on = false;                                // every collective that fits `cap` goes through the peer kernels
         bool usable = false;                            // the probe passed on every rank (ppo_dist_peer_enable may switch `on`)
+        bool coarse = false, coarse_requested = false;  // the region is plain hipMalloc memory (refused unless asked for: PPO_HIP_PEER_MEM=c)
         void* region = nullptr;                         // mine: [flag block | slots[2][world][cap]] (exported over IPC)
         size_t cap = 0;                                 // floats per slot (multiple of PEER_CHUNK)
         void* mapped[PEER_MAX_WORLD]{};                 // the other ranks' regions as this process sees them
@@ -863,7 +865,9 @@ int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* p
                 h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out, parts, n_parts,
                 h->bf.on ? h->bf.theta_bf : nullptr, h->narrow ? h->nw_img : nullptr, nullptr, nullptr, nullptr};
     if (h->nw_cur == 1) { aa.theta_in = h->nw_theta1; aa.m_in = h->nw_m1; aa.v_in = h->nw_v1; h->nw_cur = 0; }   // (always writes set 0)
-    hipLaunchKernelGGL(adam_kernel, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
+    // (the handle whose train kernels may apply Adam in their prologue uses the same 1-ulp quotient in its launches: bit-identical forms)
+    if (h->adam_fast) hipLaunchKernelGGL(adam_kernel<true>, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
+    else hipLaunchKernelGGL(adam_kernel<false>, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -1041,6 +1045,12 @@ ObsNorm no_norm() { return ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}; }
 // =================================================================================================================
 // C ABI
 // =================================================================================================================
+// (defined with the host-Env rollout forms below) retire a resident rollout kernel and book a posted transition, so that the
+// caller sees -- and changes -- the state of the step-by-step path (include/ppo_hip.h: entry points called mid-rollout)
+static int host_quiesce(ppo_handle* h);
+// entry points that synchronise the stream, read the rollout / normaliser, or change weights, seed or buffers
+#define ENTER_Q(h) do { ENTER(h); if (host_quiesce(h)) return -1; } while (0)
+
 extern "C" {
 
 int ppo_abi_version(void) { return PPO_ABI_VERSION; }
@@ -1162,9 +1172,11 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
             // second parameter / moment set of the deferred Adam (zero-filled: the padding elements are never written and must read 0)
             if (dev_alloc(h, &h->nw_theta1, P) || dev_alloc(h, &h->nw_m1, P) || dev_alloc(h, &h->nw_v1, P)) return bail(0);
             h->nw_lazy = true;
+            h->adam_fast = true;
         }
         if (dev_alloc(h, &h->nw_img, (size_t)2 * h->nw.w_total)) return bail(0);
     }
+    { const char* af = getenv("PPO_HIP_ADAM_FAST"); if (af && af[0] == '1') h->adam_fast = true; }
     const float pw[2] = {cfg->adam_beta1, cfg->adam_beta2};
     if (ppo_set_beta_powers(h, pw)) return bail(0);
     *out = h;
@@ -1228,7 +1240,7 @@ int ppo_tensor_info(const ppo_handle* h, int index, char name[32], int32_t* rows
 }
 
 int ppo_get_tensor(ppo_handle* h, int which, int index, float* dst, int64_t count) {
-    ENTER(h);
+    ENTER_Q(h);
     float* base = which_buf(h, which);
     if (!base || index < 0 || index >= (int)h->tensors.size()) return fail(h, "ppo_get_tensor: bad which/index");
     const Tensor& t = h->tensors[index];
@@ -1238,7 +1250,7 @@ int ppo_get_tensor(ppo_handle* h, int which, int index, float* dst, int64_t coun
 }
 
 int ppo_set_tensor(ppo_handle* h, int which, int index, const float* src, int64_t count) {
-    ENTER(h);
+    ENTER_Q(h);
     float* base = which_buf(h, which);
     if (!base || index < 0 || index >= (int)h->tensors.size()) return fail(h, "ppo_set_tensor: bad which/index");
     const Tensor& t = h->tensors[index];
@@ -1268,7 +1280,7 @@ int ppo_set_flat(ppo_handle* h, int which, const float* src, int64_t count) {
 }
 
 int ppo_get_beta_powers(ppo_handle* h, float pw[2]) {
-    ENTER(h);
+    ENTER_Q(h);
     float v[4];
     HIP_OK(h, hipStreamSynchronize(h->stream));
     HIP_OK(h, hipMemcpy(v, h->beta_pow, sizeof v, hipMemcpyDeviceToHost));
@@ -1277,7 +1289,7 @@ int ppo_get_beta_powers(ppo_handle* h, float pw[2]) {
 }
 
 int ppo_set_beta_powers(ppo_handle* h, const float pw[2]) {
-    ENTER(h);
+    ENTER_Q(h);
     const float v[4] = {pw[0], pw[1], pw[0], pw[1]};
     HIP_OK(h, hipStreamSynchronize(h->stream));
     HIP_OK(h, hipMemcpy(h->beta_pow, v, sizeof v, hipMemcpyHostToDevice));
@@ -1323,6 +1335,7 @@ int ppo_init_orthogonal(ppo_handle* h, uint64_t seed) {
 }
 
 int ppo_seed(ppo_handle* h, uint64_t seed) {
+    ENTER_Q(h);                                                    // a resident rollout kernel captured the old seed: retire it first
     uint64_t z = seed + 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
     h->rng_seed = (uint32_t)(z ^ (z >> 32));
@@ -1333,7 +1346,7 @@ int ppo_seed(ppo_handle* h, uint64_t seed) {
 // ---- act model ----------------------------------------------------------------------------------------------------
 static int step_common(ppo_handle* h, const float* obs, int n, const float* noise, bool sample, float* action, float* det_action,
                        float* value, float* neglogp) {
-    ENTER(h);
+    ENTER_Q(h);
     if (n < 1) return fail(h, "step: n must be positive");
     if (ensure_staging(h, n)) return -1;
     const NetDev& net = h->net;
@@ -1370,7 +1383,7 @@ int ppo_act_deterministic(ppo_handle* h, const float* obs, int32_t n, float* act
 // ---- train op -------------------------------------------------------------------------------------------------------
 int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, const float* actions, const float* advs,
                    const float* returns, const float* old_neglogp, const float* old_values, int32_t n, float losses[5]) {
-    ENTER(h);
+    ENTER_Q(h);
     if (n < 2) return fail(h, "ppo_train_step: n=%d (the reference asserts more than one row, ppo2.hpp:402)", n);
     h->bf.epoch_staged = false;
     if (ensure_staging(h, n) || ensure_train_ws(h, n)) return -1;
@@ -1446,12 +1459,8 @@ static int norm_alloc_stats(ppo_handle* h, NormDev& s, int dim) {
     return 0;
 }
 
-// (defined with the host-Env rollout forms below) the normaliser's state as a caller expects to see it: no resident rollout
-// kernel holding it in LDS, every posted transition booked
-static int host_quiesce(ppo_handle* h);
-
 int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, float clip_rew, float epsilon) {
-    ENTER(h);
+    ENTER_Q(h);
     if (n_envs < 1) return fail(h, "ppo_norm_init: n_envs must be positive");
     h->nz_envs = n_envs; h->nz_gamma = gamma; h->nz_clip_obs = clip_obs; h->nz_clip_rew = clip_rew; h->nz_eps = epsilon;
     if (norm_alloc_stats(h, h->obs_rms, h->net.O) || norm_alloc_stats(h, h->ret_rms, 1)) return -1;
@@ -1801,7 +1810,18 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
         // order them; (re)launched here when it is not running (first step, or it parked itself after a long host pause)
         unsigned* ctl = hp_ctl(h);
         const uint32_t rng_step = h->rng_calls++;
-        if (t == 0) { h->hp_posted = 0; }
+        if (t == 0) {
+            // a rollout abandoned without ppo_rollout_finish / _reset (an env exception, say) leaves its kernel resident and its
+            // sequence words raised: retire it, book what it posted, and start this rollout from clean words -- stale actions
+            // must never be handed out for step 0
+            if (h->hp_active || __atomic_load_n(ctl + PCTL_D2H, __ATOMIC_ACQUIRE) != 0u || __atomic_load_n(ctl + PCTL_H2D, __ATOMIC_ACQUIRE) != 0u) {
+                if (host_quiesce(h)) return -1;
+                HIP_OK(h, hipStreamSynchronize(h->stream));
+                __atomic_store_n(ctl + PCTL_H2D, 0u, __ATOMIC_RELEASE);
+                __atomic_store_n(ctl + PCTL_D2H, 0u, __ATOMIC_RELEASE);
+            }
+            h->hp_posted = 0;
+        }
         for (int attempt = 0; ; ++attempt) {
             if (!h->hp_active) { if (attempt > 3) return fail(h, "ppo_rollout_act: the resident kernel keeps leaving before step %d", t); if (hp_launch(h, t, rng_step)) return -1; }
             bool have = false;
@@ -2052,7 +2072,7 @@ static float* rollout_field(ppo_handle* h, int field, size_t* count) {
 }
 
 int ppo_rollout_download(ppo_handle* h, int field, float* dst, int64_t count) {
-    ENTER(h);
+    ENTER_Q(h);
     size_t c = 0;
     float* p = h->E ? rollout_field(h, field, &c) : nullptr;
     if (!p || (size_t)count != c) return fail(h, "ppo_rollout_download: bad field/count");
@@ -2062,7 +2082,7 @@ int ppo_rollout_download(ppo_handle* h, int field, float* dst, int64_t count) {
 }
 
 int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count) {
-    ENTER(h);
+    ENTER_Q(h);
     size_t c = 0;
     float* p = h->E ? rollout_field(h, field, &c) : nullptr;
     if (!p || (size_t)count != c) return fail(h, "ppo_rollout_upload: bad field/count");
@@ -2087,7 +2107,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             EpochArgs ea{};
             ea.inv_perm = explicit_perms ? h->d_inv : nullptr; ea.keys = h->d_keys + 2 * ep; ea.bits = bits;
             ea.B = B; ea.M = M; ea.T = h->T; ea.E = h->E; ea.returns = h->ro_ret; ea.values = h->ro_val; ea.gidx = h->d_gidx; ea.stats = h->d_advstats;
-            ea.xch = h->adv_xch; ea.n_global = (float)((int64_t)M * h->world);
+            ea.xch = h->adv_xch; ea.xch2 = ru(nmb, 4); ea.n_global = (float)((int64_t)M * h->world);
             if (!h->comm) {
                 ea.phase = 0;
                 hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(EP_THREADS), 0, h->stream, ea);
@@ -2099,7 +2119,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
                     hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(EP_THREADS), 0, h->stream, ea);
                     HIP_OK(h, hipGetLastError());
                     if (phase == 1 && allreduce_f32(h, h->adv_xch, (size_t)nmb)) return -1;
-                    if (phase == 2 && allreduce_f32(h, h->adv_xch + nmb, (size_t)nmb)) return -1;
+                    if (phase == 2 && allreduce_f32(h, h->adv_xch + ru(nmb, 4), (size_t)nmb)) return -1;
                 }
             }
         }
@@ -2138,7 +2158,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
 
 int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t nmb, const int32_t* perms, uint64_t seed, float* loss_rows,
                float mean_losses[5]) {
-    ENTER(h);
+    ENTER_Q(h);
     if (!h->E) return fail(h, "ppo_update: no rollout (ppo_rollout_alloc + collect first)");
     const int B = h->E * h->T;
     if (epochs < 1 || nmb < 1 || B % nmb) return fail(h, "ppo_update: n_batch %d not divisible by nminibatches %d", B, nmb);
@@ -2154,7 +2174,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
         if (h->d_perms) { (void)hipFree(h->d_perms); h->d_perms = nullptr; h->upd_cap_epochs = 0; }      // sized on demand below
         if (dev_alloc(h, &h->d_inv, cr) || dev_alloc(h, &h->d_gidx, cr) ||
             dev_alloc(h, &h->d_advstats, (size_t)2 * cs) || dev_alloc(h, &h->d_keys, (size_t)2 * cs) || dev_alloc(h, &h->d_loss_rows, (size_t)5 * cs) ||
-            dev_alloc(h, &h->d_loss_mean, 8) || dev_alloc(h, &h->adv_xch, (size_t)2 * cs))
+            dev_alloc(h, &h->d_loss_mean, 8) || dev_alloc(h, &h->adv_xch, (size_t)2 * ru(cs, 4)))
             return -1;
         h->upd_cap_rows = cr; h->upd_cap_steps = cs;
         if (h->bf.on) {
@@ -2336,7 +2356,15 @@ int ppo_dist_peer_export(ppo_handle* h, char handle[64]) {
         hipError_t e = hipErrorUnknown;
         if (kind == 0) e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocFinegrained);
         if (kind == 1 || (kind == 0 && e != hipSuccess)) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocUncached); }
-        if (e != hipSuccess) { (void)hipGetLastError(); P.region = nullptr; HIP_OK(h, hipMalloc(&P.region, bytes)); }
+        P.coarse = false;
+        if (e != hipSuccess) {
+            // plain hipMalloc: a remote write may leave a stale line in this device's L2 that even sc1 loads can hit.  Only on
+            // explicit request (PPO_HIP_PEER_MEM=c, single-device experiments); otherwise the region exists (so that the
+            // collective attach can still run and agree) but the peer path is refused there.
+            (void)hipGetLastError(); P.region = nullptr; HIP_OK(h, hipMalloc(&P.region, bytes));
+            P.coarse = true; P.coarse_requested = kind == 2;
+            if (kind != 2) fprintf(stderr, "libppo_hip: no fine-grained / uncached device memory for the peer region (rank %d): the peer all-reduce stays off, RCCL is used\n", h->rank);
+        }
         HIP_OK(h, hipMemset(P.region, 0, bytes));
         HIP_OK(h, hipMalloc((void**)&P.local, 64));
         HIP_OK(h, hipMemset(P.local, 0, 64));
@@ -2393,6 +2421,20 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
         memcpy(&ipc, handles + (size_t)r * 64, 64);
         if (hipIpcOpenMemHandle(&P.mapped[r], ipc, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); P.mapped[r] = nullptr; mapped = false; }
     }
+    // collective reset: every rank zeroes its own sequence / arrival / error words and its own flag block, then all ranks meet
+    // before anybody pushes -- a probe that failed on one rank in an earlier attach (that rank skipped a round) must not leave
+    // the sequence numbers diverged for this one
+    {
+        HIP_OK(h, hipMemset(P.local, 0, 64));
+        HIP_OK(h, hipMemset(P.region, 0, kPeerFlagBytes));
+        HIP_OK(h, hipDeviceSynchronize());
+        float* tok = nullptr;
+        HIP_OK(h, hipMalloc((void**)&tok, sizeof(float)));
+        const bool met = hipMemset(tok, 0, sizeof(float)) == hipSuccess && h->rccl.AllReduce(tok, tok, 1, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream) == 0 &&
+                         hipStreamSynchronize(h->stream) == hipSuccess;
+        (void)hipFree(tok);
+        if (!met) return fail(h, "ppo_dist_peer_attach: the ranks could not meet before the probe");
+    }
     PeerDev d{};
     for (int r = 0; r < h->world; ++r) {
         char* base = (char*)(r == h->rank ? P.region : P.mapped[r]);
@@ -2409,7 +2451,7 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
     const char* en = getenv("PPO_HIP_PEER_REDUCE");
     const bool wanted = !(en && en[0] == '0');
     // the verdict must be COMMON: a rank that could not map a peer, or whose probe failed, takes everybody back to RCCL
-    bool ok = wanted && mapped;
+    bool ok = wanted && mapped && (!P.coarse || P.coarse_requested);
     if (wanted) ok = peer_probe(h) && ok;
     float* flag = nullptr;
     HIP_OK(h, hipMalloc((void**)&flag, sizeof(float)));

@@ -1546,20 +1546,26 @@ __global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* sumsq, int
 }
 
 // TF-1.14 ApplyAdam on one element (G:30430-31383): m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); theta -= alpha m / (sqrt(v) + eps),
-// g already scaled by the clip factor.  The quotient uses the hardware's 1-ulp square root and reciprocal (v_sqrt_f32, v_rcp_f32)
-// instead of the correctly rounded sequences (~25 instructions each): the update term is ~1e-3 of the weight, so a 3-ulp error
-// in it is 4e-10 absolute -- a twentieth of the weight's own ulp -- and this expression runs redundantly in every workgroup of
-// the narrow path's deferred Adam (ppo_narrow.hpp), where the exact sequences cost 2.2 k cycles of a 25 k-cycle kernel.  (A
-// denormal v gives sqrt = 0: invisible behind eps.)  One function for every path, so all paths agree bit for bit.
+// g already scaled by the clip factor.
+//   FAST = false: correctly rounded square root and division, the arithmetic of the reference's CPU kernel.  Every path but the one
+//     below (adam_kernel on the fused fp32 families and on the bf16 path's fp32 master weights).
+//   FAST = true: the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32.  ONLY the narrow path's deferred Adam (ppo_narrow.hpp), where this
+//     expression runs redundantly in every workgroup and the exact sequences cost 2.2 k cycles of a 25 k-cycle kernel, and the
+//     adam_kernel launches of the same handle (so that the deferred and the launched form stay bit-identical).  The update term is
+//     ~1e-3 of the weight, so its 3-ulp error is 4e-10 absolute, a twentieth of the weight's own ulp -- a stated deviation from
+//     "the reference's arithmetic" on that path (include/ppo_hip.h).
+template <bool FAST>
 __device__ __forceinline__ void adam_element(float gscaled, float m, float v, float t, float one_m_b1, float one_m_b2, float alpha, float eps,
                                              float& mo, float& vo, float& to) {
     mo = m + (gscaled - m) * one_m_b1;
     vo = v + (gscaled * gscaled - v) * one_m_b2;
-    to = t - (mo * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vo) + eps);
+    if constexpr (FAST) to = t - (mo * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vo) + eps);
+    else to = t - (mo * alpha) / (sqrtf(vo) + eps);
 }
 
 // One block = 1024 consecutive parameters (4 per thread, 16-byte accesses); n_blocks counts the 256-element chunks the
 // gradient-source table and the partial sums of squares are indexed by.
+template <bool FAST>
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
@@ -1592,7 +1598,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
         float mo[4], vo[4], to[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) adam_element(gv[k] * scale, mv[k], vv[k], tv[k], 1.0f - a.beta1, 1.0f - a.beta2, alpha, a.eps, mo[k], vo[k], to[k]);
+        for (int k = 0; k < 4; ++k) adam_element<FAST>(gv[k] * scale, mv[k], vv[k], tv[k], 1.0f - a.beta1, 1.0f - a.beta2, alpha, a.eps, mo[k], vo[k], to[k]);
         st_wt4<PPO_WT_C2>(a.m + idx, make_float4(mo[0], mo[1], mo[2], mo[3]));
         st_wt4<PPO_WT_C2>(a.v + idx, make_float4(vo[0], vo[1], vo[2], vo[3]));
         st_wt4<PPO_WT_C2>(a.theta + idx, make_float4(to[0], to[1], to[2], to[3]));
@@ -1660,7 +1666,8 @@ struct EpochArgs {
     int* gidx;               // [B]
     float* stats;            // [B/M][2]
     int phase;               // 0: single rank, everything ; data parallel: 1 index + local sums, 2 local squared deviations, 3 finish
-    float* xch;              // [2][B/M] partial sums all-reduced by the host between the phases
+    float* xch;              // two vectors of B/M partial sums all-reduced by the host between the phases; the second starts at xch2
+    int xch2;                // (a multiple of 4 floats: the peer all-reduce reads its source as 16-byte vectors)
     float n_global;          // minibatch rows over all ranks
 };
 
@@ -1670,11 +1677,10 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_kernel(EpochArgs a) 
     __shared__ float red[EP_THREADS / 64];
     __shared__ float s_mean;
     const int k = blockIdx.x, tid = threadIdx.x;
-    const int nmb = a.B / a.M;
     if (a.phase == 3) {
         if (tid == 0) {
             a.stats[2 * k] = a.xch[k] / a.n_global;
-            a.stats[2 * k + 1] = (float)((double)sqrtf(a.xch[nmb + k] / a.n_global) + 1e-8);
+            a.stats[2 * k + 1] = (float)((double)sqrtf(a.xch[a.xch2 + k] / a.n_global) + 1e-8);
         }
         return;
     }
@@ -1723,7 +1729,7 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_kernel(EpochArgs a) 
     if (tid == 0) {
         float tot = 0.f;
         for (int w = 0; w < EP_THREADS / 64; ++w) tot += red[w];
-        if (a.phase == 2) a.xch[nmb + k] = tot;
+        if (a.phase == 2) a.xch[a.xch2 + k] = tot;
         else {
             const float var = tot / (float)a.M;
             a.stats[2 * k] = mean;

@@ -302,7 +302,7 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
         const float vv[4] = {R.v[k].x, R.v[k].y, R.v[k].z, R.v[k].w}, tv[4] = {R.t[k].x, R.t[k].y, R.t[k].z, R.t[k].w};
         float mo[4], vo[4], to[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) adam_element(gv[i] * scale, mv[i], vv[i], tv[i], 1.0f - z.beta1, 1.0f - z.beta2, alpha, z.eps, mo[i], vo[i], to[i]);
+        for (int i = 0; i < 4; ++i) adam_element<true>(gv[i] * scale, mv[i], vv[i], tv[i], 1.0f - z.beta1, 1.0f - z.beta2, alpha, z.eps, mo[i], vo[i], to[i]);
         const float4 t4 = make_float4(to[0], to[1], to[2], to[3]);
         bool mine;                                                              // who writes this piece back
         if (k < 2) {                                                            // W1 [64][64]: forward + transposed copies

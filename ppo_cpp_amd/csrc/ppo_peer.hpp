@@ -84,6 +84,10 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_push_kernel(PeerDev p, cons
     }
     __syncthreads();
     if (s_last) {
+        // The other workgroups' slot writes reach this point through their release fences and the arrival counter: one acquire on
+        // the counter's side and one system-scope release in front of the flags make the chain a synchronises-with edge by the
+        // memory model, not by what the caches happen to do (once per collective, in one workgroup: the L2 is clean already).
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
         if (threadIdx.x < (unsigned)p.world)
             peer_st_sys(p.flags[threadIdx.x] + ((size_t)par * PEER_MAX_WORLD + p.rank) * PEER_FLAG_STRIDE, s);
         if (threadIdx.x == 0) {
@@ -115,9 +119,11 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_sum_kernel(PeerDev p, float
             if (++it > p.spin_limit) { __hip_atomic_store(p.err, 1u + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
     }
+    // ONE system-scope acquire per workgroup by the polling wave, after its flags matched and in front of the barrier the other
+    // waves load behind (guide: one relaxed poll, one acquire, then the loads).  The slots are read with SYSTEM-scope loads
+    // (sc0 sc1: served by memory, never by a stale cache line) on top of that.
+    if (threadIdx.x < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
-    // The slots are read with SYSTEM-scope loads (sc0 sc1: served by memory, never by a stale cache line), issued after the
-    // flags were seen.  An acquire fence instead would invalidate the whole L2 once per workgroup (590 of them at 0.6 MB).
     const float* mine = p.slots[p.rank] + (unsigned long long)par * p.world * p.cap;
     // every load of the workgroup is issued before the first addition (one round trip, not one per rank); the additions run
     // in rank order, skipped -- not fed with zeros -- for ranks that do not exist (-0 + 0 would flip a sign bit)

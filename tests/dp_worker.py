@@ -42,6 +42,12 @@ def main():
         assert g.dist_graph_collectives()
     g.norm_init(El, float(d["gamma"]))
     g.rollout_alloc(El, T)
+    if os.environ.get("PPO_TEST_DRILL") == "1" and rank == world - 1:
+        # failure drill: this rank never takes part in a collective again (it stays alive for a while, like a hung peer, then leaves)
+        import time
+        time.sleep(float(os.environ.get("PPO_TEST_DRILL_SLEEP", "4")))
+        g.close()
+        return
     g.collect_synthetic(int(d["seed"]), float(d["gamma"]), float(d["lam"]), d["noise"][:, sl], env0=rank * El, step0=0, first=True)
     out = {"ro_" + f: g.rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones")}
     for which, nm in ((0, "obs"), (1, "ret")):

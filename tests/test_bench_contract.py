@@ -23,10 +23,17 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert "workload" in d["config"] and "configs[2]" in d["config"]["workload"] and "model" not in d["config"]
     assert d["value"] > 1e5 and abs(d["value"] - 65536.0 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "rocprof_avg_us", "rocprof_source"):
         assert k in r, k
+    if r["traffic"] is not None:
+        assert "profiles/" in r["traffic_source"] and "offline" in r["traffic_source"]
+    if r["rocprof_avg_us"] is not None:
+        assert "profiles/" in r["rocprof_source"] and 0.2 < r["rocprof_avg_us"] / r["avg_us"] < 1.5     # the event timing is an upper bound
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    # the stated baseline is the faster of the two single-thread legs; the other one is kept beside it
+    assert c["kind"].startswith("port") and c["cores"] == 1 and c["value"] > 0
+    other = c.get("vectorised") or c.get("scalar_port")
+    assert other and (("error" in other) or other["value"] <= c["value"])

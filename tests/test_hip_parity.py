@@ -421,11 +421,12 @@ def test_deferred_adam_is_bitwise_the_adam_launch(E, T, nmb, epochs, monkeypatch
     """Reference shape ([64,64]): inside ppo_update the clip + Adam of step k is applied by the prologue of step k+1's train
     kernel (ping-pong parameter sets, weights written straight into the LDS image).  Same expression, same norm order: loss
     rows, weights, both moments, beta powers, the reported norm and the act model after the update must equal the run with
-    an adam_kernel launch per step (PPO_HIP_NO_LAZY_ADAM=1) bit for bit -- including a one-step update (nothing to defer to),
-    ragged minibatches, and a second update replayed from the graph."""
+    an adam_kernel launch per step (PPO_HIP_NO_LAZY_ADAM=1, with the deferred form's 1-ulp quotient: PPO_HIP_ADAM_FAST=1) bit for
+    bit -- including a one-step update (nothing to defer to), ragged minibatches, and a second update replayed from the graph."""
     outs = []
     for lazy in (True, False):
         monkeypatch.setenv("PPO_HIP_NO_LAZY_ADAM", "0" if lazy else "1")
+        monkeypatch.setenv("PPO_HIP_ADAM_FAST", "0" if lazy else "1")
         orc, g, nz, ro, noise = _rollout_pair((64, 64), E, T, 23)
         for f in ("obs", "actions", "values", "neglogp", "returns"):
             g.rollout_set(f, ro[f])
