@@ -8,6 +8,7 @@
 #include "ppo_narrow.hpp"
 #include "ppo_peer.hpp"
 #include "ppo_dw2.hpp"
+#include "ppo_train8.hpp"
 
 #include <dlfcn.h>
 
@@ -89,6 +90,7 @@ struct ppo_handle {
     bool dw_has_big = false;
     // weight gradients + gradient assembly in one launch (ppo_dw2.hpp; 18-obs / [256,256] shape)
     bool dw2 = false;
+    bool t8 = false;                  // 8-wave train kernel with K-split wave pairs (ppo_train8.hpp; same shape as dw2)
     unsigned* dw2_counters = nullptr; float* dw2_parts = nullptr; SlotJob* dw2_jobs = nullptr; int dw2_n_jobs = 0, dw2_jpw = 0;
     // staging for host-pointer calls
     int st_rows = 0;
@@ -960,6 +962,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
             if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, true>), grid, blk, lds_bytes, h->stream, n, ta);
             else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0, true>), grid, blk, lds_bytes, h->stream, n, ta);
         }
+        else if (h->t8) hipLaunchKernelGGL(train8_kernel, grid, dim3(T8_THREADS), (size_t)T8_TOTAL * sizeof(float), h->stream, n, ta);
         else if (h->CT == 4 && h->CTH == 2 && h->early) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2, false, true>), grid, blk, lds_bytes, h->stream, n, ta);
         else if (h->CT == 4 && h->CTH == 2) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2, false>), grid, blk, lds_bytes, h->stream, n, ta);
         else if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
@@ -1119,6 +1122,9 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     if (upload_grad_src(h)) return bail(0);
     { const char* e = getenv("PPO_HIP_NO_DW2"); const NetDev& nn = h->net;
       h->dw2 = !(e && e[0] == '1') && h->early && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256; }
+    { const char* e = getenv("PPO_HIP_NO_T8"); const NetDev& nn = h->net;
+      h->t8 = !(e && e[0] == '1') && h->early && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256 && nn.O == 18 && nn.A == 18;
+      if (h->t8 && hipFuncSetAttribute((const void*)train8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T8_TOTAL * 4) != hipSuccess) { fail(h, "hipFuncSetAttribute failed for train8_kernel"); return bail(0); } }
     if (h->dw2) {
         if (hipFuncSetAttribute((const void*)weight_grad_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS_FLOATS * 4) != hipSuccess) { fail(h, "hipFuncSetAttribute failed for weight_grad_assemble_kernel"); return bail(0); }
         // slot jobs: every element the train kernel leaves as per-row-block partial sums (bias / logstd / value-head gradients), then the loss sums

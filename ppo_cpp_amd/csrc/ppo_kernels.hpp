@@ -900,7 +900,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void train_fwd_bwd_kernel(NetDev net
     for (int l = EARLY ? 1 : 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
         dense_tile<CT, KS, EP_BIAS_TANH>(wpre, a.theta + net.w_off[tower][l], Np, WIDE ? a.par + tower * net.par_total + net.par_b[l] : par + net.par_b[l], lds + net.lds_h[l], ldx, K,
-                                         lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, a.hg[tower][l], Np, row0, a.n, [&]() __attribute__((always_inline)) {
+                                         lds + net.lds_h[l + 1], ldy, Np, nullptr, 0, (tower == 1 && l == net.L - 1) ? nullptr : a.hg[tower][l] /* the value head's weight gradient is formed in this kernel: nobody reads that copy */, Np, row0, a.n, [&]() __attribute__((always_inline)) {
                                              if (l + 1 < net.L) dense_prefetch<CT, KS>(wpre, a.theta + net.w_off[tower][l + 1], net.Hp[l + 1], net.Hp[l + 1], Np);
                                              else {
                                                  if constexpr (CTH > 0 && !EARLY) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, Np);
