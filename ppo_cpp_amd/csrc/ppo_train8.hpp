@@ -58,13 +58,19 @@ __device__ __forceinline__ void t8_mma_small(const WFrag<2, 2>& f, const float* 
 }
 
 // The K-split 256 x 256 product of wave (p = column block, kh = K half): Y[16, 64p..64p+63] partial over k in [128 kh, 128 kh + 128).
-// fr[0], fr[1] hold stages 0 and 1 (requested by the caller); returns the partial accumulators.
-template <class Between>
+// fr[0], fr[1] hold the first two stages (requested by the caller); returns the partial accumulators.  `rot` (wave-uniform, 0..3)
+// rotates the order in which the four 32-deep stages are taken: the 32 workgroups of an XCD stream the SAME weights, and in
+// lockstep they would all ask one 32 KB block of L2 at a time; rotated by row tile they spread over the whole matrix.
+#ifndef T8_ROTATE
+#define T8_ROTATE 0                // measured: 42.0 us per train step rotated against 41.2 (no L2 hot spot to avoid; dynamic stage addresses cost)
+#endif
+__device__ __forceinline__ int t8_stage_row(int st, int rot) { return T8_ROTATE ? 32 * ((st + rot) & 3) : 32 * st; }
 __device__ __forceinline__ void t8_big_product(WFrag<4, 2> (&fr)[3], const float* Wk /* W + 128 kh rows */, const WOff<2>& off, const float* Xs /* tile + 128 kh */,
-                                               int c, int g, f32x4 (&acc)[4], Between&& between) {
+                                               int c, int g, int rot, f32x4 (&acc)[4]) {
     auto load_a = [&](WFrag<4, 2>& f, int st) __attribute__((always_inline)) {
+        const int k0 = t8_stage_row(st, rot);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) f.a[q] = *reinterpret_cast<const float4*>(Xs + c * T8_LD + 32 * st + 16 * q + 4 * g);
+        for (int q = 0; q < 2; ++q) f.a[q] = *reinterpret_cast<const float4*>(Xs + c * T8_LD + k0 + 16 * q + 4 * g);
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -72,12 +78,17 @@ __device__ __forceinline__ void t8_big_product(WFrag<4, 2> (&fr)[3], const float
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 < 4) { load_a(fr[(st + 2) % 3], st + 2); load_w_stage<4, 2>(fr[(st + 2) % 3], Wk + (size_t)(32 * (st + 2)) * 256, off); }
-        if (st == 3) between();                      // the next product's first stages go out under the last stage's matrix instructions
+#ifdef T8_NOLOAD
+        if (st + 2 < 4) load_a(fr[(st + 2) % 3], st + 2);      // timing experiment only: results are wrong
+#else
+        if (st + 2 < 4) { load_a(fr[(st + 2) % 3], st + 2); load_w_stage<4, 2>(fr[(st + 2) % 3], Wk + (size_t)t8_stage_row(st + 2, rot) * 256, off); }
+#endif
         t8_mma_stage(fr[st % 3], acc);
+#ifndef T8_NOSCHED
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
         for (int t = 0; t < 8; ++t) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -115,6 +126,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int p = wave & 3, kh = wave >> 2;
+    const int rot = uni(rb & 3);
     float* slot = a.slots[tower] + (size_t)rb * net.slot_w;
     float* par = lds + T8_PAR;
     STAMP(0);
@@ -144,8 +156,8 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     WFrag<2, 2> wl0, whd, whT;
     WFrag<4, 2> fr[3];
     load_w_stage<2, 2>(wl0, W0, off_small);
-    load_w_stage<4, 2>(fr[0], W1, off_big);
-    load_w_stage<4, 2>(fr[1], W1 + (size_t)32 * 256, off_big);
+    load_w_stage<4, 2>(fr[0], W1 + (size_t)t8_stage_row(0, rot) * 256, off_big);
+    load_w_stage<4, 2>(fr[1], W1 + (size_t)t8_stage_row(1, rot) * 256, off_big);
     if (tower == 0) {
         load_w_stage<2, 2>(whd, uni(a.theta + net.wmu_off) + (size_t)(32 * wave) * 32, make_woff<2>(32, g, 2 * c));     // rows 32w .. 32w+31 of W_mu [256][32]
         load_w_stage<2, 2>(whT, uni(a.thetaT + net.wmuT_off), off_small);                                             // W_mu^T [32][256]
@@ -186,10 +198,10 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     // ---- second layer: h2 = tanh(h1 W1 + b1), K split over the wave pair -------------------------------------------------------------
     {
         f32x4 acc[4];
-        t8_big_product(fr, W1, off_big, lds + T8_H1 + 128 * kh, c, g, acc, [&]() __attribute__((always_inline)) {});
+        t8_big_product(fr, W1, off_big, lds + T8_H1 + 128 * kh, c, g, rot, acc);
         // the backward product's transposed weights: two stages per wave, in flight through the head and the loss
-        load_w_stage<4, 2>(fr[0], W1T, off_big);
-        load_w_stage<4, 2>(fr[1], W1T + (size_t)32 * 256, off_big);
+        load_w_stage<4, 2>(fr[0], W1T + (size_t)t8_stage_row(0, rot) * 256, off_big);
+        load_w_stage<4, 2>(fr[1], W1T + (size_t)t8_stage_row(1, rot) * 256, off_big);
         float out[4][2];
         t8_exchange(acc, lds + T8_D2, p, kh, lane, out);
         const int col = 64 * p + 4 * c;
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     // ---- dY0 = (dY1 W1^T) .* (1 - h1^2), K split over the wave pair (the h2 tile is free now: exchange scratch) ------------------------
     {
         f32x4 acc[4];
-        t8_big_product(fr, W1T, off_big, d2 + 128 * kh, c, g, acc, [&]() __attribute__((always_inline)) {});
+        t8_big_product(fr, W1T, off_big, d2 + 128 * kh, c, g, rot, acc);
         float out[4][2];
         t8_exchange(acc, lds + T8_H2, p, kh, lane, out);
         const int col = 64 * p + 4 * c;

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "ppo_cpp_amd", "libppo_hip.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                       "-DPPO_STAMPS", "-DPPO_STAMP_LAYER=" + os.environ.get("STAMP_LAYER", "1"), "-o", so, os.path.join(ROOT, "ppo_cpp_amd/csrc/ppo_hip.hip"), "-ldl"])
+                       "-DPPO_STAMPS", "-DPPO_STAMP_LAYER=" + os.environ.get("STAMP_LAYER", "1")] + os.environ.get("PPO_HIP_EXTRA_FLAGS", "").split() + ["-o", so, os.path.join(ROOT, "ppo_cpp_amd/csrc/ppo_hip.hip"), "-ldl"])
 import ppo_cpp_amd
 H = [int(x) for x in os.environ.get("HIDDEN", "256,256").split(",")]
 g = ppo_cpp_amd.PPOHip(18, 18, H); g.init_orthogonal(0)
