@@ -24,10 +24,14 @@ enum {
     T8_MISC = T8_ROWV + 32, T8_TOTAL = T8_MISC + 128
 };
 
+#ifndef T8_WT
+#define T8_WT 1                   // workspace stores write-through (sc1): drain while the kernel computes instead of at its end
+#endif
 __device__ __forceinline__ void t8_st_wt2(float* p, float x, float y) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t v = {x, y};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    if constexpr (T8_WT != 0) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<float2*>(p) = make_float2(x, y);
 }
 // sum over the 32 lanes of a half-wave
 __device__ __forceinline__ float t8_sum32(float v) { v = group16_sum(v); v += __shfl_xor(v, 16); return v; }
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = (row0 + row < a.n) ? fast_tanh(out[j][i] + bb[j]) : 0.f;
             *reinterpret_cast<float4*>(lds + T8_H2 + row * T8_LD + col) = make_float4(y[0], y[1], y[2], y[3]);
-            if (tower == 0) st_wt4<true>(a.hg[0][1] + (size_t)(row0 + row) * 256 + col, make_float4(y[0], y[1], y[2], y[3]));   // (the value head's weight gradient is formed here: nobody reads a copy of its input)
+            if (tower == 0) st_wt4<T8_WT != 0>(a.hg[0][1] + (size_t)(row0 + row) * 256 + col, make_float4(y[0], y[1], y[2], y[3]));   // (the value head's weight gradient is formed here: nobody reads a copy of its input)
         }
     }
     lds_barrier();
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
                 const float h = h2[q * T8_LD + k];
                 const float d = (misc[q] * w) * (1.0f - h * h);
                 d2[q * T8_LD + k] = d;
-                st_wt<true>(a.dyg[1][1] + (size_t)(row0 + q) * 256 + k, d);             // dead rows: d == 0
+                st_wt<T8_WT != 0>(a.dyg[1][1] + (size_t)(row0 + q) * 256 + k, d);             // dead rows: d == 0
             }
         }
     }
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
             const float4 hh = *reinterpret_cast<const float4*>(lds + T8_H1 + row * T8_LD + col);
             const float4 y = make_float4(out[0][i] * (1.0f - hh.x * hh.x), out[1][i] * (1.0f - hh.y * hh.y), out[2][i] * (1.0f - hh.z * hh.z), out[3][i] * (1.0f - hh.w * hh.w));
             *reinterpret_cast<float4*>(lds + T8_D1 + row * T8_LD + col) = y;
-            st_wt4<true>(a.dyg[tower][0] + (size_t)(row0 + row) * 256 + col, y);
+            st_wt4<T8_WT != 0>(a.dyg[tower][0] + (size_t)(row0 + row) * 256 + col, y);
         }
     }
     lds_barrier();
