@@ -198,6 +198,13 @@ int ppo_dist_peer_export(ppo_handle* h, char handle[64]);
 int ppo_dist_peer_attach(ppo_handle* h, const char* handles);
 int ppo_dist_peer_active(const ppo_handle* h);
 int ppo_dist_peer_enable(ppo_handle* h, int on);
+/* Sampling under data parallelism.  Default (0): every rank shuffles its OWN B rows, global minibatch k = the union of the ranks'
+ * local minibatches k (a stratified form of the reference's shuffle; nothing but gradients and statistics crosses ranks).
+ * 1 = the reference's literal scheme (ppo2/ppo2.hpp:288-307): ONE permutation of the B * world rows of all ranks per
+ * epoch -- the same explicit `perms` [epochs][B * world] on every rank, or the same `seed` -- after an all-gather of the rollout
+ * rows (ncclAllGather, once per ppo_update); rank r trains rows [r M, (r + 1) M) of every global minibatch of M * world rows.
+ * A row index is e_global * T + t with e_global = rank * n_envs + e (runner.hpp:136-152 over the environments of all ranks). */
+int ppo_dist_global_shuffle(ppo_handle* h, int on);
 
 /* ---- measurement hooks ----------------------------------------------------------------------------------
  * per-kernel device time (ms) accumulated with hipEvents on the handle's stream since the last reset;

@@ -252,7 +252,7 @@ class PPOHip:
         pp = None
         if perms is not None:
             perms = np.ascontiguousarray(perms, np.int32)
-            assert perms.shape == (noptepochs, self.E * self.T), perms.shape
+            assert perms.shape[0] == noptepochs and perms.shape[1] % (self.E * self.T) == 0, perms.shape     # (B * world columns under ppo_dist_global_shuffle)
             pp = perms.ctypes.data_as(C.POINTER(C.c_int32))
         self._ck(self.lib.ppo_update(self.h, C.c_float(lr), C.c_float(cliprange), noptepochs, nminibatches, pp, C.c_uint64(seed),
                                      _fp(rows) if rows is not None else None, _fp(mean)))
@@ -288,6 +288,9 @@ class PPOHip:
 
     def dist_peer_active(self):
         return bool(self.lib.ppo_dist_peer_active(self.h))
+
+    def dist_global_shuffle(self, on=True):
+        self._ck(self.lib.ppo_dist_global_shuffle(self.h, int(on)))
 
     def dist_peer_enable(self, on=True):
         self._ck(self.lib.ppo_dist_peer_enable(self.h, int(on)))

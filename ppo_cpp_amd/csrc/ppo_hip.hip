@@ -177,6 +177,9 @@ struct ppo_handle {
     void* comm = nullptr;
     int world = 1, rank = 0;
     bool graph_rccl = false;          // the collectives can be captured into the update's hipGraph (probed in ppo_dist_init)
+    // literal data-parallel sampling (ppo_dist_global_shuffle): the rollout rows of all ranks, all-gathered once per update
+    bool global_shuffle = false;
+    float *gs_obs = nullptr, *gs_act = nullptr, *gs_ret = nullptr, *gs_val = nullptr, *gs_nlp = nullptr; int gs_rows = 0;
     // one-shot all-reduce over peer-mapped gather regions (ppo_peer.hpp; ppo_dist_peer_export / ppo_dist_peer_attach)
     struct Peer {
         bool on = false;                                // every collective that fits `cap` goes through the peer kernels
@@ -1205,6 +1208,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->nw_alt) (void)hipFree(h->nw_alt);
     if (h->nw_coop) (void)hipFree(h->nw_coop);
     if (h->nw_alt_counts) (void)hipFree(h->nw_alt_counts);
+    for (float* p : {h->gs_obs, h->gs_act, h->gs_ret, h->gs_val, h->gs_nlp}) if (p) (void)hipFree(p);
     if (h->dw2_jobs) (void)hipFree(h->dw2_jobs);
     if (h->dw2_counters) (void)hipFree(h->dw2_counters);
     if (h->dw2_parts) (void)hipFree(h->dw2_parts);
@@ -2105,7 +2109,8 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
     while ((1u << bits) < (uint32_t)B) ++bits;
     for (int ep = 0; ep < epochs; ++ep) {
         if (explicit_perms) {
-            hipLaunchKernelGGL(invert_perm_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->d_perms + (size_t)ep * B, h->d_inv, B);
+            const int Bp = (h->global_shuffle && h->comm && h->world > 1) ? B * h->world : B;
+            hipLaunchKernelGGL(invert_perm_kernel, dim3((Bp + 255) / 256), dim3(256), 0, h->stream, h->d_perms + (size_t)ep * Bp, h->d_inv, Bp);
             HIP_OK(h, hipGetLastError());
         }
         {
@@ -2114,7 +2119,16 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             ea.inv_perm = explicit_perms ? h->d_inv : nullptr; ea.keys = h->d_keys + 2 * ep; ea.bits = bits;
             ea.B = B; ea.M = M; ea.T = h->T; ea.E = h->E; ea.returns = h->ro_ret; ea.values = h->ro_val; ea.gidx = h->d_gidx; ea.stats = h->d_advstats;
             ea.xch = h->adv_xch; ea.xch2 = ru(nmb, 4); ea.n_global = (float)((int64_t)M * h->world);
-            if (!h->comm) {
+            const bool gs = h->global_shuffle && h->comm && h->world > 1;
+            if (gs) {
+                // ONE permutation over the rows of all ranks; the gathered returns / values are local, so the statistics of the whole
+                // minibatch need no exchange
+                uint32_t gb = 1;
+                while ((1u << gb) < (uint32_t)B * (uint32_t)h->world) ++gb;
+                ea.bits = gb; ea.world = h->world; ea.rank = h->rank; ea.returns = h->gs_ret; ea.values = h->gs_val; ea.phase = 0;
+                hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(EP_THREADS), 0, h->stream, ea);
+                HIP_OK(h, hipGetLastError());
+            } else if (!h->comm) {
                 ea.phase = 0;
                 hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(EP_THREADS), 0, h->stream, ea);
                 HIP_OK(h, hipGetLastError());
@@ -2133,6 +2147,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             ProfScope ps(h, PK_EPOCH);
             GatherArgs ga{h->d_gidx, h->d_advstats, B, M, h->net.O, h->net.A, h->ro_obs, h->ro_act, h->ro_ret, h->ro_val, h->ro_nlp,
                           h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};
+            if (h->global_shuffle && h->comm && h->world > 1) { ga.obs = h->gs_obs; ga.act = h->gs_act; ga.ret = h->gs_ret; ga.val = h->gs_val; ga.nlp = h->gs_nlp; }
             hipLaunchKernelGGL(epoch_gather_kernel, dim3((B + 15) / 16), dim3(256), 0, h->stream, ga);
             HIP_OK(h, hipGetLastError());
             if (h->bf.on) {
@@ -2171,10 +2186,19 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     const int M = B / nmb;
     if (ensure_train_ws(h, M)) return -1;
     const int steps = epochs * nmb;
-    if (B > h->upd_cap_rows || steps > h->upd_cap_steps || !h->d_keys) {
+    const bool gs = h->global_shuffle && h->comm && h->world > 1;
+    const int Bp = gs ? B * h->world : B;                      // rows one permutation covers
+    if (gs && Bp > h->gs_rows) {
         HIP_OK(h, hipStreamSynchronize(h->stream));
         if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
-        const int cr = std::max(B, h->upd_cap_rows), cs = std::max(steps, h->upd_cap_steps);
+        if (dev_alloc(h, &h->gs_obs, (size_t)Bp * h->net.O) || dev_alloc(h, &h->gs_act, (size_t)Bp * h->net.A) || dev_alloc(h, &h->gs_ret, Bp) ||
+            dev_alloc(h, &h->gs_val, Bp) || dev_alloc(h, &h->gs_nlp, Bp)) return -1;
+        h->gs_rows = Bp;
+    }
+    if (Bp > h->upd_cap_rows || steps > h->upd_cap_steps || !h->d_keys) {
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        const int cr = std::max(Bp, h->upd_cap_rows), cs = std::max(steps, h->upd_cap_steps);
         if (dev_alloc(h, &h->mb_obs, (size_t)cr * h->net.O) || dev_alloc(h, &h->mb_act, (size_t)cr * h->net.A) || dev_alloc(h, &h->mb_adv, cr) ||
             dev_alloc(h, &h->mb_ret, cr) || dev_alloc(h, &h->mb_val, cr) || dev_alloc(h, &h->mb_nlp, cr)) return -1;
         if (h->d_perms) { (void)hipFree(h->d_perms); h->d_perms = nullptr; h->upd_cap_epochs = 0; }      // sized on demand below
@@ -2191,25 +2215,36 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     if (set_hyper(h, lr, cliprange)) return -1;
     const bool explicit_perms = perms != nullptr;
     if (explicit_perms) {
-        // every epoch's row must be a permutation of [0, B): invert_perm_kernel scatters inv[perm[i]] = i
-        std::vector<unsigned char> seen((size_t)B);
+        // every epoch's row must be a permutation of [0, Bp): invert_perm_kernel scatters inv[perm[i]] = i
+        std::vector<unsigned char> seen((size_t)Bp);
         for (int ep = 0; ep < epochs; ++ep) {
             std::fill(seen.begin(), seen.end(), 0);
-            const int32_t* pe = perms + (size_t)ep * B;
-            for (int i = 0; i < B; ++i) {
+            const int32_t* pe = perms + (size_t)ep * Bp;
+            for (int i = 0; i < Bp; ++i) {
                 const int32_t d = pe[i];
-                if (d < 0 || d >= B || seen[(size_t)d]) return fail(h, "ppo_update: perms[%d] is not a permutation of [0,%d) (entry %d = %d)", ep, B, i, (int)d);
+                if (d < 0 || d >= Bp || seen[(size_t)d]) return fail(h, "ppo_update: perms[%d] is not a permutation of [0,%d) (entry %d = %d)", ep, Bp, i, (int)d);
                 seen[(size_t)d] = 1;
             }
         }
-        // [epochs, B] ints, allocated only when explicit permutations are used (on-device shuffles need none)
+        // [epochs, Bp] ints, allocated only when explicit permutations are used (on-device shuffles need none)
         if (!h->d_perms || epochs > h->upd_cap_epochs) {
             HIP_OK(h, hipStreamSynchronize(h->stream));
             if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
             if (dev_alloc(h, &h->d_perms, (size_t)epochs * h->upd_cap_rows)) return -1;
             h->upd_cap_epochs = epochs;
         }
-        HIP_OK(h, hipMemcpyAsync(h->d_perms, perms, (size_t)epochs * B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIP_OK(h, hipMemcpyAsync(h->d_perms, perms, (size_t)epochs * Bp * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    if (gs) {
+        // the rollout rows of all ranks, rank-major [world][T][E][.], once per update (10 MB per rank at config 3), outside the graph
+        if (!h->rccl.AllGather) return fail(h, "ppo_update: the collective library has no ncclAllGather (needed by ppo_dist_global_shuffle)");
+        const size_t rows = (size_t)B;
+        struct { const float* src; float* dst; size_t w; } gl[5] = {{h->ro_obs, h->gs_obs, (size_t)h->net.O}, {h->ro_act, h->gs_act, (size_t)h->net.A},
+                                                                    {h->ro_ret, h->gs_ret, 1}, {h->ro_val, h->gs_val, 1}, {h->ro_nlp, h->gs_nlp, 1}};
+        for (auto& x : gl) {
+            const int rc = h->rccl.AllGather(x.src, x.dst, rows * x.w, /*ncclFloat32*/ 7, h->comm, h->stream);
+            if (rc != 0) return fail(h, "ncclAllGather failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
+        }
     }
     std::vector<uint32_t> keys(2 * (size_t)epochs);
     for (int ep = 0; ep < epochs; ++ep) {
@@ -2224,7 +2259,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     const bool graph_ok = h->use_graph && !h->prof && (!h->comm || h->graph_rccl || h->peer.on);
     if (graph_ok) {
         const bool same = h->upd_graph && h->g_epochs == epochs && h->g_nmb == nmb && h->g_E == h->E && h->g_T == h->T &&
-                          h->g_explicit == (int)explicit_perms && h->g_world == h->world;
+                          h->g_explicit == (int)explicit_perms && h->g_world == (gs ? -h->world : h->world);
         if (!same) {
             if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
             HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -2244,7 +2279,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
                 h->use_graph = false;
                 fprintf(stderr, "libppo_hip: hipGraph capture of the update failed (%s); continuing with eager launches\n", h->err.c_str());
             } else {
-                h->g_epochs = epochs; h->g_nmb = nmb; h->g_E = h->E; h->g_T = h->T; h->g_explicit = (int)explicit_perms; h->g_world = h->world;
+                h->g_epochs = epochs; h->g_nmb = nmb; h->g_E = h->E; h->g_T = h->T; h->g_explicit = (int)explicit_perms; h->g_world = gs ? -h->world : h->world;
             }
         }
         if (h->upd_graph) HIP_OK(h, hipGraphLaunch(h->upd_graph, h->stream));
@@ -2477,6 +2512,14 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
 }
 
 int ppo_dist_peer_active(const ppo_handle* h) { return h->peer.on ? 1 : 0; }
+
+int ppo_dist_global_shuffle(ppo_handle* h, int on) {
+    ENTER(h);
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    h->global_shuffle = on != 0;
+    return 0;
+}
 
 int ppo_dist_peer_enable(ppo_handle* h, int on) {
     ENTER(h);

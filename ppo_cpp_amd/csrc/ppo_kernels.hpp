@@ -1669,6 +1669,9 @@ struct EpochArgs {
     float* xch;              // two vectors of B/M partial sums all-reduced by the host between the phases; the second starts at xch2
     int xch2;                // (a multiple of 4 floats: the peer all-reduce reads its source as 16-byte vectors)
     float n_global;          // minibatch rows over all ranks
+    // literal data-parallel sampling (ppo_dist_global_shuffle): ONE permutation of the B * world rows of all ranks; returns / values
+    // are the all-gathered [world][T][E] arrays, this rank trains rows [k Mg + rank M, k Mg + (rank + 1) M) of global minibatch k
+    int world, rank;         // world > 1 selects this mode (phase 0: the statistics of the whole minibatch are computed locally)
 };
 
 #define EP_THREADS 1024             // one workgroup per minibatch: its M rows spread over 16 waves (256 threads left 16 rows per thread
@@ -1685,6 +1688,52 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_kernel(EpochArgs a) 
         return;
     }
     const uint32_t mask = (a.bits >= 32) ? 0xFFFFFFFFu : ((1u << a.bits) - 1u);
+    if (a.world > 1) {
+        // one global permutation (ppo2.hpp:288-307 applied to the rows of ALL ranks): position p of the permuted order holds flattened
+        // env-major row r = e_global * T + t; rank e_global / E owns it, stored at [rank][t][e] of the gathered arrays
+        const int Bg = a.B * a.world, Mg = a.M * a.world;
+        auto src_of = [&](int posg) __attribute__((always_inline)) {
+            int r;
+            if (a.inv_perm) r = a.inv_perm[posg];
+            else {
+                uint32_t x = (uint32_t)posg;
+                do { x = keyed_bijection(x, a.bits, mask, a.keys[0], a.keys[1]); } while (x >= (uint32_t)Bg);
+                r = (int)x;
+            }
+            const int eg = r / a.T, t = r - eg * a.T, rs = eg / a.E, e = eg - rs * a.E;
+            return rs * (a.T * a.E) + t * a.E + e;
+        };
+        float sum = 0.f;
+        for (int i = tid; i < Mg; i += EP_THREADS) {
+            const int s = src_of(k * Mg + i);
+            const int li = i - a.rank * a.M;
+            if (li >= 0 && li < a.M) a.gidx[k * a.M + li] = s;
+            sum += a.returns[s] - a.values[s];
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if ((tid & 63) == 0) red[tid >> 6] = sum;
+        __syncthreads();
+        if (tid == 0) { float tot = 0.f; for (int w = 0; w < EP_THREADS / 64; ++w) tot += red[w]; s_mean = tot / (float)Mg; }
+        __syncthreads();
+        const float mean = s_mean;
+        float sq = 0.f;
+        for (int i = tid; i < Mg; i += EP_THREADS) {
+            const int s = src_of(k * Mg + i);
+            const float d = (a.returns[s] - a.values[s]) - mean;
+            sq += d * d;
+        }
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < EP_THREADS / 64; ++w) tot += red[w];
+            a.stats[2 * k] = mean;
+            a.stats[2 * k + 1] = (float)((double)sqrtf(tot / (float)Mg) + 1e-8);
+        }
+        return;
+    }
     float sum = 0.f;
     if (a.phase != 2) {
         for (int i = tid; i < a.M; i += EP_THREADS) {

@@ -55,7 +55,11 @@ def main():
         out[nm + "_mean"], out[nm + "_var"], out[nm + "_count"] = m, v, np.float64(c)
     for f in ("obs", "actions", "values", "neglogp", "returns"):          # identical inputs: isolate the update arithmetic
         g.rollout_set(f, d["ref_" + f][:, sl])
-    rows, mean = g.update(float(d["lr"]), float(d["cr"]), epochs, nmb, d["perms"][rank])
+    if os.environ.get("PPO_TEST_GLOBAL") == "1":
+        g.dist_global_shuffle(True)                                       # ONE permutation over the rows of all ranks, the same on every rank
+        rows, mean = g.update(float(d["lr"]), float(d["cr"]), epochs, nmb, d["gperms"])
+    else:
+        rows, mean = g.update(float(d["lr"]), float(d["cr"]), epochs, nmb, d["perms"][rank])
     out["rows"], out["mean"], out["theta"] = rows, mean, g.get_flat(0)
     out["adam_m"], out["adam_v"] = g.get_flat(1), g.get_flat(2)
     g.close()

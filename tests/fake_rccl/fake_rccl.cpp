@@ -84,6 +84,22 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
     return 0;
 }
 
+int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) {
+    Comm* c = (Comm*)comm;
+    if (dtype != 7) return 4;
+    if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+    const size_t per = SLOT_BYTES / sizeof(float);
+    for (size_t off = 0; off < count; off += per) {
+        const size_t n = count - off < per ? count - off : per;
+        if (hipMemcpy(c->slots + (size_t)c->rank * SLOT_BYTES, (const float*)send + off, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        if (int rc = barrier(c)) return rc;
+        for (int r = 0; r < c->world; ++r)
+            if (hipMemcpy((float*)recv + (size_t)r * count + off, c->slots + (size_t)r * SLOT_BYTES, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return 1;
+        if (int rc = barrier(c)) return rc;
+    }
+    return 0;
+}
+
 int ncclCommDestroy(void* comm) {
     Comm* c = (Comm*)comm;
     const bool last = c->hdr->attached.fetch_sub(1) == 1;

@@ -94,3 +94,51 @@ def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden
     for k in ("rows", "theta", "adam_m", "adam_v"):
         np.testing.assert_array_equal(outs[0][k], outs[1][k])
     assert np.abs(outs[0]["theta"] - theta0).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((64, 64), 16, 16, 4, 2), ((256, 256), 64, 8, 4, 1)])
+def test_two_ranks_literal_global_shuffle(tmp_path, hidden, E, T, nmb, epochs):
+    """ppo_dist_global_shuffle(1): the reference's sampling taken literally under data parallelism (ppo2/ppo2.hpp:288-307) --
+    ONE permutation of the rows of all ranks per epoch after an all-gather of the rollout, rank r training rows [r M, (r+1) M) of every
+    global minibatch.  Both ranks get the SAME global permutation the single-process oracle uses over the union: no equivalent-
+    permutation construction, the comparison is direct.  Loss rows and weights must match the oracle; the replicas must stay
+    bit-identical."""
+    world = 2
+    tmp = str(tmp_path)
+    fake = build_fake_rccl(tmp)
+    orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(12)
+    theta0 = orc.theta.copy()
+    rng = np.random.RandomState(43)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    nz = o.Normalizer(E, 18)
+    ro, _, _ = o.collect(orc, nz, 1234, T, noise, GAMMA, LAM)
+    El = E // world; Bl = El * T
+    gperms = np.stack([rng.permutation(E * T).astype(np.int32) for _ in range(epochs)])
+    perms = np.zeros((world, epochs, Bl), np.int32)                      # unused in this mode
+    uid = np.zeros(128, np.uint8)
+    name = ("/ppo_dp_gs_%d_%d" % (os.getpid(), rng.randint(1 << 30))).encode()
+    uid[:len(name)] = np.frombuffer(name, np.uint8)
+    fin = os.path.join(tmp, "in.npz")
+    np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
+             noise=noise, perms=perms, gperms=gperms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
+    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="0", PPO_TEST_GLOBAL="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), fin, os.path.join(tmp, "out%d.npz" % r)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("data-parallel workers timed out")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    outs = [np.load(os.path.join(tmp, "out%d.npz" % r)) for r in range(world)]
+    ref_rows, _ = orc.update(ro, gperms, nmb, LR, CR)
+    for out in outs:
+        close(out["rows"], ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows")
+        close(out["theta"], orc.theta, rtol=2e-4, atol=5e-6, msg="weights")
+    for k in ("rows", "theta", "adam_m", "adam_v"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+    assert np.abs(outs[0]["theta"] - theta0).max() > 0
