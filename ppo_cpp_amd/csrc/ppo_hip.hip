@@ -9,6 +9,7 @@
 #include "ppo_peer.hpp"
 #include "ppo_dw2.hpp"
 #include "ppo_train8.hpp"
+#include "ppo_rollout1.hpp"
 
 #include <dlfcn.h>
 
@@ -1721,6 +1722,12 @@ static int enqueue_host_step(ppo_handle* h, int t, bool act, const float* noise_
 static void launch_rollout_kernel(ppo_handle* h, const NwRolloutArgs& q, size_t lds) {
     const NetDev& n = h->net;
     const bool multi = q.E > NW_ROWS;
+    // ONE environment on the device env, reference shape: the whole rollout in one wave, weights in registers (ppo_rollout1.hpp)
+    static const bool no_r1 = [] { const char* e = getenv("PPO_HIP_NO_ROLLOUT1"); return e && e[0] == '1'; }();
+    if (h->nw_static && q.E == 1 && !q.host_mode && n.O == 18 && n.A == 18 && !no_r1) {
+        hipLaunchKernelGGL(narrow_rollout1_kernel, dim3(1), dim3(64), 0, h->stream, n, h->nw, q);
+        return;
+    }
     if (h->nw_static) {
         if (multi) hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2, true>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
         else hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2, false>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);

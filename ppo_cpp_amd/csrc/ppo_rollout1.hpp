@@ -1,0 +1,128 @@
+// ppo_rollout1.hpp -- persistent rollout of ONE environment (the reference's shipped command line: one env, ppo2.cpp:114,215-217;
+// BASELINE configs[1]) on the reference's network shape (18 obs / 18 act, [64,64]): the whole rollout in ONE launch of ONE WAVE.
+//
+// narrow_rollout_kernel (ppo_narrow.hpp) runs an env step of its 32-row group through LDS tiles, matrix instructions and nine
+// workgroup barriers: 10.5 k cycles = 4.4 us per env step, for ONE live row.  Here the policy tower's forward weights live in
+// registers (lane n holds column n of W0, W1 and W_mu: 160 registers), an activation vector is one register per lane, and a layer
+// is a k-ordered chain of `v_readlane` + `v_fma` -- no LDS, no barrier, nothing but the rollout-row stores leaves the wave.
+// The arithmetic is narrow_collect_kernel's statement for statement, so every rollout field, the running statistics and the state
+// handed to the next rollout are bit-identical to the per-step launches (test_persistent_rollout_is_bitwise_the_per_step_launches):
+//   * a dense layer reproduces nw_dense<CK>: four accumulator chains, chain q taking the k-steps s = q, q+4, ... of four k values
+//     each in k order (an exact-fp32 16x16x4 matrix instruction IS that fmaf chain), combined as (c0 + c1) + (c2 + c3);
+//   * the sums over actions reproduce the 16-lanes-per-row loop (elements j and j + 16 added in that order, then group16_sum's tree);
+//   * EnvNormalize::step / RunningStatistics::update for a batch of one row (env_normalize.hpp:64-116, running_statistics.hpp:26-104).
+// The value tower is not needed inside the loop: the host runs it afterwards, batched over the T rows (as before).
+#pragma once
+#include "ppo_narrow.hpp"
+
+#define R1_CHAIN(ACC, XV, WREG, K)                                                                      \
+    _Pragma("unroll") for (int k_ = 0; k_ < (K); ++k_) {                                               \
+        const float xk_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, XV), k_)); \
+        ACC[(k_ >> 2) & 3] = fmaf(xk_, WREG[k_], ACC[(k_ >> 2) & 3]);                                   \
+    }
+
+__global__ __launch_bounds__(64) void narrow_rollout1_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
+    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwRolloutArgs)>();
+    const int lane = threadIdx.x;
+    constexpr int O = 18, A = 18;
+    // ---- entry: this lane's weight columns, biases, statistics, state ------------------------------------------------------------------
+    float w0[32], w1[64], wm[64];
+    {
+        const float* img = q.img;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) w0[k] = img[lay.wf[0] + k * lay.wf_ld[0] + lane];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) w1[k] = img[lay.wf[1] + k * lay.wf_ld[1] + lane];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) wm[k] = lane < 32 ? img[lay.wh + k * lay.wh_ld + lane] : 0.f;
+    }
+    const float* par = q.img + lay.par;
+    const float b0 = par[net.par_b[0] + lane], b1 = par[net.par_b[1] + lane];
+    const float bmu = lane < 32 ? par[net.par_bmu + lane] : 0.f, lsj = lane < 32 ? par[net.par_ls + lane] : 0.f;
+    const bool lj = lane < O;                                 // O == A: observation / action element of this lane
+    float raw = lj ? q.st.raw_obs[lane] : 0.f;
+    float mean = lj ? q.st.obs_mean[lane] : 0.f, var = lj ? q.st.obs_var[lane] : 1.f;
+    float istd = 1.0f / sqrtf(var + q.eps);
+    float done = q.st.done[0], ret = q.st.ret[0];
+    float ret_mean = *q.st.ret_mean, ret_var = *q.st.ret_var;
+    double obs_cnt = *q.st.obs_count, ret_cnt = *q.st.ret_count;
+    auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
+        const double nb = (double)nbf, tot = cnt + nb;
+        const float bvar = bM2 / (float)nb;                                        // running_statistics.hpp:51-54
+        const float delta = bmean - mean0;                                         // :90
+        mean1 = mean0 + (delta * (float)nb) / (float)tot;                          // :94
+        const float m_a = var0 * (float)cnt, m_b = bvar * (float)nb;               // :97-98
+        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;   // :100
+        var1 = M2 / (float)tot;                                                    // :101
+    };
+    for (int t = q.t0; t < q.T; ++t) {
+        if (lane == 0) q.ro_done[t] = done;                                        // the flag that arrived with obs_t
+        float eps = 0.f;
+        if (lj) eps = q.noise ? q.noise[(size_t)t * A + lane] : ctr_normal(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t, lane);
+        // ---- normalise (env_normalize.hpp:99-104) -> rollout row t -----------------------------------------------------------------------
+        float x = 0.f;
+        if (lj) {
+            x = raw;
+            if (q.norm_obs) { x = (x - mean) * istd; x = tf_min(tf_max(x, -q.clip_obs), q.clip_obs); }
+            q.ro_obs[(size_t)t * O + lane] = x;
+        }
+        // ---- forward: lane n owns output column n --------------------------------------------------------------------------------------
+        float h1, h2, mu;
+        { float c[4] = {0.f, 0.f, 0.f, 0.f}; R1_CHAIN(c, x, w0, 32); h1 = fast_tanh(((c[0] + c[1]) + (c[2] + c[3])) + b0); }
+        { float c[4] = {0.f, 0.f, 0.f, 0.f}; R1_CHAIN(c, h1, w1, 64); h2 = fast_tanh(((c[0] + c[1]) + (c[2] + c[3])) + b1); }
+        { float c[4] = {0.f, 0.f, 0.f, 0.f}; R1_CHAIN(c, h2, wm, 64); mu = ((c[0] + c[1]) + (c[2] + c[3])) + bmu; }
+        // ---- sample + neglogp (G:5894-6672) -----------------------------------------------------------------------------------------------
+        const float logstd = mu * 0.0f + lsj;
+        const float sigma = expf(logstd);
+        const float act = mu + sigma * eps;
+        const float z = (act - mu) / sigma;
+        if (lj) q.ro_act[(size_t)t * A + lane] = act;
+        // the per-step kernels add elements j and j + 16 on lane j of a 16-lane group, then group16_sum: same order here
+        float zz = lj ? z * z : 0.f, sl = lj ? logstd : 0.f;
+        const float zz_hi = __shfl_down(zz, 16), sl_hi = __shfl_down(sl, 16);
+        float ssq = 0.f + zz, slog = 0.f + sl;
+        if (lane + 16 < A) { ssq += zz_hi; slog += sl_hi; }
+        ssq = group16_sum(ssq); slog = group16_sum(slog);
+        if (lane == 0) q.ro_nlp[t] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
+        // ---- env transition (counter hash): lane j < O new observation, lane O reward, lane O + 1 done --------------------------------------
+        const uint32_t hsh = ctr_hash(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t + 1u, (uint32_t)lane);
+        const float u = u32_to_sym_unit(hsh);
+        raw = lj ? u : 0.f;
+        const float rew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), O));
+        const float dn_l = (hsh % 300u == 0u) ? 1.0f : 0.0f;
+        done = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dn_l), O + 1));
+        // ---- EnvNormalize::step bookkeeping for a batch of ONE row ----------------------------------------------------------------------------
+        if (q.norm_obs) {
+            float sum = 0.f; sum += raw;
+            const float bmean = sum / 1.0f;                                        // colwise().mean()
+            float m2 = 0.f; { const float d = raw - bmean; m2 += d * d; }
+            float m1, v1;
+            merge(mean, var, obs_cnt, bmean, m2, 1.0f, m1, v1);
+            mean = m1; var = v1; istd = 1.0f / sqrtf(v1 + q.eps);
+            obs_cnt = (double)1.0f + obs_cnt;                                      // :103
+        }
+        {
+            ret = ret * q.gamma + rew;                                             // env_normalize.hpp:66
+            float sum = 0.f; sum += ret;
+            float m1 = ret_mean, v1 = ret_var;
+            if (q.norm_rew) {                                                      // :75-77 (training)
+                const float bmean = sum / 1.0f;
+                float m2 = 0.f; { const float d = ret - bmean; m2 += d * d; }
+                merge(ret_mean, ret_var, ret_cnt, bmean, m2, 1.0f, m1, v1);
+                ret_cnt = (double)1.0f + ret_cnt;
+            }
+            ret_mean = m1; ret_var = v1;
+            const float inv = 1.0f / sqrtf(v1 + q.eps);                            // :79
+            float y = rew;
+            if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
+            if (lane == 0) q.ro_rew[t] = y;
+            ret = ret * (1.0f - done);                                             // :88-91
+        }
+    }
+    // ---- exit: the state goes home -----------------------------------------------------------------------------------------------------------
+    if (lj) { q.st.raw_obs[lane] = raw; q.st.obs_mean[lane] = mean; q.st.obs_var[lane] = var; }
+    if (lane == 0) {
+        q.st.done[0] = done; q.st.ret[0] = ret;
+        *q.st.obs_count = obs_cnt; *q.st.ret_mean = ret_mean; *q.st.ret_var = ret_var; *q.st.ret_count = ret_cnt;
+    }
+}
