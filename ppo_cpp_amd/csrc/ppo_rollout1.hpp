@@ -11,6 +11,9 @@
 //     each in k order (an exact-fp32 16x16x4 matrix instruction IS that fmaf chain), combined as (c0 + c1) + (c2 + c3);
 //   * the sums over actions reproduce the 16-lanes-per-row loop (elements j and j + 16 added in that order, then group16_sum's tree);
 //   * EnvNormalize::step / RunningStatistics::update for a batch of one row (env_normalize.hpp:64-116, running_statistics.hpp:26-104).
+// A second wave (the helper) draws the counter-RNG noise of step t + 1 and the env transition that follows step t + 1 while the main wave
+// runs step t (both depend on the step index only): two 64-bit hashes, a log, a cos and a square root per draw leave the critical path.
+// One s_barrier per env step orders the hand-over through a double-buffered LDS block.
 // The value tower is not needed inside the loop: the host runs it afterwards, batched over the T rows (as before).
 #pragma once
 #include "ppo_narrow.hpp"
@@ -21,10 +24,28 @@
         ACC[(k_ >> 2) & 3] = fmaf(xk_, WREG[k_], ACC[(k_ >> 2) & 3]);                                   \
     }
 
-__global__ __launch_bounds__(64) void narrow_rollout1_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
+__global__ __launch_bounds__(128) void narrow_rollout1_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
+    __shared__ float s_hand[2][64];                          // [parity]: 0..17 noise of the step, 32..49 the observation that follows it, 50 reward, 51 done
     warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwRolloutArgs)>();
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     constexpr int O = 18, A = 18;
+    if (threadIdx.x >= 64) {
+        // ---- helper wave: step-indexed random quantities, one step ahead of the main wave -------------------------------------------------
+        auto produce = [&](int t) __attribute__((always_inline)) {
+            float* hw = s_hand[t & 1];
+            if (lane < A && !q.noise) hw[lane] = ctr_normal(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t, lane);
+            if (lane < O + 2) {
+                const uint32_t hs = ctr_hash(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t + 1u, (uint32_t)lane);
+                hw[32 + lane] = lane <= O ? u32_to_sym_unit(hs) : ((hs % 300u == 0u) ? 1.0f : 0.0f);
+            }
+        };
+        produce(q.t0);
+        for (int t = q.t0; t < q.T; ++t) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // what was produced for step t is visible to the main wave
+            if (t + 1 < q.T) produce(t + 1);
+        }
+        return;
+    }
     // ---- entry: this lane's weight columns, biases, statistics, state ------------------------------------------------------------------
     float w0[32], w1[64], wm[64];
     {
@@ -58,7 +79,9 @@ __global__ __launch_bounds__(64) void narrow_rollout1_kernel(NetDev net, NwLayou
     for (int t = q.t0; t < q.T; ++t) {
         if (lane == 0) q.ro_done[t] = done;                                        // the flag that arrived with obs_t
         float eps = 0.f;
-        if (lj) eps = q.noise ? q.noise[(size_t)t * A + lane] : ctr_normal(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // the helper's block of step t is complete (and it may overwrite the other one)
+        const float* hb = s_hand[t & 1];
+        if (lj) eps = q.noise ? q.noise[(size_t)t * A + lane] : hb[lane];
         // ---- normalise (env_normalize.hpp:99-104) -> rollout row t -----------------------------------------------------------------------
         float x = 0.f;
         if (lj) {
@@ -84,13 +107,10 @@ __global__ __launch_bounds__(64) void narrow_rollout1_kernel(NetDev net, NwLayou
         if (lane + 16 < A) { ssq += zz_hi; slog += sl_hi; }
         ssq = group16_sum(ssq); slog = group16_sum(slog);
         if (lane == 0) q.ro_nlp[t] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
-        // ---- env transition (counter hash): lane j < O new observation, lane O reward, lane O + 1 done --------------------------------------
-        const uint32_t hsh = ctr_hash(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t + 1u, (uint32_t)lane);
-        const float u = u32_to_sym_unit(hsh);
-        raw = lj ? u : 0.f;
-        const float rew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), O));
-        const float dn_l = (hsh % 300u == 0u) ? 1.0f : 0.0f;
-        done = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dn_l), O + 1));
+        // ---- env transition (counter hash, drawn by the helper): new observation, reward, done ----------------------------------------------
+        raw = lj ? hb[32 + lane] : 0.f;
+        const float rew = hb[32 + O];
+        done = hb[32 + O + 1];
         // ---- EnvNormalize::step bookkeeping for a batch of ONE row ----------------------------------------------------------------------------
         if (q.norm_obs) {
             float sum = 0.f; sum += raw;
