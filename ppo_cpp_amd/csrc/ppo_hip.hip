@@ -1047,6 +1047,14 @@ float* which_buf(ppo_handle* h, int which) { return which == 0 ? h->theta : whic
 
 ObsNorm no_norm() { return ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}; }
 
+// GAE scan: one lane per env (coalesced across envs); few envs x long rollouts take the LDS form (bit-identical)
+void launch_gae(ppo_handle* h, const float* rew, const float* val, const float* done, const float* last_val, const float* last_done, int T, int E,
+                float gamma, float lam, float* ret) {
+    if (E <= 64 && T >= 128 && (size_t)3 * T * sizeof(float) <= 60 * 1024)
+        hipLaunchKernelGGL(gae_long_kernel, dim3(E), dim3(GAE_LONG_THREADS), (size_t)3 * T * sizeof(float), h->stream, rew, val, done, last_val, last_done, T, E, gamma, lam, ret);
+    else hipLaunchKernelGGL(gae_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, rew, val, done, last_val, last_done, T, E, gamma, lam, ret);
+}
+
 }  // namespace
 
 // =================================================================================================================
@@ -1451,8 +1459,7 @@ int ppo_gae(ppo_handle* h, const float* rewards, const float* values, const floa
     for (int i = 0; i < 5; ++i) HIP_OK(h, hipMemcpyAsync(h->st_vec[i], src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, h->stream));
     {
         ProfScope ps(h, PK_GAE);
-        hipLaunchKernelGGL(gae_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, h->st_vec[0], h->st_vec[1], h->st_vec[2], h->st_vec[3],
-                           h->st_vec[4], T, E, gamma, lam, h->st_vec[5]);
+        launch_gae(h, h->st_vec[0], h->st_vec[1], h->st_vec[2], h->st_vec[3], h->st_vec[4], T, E, gamma, lam, h->st_vec[5]);
         HIP_OK(h, hipGetLastError());
     }
     HIP_OK(h, hipMemcpyAsync(returns, h->st_vec[5], n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1677,8 +1684,7 @@ static int enqueue_finish(ppo_handle* h, float gamma, float lam) {
     a.theta = h->theta; a.par = h->par; a.obs = h->raw_obs; a.value = h->last_val; a.nz = obs_norm(h); a.n = h->E;
     if (launch_step(h, a)) return -1;
     ProfScope ps(h, PK_GAE);
-    hipLaunchKernelGGL(gae_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, h->ro_rew, h->ro_val, h->ro_done, h->last_val, h->cur_done,
-                       h->T, h->E, gamma, lam, h->ro_ret);
+    launch_gae(h, h->ro_rew, h->ro_val, h->ro_done, h->last_val, h->cur_done, h->T, h->E, gamma, lam, h->ro_ret);
     HIP_OK(h, hipGetLastError());
     return 0;
 }

@@ -1877,6 +1877,43 @@ __global__ void gae_kernel(const float* rewards, const float* values, const floa
     }
 }
 
+// Few environments, long rollouts (the reference's own command line: ONE env x 2048 steps): the scan above is 2048 dependent
+// iterations of global loads on one lane (280 us).  One workgroup per env: every temporal-difference term delta_t and every
+// continuation flag are formed by all threads in parallel (the same expressions on the same operands) and parked in LDS; one lane then
+// runs the recurrence last = delta_t + (gamma lam) (nnt_t last) -- two dependent operations per step, its operands read ahead.
+// Bit-identical to gae_kernel (same operations in the same order per element).
+#define GAE_LONG_THREADS 256
+__global__ __launch_bounds__(GAE_LONG_THREADS) void gae_long_kernel(const float* rewards, const float* values, const float* dones, const float* last_values,
+                                                                   const float* last_dones, int T, int E, float gamma, float lam, float* returns) {
+    extern __shared__ __attribute__((aligned(16))) float gl_lds[];
+    float* s_delta = gl_lds; float* s_nnt = gl_lds + T; float* s_v = gl_lds + 2 * T;
+    const int e = blockIdx.x;
+    for (int t = threadIdx.x; t < T; t += GAE_LONG_THREADS) {
+        const size_t i = (size_t)t * E + e;
+        const float v = values[i];
+        const float nv = t == T - 1 ? last_values[e] : values[i + E];
+        const float nnt = 1.0f - (t == T - 1 ? last_dones[e] : dones[i + E]);
+        s_delta[t] = rewards[i] + gamma * (nv * nnt) - v;
+        s_nnt[t] = nnt; s_v[t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float last = 0.f;
+        const float gl = gamma * lam;
+        int t = T - 1;
+        for (; t >= 7; t -= 8) {
+            float d[8], n[8], v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { d[k] = s_delta[t - k]; n[k] = s_nnt[t - k]; v[k] = s_v[t - k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { last = d[k] + gl * (n[k] * last); s_delta[t - k] = last + v[k]; }
+        }
+        for (; t >= 0; --t) { last = s_delta[t] + gl * (s_nnt[t] * last); s_delta[t] = last + s_v[t]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += GAE_LONG_THREADS) returns[(size_t)t * E + e] = s_delta[t];
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // EnvNormalize::step for a whole batch of envs (env_normalize.hpp:64-116) in ONE multi-block launch:
 //   obs job   : obs_rms.update(raw_obs)   (:94-98; scale + clip are fused into the next policy step's input staging)

@@ -126,6 +126,11 @@ def test_gae_and_advantage_normalisation_kernels():
     np.testing.assert_array_equal(g.gae(rew, val, dones, lv, ld, GAMMA, LAM), o.gae(rew, val, dones, lv, ld, GAMMA, LAM))
     got = g.gae(rew[:5, :3], val[:5, :3], dones[:5, :3], lv[:3], ld[:3], 0.9, 1.0)      # ragged small case
     np.testing.assert_array_equal(got, o.gae(rew[:5, :3], val[:5, :3], dones[:5, :3], lv[:3], ld[:3], 0.9, 1.0))
+    for Tl, El in ((2048, 1), (300, 7), (131, 64)):             # few environments, long rollouts: the LDS form of the scan (gae_long_kernel), bit for bit
+        rw, vl = rng.normal(size=(Tl, El)).astype(np.float32), rng.normal(size=(Tl, El)).astype(np.float32)
+        dn = (rng.uniform(size=(Tl, El)) < 0.02).astype(np.float32)
+        lv2, ld2 = rng.normal(size=El).astype(np.float32), (rng.uniform(size=El) < 0.3).astype(np.float32)
+        np.testing.assert_array_equal(g.gae(rw, vl, dn, lv2, ld2, GAMMA, LAM), o.gae(rw, vl, dn, lv2, ld2, GAMMA, LAM))
     for n in (16, 2048, 1000):
         r, v = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
         close(g.adv_normalize(r, v), o.adv_normalize(r, v), rtol=2e-5, atol=2e-6)
