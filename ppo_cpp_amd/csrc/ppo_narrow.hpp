@@ -416,13 +416,23 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
         });
         __syncthreads();
         NSTAMP(6);
+        // every lane keeps its (at most four: A <= 64) elements' z and sigma from the first pass: the second pass used to recompute both
+        // (an exp and a division per element) -- same values, same results
         float ssq = 0.f, slog = 0.f, sent = 0.f;
-        for (int j = part; j < net.A; j += 16) {
-            const float mu = mus[r * ldm + j];
-            const float logstd = mu * 0.0f + par[net.par_ls + j];
-            const float act = live ? acts[r * Ap + j] : mu;
-            const float z = (act - mu) / expf(logstd);
-            ssq += z * z; slog += logstd; sent += logstd + HALF_LOG_2PIE;
+        float zk[4], sk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                 // (compile-time k: the kept values stay in registers)
+            const int j = part + 16 * k;
+            zk[k] = 0.f; sk[k] = 1.f;
+            if (j < net.A) {
+                const float mu = mus[r * ldm + j];
+                const float logstd = mu * 0.0f + par[net.par_ls + j];
+                const float act = live ? acts[r * Ap + j] : mu;
+                const float sigma = expf(logstd);
+                const float z = (act - mu) / sigma;
+                zk[k] = z; sk[k] = sigma;
+                ssq += z * z; slog += logstd; sent += logstd + HALF_LOG_2PIE;
+            }
         }
         ssq = group16_sum(ssq); slog = group16_sum(slog); sent = group16_sum(sent);
         const float nlp = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
@@ -447,17 +457,19 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
             misc[r * 4 + 3] = (live && fabsf(ratio - 1.0f) > cr) ? 1.0f : 0.f;
         }
         float* dmu_t = P + lay.dmu;
-        for (int j = part; j < Ap; j += 16) {
-            float dmu = 0.f, dl = 0.f;
-            if (j < net.A && live) {
-                const float mu = mus[r * ldm + j];
-                const float sigma = expf(mu * 0.0f + par[net.par_ls + j]);
-                const float z = (acts[r * Ap + j] - mu) / sigma;
-                dl = d_nlp * (1.0f - z * z) - net.ent_coef * gg;                          // AddN_2 G:21299
-                dmu = d_nlp * (-(z / sigma)) + dl * 0.0f;                                 // AddN_3 G:22656
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = part + 16 * k;
+            if (j < Ap) {
+                float dmu = 0.f, dl = 0.f;
+                if (j < net.A && live) {
+                    const float z = zk[k], sigma = sk[k];
+                    dl = d_nlp * (1.0f - z * z) - net.ent_coef * gg;                          // AddN_2 G:21299
+                    dmu = d_nlp * (-(z / sigma)) + dl * 0.0f;                                 // AddN_3 G:22656
+                }
+                dmu_t[r * ldm + j] = dmu;
+                dls[r * Ap + j] = dl;
             }
-            dmu_t[r * ldm + j] = dmu;
-            dls[r * Ap + j] = dl;
         }
         __syncthreads();
         NSTAMP(7);
