@@ -1417,6 +1417,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
     ta.obs = h->st_obs; ta.actions = h->st_act; ta.advs = h->st_vec[2]; ta.returns = h->st_vec[3]; ta.old_neglogp = h->st_vec[4];
     ta.old_values = h->st_vec[5]; ta.adv_stats = nullptr; ta.n = n;
     ta.inv_n = 1.0f / (float)((int64_t)n * h->world);
+    if (h->dw2) HIP_OK(h, hipMemsetAsync(h->dw2_counters, 0, DW2_TILES * sizeof(unsigned), h->stream));
     if (enqueue_train(h, ta, h->st_loss)) return -1;
     HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -2117,6 +2118,9 @@ int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count
 // ---- update -----------------------------------------------------------------------------------------------------------
 static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perms) {
     const int B = h->E * h->T, M = B / nmb;
+    // the per-tile arrival counters of weight_grad_assemble_kernel are reset by their last arriver; an update that was cut short
+    // (a failed launch) must not leave them half-counted for the next one: zeroed here, a memset node of the replayed graph
+    if (h->dw2) HIP_OK(h, hipMemsetAsync(h->dw2_counters, 0, DW2_TILES * sizeof(unsigned), h->stream));
     h->nw_pending = false; h->nw_cur = 0;                      // outside an update the weights always live in set 0
     uint32_t bits = 1;
     while ((1u << bits) < (uint32_t)B) ++bits;

@@ -83,7 +83,8 @@ def test_on_device_noise_is_standard_normal():
 
 @pytest.mark.parametrize("hidden,n,src", [((4, 5), 64, "ginit"), ((4, 5), 2048, "ckpt"), ((64, 64), 64, "orth"),
                                           ((64, 64), 256, "orth"), ((256, 256), 2048, "orth"), ((16, 8, 8), 48, "orth"),
-                                          ((64, 64), 75, "orth"), ((256, 256), 1000, "orth"), ((4, 5), 17, "ckpt")])   # ragged: not multiples of 16
+                                          ((64, 64), 75, "orth"), ((256, 256), 1000, "orth"), ((4, 5), 17, "ckpt"),    # ragged: not multiples of 16
+                                          ((256, 256), 512, "orth"), ((256, 256), 4096, "orth")])   # one and eight 64-row chunks per split of the weight-gradient kernel
 def test_train_step_losses_gradient_and_weights(hidden, n, src):
     orc, g = pair(hidden, src)
     for it in range(3):
