@@ -8,13 +8,16 @@
 // 4096 x 1024, microseconds at HBM rates).  Master weights, gradients, the global-norm clip and Adam stay fp32
 // (adam_kernel of ppo_kernels.hpp, unchanged); bf16_mirror_kernel refreshes the bf16 operand copies after every step.
 //
-// ONE GEMM form serves every product of the train step.  Both operands are stored with the REDUCTION index contiguous
-// ("NT": C[i][j] = sum_k A[i][k] * B[j][k]), which is exactly what the 16x16x32 operand map wants (8 consecutive k per
-// lane = one 16-byte LDS read) and what LDS-DMA can stage without a transpose.  Every activation / gradient matrix is
-// therefore written in two layouts by the epilogue that produces it, [rows][features] and [features][rows]:
-//     forward   H_{l+1} = tanh(X_l W_l + b)        A = X_l   [M][K]      B = W_l^T  [N][K]   (transposed bf16 mirror)
-//     backward  dY_{l-1} = (dY_l W_l^T) .* (1-H^2)  A = dY_l  [M][N]      B = W_l    [K][N]   (straight bf16 mirror)
-//     weights   dW_l = X_l^T dY_l                   A = X_l^T [K][M]      B = dY_l^T [N][M]   (split over M, fp32 slabs)
+// Every activation / gradient matrix lives in ONE layout, [rows][features] (round 3; rounds 1-2 wrote a second, [features][rows],
+// copy of each from the producing epilogue so that the weight-gradient product could use the same GEMM form: 16 MB more stores per
+// launch, and the epilogues were 76 of the 177 us of a train step's forward + backward).  Two GEMM forms:
+//     forward   H_{l+1} = tanh(X_l W_l + b)        "NT"  A = X_l   [M][K]      B = W_l^T  [N][K]   (transposed bf16 mirror)
+//     backward  dY_{l-1} = (dY_l W_l^T) .* (1-H^2)  "NT"  A = dY_l  [M][N]      B = W_l    [K][N]   (straight bf16 mirror)
+//     weights   dW_l = X_l^T dY_l                   "TN"  A = X_l   [M][K]      B = dY_l   [M][N]   (split over M, fp32 slabs)
+// NT: both operands have the REDUCTION index contiguous, which is what the 16x16x32 operand map wants (8 consecutive k per lane =
+// one 16-byte LDS read) and what LDS-DMA can stage without a transpose.  TN: the reduction index is the ROW of both operands; the
+// tiles are staged as they lie (LDS-DMA, [64 rows][128 features] images) and the fragments come out of LDS through
+// ds_read_b64_tr_b16, the hardware transpose read (two per fragment).
 // Reference arithmetic replaced: G:6889-9187 (train forward), G:11773-23699 (backward), with bf16 operands and fp32
 // accumulation; there is no reference counterpart for the precision (cfg 5 tolerance ~1e-2 on losses).
 #pragma once
@@ -30,6 +33,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define GB_K 64                    // reduction depth per LDS stage: 128-byte rows
 #define GB_STAGES 3                // LDS ring: stage t+2 is in flight while stage t is multiplied
 #define GB_PAD 128                 // every dimension of the bf16 path is padded to this
+#define GB_HEAD_SPLIT 4             // most reduction ranges of the head GEMM (GemmArgs::ksplit)
 // WM = waves along i (2 or 4): tile rows BM = 64 WM, 2 WM waves (WM x 2), each a 64 x 64 accumulator block (4 x 4 MFMA tiles)
 #define GB_BM(WM) (64 * (WM))
 #define GB_THREADS(WM) (128 * (WM))
@@ -40,26 +44,62 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 enum { GEPI_TANH = 0, GEPI_TANHGRAD = 1, GEPI_F32 = 2, GEPI_DW = 3 };
 
 struct GemmArgs {
-    const bf16_t* A[2]; const bf16_t* B[2];   // per tower; row-major, reduction index contiguous
+    const bf16_t* A[2]; const bf16_t* B[2];   // per tower; row-major: A [I][K]; B [J][K] (TANHGRAD) or [K][J] (TANH, F32: the weights as they lie)
     int lda, ldb;
     int K;                                    // reduction length
     int tiles_i;                              // tiles along i (block id -> (ti, tj) = (id % tiles_i, id / tiles_i))
     const float* bias[2];                     // [J] fp32 (TANH, F32) or null
-    const bf16_t* HT[2]; int ldht;            // TANHGRAD: tanh outputs of this layer in the [features][rows] layout
-    bf16_t* C[2]; int ldc;                    // out [I][J] bf16 (may be null)
-    bf16_t* CT[2]; int ldct;                  // out [J][I] bf16 (may be null)
+    const bf16_t* H[2]; int ldh;              // TANHGRAD: tanh outputs of this layer, [I][J]
+    bf16_t* C[2]; int ldc;                    // out [I][J] bf16
     float* F[2]; int ldf;                     // F32: out [I][J] fp32
+    int tiles_ij, ksplit; size_t f_split;     // F32 only: the reduction is cut into ksplit ranges, blocks [ks * tiles_ij, (ks+1) * tiles_ij) write the partial
+                                              // products of range ks to F + ks * f_split (bias in range 0); the consumers add the partials in range order
     float* bsum[2]; int bsum_ld;              // TANHGRAD: per row-tile column sums of the fp32 outputs, [tiles_i][bsum_ld] (bias gradients; may be null)
+#ifdef PPO_STAMPS
+    unsigned long long* stamps;               // diagnostic builds only: [EPI][tower][block][8] cycle stamps of wave 0
+#endif
 };
+#ifdef PPO_STAMPS
+#define GSTAMP(i) do { if (gst && threadIdx.x == 0) gst[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
 
 // 16-byte chunk c (0..7) of row r of a [rows][64 bf16] LDS tile lives at chunk c ^ (r & 7): a 16-lane group of a
 // ds_read_b128 (16 different rows, same k range) then spreads over 8 slots of the 256-byte bank row instead of 2.
 // LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address and again on the read.
 __device__ __forceinline__ int gb_swz(int row, int chunk) { return chunk ^ (row & 7); }
 
+// ---- operands whose REDUCTION index is the row ([64 rows][128 features] LDS images, transposed reads) -----------------------------
+// 256-byte rows; the 16-byte chunk ch of row m sits at slot ch ^ (((m & 3) << 2) | ((m >> 2) & 3)) (the guide's image (b): the
+// transposed reads of a 16x16x32 operand -- per 32-lane half two 4-row blocks 8 rows apart in the same 16 columns -- are conflict-free)
+__device__ __forceinline__ int gt_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// operand fragment of k-step ks (rows m = 32 ks .. + 31 of the stage) for the 16 features starting at f0 of a sub-tile: lane
+// (r = lane & 15, g = lane >> 4) must hold rows 32 ks + 8 g .. + 7 of feature f0 + r.  Two transposed reads: the 16 lanes of group g
+// address the block of rows 32 ks + 8 g + 4 half .. + 3 x columns f0 .. f0 + 15 (lane 4q + p: row q, columns 4p .. 4p + 3) and
+// lane r receives column r, row q in element q.
+__device__ __forceinline__ bf16x8 gt_frag(const char* sub, int f0, int ks) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    s16x4 v[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = 32 * ks + 8 * g + 4 * half + q;
+        v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(sub + row * 256 + 16 * (((f0 >> 3) + (p >> 1)) ^ gt_swz(row)) + 8 * (p & 1)));
+    }
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 w = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
 // One stage = the [BM][64] A tile followed by the [128][64] B tile, (BM + 128) / 8 pieces of 1 KB (8 rows x 128 B), dealt
 // to the waves round robin; lane l of a piece lands on (row 8p + l/8, chunk l%8) and fetches the chunk that belongs there.
-template <int WM>
+// BT: the B operand is stored [K][J] (reduction index = row, e.g. a weight matrix as it lies): its 16 pieces are 4 k-rows x 256 B
+// of a [64][128] image read back with transposed reads (gt_frag) instead of [128][64] rows read with ds_read_b128.
+template <int WM, bool BT = false>
 __device__ __forceinline__ void gb_stage(const bf16_t* __restrict__ A, int lda, int i0, const bf16_t* __restrict__ B, int ldb, int j0, int k0, char* st) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int PA = GB_BM(WM) / 8;
@@ -68,7 +108,10 @@ __device__ __forceinline__ void gb_stage(const bf16_t* __restrict__ A, int lda, 
         const int piece = wave + 2 * WM * q;                 // wave-uniform
         const bool isA = piece < PA;
         const int r = (isA ? piece : piece - PA) * 8 + (lane >> 3), c = lane & 7;
-        const bf16_t* src = isA ? A + (size_t)(i0 + r) * lda + k0 + gb_swz(r, c) * 8 : B + (size_t)(j0 + r) * ldb + k0 + gb_swz(r, c) * 8;
+        const int rt = 4 * (piece - PA) + (lane >> 4), cht = (lane & 15) ^ gt_swz(rt);
+        const bf16_t* src = isA ? A + (size_t)(i0 + r) * lda + k0 + gb_swz(r, c) * 8
+                          : BT  ? B + (size_t)(k0 + rt) * ldb + j0 + 8 * cht
+                                : B + (size_t)(j0 + r) * ldb + k0 + gb_swz(r, c) * 8;
         typedef const __attribute__((address_space(1))) void* gptr;
         typedef __attribute__((address_space(3))) void* lptr;
         __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(st + piece * 1024), 16, 0, 0);
@@ -83,17 +126,44 @@ __device__ __forceinline__ bf16x8 gb_frag(const char* lds_tile, int r0, int ks) 
     return *reinterpret_cast<const bf16x8*>(lds_tile + r * 128 + gb_swz(r, c) * 16);
 }
 
-struct GemmAcc { f32x4 v[4][4]; };           // [mi][ni]: rows 16 mi + 4 g + reg, column 16 ni + (lane & 15) of the wave's 64 x 64 block
+struct GemmAcc { f32x4 v[4][4]; };           // [mi][ni]: row 16 mi + (lane & 15), columns 16 ni + 4 g + reg of the wave's 64 x 64 block (the B fragment
+                                             // goes in as the matrix instruction's FIRST operand: a lane then holds 4 CONSECUTIVE columns of one output row)
 
 template <int N> __device__ __forceinline__ void gb_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// The epilogue's LDS image of a [BM][128] bf16 tile: 256-byte rows, the 16-byte chunk P of row i at slot P ^ (i & 15).  It is
+// where the TanhGrad epilogue finds the layer's tanh outputs (brought in by LDS-DMA during the LAST TWO k stages, into ring buffers
+// the loop no longer needs: the loop starts on the buffer that makes buffer 2 its last one, so the image always lies in buffers
+// 0 and 1) and where every epilogue parks its result, IN PLACE (a lane overwrites exactly the 8 bytes it read), before the tile
+// is streamed out in whole rows.  A lane's 8-byte element (row i, columns 4q .. 4q+3) is half q & 1 of chunk q >> 1: the 16 rows
+// of a 32-lane half land on 16 different 16-byte slots (no conflict on the 64-bank reads, 2-way on the 32-bank writes).
+#define GB_IMG_ROWS1(WM) ((GB_STAGE_BYTES(WM) / 256) < GB_BM(WM) ? (GB_STAGE_BYTES(WM) / 256) : GB_BM(WM))     // rows of the image inside ring buffer 0
+#define GB_IMG_P1(WM) (GB_IMG_ROWS1(WM) / 4 / (2 * (WM)))                                                  // 1-KB pieces per wave: part 1 / part 2
+#define GB_IMG_P2(WM) ((GB_BM(WM) - GB_IMG_ROWS1(WM)) / 4 / (2 * (WM)))
+__device__ __forceinline__ int gb_img_off(int i, int q) { return i * 256 + 16 * ((q >> 1) ^ (i & 15)) + 8 * (q & 1); }
+
+template <int WM, int NPW>
+__device__ __forceinline__ void gb_stage_image(const bf16_t* __restrict__ H, int ldh, int i0, int j0, char* img, int piece0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+        const int piece = piece0 + wave + 2 * WM * q;        // 4 rows of 256 B
+        const int row = 4 * piece + (lane >> 4), P = (lane & 15) ^ (row & 15);
+        typedef const __attribute__((address_space(1))) void* gptr;
+        typedef __attribute__((address_space(3))) void* lptr;
+        __builtin_amdgcn_global_load_lds((gptr)(H + (size_t)(i0 + row) * ldh + j0 + 8 * P), (lptr)(img + piece * 1024), 16, 0, 0);
+    }
+}
 
 // Main loop.  Per step ONE barrier: [wait until this wave's pieces of stage t have landed: all but the youngest stage's
 // loads] -> barrier (every wave's pieces of stage t are in LDS; every wave is done multiplying stage t-1) -> issue stage
 // t+2 into the buffer stage t-1 used -> read fragments of stage t, 32 MFMAs per wave.  A __syncthreads() would drain the
 // LDS-DMA queue (it waits vmcnt(0)), so the barrier is the raw instruction and the wait is counted.
-template <int WM>
+// The k loop is bound by the bytes a CU can pull from L2 into LDS (measured: 48 KB per stage in ~1975 cycles = 25 B/clk per CU,
+// against 1024 cycles of matrix instructions per SIMD), not by the matrix pipe.
+template <int WM, bool IMG, bool BT = false>
 __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restrict__ A, int lda, int i0, const bf16_t* __restrict__ B, int ldb, int j0,
-                                            int kbeg, int K, char* lds) {
+                                            int kbeg, int K, char* lds, const bf16_t* __restrict__ H = nullptr, int ldh = 0, unsigned long long* gst = nullptr) {
     const int wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     constexpr int SB = GB_STAGE_BYTES(WM), NP = GB_PIECES(WM);
@@ -102,28 +172,39 @@ __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restri
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc.v[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nt = K / GB_K;
-    gb_stage<WM>(A, lda, i0, B, ldb, j0, kbeg, lds);
-    if (nt > 1) gb_stage<WM>(A, lda, i0, B, ldb, j0, kbeg + GB_K, lds + SB);
-    int cur = 0;
+    int cur = (3 - nt % 3) % 3;                              // the last stage then sits in buffer 2: buffers 0 and 1 are free for the image
+    {
+        int nx = cur + 1; if (nx >= GB_STAGES) nx -= GB_STAGES;
+        gb_stage<WM, BT>(A, lda, i0, B, ldb, j0, kbeg, lds + cur * SB);
+        if (nt > 1) gb_stage<WM, BT>(A, lda, i0, B, ldb, j0, kbeg + GB_K, lds + nx * SB);
+    }
+    GSTAMP(1);
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) gb_wait_vm<NP>(); else gb_wait_vm<0>();
+        if (t + 1 < nt) gb_wait_vm<NP>();
+        else if (IMG && nt > 1) gb_wait_vm<GB_IMG_P1(WM)>();   // the image's first part was requested after the last stage
+        else gb_wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifndef GB_NOLOAD
         if (t + 2 < nt) {
             int nb = cur + 2; if (nb >= GB_STAGES) nb -= GB_STAGES;
-            gb_stage<WM>(A, lda, i0, B, ldb, j0, kbeg + (t + 2) * GB_K, lds + nb * SB);
+            gb_stage<WM, BT>(A, lda, i0, B, ldb, j0, kbeg + (t + 2) * GB_K, lds + nb * SB);
+        }
+#endif
+        if constexpr (IMG) {
+            if (t == (nt > 1 ? nt - 2 : 0)) gb_stage_image<WM, GB_IMG_P1(WM)>(H, ldh, i0, j0, lds, 0);                                   // buffer 0 is free
+            if constexpr (GB_IMG_P2(WM) > 0) { if (t == nt - 1) gb_stage_image<WM, GB_IMG_P2(WM)>(H, ldh, i0, j0, lds, GB_IMG_ROWS1(WM) / 4); }   // buffer 1 too
         }
         const char* at = lds + cur * SB;
         const char* bt = at + GB_BM(WM) * GB_K * 2;
-        // all 16 fragment reads of the stage go out first; the first k-step's MFMAs start when its 8 have landed while the
-        // second k-step's are still in flight (two register sets: 64 accumulator + 64 fragment VGPRs per lane)
+        // all 16 fragment reads of the stage go out first (two register sets: 64 accumulator + 64 fragment VGPRs per lane)
         bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) af[ks][a] = gb_frag(at, wm + 16 * a, ks);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bfr[ks][b] = gb_frag(bt, wn + 16 * b, ks);
+            for (int b = 0; b < 4; ++b) bfr[ks][b] = BT ? gt_frag(bt, wn + 16 * b, ks) : gb_frag(bt, wn + 16 * b, ks);
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -131,63 +212,99 @@ __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restri
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc.v[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][a], bfr[ks][b], acc.v[a][b], 0, 0, 0);
+#ifndef GB_NOMFMA
+                for (int b = 0; b < 4; ++b) acc.v[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][b], af[ks][a], acc.v[a][b], 0, 0, 0);
+#else
+                for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(af[ks][a]), "v"(bfr[ks][b]));
+#endif
         __builtin_amdgcn_s_setprio(0);
         if (++cur == GB_STAGES) cur = 0;
     }
-    __syncthreads();                                         // the epilogue reuses the ring as its staging tile
+    GSTAMP(2);
+    __syncthreads();                                         // the image has landed (vmcnt(0)); the epilogue may write buffers 0 and 1
+    GSTAMP(3);
 }
 
-// Epilogue through LDS: the accumulator layout has 4 consecutive ROWS per lane for one column, i.e. 8 contiguous bytes
-// of the [column][row] image; that image is parked in LDS (row stride BM + 8 elements: conflict-light 8-byte writes),
-// streamed out as the [J][I] output with 16-byte stores, and gathered column-wise for the [I][J] output.
+// tanh for the bf16 path: 1 - 2 / (e^{2x} + 1) on the hardware exp2 / rcp units, no small-|x| branch (the absolute error of the
+// cancellation, ~1e-7, is far below the 2^-9 of the bf16 value it is rounded to); e^{2x} = inf gives 1, 0 gives -1.
+__device__ __forceinline__ float bf16_tanh_scaled(float x_times_2log2e) {
+    const float e = __builtin_amdgcn_exp2f(x_times_2log2e);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+// Epilogue: bias + tanh, or TanhGrad against the image, into the image; bias-gradient column sums; then the tile goes out in whole
+// 256-byte rows (16-byte stores).  A lane holds 4 consecutive COLUMNS of one output row per accumulator tile.
 template <int WM, int EPI>
-__device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a, int tw, int i0, int j0, char* lds) {
+__device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a, int tw, int i0, int j0, char* lds, const float4 (&bias4)[4], unsigned long long* gst = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int g = lane >> 4, c = lane & 15;
-    constexpr int BM = GB_BM(WM), TLD = BM + 8, NT = GB_THREADS(WM);
-    bf16_t* tt = reinterpret_cast<bf16_t*>(lds);              // [128 cols j][TLD rows i]
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int BM = GB_BM(WM), NT = GB_THREADS(WM);
+    constexpr float K2 = 2.8853900817779268f;               // 2 log2(e)
+    float csum[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[nb][r] = 0.f;
+    bf16x4 h4[4][4];
+#ifndef GB_NOTANH
+    if constexpr (EPI == GEPI_TANHGRAD) {                     // every LDS read in flight before the first use
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) h4[ma][nb] = *reinterpret_cast<const bf16x4*>(lds + gb_img_off(wm + 16 * ma + c, (wn >> 2) + 4 * nb + g));
+    }
+#endif
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-        const int j = wn + 16 * nb + c;
-        float bj = 0.f;
-        if constexpr (EPI == GEPI_TANH) bj = a.bias[tw][j0 + j];
+        const float bb[4] = {bias4[nb].x * K2, bias4[nb].y * K2, bias4[nb].z * K2, bias4[nb].w * K2};
 #pragma unroll
         for (int ma = 0; ma < 4; ++ma) {
-            const int i = wm + 16 * ma + 4 * g;
             float y[4];
+#ifdef GB_NOTANH
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = acc.v[ma][nb][r] + bb[r];
+#else
             if constexpr (EPI == GEPI_TANH) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = fast_tanh(acc.v[ma][nb][r] + bj);
-            } else {                                          // TanhGrad: dY = dX .* (1 - h^2), h from the [features][rows] copy
-                const bf16x4 h4 = *reinterpret_cast<const bf16x4*>(a.HT[tw] + (size_t)(j0 + j) * a.ldht + i0 + i);
+                for (int r = 0; r < 4; ++r) y[r] = bf16_tanh_scaled(fmaf(acc.v[ma][nb][r], K2, bb[r]));
+            } else {                                          // TanhGrad: dY = dX .* (1 - h^2)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float h = (float)h4[r]; y[r] = acc.v[ma][nb][r] * (1.0f - h * h); }
+                for (int r = 0; r < 4; ++r) { const float h = (float)h4[ma][nb][r]; y[r] = acc.v[ma][nb][r] * (1.0f - h * h); csum[nb][r] += y[r]; }
             }
+#endif
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (bf16_t)y[r];
-            *reinterpret_cast<bf16x4*>(tt + j * TLD + i) = o;
-            if constexpr (EPI == GEPI_TANHGRAD) csum[nb] += (y[0] + y[1]) + (y[2] + y[3]);
+            *reinterpret_cast<bf16x4*>(lds + gb_img_off(wm + 16 * ma + c, (wn >> 2) + 4 * nb + g)) = o;
         }
     }
-    // bias gradients ride along: db[j] = sum over rows of dY[:, j].  Each wave adds its 64 rows (16 values per lane, then the
-    // four lane groups), the WM waves that share the columns meet in LDS behind the parked image, and the tile's sums go
-    // to row `ti` of a small [row tiles][features] table the gradient assembly adds up in tile order (fixed order).
-    float* cs = reinterpret_cast<float*>(lds + GB_N * TLD * 2);           // [WM][128]
+    GSTAMP(4);
+    // bias gradients ride along: db[j] = sum over rows of dY[:, j].  A lane's 4 row blocks are added in registers, the 16 lanes of
+    // a group (16 different rows) in a fixed-shape tree, the WM waves that share the columns meet in LDS behind the image,
+    // and the tile's sums go to row `ti` of a small [row tiles][features] table the gradient assembly adds up in tile order.
+    float* cs = reinterpret_cast<float*>(lds + BM * 256);                  // [WM][128]
     if constexpr (EPI == GEPI_TANHGRAD) {
         if (a.bsum[tw]) {
+            // 16 sums over the 16 lanes of a group in 15 exchanges: each step hands half of the values to the partner lane and adds the
+            // half it keeps, so that lane c ends with the complete sum of value c (= column 16 (c >> 2) + 4 g + (c & 3) of the wave's block)
+            float v8[8], v4[4], v2[2];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                float v = csum[nb];
-                v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-                if (g == 0) cs[(wave >> 1) * GB_N + wn + 16 * nb + c] = v;
+            for (int k = 0; k < 8; ++k) {
+                const float lo = csum[k >> 2][k & 3], hi = csum[2 + (k >> 2)][k & 3];
+                const float got = __shfl_xor((c & 8) ? lo : hi, 8);
+                v8[k] = ((c & 8) ? hi : lo) + got;
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float got = __shfl_xor((c & 4) ? v8[k] : v8[k + 4], 4); v4[k] = ((c & 4) ? v8[k + 4] : v8[k]) + got; }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const float got = __shfl_xor((c & 2) ? v4[k] : v4[k + 2], 2); v2[k] = ((c & 2) ? v4[k + 2] : v4[k]) + got; }
+            const float got = __shfl_xor((c & 1) ? v2[0] : v2[1], 1);
+            cs[(wave >> 1) * GB_N + wn + 16 * (c >> 2) + 4 * g + (c & 3)] = ((c & 1) ? v2[1] : v2[0]) + got;
         }
     }
     __syncthreads();
+    GSTAMP(5);
     if constexpr (EPI == GEPI_TANHGRAD) {
         if (a.bsum[tw] && tid < GB_N) {
             float v = 0.f;
@@ -196,84 +313,201 @@ __device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a
             a.bsum[tw][(size_t)(i0 / BM) * a.bsum_ld + j0 + tid] = v;
         }
     }
-    if (a.CT[tw]) {                                           // [J][I]: rows of the parked image, BM/8 chunks of 16 B per row
-        constexpr int CH = BM / 8;
-#pragma unroll
-        for (int q = 0; q < GB_N * CH / NT; ++q) {
-            const int id = tid + NT * q;
-            const int j = id / CH, ch = id % CH;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(tt + j * TLD + ch * 8);
-            *reinterpret_cast<bf16x8*>(a.CT[tw] + (size_t)(j0 + j) * a.ldct + i0 + ch * 8) = v;
-        }
-    }
-    if (a.C[tw]) {                                            // [I][J]: 8 consecutive j of one row i = 8 two-byte LDS gathers
+    if (a.C[tw]) {
 #pragma unroll
         for (int q = 0; q < BM * 16 / NT; ++q) {
             const int id = tid + NT * q;
-            const int i = id % BM, ch = id / BM;              // consecutive lanes = consecutive i: same LDS dwords pairwise, no conflicts
-            bf16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tt[(ch * 8 + e) * TLD + i];
-            *reinterpret_cast<bf16x8*>(a.C[tw] + (size_t)(i0 + i) * a.ldc + j0 + ch * 8) = v;
+            const int i = id >> 4, p = id & 15;
+            const uint4 o = *reinterpret_cast<const uint4*>(lds + i * 256 + 16 * (p ^ (i & 15)));
+#ifdef GB_NOSTORE
+            if (o.x == 0x12345678u)
+#endif
+            *reinterpret_cast<uint4*>(a.C[tw] + (size_t)(i0 + i) * a.ldc + j0 + 8 * p) = o;
         }
     }
+    GSTAMP(6);
+#ifdef PPO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSTAMP(7);
+#endif
 }
 
 template <int WM, int EPI>
 __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_nt_bf16_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char gb_lds[];
     const int tw = blockIdx.y;
-    const int ti = blockIdx.x % a.tiles_i, tj = blockIdx.x / a.tiles_i;
+    const int ks = EPI == GEPI_F32 ? blockIdx.x / a.tiles_ij : 0, bt = EPI == GEPI_F32 ? blockIdx.x % a.tiles_ij : blockIdx.x;
+    const int ti = bt % a.tiles_i, tj = bt / a.tiles_i;
     const int i0 = ti * GB_BM(WM), j0 = tj * GB_N;
     GemmAcc acc;
-    gb_mainloop<WM>(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, 0, a.K, gb_lds);
+#ifdef PPO_STAMPS
+    unsigned long long* gst = a.stamps ? a.stamps + ((size_t)(EPI * 2 + tw) * 256 + blockIdx.x) * 8 : nullptr;
+#else
+    unsigned long long* gst = nullptr;
+#endif
+    GSTAMP(0);
+    float4 bias4[4];                                         // this lane's 16 bias values: requested before the loop, used after it
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) bias4[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI == GEPI_TANH) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) bias4[nb] = *reinterpret_cast<const float4*>(a.bias[tw] + j0 + (wave & 1) * 64 + 16 * nb + 4 * (lane >> 4));
+    }
+    if constexpr (EPI == GEPI_TANHGRAD) gb_mainloop<WM, true>(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, 0, a.K, gb_lds, a.H[tw], a.ldh, gst);
+    else if constexpr (EPI == GEPI_F32) gb_mainloop<WM, false, true>(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, ks * (a.K / a.ksplit), a.K / a.ksplit, gb_lds, nullptr, 0, gst);
+    else gb_mainloop<WM, false, true>(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, 0, a.K, gb_lds, nullptr, 0, gst);
     if constexpr (EPI == GEPI_F32) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, g = lane >> 4, c = lane & 15;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const int j = j0 + wn + 16 * nb + c;
-            const float bj = a.bias[tw] ? a.bias[tw][j] : 0.f;
+            const int j = j0 + wn + 16 * nb + 4 * g;
+            float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias[tw] && ks == 0) bj = *reinterpret_cast<const float4*>(a.bias[tw] + j);
 #pragma unroll
             for (int ma = 0; ma < 4; ++ma)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a.F[tw][(size_t)(i0 + wm + 16 * ma + 4 * g + r) * a.ldf + j] = acc.v[ma][nb][r] + bj;
+                *reinterpret_cast<float4*>(a.F[tw] + (size_t)ks * a.f_split + (size_t)(i0 + wm + 16 * ma + c) * a.ldf + j) =
+                    make_float4(acc.v[ma][nb][0] + bj.x, acc.v[ma][nb][1] + bj.y, acc.v[ma][nb][2] + bj.z, acc.v[ma][nb][3] + bj.w);
         }
     } else {
-        gb_epilogue_bf16<WM, EPI>(acc, a, tw, i0, j0, gb_lds);
+#ifndef GB_NOEPI
+        gb_epilogue_bf16<WM, EPI>(acc, a, tw, i0, j0, gb_lds, bias4, gst);
+#else
+        if (acc.v[0][0][0] == 123.456f) a.C[tw][0] = (bf16_t)acc.v[1][1][1];
+#endif
     }
 }
 
 // ---- weight gradients: every matrix of both towers in one grouped launch, split over the minibatch rows -------------
+// dW[i][j] = sum over rows m of X[m][i] * dY[m][j]: the "TN" form.  A stage is 64 rows m of the X tile (BM features, as BM / 128
+// sub-tiles) and of the dY tile (128 features): [64][128] sub-tiles with 256-byte rows, brought in by LDS-DMA as they lie.  The
+// 16-byte chunk ch of row m sits at slot ch ^ (((m & 3) << 2) | ((m >> 2) & 3)) (the guide's image (b): the transposed reads of
+// a 16x16x32 operand -- per 32-lane half two 4-row blocks 8 rows apart in the same 16 columns -- are conflict-free on it).
 struct DwTileB { const bf16_t* A; const bf16_t* B; int lda, ldb; int i0, j0; int out_off, ldo; int is_x0; };
-struct DwArgsB { const DwTileB* tiles; int nsplit; int rows_per_split; float* slabs; size_t slab_stride;
-                 const bf16_t* x0T; int x0_ld; };     // epoch-staged transposed observations of this minibatch (null: the tiles' own x0T)
+// The launch is WORK-balanced, not tile-balanced: the (tile, 64-row stage) pairs of all tiles form one sequence (tile-major) and
+// workgroup w takes `per` consecutive stages of it, i.e. the tail of one tile's reduction and/or the head of the next one's
+// (per <= nst: at most two segments).  At configs[4] that is 152 tiles x 64 stages over 256 workgroups of 38 stages: ONE round on
+// the 256 CUs, where 4 row splits per tile were 608 workgroups = three rounds, the last one 37 % full.  A tile's partial sums go
+// to slabs 0 .. (number of workgroups that touch it) - 1; the gradient assembly recomputes that count from (nst, per).
+struct DwArgsB { const DwTileB* tiles; int nst, per, total; float* slabs; size_t slab_stride;
+                 const bf16_t* x0; int x0_ld          // epoch-staged observations of this minibatch (null: the tiles' own x0)
+#ifdef PPO_STAMPS
+                 ; unsigned long long* stamps
+#endif
+                 ; };
+
+template <int WM>
+__device__ __forceinline__ void gt_stage(const bf16_t* __restrict__ X, int ldx, int i0, const bf16_t* __restrict__ Y, int ldy, int j0, int m0, char* st) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NA = WM / 2;                               // sub-tiles of X
+#pragma unroll
+    for (int q = 0; q < GB_PIECES(WM); ++q) {
+        const int piece = wave + 2 * WM * q;                 // wave-uniform; 16 pieces (4 rows x 256 B each) per sub-tile
+        const int sub = piece >> 4;
+        const int row = 4 * (piece & 15) + (lane >> 4), ch = (lane & 15) ^ gt_swz(row);
+        const bf16_t* src = sub < NA ? X + (size_t)(m0 + row) * ldx + i0 + 128 * sub + 8 * ch : Y + (size_t)(m0 + row) * ldy + j0 + 8 * ch;
+        typedef const __attribute__((address_space(1))) void* gptr;
+        typedef __attribute__((address_space(3))) void* lptr;
+        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(st + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <int WM>
+__device__ __forceinline__ void gt_mainloop(GemmAcc& acc, const bf16_t* __restrict__ X, int ldx, int i0, const bf16_t* __restrict__ Y, int ldy, int j0,
+                                            int mbeg, int M, char* lds) {
+    const int wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    constexpr int SB = GB_STAGE_BYTES(WM), NP = GB_PIECES(WM);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc.v[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nt = M / GB_K;
+    gt_stage<WM>(X, ldx, i0, Y, ldy, j0, mbeg, lds);
+    if (nt > 1) gt_stage<WM>(X, ldx, i0, Y, ldy, j0, mbeg + GB_K, lds + SB);
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) gb_wait_vm<NP>(); else gb_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef GT_NOLOAD
+        if (t + 2 < nt) {
+            int nb = cur + 2; if (nb >= GB_STAGES) nb -= GB_STAGES;
+            gt_stage<WM>(X, ldx, i0, Y, ldy, j0, mbeg + (t + 2) * GB_K, lds + nb * SB);
+        }
+#endif
+        const char* at = lds + cur * SB + (wm >> 7) * 16384;             // the X sub-tile this wave's 64 features lie in
+        const char* bt = lds + cur * SB + (WM / 2) * 16384;
+        bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[ks][a] = gt_frag(at, (wm & 127) + 16 * a, ks);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bfr[ks][b] = gt_frag(bt, wn + 16 * b, ks);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc.v[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][b], af[ks][a], acc.v[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (++cur == GB_STAGES) cur = 0;
+    }
+}
 
 template <int WM>
 __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_dw_bf16_kernel(DwArgsB a) {
     extern __shared__ __attribute__((aligned(16))) char gb_lds[];
-    const DwTileB t = a.tiles[blockIdx.x / a.nsplit];
-    const int split = blockIdx.x % a.nsplit;                 // the splits of one tile sit on different XCDs; tiles of one split share X^T / dY^T panels
-    GemmAcc acc;
-    const bool ov = t.is_x0 && a.x0T;
-    gb_mainloop<WM>(acc, ov ? a.x0T : t.A, ov ? a.x0_ld : t.lda, t.i0, t.B, t.ldb, t.j0, split * a.rows_per_split, a.rows_per_split, gb_lds);
+    // consecutive work ranges on ONE XCD (they share the X panel of their tile row): workgroup b runs on XCD b % 8
+    const int G = gridDim.x;
+#ifndef GT_NOREMAP
+    const int w = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+#else
+    const int w = blockIdx.x;
+#endif
+    const int begin = w * a.per, end = min(begin + a.per, a.total);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, g = lane >> 4, c = lane & 15;
-    float* out = a.slabs + (size_t)split * a.slab_stride + t.out_off;
+    int s0 = begin;
+#ifdef PPO_STAMPS
+    unsigned long long* gst = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    int sti = 1;
+#endif
+    GSTAMP(0);
+    while (s0 < end) {
+        const int tile = s0 / a.nst;
+        const int s1 = min(end, (tile + 1) * a.nst);
+        const DwTileB t = a.tiles[tile];
+        const int slab = w - (tile * a.nst) / a.per;           // this workgroup's rank among the tile's contributors
+        const bool ov = t.is_x0 && a.x0;
+        GemmAcc acc;
+        __syncthreads();                                     // the ring is free again (second segment)
+        gt_mainloop<WM>(acc, ov ? a.x0 : t.A, ov ? a.x0_ld : t.lda, t.i0, t.B, t.ldb, t.j0, (s0 - tile * a.nst) * GB_K, (s1 - s0) * GB_K, gb_lds);
+        float* out = a.slabs + (size_t)slab * a.slab_stride + t.out_off;
+#ifdef PPO_STAMPS
+        GSTAMP(sti); if (gst && threadIdx.x == 0) gst[5 + (sti >> 1)] = (unsigned long long)(s1 - s0);
+        ++sti;
+#endif
 #pragma unroll
-    for (int ma = 0; ma < 4; ++ma)
+        for (int ma = 0; ma < 4; ++ma) {
+            float* row = out + (size_t)(t.i0 + wm + 16 * ma + c) * t.ldo + t.j0 + wn + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* row = out + (size_t)(t.i0 + wm + 16 * ma + 4 * g + r) * t.ldo + t.j0 + wn + c;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) row[16 * nb] = acc.v[ma][nb][r];
+            for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<float4*>(row + 16 * nb) = make_float4(acc.v[ma][nb][0], acc.v[ma][nb][1], acc.v[ma][nb][2], acc.v[ma][nb][3]);
         }
+#ifdef PPO_STAMPS
+        GSTAMP(sti); ++sti;
+#endif
+        s0 = s1;
+    }
 }
 
-// ---- input staging: fp32 observations -> bf16 [rows_pad][Kp0] (+ the [Kp0][rows_pad] copy the first layer's weight
-// gradient needs); the act path normalises here (env_normalize.hpp:99-104) and writes the normalised fp32 rows into
+// ---- input staging: fp32 observations -> bf16 [rows_pad][Kp0]; the act path normalises here (env_normalize.hpp:99-104) and writes the normalised fp32 rows into
 // the rollout buffer, as stage_block_inputs does for the fused kernels --------------------------------------------------
-struct StageArgsB { const float* obs; int n, O, Kp0, rows_pad; ObsNorm nz; float* obs_out; bf16_t* X; bf16_t* XT; int ldt; };
+struct StageArgsB { const float* obs; int n, O, Kp0, rows_pad; ObsNorm nz; float* obs_out; bf16_t* X; };
 
 __global__ __launch_bounds__(256) void bf16_stage_kernel(StageArgsB a) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -289,12 +523,18 @@ __global__ __launch_bounds__(256) void bf16_stage_kernel(StageArgsB a) {
         if (a.obs_out) a.obs_out[(size_t)row * a.O + j] = x;
     }
     a.X[idx] = (bf16_t)x;
-    if (a.XT) a.XT[(size_t)j * a.ldt + row] = (bf16_t)x;
 }
 
 // ---- act epilogue: sampling + neglogp (G:5894-6672) from the head GEMM's fp32 outputs ---------------------------------
+// head outputs arrive as `hsplit` partial products hstride floats apart (GemmArgs::ksplit), added here in range order
+__device__ __forceinline__ float head_sum(const float* p, size_t idx, int hsplit, size_t hstride) {
+    float s = p[idx];
+    for (int k = 1; k < hsplit; ++k) s += p[idx + (size_t)k * hstride];
+    return s;
+}
+
 struct SampleArgsB {
-    const float* head[2]; int ldh;      // [rows_pad][Ap] fp32: tower 0 = mu, tower 1 column 0 = value
+    const float* head[2]; int ldh; int hsplit; size_t hstride;      // [hsplit][rows_pad][Ap] fp32: tower 0 = mu, tower 1 column 0 = value
     const float* logstd;                // fp32 master
     const float* noise; float* action; float* det_action; float* value; float* neglogp;
     int n, A; uint32_t seed, rng_step, row_base;
@@ -306,7 +546,7 @@ __global__ __launch_bounds__(256) void bf16_sample_kernel(SampleArgsB a) {
     const bool live = row < a.n;
     float ssq = 0.f, slog = 0.f;
     for (int j = part; j < a.A; j += 16) {
-        const float mu = live ? a.head[0][(size_t)row * a.ldh + j] : 0.f;
+        const float mu = live ? head_sum(a.head[0], (size_t)row * a.ldh + j, a.hsplit, a.hstride) : 0.f;
         const float logstd = mu * 0.0f + a.logstd[j];
         const float sigma = expf(logstd);
         float eps = 0.f;
@@ -322,20 +562,20 @@ __global__ __launch_bounds__(256) void bf16_sample_kernel(SampleArgsB a) {
     ssq = group16_sum(ssq); slog = group16_sum(slog);
     if (part == 0 && live) {
         if (a.neglogp) a.neglogp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)a.A + slog;
-        if (a.value) a.value[row] = a.head[1][(size_t)row * a.ldh];
+        if (a.value) a.value[row] = head_sum(a.head[1], (size_t)row * a.ldh, a.hsplit, a.hstride);
     }
 }
 
 // ---- loss + its gradient w.r.t. the head outputs (G:9428-11290, G:12609-22656): the arithmetic of
-// train_fwd_bwd_kernel's middle section, 16 lanes per row, fp32; writes d mu / d v as bf16 in both layouts and the
+// train_fwd_bwd_kernel's middle section, 16 lanes per row, fp32; writes d mu / d v as bf16 and the
 // per-block partial sums (bias / logstd gradients, loss terms) the gradient assembly adds up in a fixed order ---------
 struct LossArgsB {
-    const float* head[2]; int ldh;
+    const float* head[2]; int ldh; int hsplit; size_t hstride;
     const float* logstd;
     const float* actions; const float* advs; const float* returns; const float* old_values; const float* old_neglogp;
     const float* hyper;                 // {lr, cliprange}
     int n, A, Ap, rows_pad; float inv_n, ent_coef, vf_coef;
-    bf16_t* dhead[2]; bf16_t* dheadT[2];   // [rows_pad][Ap], [Ap][rows_pad]  (tower 1: only column / row 0 is ever non-zero)
+    bf16_t* dhead[2];                   // [rows_pad][Ap]  (tower 1: only column 0 is ever non-zero)
     float* slots[2]; int slot_w, slot_head, slot_aux, slot_loss;
 };
 
@@ -351,7 +591,8 @@ __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
     // policy tower
     float ssq = 0.f, slog = 0.f, sent = 0.f;
     for (int j = part; j < a.A; j += 16) {
-        const float mu = a.head[0][(size_t)row * a.ldh + j];
+        const float mu = head_sum(a.head[0], (size_t)row * a.ldh + j, a.hsplit, a.hstride);
+        dmu_s[r * a.Ap + j] = mu;                            // kept for the gradient pass below (same thread, same element)
         const float logstd = mu * 0.0f + a.logstd[j];
         const float act = live ? a.actions[(size_t)row * a.A + j] : mu;
         const float z = (act - mu) / expf(logstd);
@@ -381,7 +622,7 @@ __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
     for (int j = part; j < a.Ap; j += 16) {
         float dmu = 0.f, dl = 0.f;
         if (j < a.A && live) {
-            const float mu = a.head[0][(size_t)row * a.ldh + j];
+            const float mu = dmu_s[r * a.Ap + j];
             const float sigma = expf(mu * 0.0f + a.logstd[j]);
             const float z = (a.actions[(size_t)row * a.A + j] - mu) / sigma;
             dl = d_nlp * (1.0f - z * z) - a.ent_coef * g;                            // AddN_2 G:21299
@@ -394,7 +635,7 @@ __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
     if (part == 0) {
         float dv = 0.f, lossv = 0.f;
         if (live) {
-            const float v = a.head[1][(size_t)row * a.ldh];
+            const float v = head_sum(a.head[1], (size_t)row * a.ldh, a.hsplit, a.hstride);
             const float R = a.returns[row], vo = a.old_values[row];
             const float dvo = v - vo;
             const float vmin = tf_min(dvo, cr);
@@ -409,17 +650,8 @@ __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
         }
         vt[r * 2] = dv; vt[r * 2 + 1] = lossv;
         a.dhead[1][(size_t)row * a.Ap] = (bf16_t)dv;
-        a.dheadT[1][row] = (bf16_t)dv;
     }
     __syncthreads();
-    // the [features][rows] copy of d mu from the LDS tile: 8 consecutive rows of one feature = one 16-byte store
-    for (int i = tid; i < a.Ap * (BL_ROWS / 8); i += 16 * BL_ROWS) {
-        const int j = i / (BL_ROWS / 8), pr = i - j * (BL_ROWS / 8);
-        bf16x8 v;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (bf16_t)dmu_s[(8 * pr + q) * a.Ap + j];
-        *reinterpret_cast<bf16x8*>(a.dheadT[0] + (size_t)j * a.rows_pad + (size_t)blockIdx.x * BL_ROWS + 8 * pr) = v;
-    }
     float* s0 = a.slots[0] + (size_t)blockIdx.x * a.slot_w;
     float* s1 = a.slots[1] + (size_t)blockIdx.x * a.slot_w;
     for (int j = tid; j < a.Ap; j += 16 * BL_ROWS) {
@@ -452,32 +684,13 @@ __global__ __launch_bounds__(256) void bf16_rowsum_kernel(RowSumArgsB a) {
     if (lane == 0) a.dst[m][j] = s;
 }
 
-// ---- bf16 operand mirrors of the fp32 master weights: the straight copy keeps theta's padded layout (a cast of the
-// whole vector); the transposed copies come from a table of matrices, 32 x 32 tiles through LDS ------------------------
+// ---- bf16 operand mirror of the fp32 master weights: keeps theta's padded layout (a cast of the whole vector) ----------------
 __global__ __launch_bounds__(256) void bf16_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const float4 v = reinterpret_cast<const float4*>(src)[i];
     bf16x4 o; o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
     reinterpret_cast<bf16x4*>(dst)[i] = o;
-}
-
-struct TrMat { int src_off, dst_off, rows, cols, first_tile; };      // src [rows][cols] fp32 -> dst [cols][rows] bf16; tiles of 32 x 32
-struct TrArgs { const TrMat* mats; int n_mats; const float* src; bf16_t* dst; };
-
-__global__ __launch_bounds__(256) void bf16_transpose_kernel(TrArgs a) {
-    __shared__ float tile[32][33];
-    int m = 0;
-    while (m + 1 < a.n_mats && (int)blockIdx.x >= a.mats[m + 1].first_tile) ++m;
-    const TrMat t = a.mats[m];
-    const int tl = blockIdx.x - t.first_tile, tc = t.cols / 32;
-    const int r0 = (tl / tc) * 32, c0 = (tl % tc) * 32;
-    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) tile[y + 8 * k][x] = a.src[t.src_off + (size_t)(r0 + y + 8 * k) * t.cols + c0 + x];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a.dst[t.dst_off + (size_t)(c0 + y + 8 * k) * t.rows + r0 + x] = (bf16_t)tile[x][y + 8 * k];
 }
 
 // ---- gradient assembly for the bf16 path: one WAVE per 256-element chunk of the padded parameter vector, four consecutive
@@ -506,7 +719,11 @@ __global__ __launch_bounds__(256) void bf16_grad_reduce_kernel(ReduceArgs a) {
     const size_t idx = (size_t)chunk * 256 + 4 * lane;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
     if (s.kind == 0) {
-        for (int k = 0; k < a.nsplit; ++k) {
+        // the lane's 4 elements lie in one tile of the weight-gradient GEMM: as many partial sums as workgroups touched that tile
+        const int e = (int)(idx - (size_t)s.base), row = e / s.pcol, col = e - row * s.pcol;
+        const int tile = s.tile0 + (row / a.sk_bm) * (s.pcol / GB_N) + col / GB_N;
+        const int cnt = (tile * a.sk_nst + a.sk_nst - 1) / a.sk_per - (tile * a.sk_nst) / a.sk_per + 1;
+        for (int k = 0; k < cnt; ++k) {
             const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)k * a.slab_stride + idx);
             g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
         }

@@ -146,18 +146,18 @@ struct ppo_handle {
     struct Bf16 {
         bool on = false;
         int Rcap = 0;                                   // row capacity of the workspaces (multiple of 128)
-        bf16_t* theta_bf = nullptr;                     // straight cast of theta (same padded offsets): B operand of the backward products
-        bf16_t* thetaT_bf = nullptr;                    // W^T of every matrix: B operand of the forward products
-        int wt_off[2][PPO_MAX_LAYERS]{}; int whT_off[2]{}; int nT = 0;
-        TrMat* d_trmats = nullptr; int n_trmats = 0, n_trtiles = 0;
-        bf16_t *x0 = nullptr, *x0T = nullptr;
-        bf16_t *xe = nullptr, *xeT = nullptr; int xe_rows = 0; bool epoch_staged = false;   // observations of a whole epoch staged once (bf16, both layouts)
+        bf16_t* theta_bf = nullptr;                     // straight cast of theta (same padded offsets): B operand of the forward ([K][J], transposed LDS reads)
+                                                        // and of the backward products ([J][K] as it lies); no transposed mirror since round 3
+        bf16_t *x0 = nullptr;
+        bf16_t *xe = nullptr; int xe_rows = 0; bool epoch_staged = false;   // observations of a whole epoch staged once (bf16)
         int db_tiles = 0;                               // row tiles the bias-gradient table is sized for
-        bf16_t *hb[2][PPO_MAX_LAYERS]{}, *hT[2][PPO_MAX_LAYERS]{}, *dy[2][PPO_MAX_LAYERS]{}, *dyT[2][PPO_MAX_LAYERS]{};
-        float* head_out[2]{};                           // [Rcap][Ap] fp32
-        bf16_t *dhead[2]{}, *dheadT[2]{};
+        bf16_t *hb[2][PPO_MAX_LAYERS]{}, *dy[2][PPO_MAX_LAYERS]{};     // [Rcap][Hp_l]: tanh outputs and the gradients w.r.t. the pre-activations
+        float* head_out[2]{};                           // [GB_HEAD_SPLIT][Rcap][Ap] fp32 partial products of the head GEMM's reduction ranges
+        int head_split = 1;                             // ranges the last bf16_forward used
+        bf16_t *dhead[2]{};
         float* dbias = nullptr; int db_off[2][PPO_MAX_LAYERS]{}; int n_dbias = 0;
         DwTileB* dw_tiles = nullptr; int n_dw_tiles = 0; int dw_wm = 4;
+        int tile0[2][PPO_MAX_LAYERS + 1]{};             // first weight-gradient tile of every matrix ([L] = the head), in the order of the tile table
     } bf;
     // narrow-network path (every hidden width <= 64; kernels in ppo_narrow.hpp)
     bool narrow = false;
@@ -372,12 +372,6 @@ int build_layout(ppo_handle* h) {
         return (size_t)o * sizeof(float) <= 160 * 1024;
     };
     if (bf) {
-        // bf16 operand mirrors: offsets of the transposed copies (the straight copy shares theta's offsets)
-        int o = 0;
-        for (int tw = 0; tw < 2; ++tw)
-            for (int l = 0; l < n.L; ++l) { h->bf.wt_off[tw][l] = o; o += n.Hp[l] * (l ? n.Hp[l - 1] : n.Kp0); }
-        for (int tw = 0; tw < 2; ++tw) { h->bf.whT_off[tw] = o; o += n.Ap * HpL; }
-        h->bf.nT = o;
         int d = 0;
         for (int tw = 0; tw < 2; ++tw)
             for (int l = 0; l < n.L; ++l) { h->bf.db_off[tw][l] = d; d += n.Hp[l]; }
@@ -446,7 +440,7 @@ int upload_grad_src(ppo_handle* h) {
     const NetDev& n = h->net;
     std::vector<GradSrc> src(h->n_blocks);
     for (const Tensor& t : h->tensors) {
-        GradSrc g{2, 0, 0, 0, t.off_pad, -1, t.prow, t.pcol, -1, 0, -1, 0, -1, 0, -1};
+        GradSrc g{2, 0, 0, 0, t.off_pad, -1, t.prow, t.pcol, -1, 0, -1, 0, -1, 0, -1, -1};
         const std::string nm = t.name;
         int l = -1;
         if (nm.find("_fc") != std::string::npos) l = atoi(nm.c_str() + 5);
@@ -467,7 +461,7 @@ int upload_grad_src(ppo_handle* h) {
             // from the row-sum kernel's vector (kind 3), head bias / logstd / value bias from the loss kernel's per-block slots;
             // the fp32 transposed copies and the small-parameter mirror do not exist on this path
             g.t_off = -1; g.p_off = -1; g.p_count = 0;
-            if (nm.size() > 2 && nm.substr(nm.size() - 2) == "/w") g.kind = 0;
+            if (nm.size() > 2 && nm.substr(nm.size() - 2) == "/w") { g.kind = 0; g.tile0 = h->bf.tile0[tower][l >= 0 ? l : n.L]; }
             else if (l >= 0) { g.kind = 3; g.slot_off = h->bf.db_off[tower][l]; g.count = n.Hp[l]; }
             else if (nm == "vf/b") { g.kind = 1; g.tower = 1; g.slot_off = n.slot_head; g.count = 1; }
             else if (nm == "pi/b") { g.kind = 1; g.tower = 0; g.slot_off = n.slot_head; g.count = n.Ap; }
@@ -577,22 +571,11 @@ int ensure_staging(ppo_handle* h, int rows) {
 ObsNorm no_norm_fwd() { return ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}; }
 
 // ---- bf16 matrix-core path (ppo_bf16.hpp) ------------------------------------------------------------------------
-// bf16 operand copies of the fp32 master weights: a cast of the whole padded vector + the transposed copies
-int bf16_refresh_transposes(ppo_handle* h) {
-    ppo_handle::Bf16& b = h->bf;
-    TrArgs ta{b.d_trmats, b.n_trmats, h->theta, b.thetaT_bf};
-    hipLaunchKernelGGL(bf16_transpose_kernel, dim3(b.n_trtiles), dim3(256), 0, h->stream, ta);
-    HIP_OK(h, hipGetLastError());
-    return 0;
-}
-
+// bf16 operand copy of the fp32 master weights: a cast of the whole padded vector (adam_kernel keeps it current afterwards)
 int bf16_refresh_mirrors(ppo_handle* h) {
     ppo_handle::Bf16& b = h->bf;
     const size_t n4 = (size_t)h->P_pad / 4;
     hipLaunchKernelGGL(bf16_cast_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->stream, h->theta, b.theta_bf, n4);
-    HIP_OK(h, hipGetLastError());
-    TrArgs ta{b.d_trmats, b.n_trmats, h->theta, b.thetaT_bf};
-    hipLaunchKernelGGL(bf16_transpose_kernel, dim3(b.n_trtiles), dim3(256), 0, h->stream, ta);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -600,18 +583,7 @@ int bf16_refresh_mirrors(ppo_handle* h) {
 int bf16_create(ppo_handle* h) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
-    if (dev_alloc(h, &b.theta_bf, (size_t)h->P_pad) || dev_alloc(h, &b.thetaT_bf, (size_t)b.nT)) return -1;
-    std::vector<TrMat> mats;
-    int tiles = 0;
-    auto add = [&](int src_off, int dst_off, int rows, int cols) { mats.push_back(TrMat{src_off, dst_off, rows, cols, tiles}); tiles += (rows / 32) * (cols / 32); };
-    for (int tw = 0; tw < 2; ++tw)
-        for (int l = 0; l < n.L; ++l) add(n.w_off[tw][l], b.wt_off[tw][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l]);
-    add(n.wmu_off, b.whT_off[0], n.Hp[n.L - 1], n.Ap);
-    add(n.wv_off, b.whT_off[1], n.Hp[n.L - 1], n.Ap);
-    b.n_trmats = (int)mats.size(); b.n_trtiles = tiles;
-    if (dev_alloc(h, &b.d_trmats, mats.size())) return -1;
-    HIP_OK(h, hipMemcpyAsync(b.d_trmats, mats.data(), mats.size() * sizeof(TrMat), hipMemcpyHostToDevice, h->stream));
-    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (dev_alloc(h, &b.theta_bf, (size_t)h->P_pad)) return -1;
     bool ok = true;
     auto lds_attr = [&](const void* f, int bytes) { ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
     lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_TANH>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_TANH>, GB_LDS_BYTES(2));
@@ -622,6 +594,13 @@ int bf16_create(ppo_handle* h) {
     b.dw_wm = 4;
     if (n.Kp0 % 256) b.dw_wm = 2;
     for (int l = 0; l < n.L; ++l) if (n.Hp[l] % 256) b.dw_wm = 2;
+    {
+        int t0 = 0;
+        for (int t = 0; t < 2; ++t) {
+            for (int l = 0; l < n.L; ++l) { b.tile0[t][l] = t0; t0 += ((l ? n.Hp[l - 1] : n.Kp0) / GB_BM(b.dw_wm)) * (n.Hp[l] / GB_N); }
+            b.tile0[t][n.L] = t0; t0 += (n.Hp[n.L - 1] / GB_BM(b.dw_wm)) * (n.Ap / GB_N);
+        }
+    }
     if (!ok) return fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 GEMM kernels");
     return 0;
 }
@@ -633,26 +612,26 @@ int bf16_ensure_ws(ppo_handle* h, int rows) {
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
     HIP_OK(h, hipStreamSynchronize(h->stream));
     const NetDev& n = h->net;
-    if (dev_alloc(h, &b.x0, (size_t)R * n.Kp0) || dev_alloc(h, &b.x0T, (size_t)R * n.Kp0)) return -1;
+    if (dev_alloc(h, &b.x0, (size_t)R * n.Kp0)) return -1;
     for (int t = 0; t < 2; ++t) {
         for (int l = 0; l < n.L; ++l) {
             const size_t cnt = (size_t)R * n.Hp[l];
-            if (dev_alloc(h, &b.hb[t][l], cnt) || dev_alloc(h, &b.hT[t][l], cnt) || dev_alloc(h, &b.dy[t][l], cnt) || dev_alloc(h, &b.dyT[t][l], cnt)) return -1;
+            if (dev_alloc(h, &b.hb[t][l], cnt) || dev_alloc(h, &b.dy[t][l], cnt)) return -1;
         }
-        if (dev_alloc(h, &b.head_out[t], (size_t)R * n.Ap) || dev_alloc(h, &b.dhead[t], (size_t)R * n.Ap) || dev_alloc(h, &b.dheadT[t], (size_t)R * n.Ap)) return -1;
+        if (dev_alloc(h, &b.head_out[t], (size_t)GB_HEAD_SPLIT * R * n.Ap) || dev_alloc(h, &b.dhead[t], (size_t)R * n.Ap)) return -1;
         if (dev_alloc(h, &h->slots[t], (size_t)(R / 16) * n.slot_w)) return -1;
     }
     if (!h->slabs && dev_alloc(h, &h->slabs, (size_t)h->max_split * h->P_pad)) return -1;
     b.db_tiles = R / 128;
     if (dev_alloc(h, &b.dbias, (size_t)b.db_tiles * b.n_dbias)) return -1;
-    // grouped weight-gradient tile table: dW = X^T dY for every layer and both heads, operands in the [features][rows] layout
+    // grouped weight-gradient tile table: dW = X^T dY for every layer and both heads, operands as they lie ([rows][features])
     std::vector<DwTileB> tiles;
     auto add = [&](const bf16_t* A, const bf16_t* B, int Kp, int Np, int out_off) {
-        for (int i = 0; i < Kp; i += GB_BM(b.dw_wm)) for (int j = 0; j < Np; j += GB_N) tiles.push_back(DwTileB{A, B, R, R, i, j, out_off, Np, A == b.x0T ? 1 : 0});
+        for (int i = 0; i < Kp; i += GB_BM(b.dw_wm)) for (int j = 0; j < Np; j += GB_N) tiles.push_back(DwTileB{A, B, Kp, Np, i, j, out_off, Np, A == b.x0 ? 1 : 0});
     };
     for (int t = 0; t < 2; ++t) {
-        for (int l = 0; l < n.L; ++l) add(l ? b.hT[t][l - 1] : b.x0T, b.dyT[t][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l], n.w_off[t][l]);
-        add(b.hT[t][n.L - 1], b.dheadT[t], n.Hp[n.L - 1], n.Ap, t ? n.wv_off : n.wmu_off);
+        for (int l = 0; l < n.L; ++l) add(l ? b.hb[t][l - 1] : b.x0, b.dy[t][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l], n.w_off[t][l]);
+        add(b.hb[t][n.L - 1], b.dhead[t], n.Hp[n.L - 1], n.Ap, t ? n.wv_off : n.wmu_off);
     }
     b.n_dw_tiles = (int)tiles.size();
     if (dev_alloc(h, &b.dw_tiles, tiles.size())) return -1;
@@ -665,44 +644,56 @@ int bf16_ensure_ws(ppo_handle* h, int rows) {
 template <int EPI>
 int bf16_gemm(ppo_handle* h, const GemmArgs& a, int I, int J) {
     GemmArgs g = a;
+    if (EPI != GEPI_F32) g.ksplit = 1;
+    const unsigned ks = (unsigned)g.ksplit;
+#ifdef PPO_STAMPS
+    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+    g.stamps = (I / 256) * (J / GB_N) <= 256 ? g_stamps : nullptr;
+#endif
     if (I % 256 == 0) {                                      // 256 x 128 tiles, 8 waves
-        g.tiles_i = I / 256;
-        hipLaunchKernelGGL((gemm_nt_bf16_kernel<4, EPI>), dim3((I / 256) * (J / GB_N), 2), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, g);
+        g.tiles_i = I / 256; g.tiles_ij = (I / 256) * (J / GB_N);
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<4, EPI>), dim3(g.tiles_ij * ks, 2), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, g);
     } else {
-        g.tiles_i = I / 128;
-        hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, EPI>), dim3((I / 128) * (J / GB_N), 2), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, g);
+        g.tiles_i = I / 128; g.tiles_ij = (I / 128) * (J / GB_N);
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, EPI>), dim3(g.tiles_ij * ks, 2), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, g);
     }
     HIP_OK(h, hipGetLastError());
     return 0;
 }
 
 // forward of both towers on `rows` staged rows: hidden layers (bias + tanh) and the padded heads (fp32 out)
-int bf16_forward(ppo_handle* h, int Rp, bool want_transposed, const bf16_t* x0_override = nullptr) {
+int bf16_forward(ppo_handle* h, int Rp, const bf16_t* x0_override = nullptr) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
     for (int l = 0; l < n.L; ++l) {
         GemmArgs a{};
         const int Kp = l ? n.Hp[l - 1] : n.Kp0;
         for (int t = 0; t < 2; ++t) {
-            a.A[t] = l ? b.hb[t][l - 1] : (x0_override ? x0_override : b.x0); a.B[t] = b.thetaT_bf + b.wt_off[t][l]; a.bias[t] = h->theta + n.b_off[t][l];
-            a.C[t] = b.hb[t][l]; a.CT[t] = want_transposed ? b.hT[t][l] : nullptr;
+            a.A[t] = l ? b.hb[t][l - 1] : (x0_override ? x0_override : b.x0); a.B[t] = b.theta_bf + n.w_off[t][l]; a.bias[t] = h->theta + n.b_off[t][l];
+            a.C[t] = b.hb[t][l];
         }
-        a.lda = Kp; a.ldb = Kp; a.K = Kp; a.ldc = n.Hp[l]; a.ldct = b.Rcap;
+        a.lda = Kp; a.ldb = n.Hp[l]; a.K = Kp; a.ldc = n.Hp[l];
         if (bf16_gemm<GEPI_TANH>(h, a, Rp, n.Hp[l])) return -1;
     }
     GemmArgs a{};
     const int HpL = n.Hp[n.L - 1];
     for (int t = 0; t < 2; ++t) {
-        a.A[t] = b.hb[t][n.L - 1]; a.B[t] = b.thetaT_bf + b.whT_off[t]; a.bias[t] = h->theta + (t ? n.bv_off : n.bmu_off); a.F[t] = b.head_out[t];
+        a.A[t] = b.hb[t][n.L - 1]; a.B[t] = b.theta_bf + (t ? n.wv_off : n.wmu_off); a.bias[t] = h->theta + (t ? n.bv_off : n.bmu_off); a.F[t] = b.head_out[t];
     }
-    a.lda = HpL; a.ldb = HpL; a.K = HpL; a.ldf = n.Ap;
+    a.lda = HpL; a.ldb = n.Ap; a.K = HpL; a.ldf = n.Ap;
+    // the heads are few tiles (Ap = 128 columns): cut the reduction so that the launch covers the chip; the partial products are
+    // added by the consumers (bf16_sample_kernel / bf16_loss_kernel) in range order
+    const int tiles = 2 * (Rp / (Rp % 256 == 0 ? 256 : 128)) * (n.Ap / GB_N);
+    int ks = 1;
+    while (ks < GB_HEAD_SPLIT && tiles * ks < 256 && (HpL / (2 * ks)) % GB_K == 0 && HpL / (2 * ks) >= 2 * GB_K) ks *= 2;
+    a.ksplit = ks; a.f_split = (size_t)b.Rcap * n.Ap; b.head_split = ks;
     return bf16_gemm<GEPI_F32>(h, a, Rp, n.Ap);
 }
 
-int bf16_stage(ppo_handle* h, const float* obs, int nrows, int Rp, ObsNorm nz, float* obs_out, bool want_transposed) {
+int bf16_stage(ppo_handle* h, const float* obs, int nrows, int Rp, ObsNorm nz, float* obs_out) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
-    StageArgsB sa{obs, nrows, n.O, n.Kp0, Rp, nz, obs_out, b.x0, want_transposed ? b.x0T : nullptr, b.Rcap};
+    StageArgsB sa{obs, nrows, n.O, n.Kp0, Rp, nz, obs_out, b.x0};
     const size_t cnt = (size_t)Rp * n.Kp0;
     hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
     HIP_OK(h, hipGetLastError());
@@ -714,9 +705,9 @@ int launch_step_bf16(ppo_handle* h, const StepArgs& a) {
     ProfScope ps(h, PK_STEP);
     const NetDev& n = h->net;
     const int Rp = ru(a.n, GB_PAD);
-    if (bf16_stage(h, a.obs, a.n, Rp, a.nz, a.obs_out, false) || bf16_forward(h, Rp, false)) return -1;
+    if (bf16_stage(h, a.obs, a.n, Rp, a.nz, a.obs_out) || bf16_forward(h, Rp)) return -1;
     SampleArgsB sa{};
-    sa.head[0] = h->bf.head_out[0]; sa.head[1] = h->bf.head_out[1]; sa.ldh = n.Ap; sa.logstd = h->theta + n.ls_off;
+    sa.head[0] = h->bf.head_out[0]; sa.head[1] = h->bf.head_out[1]; sa.ldh = n.Ap; sa.hsplit = h->bf.head_split; sa.hstride = (size_t)h->bf.Rcap * n.Ap; sa.logstd = h->theta + n.ls_off;
     sa.noise = a.noise; sa.action = a.action; sa.det_action = a.det_action; sa.value = a.value; sa.neglogp = a.neglogp;
     sa.n = a.n; sa.A = n.A; sa.seed = a.seed; sa.rng_step = a.rng_step; sa.row_base = a.row_base;
     hipLaunchKernelGGL(bf16_sample_kernel, dim3((a.n + 15) / 16), dim3(256), 0, h->stream, sa);
@@ -736,11 +727,11 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
     const long er = bf16_epoch_row(h, ta, Rp);
-    if (er < 0 && bf16_stage(h, ta.obs, ta.n, Rp, no_norm_fwd(), nullptr, true)) return -1;
-    if (bf16_forward(h, Rp, true, er >= 0 ? b.xe + (size_t)er * n.Kp0 : nullptr)) return -1;
+    if (er < 0 && bf16_stage(h, ta.obs, ta.n, Rp, no_norm_fwd(), nullptr)) return -1;
+    if (bf16_forward(h, Rp, er >= 0 ? b.xe + (size_t)er * n.Kp0 : nullptr)) return -1;
     LossArgsB la{};
-    for (int t = 0; t < 2; ++t) { la.head[t] = b.head_out[t]; la.dhead[t] = b.dhead[t]; la.dheadT[t] = b.dheadT[t]; la.slots[t] = h->slots[t]; }
-    la.ldh = n.Ap; la.logstd = h->theta + n.ls_off; la.actions = ta.actions; la.advs = ta.advs; la.returns = ta.returns; la.old_values = ta.old_values;
+    for (int t = 0; t < 2; ++t) { la.head[t] = b.head_out[t]; la.dhead[t] = b.dhead[t]; la.slots[t] = h->slots[t]; }
+    la.ldh = n.Ap; la.hsplit = b.head_split; la.hstride = (size_t)b.Rcap * n.Ap; la.logstd = h->theta + n.ls_off; la.actions = ta.actions; la.advs = ta.advs; la.returns = ta.returns; la.old_values = ta.old_values;
     la.old_neglogp = ta.old_neglogp; la.hyper = h->hyper; la.n = ta.n; la.A = n.A; la.Ap = n.Ap; la.rows_pad = b.Rcap; la.inv_n = ta.inv_n;
     la.ent_coef = n.ent_coef; la.vf_coef = n.vf_coef; la.slot_w = n.slot_w; la.slot_head = n.slot_head; la.slot_aux = n.slot_aux; la.slot_loss = n.slot_loss;
     hipLaunchKernelGGL(bf16_loss_kernel, dim3(Rp / BL_ROWS), dim3(16 * BL_ROWS), (size_t)(2 * BL_ROWS * n.Ap + 6 * BL_ROWS) * sizeof(float), h->stream, la);
@@ -750,9 +741,9 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
     {
         GemmArgs a{};
         for (int t = 0; t < 2; ++t) {
-            a.A[t] = b.dhead[t]; a.B[t] = b.theta_bf + (t ? n.wv_off : n.wmu_off); a.HT[t] = b.hT[t][n.L - 1]; a.C[t] = b.dy[t][n.L - 1]; a.CT[t] = b.dyT[t][n.L - 1];
+            a.A[t] = b.dhead[t]; a.B[t] = b.theta_bf + (t ? n.wv_off : n.wmu_off); a.H[t] = b.hb[t][n.L - 1]; a.C[t] = b.dy[t][n.L - 1];
         }
-        a.lda = n.Ap; a.ldb = n.Ap; a.K = n.Ap; a.ldht = b.Rcap; a.ldc = HpL; a.ldct = b.Rcap;
+        a.lda = n.Ap; a.ldb = n.Ap; a.K = n.Ap; a.ldh = HpL; a.ldc = HpL;
         for (int t = 0; t < 2; ++t) a.bsum[t] = b.dbias + b.db_off[t][n.L - 1];
         a.bsum_ld = b.n_dbias;
         if (bf16_gemm<GEPI_TANHGRAD>(h, a, Rp, HpL)) return -1;
@@ -760,10 +751,9 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
     for (int l = n.L - 1; l >= 1; --l) {
         GemmArgs a{};
         for (int t = 0; t < 2; ++t) {
-            // (the bottom layer's gradient is only ever an operand of its weight gradient: no [rows][features] copy)
-            a.A[t] = b.dy[t][l]; a.B[t] = b.theta_bf + n.w_off[t][l]; a.HT[t] = b.hT[t][l - 1]; a.C[t] = l > 1 ? b.dy[t][l - 1] : nullptr; a.CT[t] = b.dyT[t][l - 1];
+            a.A[t] = b.dy[t][l]; a.B[t] = b.theta_bf + n.w_off[t][l]; a.H[t] = b.hb[t][l - 1]; a.C[t] = b.dy[t][l - 1];
         }
-        a.lda = n.Hp[l]; a.ldb = n.Hp[l]; a.K = n.Hp[l]; a.ldht = b.Rcap; a.ldc = n.Hp[l - 1]; a.ldct = b.Rcap;
+        a.lda = n.Hp[l]; a.ldb = n.Hp[l]; a.K = n.Hp[l]; a.ldh = n.Hp[l - 1]; a.ldc = n.Hp[l - 1];
         for (int t = 0; t < 2; ++t) a.bsum[t] = b.dbias + b.db_off[t][l - 1];
         a.bsum_ld = b.n_dbias;
         if (bf16_gemm<GEPI_TANHGRAD>(h, a, Rp, n.Hp[l - 1])) return -1;
@@ -771,12 +761,28 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
     return 0;
 }
 
-int bf16_weight_grads(ppo_handle* h, const TrainArgs& ta, int Rp, int nsplit) {
+// work split of the weight-gradient GEMM for `Rp` rows: stages per workgroup (see DwArgsB).  One round on the 256 CUs when there is
+// that much work; never more contributors per tile than there are slabs.
+void bf16_dw_split(ppo_handle* h, int Rp, int& nst, int& per, int& groups) {
+    nst = Rp / GB_K;
+    const int total = h->bf.n_dw_tiles * nst;
+    per = std::max((total + 255) / 256, (nst + h->max_split - 3) / (h->max_split - 2));
+    per = std::min(std::max(per, 1), nst);
+    groups = (total + per - 1) / per;
+}
+
+int bf16_weight_grads(ppo_handle* h, const TrainArgs& ta, int Rp) {
     ppo_handle::Bf16& b = h->bf;
     const long er = bf16_epoch_row(h, ta, Rp);
-    DwArgsB da{b.dw_tiles, nsplit, Rp / nsplit, h->slabs, (size_t)h->P_pad, er >= 0 ? b.xeT + er : nullptr, b.xe_rows};
-    if (b.dw_wm == 4) hipLaunchKernelGGL(gemm_dw_bf16_kernel<4>, dim3(b.n_dw_tiles * nsplit), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, da);
-    else hipLaunchKernelGGL(gemm_dw_bf16_kernel<2>, dim3(b.n_dw_tiles * nsplit), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, da);
+    int nst, per, groups;
+    bf16_dw_split(h, Rp, nst, per, groups);
+    DwArgsB da{b.dw_tiles, nst, per, b.n_dw_tiles * nst, h->slabs, (size_t)h->P_pad, er >= 0 ? b.xe + (size_t)er * h->net.Kp0 : nullptr, h->net.Kp0};
+#ifdef PPO_STAMPS
+    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+    da.stamps = groups <= 512 ? g_stamps + 4096 * 16 : nullptr;
+#endif
+    if (b.dw_wm == 4) hipLaunchKernelGGL(gemm_dw_bf16_kernel<4>, dim3(groups), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, da);
+    else hipLaunchKernelGGL(gemm_dw_bf16_kernel<2>, dim3(groups), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, da);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -933,16 +939,14 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
     }
     if (h->bf.on) {
         const int Rp = ru(ta.n, GB_PAD);
-        // row splits of the weight-gradient GEMM: just enough workgroups for two rounds on 256 CUs -- every extra split is
-        // another P_pad floats of slab written and read back (HBM write bandwidth, not the matrix cores, prices it)
-        int nsplit = 1;
-        while (nsplit < h->max_split && h->bf.n_dw_tiles * nsplit < 512 && (Rp / (2 * nsplit)) % GB_K == 0 && Rp / (2 * nsplit) >= 256) nsplit *= 2;
         { ProfScope ps(h, PK_TRAIN_FB); if (bf16_train_fwd_bwd(h, ta, Rp)) return -1; }
-        { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, ta, Rp, nsplit)) return -1; }
+        { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, ta, Rp)) return -1; }
         {
             ProfScope ps(h, PK_REDUCE);
             ReduceArgs ra{};
-            ra.src = h->grad_src; ra.n_blocks = h->n_blocks; ra.slabs = h->slabs; ra.slab_stride = (size_t)h->P_pad; ra.nsplit = nsplit;
+            int groups;
+            bf16_dw_split(h, Rp, ra.sk_nst, ra.sk_per, groups); ra.sk_bm = GB_BM(h->bf.dw_wm);
+            ra.src = h->grad_src; ra.n_blocks = h->n_blocks; ra.slabs = h->slabs; ra.slab_stride = (size_t)h->P_pad; ra.nsplit = 0;
             ra.slots[0] = h->slots[0]; ra.slots[1] = h->slots[1]; ra.n_rowblocks = Rp / BL_ROWS; ra.slot_w = n.slot_w; ra.slot_loss = n.slot_loss;
             ra.grad = h->grad; ra.sumsq = h->sumsq; ra.n_local = (float)ta.n; ra.beta_pow = h->beta_pow; ra.direct = h->bf.dbias;
             ra.n_direct = Rp / (Rp % 256 == 0 ? 256 : 128); ra.direct_stride = h->bf.n_dbias;
@@ -950,9 +954,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
             HIP_OK(h, hipGetLastError());
         }
         if (h->comm && enqueue_grad_allreduce(h)) return -1;
-        if (enqueue_adam(h, loss_row)) return -1;
-        ProfScope ps(h, PK_ADAM);
-        return bf16_refresh_transposes(h);                 // (adam_kernel itself keeps the straight bf16 copy current)
+        return enqueue_adam(h, loss_row);                  // (adam_kernel keeps the bf16 copy of the weights current)
     }
     const int n_pad = ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
     const bool use_dw2 = h->dw2 && n_pad % 512 == 0 && n_rb <= 32 * DW2_SLOTK;
@@ -1231,9 +1233,9 @@ void ppo_destroy(ppo_handle* h) {
     for (int i = 0; i < 6; ++i) if (h->st_vec[i]) (void)hipFree(h->st_vec[i]);
     {
         ppo_handle::Bf16& b = h->bf;
-        void* bp[] = {b.theta_bf, b.thetaT_bf, b.d_trmats, b.x0, b.x0T, b.xe, b.xeT, b.head_out[0], b.head_out[1], b.dhead[0], b.dhead[1], b.dheadT[0], b.dheadT[1], b.dbias, b.dw_tiles};
+        void* bp[] = {b.theta_bf, b.x0, b.xe, b.head_out[0], b.head_out[1], b.dhead[0], b.dhead[1], b.dbias, b.dw_tiles};
         for (void* p : bp) if (p) (void)hipFree(p);
-        for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) for (bf16_t* p : {b.hb[t][l], b.hT[t][l], b.dy[t][l], b.dyT[t][l]}) if (p) (void)hipFree(p);
+        for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) for (bf16_t* p : {b.hb[t][l], b.dy[t][l]}) if (p) (void)hipFree(p);
     }
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -2168,11 +2170,11 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             hipLaunchKernelGGL(epoch_gather_kernel, dim3((B + 15) / 16), dim3(256), 0, h->stream, ga);
             HIP_OK(h, hipGetLastError());
             if (h->bf.on) {
-                // bf16 path: the epoch's observations become bf16 once, in both layouts; a minibatch is then a row / column slice
+                // bf16 path: the epoch's observations become bf16 once; a minibatch is then a row slice
                 ppo_handle::Bf16& bb = h->bf;
                 bb.epoch_staged = M % GB_PAD == 0 && bb.xe_rows >= B;
                 if (bb.epoch_staged) {
-                    StageArgsB sa{h->mb_obs, B, h->net.O, h->net.Kp0, B, no_norm(), nullptr, bb.xe, bb.xeT, bb.xe_rows};
+                    StageArgsB sa{h->mb_obs, B, h->net.O, h->net.Kp0, B, no_norm(), nullptr, bb.xe};
                     const size_t cnt = (size_t)B * h->net.Kp0;
                     hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
                     HIP_OK(h, hipGetLastError());
@@ -2225,7 +2227,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
             return -1;
         h->upd_cap_rows = cr; h->upd_cap_steps = cs;
         if (h->bf.on) {
-            if (dev_alloc(h, &h->bf.xe, (size_t)cr * h->net.Kp0) || dev_alloc(h, &h->bf.xeT, (size_t)cr * h->net.Kp0)) return -1;
+            if (dev_alloc(h, &h->bf.xe, (size_t)cr * h->net.Kp0)) return -1;
             h->bf.xe_rows = cr;
         }
     }

@@ -1411,12 +1411,15 @@ struct GradSrc { int kind; int tower; int slot_off; int count; int base;   // ba
                  // narrow path: packed LDS images (one per tower, [2][img_stride]) of the weights in exactly the layout its kernels
                  // copy into LDS; a tensor's element (r, c) lives at img[i_off + r*i_ld + c] (forward copy), img[it_off + c*it_ld + r]
                  // (transposed copy) and a small parameter e at img[ip_off + e]; < 0: none
-                 int i_off, i_ld, it_off, it_ld, ip_off; };
+                 int i_off, i_ld, it_off, it_ld, ip_off;
+                 int tile0; };                                                // bf16 path: index of the tensor's first weight-gradient tile (tiles row-major over [prow / BM][pcol / 128])
 
 struct ReduceArgs {
     const GradSrc* src;          // [n_blocks]
     int n_blocks;                // blocks covering P_pad ; block n_blocks = loss block
     const float* slabs; size_t slab_stride; int nsplit;
+    int sk_nst, sk_per, sk_bm;   // bf16 path (work-balanced weight-gradient GEMM): stages per tile, stages per workgroup, tile rows; a tile's
+                                 // partial sums are slabs 0 .. (last - first) of the workgroups first = t*nst/per .. last = (t*nst+nst-1)/per
     const float* slots[2]; int n_rowblocks; int slot_w;
     int slot_loss;
     const float* direct;         // kind 3: per-row-tile sums (bias gradients from the bf16 path's TanhGrad epilogues), [n_direct][direct_stride], indexed slot_off + e
