@@ -8,7 +8,7 @@ so = os.path.join(ROOT, "ppo_cpp_amd", "libppo_hip.so")
 base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 subprocess.check_call(base + ["-DPPO_STAMPS", "-o", so, os.path.join(ROOT, "ppo_cpp_amd/csrc/ppo_hip.hip"), "-ldl"] + os.environ.get("PPO_HIP_EXTRA_FLAGS", "").split())
 import ppo_cpp_amd
-E, T, nmb = 1024, 64, 32
+E, T, nmb = (int(sys.argv[1]), int(sys.argv[2]), 32) if len(sys.argv) > 2 else (1024, 64, 32)
 g = ppo_cpp_amd.PPOHip(18, 18, [64, 64]); g.init_orthogonal(0); g.norm_init(E, 0.99); g.rollout_alloc(E, T)
 g.collect_synthetic(1234, 0.99, 0.95, None, env0=0, step0=0, first=True)
 rng = np.random.RandomState(0); o_ = rng.uniform(-1, 1, (64, 18)).astype(np.float32); a_, v_, n_ = g.step(o_, rng.normal(size=(64, 18)).astype(np.float32))
