@@ -1734,7 +1734,7 @@ static void launch_rollout_kernel(ppo_handle* h, const NwRolloutArgs& q, size_t 
     // ONE environment on the device env, reference shape: the whole rollout in one wave, weights in registers (ppo_rollout1.hpp)
     static const bool no_r1 = [] { const char* e = getenv("PPO_HIP_NO_ROLLOUT1"); return e && e[0] == '1'; }();
     if (h->nw_static && q.E == 1 && !q.host_mode && n.O == 18 && n.A == 18 && !no_r1) {
-        hipLaunchKernelGGL(narrow_rollout1_kernel, dim3(1), dim3(128), 0, h->stream, n, h->nw, q);
+        hipLaunchKernelGGL(narrow_rollout1_kernel, dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
         return;
     }
     if (h->nw_static) {

@@ -11,8 +11,11 @@
 //     each in k order (an exact-fp32 16x16x4 matrix instruction IS that fmaf chain), combined as (c0 + c1) + (c2 + c3);
 //   * the sums over actions reproduce the 16-lanes-per-row loop (elements j and j + 16 added in that order, then group16_sum's tree);
 //   * EnvNormalize::step / RunningStatistics::update for a batch of one row (env_normalize.hpp:64-116, running_statistics.hpp:26-104).
-// A second wave (the helper) draws the counter-RNG noise of step t + 1 and the env transition that follows step t + 1 while the main wave
-// runs step t (both depend on the step index only): two 64-bit hashes, a log, a cos and a square root per draw leave the critical path.
+// Two more waves run AHEAD of the main wave, on their own SIMDs: the noise wave draws the counter-RNG noise of step t + 1 (two 64-bit hashes,
+// a log, a cos and a square root per draw), the env wave owns the whole environment side -- the transition that follows step t, the
+// running-statistics recurrences (four dependent divisions and a square root per step), the reward branch and the normalised
+// observation of step t + 1, which it also writes to the rollout -- while the main wave runs step t.  All of that depends on the step
+// index and on earlier env-side state only, never on the policy's output (the synthetic env ignores the actions, env_mock.hpp:47-60).
 // One s_barrier per env step orders the hand-over through a double-buffered LDS block.
 // The value tower is not needed inside the loop: the host runs it afterwards, batched over the T rows (as before).
 #pragma once
@@ -24,20 +27,16 @@
         ACC[(k_ >> 2) & 3] = fmaf(xk_, WREG[k_], ACC[(k_ >> 2) & 3]);                                   \
     }
 
-__global__ __launch_bounds__(128) void narrow_rollout1_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
-    __shared__ float s_hand[2][64];                          // [parity]: 0..17 noise of the step, 32..49 the observation that follows it, 50 reward, 51 done
+__global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
+    __shared__ float s_hand[2][64];                          // [parity of t]: 0..17 noise of step t, 32..49 the normalised observation of step t
     warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwRolloutArgs)>();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     constexpr int O = 18, A = 18;
-    if (threadIdx.x >= 64) {
-        // ---- helper wave: step-indexed random quantities, one step ahead of the main wave -------------------------------------------------
+    const bool lj = lane < O;                                 // O == A: observation / action element of this lane
+    if (role == 1) {
+        // ---- noise wave: one step ahead of the main wave ----------------------------------------------------------------------------------
         auto produce = [&](int t) __attribute__((always_inline)) {
-            float* hw = s_hand[t & 1];
-            if (lane < A && !q.noise) hw[lane] = ctr_normal(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t, lane);
-            if (lane < O + 2) {
-                const uint32_t hs = ctr_hash(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t + 1u, (uint32_t)lane);
-                hw[32 + lane] = lane <= O ? u32_to_sym_unit(hs) : ((hs % 300u == 0u) ? 1.0f : 0.0f);
-            }
+            if (lane < A && !q.noise) s_hand[t & 1][lane] = ctr_normal(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t, lane);
         };
         produce(q.t0);
         for (int t = q.t0; t < q.T; ++t) {
@@ -46,7 +45,83 @@ __global__ __launch_bounds__(128) void narrow_rollout1_kernel(NetDev net, NwLayo
         }
         return;
     }
-    // ---- entry: this lane's weight columns, biases, statistics, state ------------------------------------------------------------------
+    if (role == 2) {
+        // ---- env wave: transition, EnvNormalize::step / RunningStatistics::update for a batch of ONE row, rollout rows obs / rewards / dones ----
+        float raw = lj ? q.st.raw_obs[lane] : 0.f;
+        float mean = lj ? q.st.obs_mean[lane] : 0.f, var = lj ? q.st.obs_var[lane] : 1.f;
+        float istd = 1.0f / sqrtf(var + q.eps);
+        float done = q.st.done[0], ret = q.st.ret[0];
+        float ret_mean = *q.st.ret_mean, ret_var = *q.st.ret_var;
+        double obs_cnt = *q.st.obs_count, ret_cnt = *q.st.ret_count;
+        auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
+            const double nb = (double)nbf, tot = cnt + nb;
+            const float bvar = bM2 / (float)nb;                                        // running_statistics.hpp:51-54
+            const float delta = bmean - mean0;                                         // :90
+            mean1 = mean0 + (delta * (float)nb) / (float)tot;                          // :94
+            const float m_a = var0 * (float)cnt, m_b = bvar * (float)nb;               // :97-98
+            const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;   // :100
+            var1 = M2 / (float)tot;                                                    // :101
+        };
+        // rollout row t: the flag that arrived with obs_t, the observation normalised with the statistics that already include it
+        auto publish = [&](int t) __attribute__((always_inline)) {
+            if (lane == 0) q.ro_done[t] = done;
+            if (lj) {
+                float x = raw;
+                if (q.norm_obs) { x = (x - mean) * istd; x = tf_min(tf_max(x, -q.clip_obs), q.clip_obs); }   // env_normalize.hpp:99-104
+                q.ro_obs[(size_t)t * O + lane] = x;
+                s_hand[t & 1][32 + lane] = x;
+            }
+        };
+        publish(q.t0);
+        for (int t = q.t0; t < q.T; ++t) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // block t is complete; the main wave is done with block t + 1's buffer
+            // ---- env transition that follows step t (counter hash): new observation, reward, done ------------------------------------------------
+            float tv = 0.f;
+            if (lane < O + 2) {
+                const uint32_t hs = ctr_hash(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t + 1u, (uint32_t)lane);
+                tv = lane <= O ? u32_to_sym_unit(hs) : ((hs % 300u == 0u) ? 1.0f : 0.0f);
+            }
+            raw = lj ? tv : 0.f;
+            const float rew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), O));
+            done = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), O + 1));
+            // ---- EnvNormalize::step bookkeeping for a batch of ONE row ----------------------------------------------------------------------------
+            if (q.norm_obs) {
+                float sum = 0.f; sum += raw;
+                const float bmean = sum / 1.0f;                                        // colwise().mean()
+                float m2 = 0.f; { const float d = raw - bmean; m2 += d * d; }
+                float m1, v1;
+                merge(mean, var, obs_cnt, bmean, m2, 1.0f, m1, v1);
+                mean = m1; var = v1; istd = 1.0f / sqrtf(v1 + q.eps);
+                obs_cnt = (double)1.0f + obs_cnt;                                      // :103
+            }
+            {
+                ret = ret * q.gamma + rew;                                             // env_normalize.hpp:66
+                float sum = 0.f; sum += ret;
+                float m1 = ret_mean, v1 = ret_var;
+                if (q.norm_rew) {                                                      // :75-77 (training)
+                    const float bmean = sum / 1.0f;
+                    float m2 = 0.f; { const float d = ret - bmean; m2 += d * d; }
+                    merge(ret_mean, ret_var, ret_cnt, bmean, m2, 1.0f, m1, v1);
+                    ret_cnt = (double)1.0f + ret_cnt;
+                }
+                ret_mean = m1; ret_var = v1;
+                const float inv = 1.0f / sqrtf(v1 + q.eps);                            // :79
+                float y = rew;
+                if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
+                if (lane == 0) q.ro_rew[t] = y;
+                ret = ret * (1.0f - done);                                             // :88-91
+            }
+            if (t + 1 < q.T) publish(t + 1);
+        }
+        // ---- exit: the state goes home ---------------------------------------------------------------------------------------------------------
+        if (lj) { q.st.raw_obs[lane] = raw; q.st.obs_mean[lane] = mean; q.st.obs_var[lane] = var; }
+        if (lane == 0) {
+            q.st.done[0] = done; q.st.ret[0] = ret;
+            *q.st.obs_count = obs_cnt; *q.st.ret_mean = ret_mean; *q.st.ret_var = ret_var; *q.st.ret_count = ret_cnt;
+        }
+        return;
+    }
+    // ---- main wave: this lane's weight columns and biases ------------------------------------------------------------------------------------
     float w0[32], w1[64], wm[64];
     {
         const float* img = q.img;
@@ -60,35 +135,11 @@ __global__ __launch_bounds__(128) void narrow_rollout1_kernel(NetDev net, NwLayo
     const float* par = q.img + lay.par;
     const float b0 = par[net.par_b[0] + lane], b1 = par[net.par_b[1] + lane];
     const float bmu = lane < 32 ? par[net.par_bmu + lane] : 0.f, lsj = lane < 32 ? par[net.par_ls + lane] : 0.f;
-    const bool lj = lane < O;                                 // O == A: observation / action element of this lane
-    float raw = lj ? q.st.raw_obs[lane] : 0.f;
-    float mean = lj ? q.st.obs_mean[lane] : 0.f, var = lj ? q.st.obs_var[lane] : 1.f;
-    float istd = 1.0f / sqrtf(var + q.eps);
-    float done = q.st.done[0], ret = q.st.ret[0];
-    float ret_mean = *q.st.ret_mean, ret_var = *q.st.ret_var;
-    double obs_cnt = *q.st.obs_count, ret_cnt = *q.st.ret_count;
-    auto merge = [&](float mean0, float var0, double cnt, float bmean, float bM2, float nbf, float& mean1, float& var1) __attribute__((always_inline)) {
-        const double nb = (double)nbf, tot = cnt + nb;
-        const float bvar = bM2 / (float)nb;                                        // running_statistics.hpp:51-54
-        const float delta = bmean - mean0;                                         // :90
-        mean1 = mean0 + (delta * (float)nb) / (float)tot;                          // :94
-        const float m_a = var0 * (float)cnt, m_b = bvar * (float)nb;               // :97-98
-        const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;   // :100
-        var1 = M2 / (float)tot;                                                    // :101
-    };
     for (int t = q.t0; t < q.T; ++t) {
-        if (lane == 0) q.ro_done[t] = done;                                        // the flag that arrived with obs_t
-        float eps = 0.f;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // the helper's block of step t is complete (and it may overwrite the other one)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // the other waves' block of step t is complete (and they may overwrite the other one)
         const float* hb = s_hand[t & 1];
-        if (lj) eps = q.noise ? q.noise[(size_t)t * A + lane] : hb[lane];
-        // ---- normalise (env_normalize.hpp:99-104) -> rollout row t -----------------------------------------------------------------------
-        float x = 0.f;
-        if (lj) {
-            x = raw;
-            if (q.norm_obs) { x = (x - mean) * istd; x = tf_min(tf_max(x, -q.clip_obs), q.clip_obs); }
-            q.ro_obs[(size_t)t * O + lane] = x;
-        }
+        float eps = 0.f, x = 0.f;
+        if (lj) { eps = q.noise ? q.noise[(size_t)t * A + lane] : hb[lane]; x = hb[32 + lane]; }
         // ---- forward: lane n owns output column n --------------------------------------------------------------------------------------
         float h1, h2, mu;
         { float c[4] = {0.f, 0.f, 0.f, 0.f}; R1_CHAIN(c, x, w0, 32); h1 = fast_tanh(((c[0] + c[1]) + (c[2] + c[3])) + b0); }
@@ -107,42 +158,5 @@ __global__ __launch_bounds__(128) void narrow_rollout1_kernel(NetDev net, NwLayo
         if (lane + 16 < A) { ssq += zz_hi; slog += sl_hi; }
         ssq = group16_sum(ssq); slog = group16_sum(slog);
         if (lane == 0) q.ro_nlp[t] = 0.5f * ssq + HALF_LOG_2PI * (float)A + slog;
-        // ---- env transition (counter hash, drawn by the helper): new observation, reward, done ----------------------------------------------
-        raw = lj ? hb[32 + lane] : 0.f;
-        const float rew = hb[32 + O];
-        done = hb[32 + O + 1];
-        // ---- EnvNormalize::step bookkeeping for a batch of ONE row ----------------------------------------------------------------------------
-        if (q.norm_obs) {
-            float sum = 0.f; sum += raw;
-            const float bmean = sum / 1.0f;                                        // colwise().mean()
-            float m2 = 0.f; { const float d = raw - bmean; m2 += d * d; }
-            float m1, v1;
-            merge(mean, var, obs_cnt, bmean, m2, 1.0f, m1, v1);
-            mean = m1; var = v1; istd = 1.0f / sqrtf(v1 + q.eps);
-            obs_cnt = (double)1.0f + obs_cnt;                                      // :103
-        }
-        {
-            ret = ret * q.gamma + rew;                                             // env_normalize.hpp:66
-            float sum = 0.f; sum += ret;
-            float m1 = ret_mean, v1 = ret_var;
-            if (q.norm_rew) {                                                      // :75-77 (training)
-                const float bmean = sum / 1.0f;
-                float m2 = 0.f; { const float d = ret - bmean; m2 += d * d; }
-                merge(ret_mean, ret_var, ret_cnt, bmean, m2, 1.0f, m1, v1);
-                ret_cnt = (double)1.0f + ret_cnt;
-            }
-            ret_mean = m1; ret_var = v1;
-            const float inv = 1.0f / sqrtf(v1 + q.eps);                            // :79
-            float y = rew;
-            if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
-            if (lane == 0) q.ro_rew[t] = y;
-            ret = ret * (1.0f - done);                                             // :88-91
-        }
-    }
-    // ---- exit: the state goes home -----------------------------------------------------------------------------------------------------------
-    if (lj) { q.st.raw_obs[lane] = raw; q.st.obs_mean[lane] = mean; q.st.obs_var[lane] = var; }
-    if (lane == 0) {
-        q.st.done[0] = done; q.st.ret[0] = ret;
-        *q.st.obs_count = obs_cnt; *q.st.ret_mean = ret_mean; *q.st.ret_var = ret_var; *q.st.ret_count = ret_cnt;
     }
 }
