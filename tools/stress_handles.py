@@ -12,6 +12,7 @@ for i in range(40):
     assert np.isfinite(rows).all()
     g.close()
     if i % 10 == 9: print(i, "rss MB %.0f" % rss(), "t %.1f" % (time.time() - t0), flush=True)
-import torch
-free, total = torch.cuda.mem_get_info()
-print("device free MB", free / 1e6, "of", total / 1e6)
+hip = ctypes.CDLL("libamdhip64.so")
+free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+print("device free MB", free.value / 1e6, "of", total.value / 1e6)
