@@ -376,6 +376,17 @@ int build_layout(ppo_handle* h) {
         for (int tw = 0; tw < 2; ++tw)
             for (int l = 0; l < n.L; ++l) { h->bf.db_off[tw][l] = d; d += n.Hp[l]; }
         h->bf.n_dbias = d;
+        // weight-gradient tiles (needed by upload_grad_src, i.e. before bf16_create): 256 features tall when every reduction-side width
+        // allows it; tile0 = first tile of every matrix in the order of the tile table (bf16_ensure_ws)
+        ppo_handle::Bf16& b = h->bf;
+        b.dw_wm = 4;
+        if (n.Kp0 % 256) b.dw_wm = 2;
+        for (int l = 0; l < n.L; ++l) if (n.Hp[l] % 256) b.dw_wm = 2;
+        int t0 = 0;
+        for (int t = 0; t < 2; ++t) {
+            for (int l = 0; l < n.L; ++l) { b.tile0[t][l] = t0; t0 += ((l ? n.Hp[l - 1] : n.Kp0) / GB_BM(b.dw_wm)) * (n.Hp[l] / GB_N); }
+            b.tile0[t][n.L] = t0; t0 += (n.Hp[n.L - 1] / GB_BM(b.dw_wm)) * (n.Ap / GB_N);
+        }
         n.lds_total = 0; h->lds_step_total = 0; h->CTH = 0;
         n.slot_head = 0; n.slot_aux = n.Ap; n.slot_loss = 2 * n.Ap; n.slot_w = 2 * n.Ap + 8;
         return 0;
@@ -590,17 +601,6 @@ int bf16_create(ppo_handle* h) {
     lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_TANHGRAD>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_TANHGRAD>, GB_LDS_BYTES(2));
     lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_F32>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_F32>, GB_LDS_BYTES(2));
     lds_attr((const void*)gemm_dw_bf16_kernel<4>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_dw_bf16_kernel<2>, GB_LDS_BYTES(2));
-    // the weight-gradient tiles are 256 features tall when every reduction-side width allows it
-    b.dw_wm = 4;
-    if (n.Kp0 % 256) b.dw_wm = 2;
-    for (int l = 0; l < n.L; ++l) if (n.Hp[l] % 256) b.dw_wm = 2;
-    {
-        int t0 = 0;
-        for (int t = 0; t < 2; ++t) {
-            for (int l = 0; l < n.L; ++l) { b.tile0[t][l] = t0; t0 += ((l ? n.Hp[l - 1] : n.Kp0) / GB_BM(b.dw_wm)) * (n.Hp[l] / GB_N); }
-            b.tile0[t][n.L] = t0; t0 += (n.Hp[n.L - 1] / GB_BM(b.dw_wm)) * (n.Ap / GB_N);
-        }
-    }
     if (!ok) return fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 GEMM kernels");
     return 0;
 }
