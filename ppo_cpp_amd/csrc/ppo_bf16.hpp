@@ -579,7 +579,9 @@ struct LossArgsB {
     float* slots[2]; int slot_w, slot_head, slot_aux, slot_loss;
 };
 
+#ifndef BL_ROWS
 #define BL_ROWS 32                 // rows per block of the loss kernel (16 lanes each): one slot row of partial sums per block
+#endif
 __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
     extern __shared__ __attribute__((aligned(16))) float ls[];      // [R][Ap] dmu | [R][Ap] dlogstd | [R][4] pi terms | [R][2] vf terms
     float* dmu_s = ls; float* dls_s = ls + BL_ROWS * a.Ap; float* pt = dls_s + BL_ROWS * a.Ap; float* vt = pt + 4 * BL_ROWS;
@@ -660,8 +662,8 @@ __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
         s0[a.slot_head + j] = sb;                              // db_mu  (fp32 sums of the fp32 values, not of their bf16 roundings)
         s0[a.slot_aux + j] = sl;                               // dlogstd
     }
-    if (tid >= 256 && tid < 260) { const int k = tid - 256; float s = 0.f; for (int q = 0; q < BL_ROWS; ++q) s += pt[q * 4 + k]; s0[a.slot_loss + k] = s; }
-    if (tid == 320) { float sb = 0.f, sl = 0.f; for (int q = 0; q < BL_ROWS; ++q) { sb += vt[q * 2]; sl += vt[q * 2 + 1]; } s1[a.slot_head] = sb; s1[a.slot_loss] = sl; }
+    if (tid >= 8 * BL_ROWS && tid < 8 * BL_ROWS + 4) { const int k = tid - 8 * BL_ROWS; float s = 0.f; for (int q = 0; q < BL_ROWS; ++q) s += pt[q * 4 + k]; s0[a.slot_loss + k] = s; }
+    if (tid == 8 * BL_ROWS + 64) { float sb = 0.f, sl = 0.f; for (int q = 0; q < BL_ROWS; ++q) { sb += vt[q * 2]; sl += vt[q * 2 + 1]; } s1[a.slot_head] = sb; s1[a.slot_loss] = sl; }
 }
 
 // ---- bias gradients of the hidden layers: db[j] = sum over rows of dY, one wave per row of the [features][rows] copy ----
@@ -696,55 +698,77 @@ __global__ __launch_bounds__(256) void bf16_cast_kernel(const float* __restrict_
 // ---- gradient assembly for the bf16 path: one WAVE per 256-element chunk of the padded parameter vector, four consecutive
 // elements per lane (16-byte slab loads); the chunk's sum of squares is a wave reduction.  Same sources as grad_reduce_kernel
 // (kind 0 slabs, kind 1 per-block slots, kind 3 per-row-tile bias sums), same fixed summation orders. ---------------------
-__global__ __launch_bounds__(256) void bf16_grad_reduce_kernel(ReduceArgs a) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    // highest chunks first: the slot-summed vectors (head bias, logstd: hundreds of dependent-free but latency-bound loads per
-    // lane) sit at the END of the parameter vector and must not be the launch's tail
-    const int chunk = a.n_blocks - (int)(blockIdx.x * 4 + (tid >> 6));
-    if (chunk < 0) return;
+#define BGR_WAVES 16                // chunks (waves) per workgroup of bf16_grad_reduce_kernel: one sum-of-squares partial per workgroup
+__global__ __launch_bounds__(64 * BGR_WAVES) void bf16_grad_reduce_kernel(ReduceArgs a) {
+    __shared__ float wq[BGR_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // highest chunks first: the slot-summed vectors (head bias, logstd: many dependent-free but latency-bound loads per lane) sit at
+    // the END of the parameter vector and must not be the launch's tail
+    const int chunk = a.n_blocks - (int)(blockIdx.x * BGR_WAVES + wave);
+    float q = 0.f;
     if (chunk == a.n_blocks) {                              // loss tail: {pg, vf, ent, kl, cf, rows}
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {                       // lanes take the slot rows round robin, then meet in a fixed-shape tree
-            const int tower = (q == 1) ? 1 : 0, off = a.slot_loss + (q <= 1 ? 0 : q - 1);
+        for (int k = 0; k < 5; ++k) {                       // lanes take the slot rows round robin, then meet in a fixed-shape tree
+            const int tower = (k == 1) ? 1 : 0, off = a.slot_loss + (k <= 1 ? 0 : k - 1);
             float s = 0.f;
             for (int b = lane; b < a.n_rowblocks; b += 64) s += a.slots[tower][(size_t)b * a.slot_w + off];
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) a.grad[(size_t)a.n_blocks * 256 + q] = s;
+            if (lane == 0) a.grad[(size_t)a.n_blocks * 256 + k] = s;
         }
         if (lane == 5) a.grad[(size_t)a.n_blocks * 256 + 5] = a.n_local;
         if (lane == 6) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }
-        return;
-    }
-    const GradSrc s = a.src[chunk];
-    const size_t idx = (size_t)chunk * 256 + 4 * lane;
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    if (s.kind == 0) {
-        // the lane's 4 elements lie in one tile of the weight-gradient GEMM: as many partial sums as workgroups touched that tile
-        const int e = (int)(idx - (size_t)s.base), row = e / s.pcol, col = e - row * s.pcol;
-        const int tile = s.tile0 + (row / a.sk_bm) * (s.pcol / GB_N) + col / GB_N;
-        const int cnt = (tile * a.sk_nst + a.sk_nst - 1) / a.sk_per - (tile * a.sk_nst) / a.sk_per + 1;
-        for (int k = 0; k < cnt; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)k * a.slab_stride + idx);
-            g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
-        }
-    } else if (s.kind == 1 || s.kind == 3) {
-        // rows of a small table, 16 bytes per lane and row, all loads independent (offsets are multiples of 4 floats on this path)
-        const int e0 = (int)(idx - (size_t)s.base);
-        const float* p = (s.kind == 1 ? a.slots[s.tower] : a.direct) + s.slot_off + e0;
-        const int rows = s.kind == 1 ? a.n_rowblocks : a.n_direct;
-        const size_t stride = s.kind == 1 ? (size_t)a.slot_w : (size_t)a.direct_stride;
-        if (e0 < s.count) {
-#pragma unroll 8
-            for (int b = 0; b < rows; ++b) {
-                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * stride);
+    } else if (chunk >= 0) {
+        const GradSrc s = a.src[chunk];
+        const size_t idx = (size_t)chunk * 256 + 4 * lane;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s.kind == 0) {
+            // the lane's 4 elements lie in one tile of the weight-gradient GEMM: as many partial sums as workgroups touched that tile
+            const int e = (int)(idx - (size_t)s.base), row = e / s.pcol, col = e - row * s.pcol;
+            const int tile = s.tile0 + (row / a.sk_bm) * (s.pcol / GB_N) + col / GB_N;
+            const int cnt = (tile * a.sk_nst + a.sk_nst - 1) / a.sk_per - (tile * a.sk_nst) / a.sk_per + 1;
+            for (int k = 0; k < cnt; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)k * a.slab_stride + idx);
                 g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
             }
+        } else if (s.kind == 1 || s.kind == 3) {
+            // rows of a small table, 16 bytes per lane and row, all loads independent (offsets are multiples of 4 floats on this path).
+            // A vector of <= 64 (<= 128) elements occupies 16 (32) lanes: the other lanes take every 4th (2nd) row, and the partial sums
+            // meet as (S0 + S1) + (S2 + S3) -- a quarter of the dependent-free but latency-bound loads per lane (the head bias / logstd
+            // rows, one per 32 minibatch rows, were this launch's critical path)
+            const int split = s.count <= 64 ? 4 : (s.count <= 128 ? 2 : 1);
+            const int el = lane & (64 / split - 1), sub = lane / (64 / split);
+            const int e0 = (int)((size_t)chunk * 256 - (size_t)s.base) + 4 * el;
+            const float* p = (s.kind == 1 ? a.slots[s.tower] : a.direct) + s.slot_off + e0;
+            const int rows = s.kind == 1 ? a.n_rowblocks : a.n_direct;
+            const size_t stride = s.kind == 1 ? (size_t)a.slot_w : (size_t)a.direct_stride;
+            if (e0 < s.count) {
+#pragma unroll 8
+                for (int b = sub; b < rows; b += split) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * stride);
+                    g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
+                }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (e0 + q >= s.count) g[q] = 0.f;
+                for (int k = 0; k < 4; ++k) if (e0 + k >= s.count) g[k] = 0.f;
+            }
+            if (split > 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (split == 4) g[k] += __shfl_xor(g[k], 16);
+                    g[k] += __shfl_xor(g[k], 32);
+                    if (sub != 0) g[k] = 0.f;               // (these lanes' own positions are padding)
+                }
+            }
         }
+        *reinterpret_cast<float4*>(a.grad + idx) = make_float4(g[0], g[1], g[2], g[3]);
+        q = (g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]);
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     }
-    *reinterpret_cast<float4*>(a.grad + idx) = make_float4(g[0], g[1], g[2], g[3]);
-    float q = (g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]);
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    if (lane == 0) a.sumsq[chunk] = q;
+    if (lane == 0) wq[wave] = q;
+    __syncthreads();
+    if (tid == 0) {                                          // the workgroup's chunks in index order (wave BGR_WAVES-1 holds the lowest)
+        float t = 0.f;
+#pragma unroll
+        for (int w = BGR_WAVES - 1; w >= 0; --w) t += wq[w];
+        a.sumsq[blockIdx.x] = t;
+    }
 }

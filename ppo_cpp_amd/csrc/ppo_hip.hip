@@ -950,11 +950,11 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
             ra.slots[0] = h->slots[0]; ra.slots[1] = h->slots[1]; ra.n_rowblocks = Rp / BL_ROWS; ra.slot_w = n.slot_w; ra.slot_loss = n.slot_loss;
             ra.grad = h->grad; ra.sumsq = h->sumsq; ra.n_local = (float)ta.n; ra.beta_pow = h->beta_pow; ra.direct = h->bf.dbias;
             ra.n_direct = Rp / (Rp % 256 == 0 ? 256 : 128); ra.direct_stride = h->bf.n_dbias;
-            hipLaunchKernelGGL(bf16_grad_reduce_kernel, dim3((h->n_blocks + 1 + 3) / 4), dim3(256), 0, h->stream, ra);
+            hipLaunchKernelGGL(bf16_grad_reduce_kernel, dim3((h->n_blocks + 1 + BGR_WAVES - 1) / BGR_WAVES), dim3(64 * BGR_WAVES), 0, h->stream, ra);
             HIP_OK(h, hipGetLastError());
         }
-        if (h->comm && enqueue_grad_allreduce(h)) return -1;
-        return enqueue_adam(h, loss_row);                  // (adam_kernel keeps the bf16 copy of the weights current)
+        if (h->comm) return enqueue_grad_allreduce(h) ? -1 : enqueue_adam(h, loss_row);      // (the exchange recomputes the per-chunk sums of squares)
+        return enqueue_adam(h, loss_row, (h->n_blocks + 1 + BGR_WAVES - 1) / BGR_WAVES);       // one partial per assembly workgroup (adam_kernel keeps the bf16 copy of the weights current)
     }
     const int n_pad = ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
     const bool use_dw2 = h->dw2 && n_pad % 512 == 0 && n_rb <= 32 * DW2_SLOTK;

@@ -1589,7 +1589,18 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     const float b1p = a.beta_pow[0], b2p = a.beta_pow[1], lr = a.hyper[0];
     // global norm from the per-chunk partial sums, same fixed order in every block (and on every rank)
     float s = 0.f;
-    for (int i = tid; i < a.n_parts; i += 256) s += a.norm_parts[i];
+    if (a.n_parts > 512) {
+        // many partials (the bf16 path's one per assembly workgroup): a thread's first eight are requested together -- one memory round
+        // trip, not one per partial -- and added in the same index order
+        float pv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = tid + 256 * k; pv[k] = i < a.n_parts ? a.norm_parts[i] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (tid + 256 * k < a.n_parts) s += pv[k];
+        for (int i = tid + 2048; i < a.n_parts; i += 256) s += a.norm_parts[i];
+    } else {
+        for (int i = tid; i < a.n_parts; i += 256) s += a.norm_parts[i];
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
