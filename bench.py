@@ -360,21 +360,26 @@ def main():
     # PMC passes and the profiler's kernel trace cannot run inside the timed process: both come from the committed files that
     # profiles/current.json names (written with the round's profiles), and the JSON line says so
     traffic = traffic_source = rocprof_avg_us = rocprof_source = None
-    kname = {"train_fwd_bwd": "train_fwd_bwd_kernel", "weight_grad": "weight_grad", "policy_step": "policy_step_kernel"}[dom]
+    # kernel names of the dominant class, most specific first (the class "train_fwd_bwd" is train8_kernel on the 18-obs / [256,256] shape,
+    # train_fwd_bwd_kernel on other wide fp32 shapes, narrow_train_kernel for nets <= 64 wide, the tanh GEMM on the bf16 path)
+    knames = {"train_fwd_bwd": ["train8_kernel", "train_fwd_bwd_kernel", "narrow_train_kernel", "gemm_nt_bf16_kernel<4, 0>"],
+              "weight_grad": ["weight_grad_assemble_kernel", "weight_grad_kernel", "gemm_dw_bf16_kernel"],
+              "policy_step": ["policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_step_kernel"]}[dom]
     try:
         idx = json.load(open(os.path.join(ROOT, "profiles", "current.json"))).get(args.config, {})
         if idx.get("hbm_traffic"):
-            t = [v for k, v in json.load(open(os.path.join(ROOT, "profiles", idx["hbm_traffic"])))["kernels"].items() if kname in k]
+            kk = json.load(open(os.path.join(ROOT, "profiles", idx["hbm_traffic"])))["kernels"]
+            t = [v for kn in knames for k, v in kk.items() if kn in k][:1]
             if t:
                 traffic = (2.0 * t[0]["FETCH_SIZE"] + t[0]["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in t[0] else (2.0 * t[0]["FETCH_SIZE_KB"] + t[0]["WRITE_SIZE_KB"]) * 1024.0
                 traffic_source = "profiles/%s (offline rocprofv3 --pmc passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % idx["hbm_traffic"]
         if idx.get("kernel_stats"):
             import csv
-            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", idx["kernel_stats"]))):
-                if kname in r["Name"]:
-                    rocprof_avg_us = float(r["AverageNs"]) / 1e3
-                    rocprof_source = "profiles/%s (rocprofv3 --kernel-trace --stats of this command)" % idx["kernel_stats"]
-                    break
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", idx["kernel_stats"]))))
+            hit = [r for kn in knames for r in rows if kn in r["Name"]][:1]
+            if hit:
+                rocprof_avg_us = float(hit[0]["AverageNs"]) / 1e3
+                rocprof_source = "profiles/%s (rocprofv3 --kernel-trace --stats of this command; kernel %s)" % (idx["kernel_stats"], hit[0]["Name"].split("(")[0])
     except Exception as e:
         traffic_source = "unavailable: %r" % (e,)
     step_flops = (f_fwd + f_dx + f_dw) * M
