@@ -33,7 +33,7 @@ def cosine(a, b):
 
 @pytest.mark.parametrize("hidden,O,A,n", [((1024, 1024, 1024), 256, 64, 256), ((256, 256), 18, 18, 200), ((300, 200), 40, 7, 130),
                                           ((300, 200), 40, 7, 100), ((256, 128), 18, 18, 384),            # 128-row tiles (rows % 256 != 0)
-                                          ((1024, 1024, 1024), 256, 64, 1024), ((1024, 1024, 1024), 256, 64, 4096)])   # 16 and 64 stages per weight-gradient tile: the work-balanced split (configs[4]'s own minibatch)
+                                          ((1024, 1024, 1024), 256, 64, 1024), ((1024, 1024, 1024), 256, 64, 4096), ((1024, 512), 300, 100, 1000), ((384,), 18, 18, 640)])   # 16 and 64 stages per weight-gradient tile: the work-balanced split (configs[4]'s own minibatch)
 def test_bf16_step_and_train_step_against_fp32_oracle(hidden, O, A, n):
     """act outputs, the five losses, every gradient tensor and one Adam step of the bf16 path against the fp32 oracle.
     Tolerances: values 3e-2, actions / neglogp 5e-3 (the policy head's gain is 0.01), vf_loss 3 % relative, entropy exact
