@@ -6,7 +6,7 @@
 // rate).  Wide nets at thousands of rows per minibatch are therefore run layer by layer as 128x128-tile GEMMs
 // (both towers batched in one launch), activations round-tripping through HBM/L2 as bf16 (8 MB per layer at
 // 4096 x 1024, microseconds at HBM rates).  Master weights, gradients, the global-norm clip and Adam stay fp32
-// (adam_kernel of ppo_kernels.hpp, unchanged); bf16_mirror_kernel refreshes the bf16 operand copies after every step.
+// (adam_kernel of ppo_kernels.hpp, which also keeps the bf16 copy of the weights current: bf16_cast_kernel only runs after a weight upload).
 //
 // Every activation / gradient matrix lives in ONE layout, [rows][features] (round 3; rounds 1-2 wrote a second, [features][rows],
 // copy of each from the producing epilogue so that the weight-gradient product could use the same GEMM form: 16 MB more stores per
@@ -664,26 +664,6 @@ __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
     }
     if (tid >= 8 * BL_ROWS && tid < 8 * BL_ROWS + 4) { const int k = tid - 8 * BL_ROWS; float s = 0.f; for (int q = 0; q < BL_ROWS; ++q) s += pt[q * 4 + k]; s0[a.slot_loss + k] = s; }
     if (tid == 8 * BL_ROWS + 64) { float sb = 0.f, sl = 0.f; for (int q = 0; q < BL_ROWS; ++q) { sb += vt[q * 2]; sl += vt[q * 2 + 1]; } s1[a.slot_head] = sb; s1[a.slot_loss] = sl; }
-}
-
-// ---- bias gradients of the hidden layers: db[j] = sum over rows of dY, one wave per row of the [features][rows] copy ----
-struct RowSumArgsB { const bf16_t* src[2 * PPO_MAX_LAYERS]; float* dst[2 * PPO_MAX_LAYERS]; int rows[2 * PPO_MAX_LAYERS]; int first[2 * PPO_MAX_LAYERS + 1]; int n_mats; int ld; int len; };
-
-__global__ __launch_bounds__(256) void bf16_rowsum_kernel(RowSumArgsB a) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int m = 0;
-    while (m + 1 < a.n_mats && w >= a.first[m + 1]) ++m;
-    const int j = w - a.first[m];
-    if (j >= a.rows[m]) return;
-    const bf16_t* p = a.src[m] + (size_t)j * a.ld;
-    float s = 0.f;
-    for (int i = lane * 8; i < a.len; i += 512) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + i);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)v[e];
-    }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) a.dst[m][j] = s;
 }
 
 // ---- bf16 operand mirror of the fp32 master weights: keeps theta's padded layout (a cast of the whole vector) ----------------
