@@ -142,3 +142,59 @@ def test_two_ranks_literal_global_shuffle(tmp_path, hidden, E, T, nmb, epochs):
     for k in ("rows", "theta", "adam_m", "adam_v"):
         np.testing.assert_array_equal(outs[0][k], outs[1][k])
     assert np.abs(outs[0]["theta"] - theta0).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((256, 256), 64, 8, 4, 1), ((384, 256), 128, 16, 4, 2)])
+def test_two_ranks_bf16_path(tmp_path, hidden, E, T, nmb, epochs):
+    """The bf16 matrix-core path under data parallelism (the configuration SURVEY 8e expects DP to pay for): gradient assembly per rank,
+    all-reduce, recomputed sums of squares, fold, clip + Adam.  Against the fp32 oracle over the union at the bf16 path's stated
+    tolerances (tests/test_bf16_path.py); the replicas must stay bit-identical."""
+    world = 2
+    tmp = str(tmp_path)
+    fake = build_fake_rccl(tmp)
+    orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(13)
+    theta0 = orc.theta.copy()
+    rng = np.random.RandomState(47)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    nz = o.Normalizer(E, 18)
+    ro, _, _ = o.collect(orc, nz, 1234, T, noise, GAMMA, LAM)
+    El = E // world; Bl = El * T; m = Bl // nmb; M = m * world
+    perms = np.empty((world, epochs, Bl), np.int32); gperms = np.empty((epochs, E * T), np.int32)
+    for ep in range(epochs):
+        for r in range(world):
+            p = rng.permutation(Bl).astype(np.int32)
+            perms[r, ep] = p
+            gperms[ep, r * Bl:(r + 1) * Bl] = (p // m) * M + r * m + (p % m)
+    uid = np.zeros(128, np.uint8)
+    name = ("/ppo_dp_bf_%d_%d" % (os.getpid(), rng.randint(1 << 30))).encode()
+    uid[:len(name)] = np.frombuffer(name, np.uint8)
+    fin = os.path.join(tmp, "in.npz")
+    np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
+             noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
+    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="0", PPO_TEST_BF16="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), fin, os.path.join(tmp, "out%d.npz" % r)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("data-parallel workers timed out")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    outs = [np.load(os.path.join(tmp, "out%d.npz" % r)) for r in range(world)]
+    ref_rows, _ = orc.update(ro, gperms, nmb, LR, CR)
+    for out in outs:
+        rows = out["rows"]
+        np.testing.assert_allclose(rows[:, 1], ref_rows[:, 1], rtol=3e-2, err_msg="vf_loss")
+        np.testing.assert_allclose(rows[:, 2], ref_rows[:, 2], rtol=1e-4, err_msg="entropy")
+        np.testing.assert_allclose(rows[:, 0], ref_rows[:, 0], atol=1e-2, err_msg="pg_loss")
+        np.testing.assert_allclose(rows[:, 3], ref_rows[:, 3], rtol=5e-2, atol=2e-3, err_msg="approxkl")
+        np.testing.assert_allclose(rows[:, 4], ref_rows[:, 4], atol=0.08, err_msg="clipfrac")
+        da, db = (out["theta"] - theta0).astype(np.float64), (orc.theta - theta0).astype(np.float64)
+        assert float(da @ db / (np.linalg.norm(da) * np.linalg.norm(db))) > 0.9           # the run moved the weights the oracle's way
+        assert np.abs(out["theta"] - orc.theta).max() <= 2.5 * LR * epochs * nmb
+    for k in ("rows", "theta", "adam_m", "adam_v"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
