@@ -7,6 +7,7 @@ then noptepochs x nminibatches clipped-surrogate train steps (fwd + loss + backw
 `value` = total env-steps of all ranks / wall time (the reference's own `fps`, ppo2/ppo2.hpp:337-343).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N ...        (starts its N ranks itself, as a child torch.distributed.run; one rank per GPU over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -215,6 +216,43 @@ def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` -- as a CHILD process (never exec: this
+    process stays a plain parent that has not touched the GPU), relay rank 0's single JSON line to stdout, everything else to stderr,
+    and return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    if not os.environ.get("PPO_RCCL_LIBRARY"):
+        # RCCL takes ONE rank per device.  (PPO_RCCL_LIBRARY = a stand-in such as tests/fake_rccl lets N ranks share a device: a dry
+        # run of the flow, not a measurement.)  Counting devices does not initialise the GPU in this process.
+        try:
+            import torch
+            ndev = torch.cuda.device_count()
+        except Exception:
+            ndev = None
+        if ndev is not None and ndev < n:
+            print(json.dumps({"error": "bench.py --gpus %d: this node exposes %d HIP device(s); RCCL needs one device per rank" % (n, ndev)}), flush=True)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")                   # (what the launcher would set itself, without its warning)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
+    try:
+        for line in child.stdout:
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+            (sys.stdout if line.startswith("{") else sys.stderr).flush()
+        return child.wait()
+    except BaseException:
+        child.kill()
+        child.wait()
+        raise
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":          # child of cpu_baseline_all_cores: CPU only
         name, e_rows, m_rows, reps, t_start = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
@@ -237,12 +275,12 @@ def main():
                          "a few steps and keep the faster one for the timed region (both timings go into `collectives`)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))                     # BEFORE the package is imported or any GPU call is made
     from ppo_cpp_amd import dist as ppodist
     rank, world, local_rank = ppodist.env_rank_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world                                    # under a launcher the launcher's world size is the truth
 
     import ppo_cpp_amd
     dist = None
@@ -316,8 +354,15 @@ def main():
         import hashlib
         used = "peer" if g.dist_peer_active() else "rccl"
         digests = ppodist.allgather_bytes(dist, hashlib.sha256(g.get_flat(0).tobytes()).digest(), 32)
+        info = g.dist_info()
+        mine = json.dumps({"rank": rank, "local_rank": local_rank, "device": info["device"], "pci_bus_id": info["pci_bus_id"], "pid": os.getpid()}).encode()
+        devices = [json.loads(b.rstrip(b" ").decode()) for b in ppodist.allgather_bytes(dist, mine.ljust(160), 160)]
         collectives = {"used": used, "graph_captured": g.dist_graph_collectives(), "replicas_bit_identical": len(set(digests)) == 1,
-                       used: {"ms_per_step": 1e3 * dt / args.steps}}
+                       used: {"ms_per_step": 1e3 * dt / args.steps},
+                       # what lets a reader check the ranks: the communicator's own rank count (ncclCommCount), every rank's HIP ordinal +
+                       # PCI bus id (distinct devices on a real node; all the same on a one-GPU dry run), the library behind the nccl* calls
+                       "rccl_nranks": info["comm_nranks"], "devices": devices, "library": info["library"],
+                       "distinct_devices": len({d["pci_bus_id"] for d in devices})}
         if probe is not None:
             collectives["auto_probe_ms_per_step"] = probe
         if not collectives["replicas_bit_identical"]:

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define PPO_MAX_LAYERS 8
-#define PPO_ABI_VERSION 2
+#define PPO_ABI_VERSION 3
 
 typedef struct ppo_handle ppo_handle;
 
@@ -178,6 +178,10 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t noptepochs, int
 int ppo_dist_unique_id(char uid[128]);
 int ppo_dist_init(ppo_handle* h, int32_t world_size, int32_t rank, const char uid[128]);
 int ppo_dist_world(const ppo_handle* h);
+/* What a reader of a scaling run needs in order to check the ranks (all out-pointers optional): the number of ranks the
+ * COMMUNICATOR reports (ncclCommCount; -1 when the library has no such entry point, 0 without a communicator), this handle's HIP
+ * device ordinal, its PCI bus id ("0000:05:00.0") and the path of the collective library that was actually loaded. */
+int ppo_dist_info(ppo_handle* h, int32_t* comm_nranks, int32_t* device, char pci_bus_id[32], char library[256]);
 /* 1 when ppo_update replays the collectives from its hipGraph (the communicator's library passed the capture probe of
  * ppo_dist_init, or PPO_HIP_GRAPH_RCCL=1), 0 when they are issued eagerly between the launches */
 int ppo_dist_graph_collectives(const ppo_handle* h);

@@ -79,6 +79,7 @@ class PPOHip:
             self._ck(self.lib.ppo_tensor_info(self.h, i, name, C.byref(r), C.byref(c)))
             self.tensors.append((name.value.decode(), (r.value, c.value) if c.value else (r.value,)))
         self.E = self.T = 0
+        self.world, self._global_shuffle = 1, False
 
     def close(self):
         if getattr(self, "h", None):
@@ -252,7 +253,8 @@ class PPOHip:
         pp = None
         if perms is not None:
             perms = np.ascontiguousarray(perms, np.int32)
-            assert perms.shape[0] == noptepochs and perms.shape[1] % (self.E * self.T) == 0, perms.shape     # (B * world columns under ppo_dist_global_shuffle)
+            cols = self.E * self.T * (self.world if self._global_shuffle else 1)      # (B * world columns under ppo_dist_global_shuffle)
+            assert perms.shape == (noptepochs, cols), (perms.shape, (noptepochs, cols))
             pp = perms.ctypes.data_as(C.POINTER(C.c_int32))
         self._ck(self.lib.ppo_update(self.h, C.c_float(lr), C.c_float(cliprange), noptepochs, nminibatches, pp, C.c_uint64(seed),
                                      _fp(rows) if rows is not None else None, _fp(mean)))
@@ -269,7 +271,15 @@ class PPOHip:
 
     def dist_init(self, world, rank, uid):
         assert len(uid) == 128
-        self._ck(self.lib.ppo_dist_init(self.h, world, rank, C.c_char_p(uid) if False else C.create_string_buffer(uid, 128)))
+        self._ck(self.lib.ppo_dist_init(self.h, world, rank, C.create_string_buffer(uid, 128)))
+        self.world = world
+
+    def dist_info(self):
+        """{comm_nranks (ncclCommCount), device (HIP ordinal), pci_bus_id, library (path of the collective library loaded)}"""
+        n, d = C.c_int32(), C.c_int32()
+        pci, lib = C.create_string_buffer(32), C.create_string_buffer(256)
+        self._ck(self.lib.ppo_dist_info(self.h, C.byref(n), C.byref(d), pci, lib))
+        return {"comm_nranks": n.value, "device": d.value, "pci_bus_id": pci.value.decode(), "library": lib.value.decode()}
 
     def dist_graph_collectives(self):
         return bool(self.lib.ppo_dist_graph_collectives(self.h))
@@ -291,6 +301,7 @@ class PPOHip:
 
     def dist_global_shuffle(self, on=True):
         self._ck(self.lib.ppo_dist_global_shuffle(self.h, int(on)))
+        self._global_shuffle = bool(on) and self.world > 1
 
     def dist_peer_enable(self, on=True):
         self._ck(self.lib.ppo_dist_peer_enable(self.h, int(on)))

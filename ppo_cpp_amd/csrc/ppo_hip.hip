@@ -52,6 +52,7 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -2327,6 +2328,7 @@ static int load_rccl(Rccl& r, std::string& err) {
     r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclAllReduce");
     r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(r.lib, "ncclAllGather");
     r.CommDestroy = (int (*)(void*))dlsym(r.lib, "ncclCommDestroy");
+    r.CommCount = (int (*)(void*, int*))dlsym(r.lib, "ncclCommCount");
     r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) { err = "librccl lacks the expected nccl* symbols"; return -1; }
     return 0;
@@ -2392,6 +2394,26 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
 }
 
 int ppo_dist_world(const ppo_handle* h) { return h->world; }
+
+int ppo_dist_info(ppo_handle* h, int32_t* comm_nranks, int32_t* device, char pci_bus_id[32], char library[256]) {
+    ENTER(h);
+    if (comm_nranks) {
+        *comm_nranks = 0;
+        if (h->comm) {
+            int n = -1;
+            if (!h->rccl.CommCount || h->rccl.CommCount(h->comm, &n) != 0) n = -1;
+            *comm_nranks = n;
+        }
+    }
+    if (device) *device = h->device;
+    if (pci_bus_id) { pci_bus_id[0] = 0; HIP_OK(h, hipDeviceGetPCIBusId(pci_bus_id, 32, h->device)); }
+    if (library) {
+        library[0] = 0;
+        Dl_info di;
+        if (h->rccl.lib && h->rccl.AllReduce && dladdr((void*)h->rccl.AllReduce, &di) && di.dli_fname) snprintf(library, 256, "%s", di.dli_fname);
+    }
+    return 0;
+}
 int ppo_dist_graph_collectives(const ppo_handle* h) { return h->comm && (h->graph_rccl || h->peer.on) && h->use_graph ? 1 : 0; }
 
 // ---- one-shot peer all-reduce (ppo_peer.hpp) ---------------------------------------------------------------------------------
@@ -2533,7 +2555,11 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
 int ppo_dist_peer_active(const ppo_handle* h) { return h->peer.on ? 1 : 0; }
 
 int ppo_dist_global_shuffle(ppo_handle* h, int on) {
-    ENTER(h);
+    ENTER_Q(h);
+    // refused at toggle time, not at the first ppo_update: without a communicator the flag would be silently ignored, and the
+    // literal scheme needs ncclAllGather (with ONE rank the global permutation is the local one: accepted, nothing to gather)
+    if (on && !h->comm) return fail(h, "ppo_dist_global_shuffle: call ppo_dist_init first (no communicator)");
+    if (on && h->world > 1 && !h->rccl.AllGather) return fail(h, "ppo_dist_global_shuffle: the collective library has no ncclAllGather");
     HIP_OK(h, hipStreamSynchronize(h->stream));
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
     h->global_shuffle = on != 0;

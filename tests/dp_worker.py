@@ -62,6 +62,7 @@ def main():
         rows, mean = g.update(float(d["lr"]), float(d["cr"]), epochs, nmb, d["perms"][rank])
     out["rows"], out["mean"], out["theta"] = rows, mean, g.get_flat(0)
     out["adam_m"], out["adam_v"] = g.get_flat(1), g.get_flat(2)
+    out["comm_nranks"] = np.int32(g.dist_info()["comm_nranks"])
     g.close()
     np.savez(fout, **out)
 

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib = ppo_cpp_amd.load_library()
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.ppo_abi_version() == 2
+    assert lib.ppo_abi_version() == 3
 
 
 def test_config_defaults_are_the_graph_baked_constants():

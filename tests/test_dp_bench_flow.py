@@ -43,6 +43,49 @@ def test_two_rank_bench_flow(tmp_path, collective, scaling, config):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus,extra", [(2, ["--config", "cfg4"]),
+                                        # BASELINE configs[3] as written: 1024 envs over 8 GPUs = 128 envs x 64 steps, 256 minibatch rows per rank
+                                        (8, ["--config", "cfg4", "--scaling", "strong"]),
+                                        (4, ["--config", "cfg3", "--scaling", "strong", "--collective", "peer"])])
+def test_bench_starts_its_own_ranks(tmp_path, gpus, extra):
+    """`python bench.py --gpus N` with NO launcher in the command line (the form the driver's own command has): bench.py starts
+    torch.distributed.run as a child before touching the GPU, relays rank 0's ONE JSON line and exits with the child's code.  The line
+    says what the ranks were: ncclCommCount, every rank's device ordinal + PCI bus id, the collective library."""
+    fake = build_fake_rccl(str(tmp_path))
+    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]      # stdout carries the JSON line and nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["steps"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "dp%d" % gpus
+    c = d["collectives"]
+    assert c["replicas_bit_identical"] is True and c["rccl_nranks"] == gpus
+    assert [x["rank"] for x in c["devices"]] == list(range(gpus)) and all(x["pci_bus_id"] for x in c["devices"])
+    assert len({x["pid"] for x in c["devices"]}) == gpus                          # one process per rank
+    assert c["distinct_devices"] == 1                                             # (the one test GPU; a real node shows `gpus`)
+    assert os.path.samefile(c["library"], fake)
+    if "strong" in extra:
+        E = {"cfg4": 1024, "cfg3": 4096}[extra[1]]
+        assert d["scaling"] == "strong" and d["config"]["n_envs_per_gpu"] == E // gpus
+
+
+def test_bench_refuses_more_ranks_than_devices_without_a_stand_in():
+    """CPU-runnable: with no stand-in library and fewer devices than ranks, `bench.py --gpus N` says so in one JSON line and exits
+    non-zero instead of handing RCCL two ranks per device."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU node")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PPO_RCCL_LIBRARY")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 2
+    assert "RCCL needs one device per rank" in json.loads(out.stdout.strip().splitlines()[-1])["error"]
+
+
+@pytest.mark.gpu
 def test_a_peer_that_stops_answering_is_an_error_not_a_hang(tmp_path):
     """Rank 1 attaches, then never joins a collective again.  Rank 0's first exchange (the running-statistics table of its first env
     step) gives up after PPO_HIP_PEER_TIMEOUT_MS: the error surfaces from the rollout / update call and the process exits non-zero,

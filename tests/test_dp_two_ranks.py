@@ -1,4 +1,4 @@
-"""Data-parallel path with TWO ranks on one GPU.
+"""Data-parallel path with 2, 4 and 8 ranks on one GPU.
 
 RCCL refuses two ranks on the same device, so the collective library is swapped (PPO_RCCL_LIBRARY) for
 tests/fake_rccl: the same five nccl* entry points over POSIX shared memory.  Everything else is the product path: two
@@ -29,17 +29,42 @@ def build_fake_rccl(tmp):
     return so
 
 
+def run_workers(tmp, world, fin, env, timeout=900):
+    """world processes of tests/dp_worker.py on the one test GPU; returns their output files' contents in rank order"""
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), fin, os.path.join(tmp, "out%d.npz" % r)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=timeout)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("data-parallel workers timed out")
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    return [np.load(os.path.join(tmp, "out%d.npz" % r)) for r in range(world)]
+
+
+SHAPES_UNION = [(2, (64, 64), 16, 16, 4, 2), (2, (256, 256), 64, 8, 4, 1),
+                # BASELINE configs[3] at its per-rank workload (1024 envs over 8 GPUs = 128 envs x 64 steps
+                # per rank, MLP [64,64], 32 minibatches of 256 rows per rank)
+                (2, (64, 64), 256, 64, 32, 1),
+                # world 4 and 8 (the target is 8 GPUs): the 8-slot rank-ordered sum, the (rank + k) % world push order, the statistics
+                # table of 8 ranks, the regions' capacity at 8 ranks -- one narrow and one [256,256] shape each
+                (4, (64, 64), 16, 16, 4, 2), (4, (256, 256), 64, 8, 4, 1),
+                (8, (64, 64), 16, 16, 4, 2), (8, (256, 256), 64, 8, 4, 1),
+                # ... and configs[3]'s literal strong-scaling shard at 8 ranks: 1024 envs -> 128 per rank, 256 minibatch rows per rank
+                (8, (64, 64), 1024, 64, 32, 1)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((64, 64), 16, 16, 4, 2), ((256, 256), 64, 8, 4, 1),
-                                                   # BASELINE configs[3] at its per-rank workload (1024 envs over 8 GPUs = 128 envs x 64 steps
-                                                   # per rank, MLP [64,64], 32 minibatches of 256 rows per rank)
-                                                   ((64, 64), 256, 64, 32, 1)])
+@pytest.mark.parametrize("world,hidden,E,T,nmb,epochs", SHAPES_UNION)
 @pytest.mark.parametrize("peer", [False, True])
-def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden, E, T, nmb, epochs, peer):
-    """peer = True: every collective goes through the one-shot peer all-reduce (ppo_peer.hpp) -- the two processes map each
-    other's gather region over hipIpc (same mechanism as two GPUs of a node; here both regions live on the one test GPU) and
+def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, world, hidden, E, T, nmb, epochs, peer):
+    """`world` ranks (2, 4, 8) as processes on the one test GPU against the single-process oracle over the union of their rows.
+    peer = True: every collective goes through the one-shot peer all-reduce (ppo_peer.hpp) -- the processes map each
+    other's gather region over hipIpc (same mechanism as the GPUs of a node; here all regions live on the one test GPU) and
     the whole update, collectives included, replays from the hipGraph."""
-    world = 2
     tmp = str(tmp_path)
     fake = build_fake_rccl(tmp)
     orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(11)
@@ -63,18 +88,9 @@ def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden
     np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
              noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
     env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="1" if peer else "0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), fin, os.path.join(tmp, "out%d.npz" % r)],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    logs = []
-    for p in procs:
-        try:
-            logs.append(p.communicate(timeout=600)[0].decode())
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            pytest.fail("data-parallel workers timed out")
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    outs = [np.load(os.path.join(tmp, "out%d.npz" % r)) for r in range(world)]
+    outs = run_workers(tmp, world, fin, env)
+    for out in outs:                                                           # the communicator itself reports `world` ranks
+        assert int(out["comm_nranks"]) == world
     # ---- rollout: every rank's shard equals the oracle's columns; the running statistics are over ALL environments ----
     for r, out in enumerate(outs):
         sl = slice(r * El, (r + 1) * El)
@@ -85,26 +101,27 @@ def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, hidden
         close(out["ret_var"], nz.ret_rms.var, rtol=1e-5)
         assert float(out["obs_count"]) == nz.obs_rms.count and float(out["ret_count"]) == nz.ret_rms.count
     for k in ("obs_mean", "obs_var", "ret_mean", "ret_var"):
-        np.testing.assert_array_equal(outs[0][k], outs[1][k])                 # bit-identical on every rank
+        for out in outs[1:]:
+            np.testing.assert_array_equal(outs[0][k], out[k])                 # bit-identical on every rank
     # ---- update: loss rows and weights equal the oracle's update over the union; replicas stay bit-identical ----------
     ref_rows, _ = orc.update(ro, gperms, nmb, LR, CR)
     for out in outs:
         close(out["rows"], ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows")
         close(out["theta"], orc.theta, rtol=2e-4, atol=5e-6, msg="weights")
     for k in ("rows", "theta", "adam_m", "adam_v"):
-        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+        for out in outs[1:]:
+            np.testing.assert_array_equal(outs[0][k], out[k])
     assert np.abs(outs[0]["theta"] - theta0).max() > 0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((64, 64), 16, 16, 4, 2), ((256, 256), 64, 8, 4, 1)])
-def test_two_ranks_literal_global_shuffle(tmp_path, hidden, E, T, nmb, epochs):
+@pytest.mark.parametrize("world,hidden,E,T,nmb,epochs", [(2, (64, 64), 16, 16, 4, 2), (2, (256, 256), 64, 8, 4, 1), (4, (64, 64), 16, 16, 4, 2)])
+def test_two_ranks_literal_global_shuffle(tmp_path, world, hidden, E, T, nmb, epochs):
     """ppo_dist_global_shuffle(1): the reference's sampling taken literally under data parallelism (ppo2/ppo2.hpp:288-307) --
     ONE permutation of the rows of all ranks per epoch after an all-gather of the rollout, rank r training rows [r M, (r+1) M) of every
     global minibatch.  Both ranks get the SAME global permutation the single-process oracle uses over the union: no equivalent-
     permutation construction, the comparison is direct.  Loss rows and weights must match the oracle; the replicas must stay
     bit-identical."""
-    world = 2
     tmp = str(tmp_path)
     fake = build_fake_rccl(tmp)
     orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(12)
@@ -123,34 +140,23 @@ def test_two_ranks_literal_global_shuffle(tmp_path, hidden, E, T, nmb, epochs):
     np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
              noise=noise, perms=perms, gperms=gperms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
     env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="0", PPO_TEST_GLOBAL="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), fin, os.path.join(tmp, "out%d.npz" % r)],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    logs = []
-    for p in procs:
-        try:
-            logs.append(p.communicate(timeout=600)[0].decode())
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            pytest.fail("data-parallel workers timed out")
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    outs = [np.load(os.path.join(tmp, "out%d.npz" % r)) for r in range(world)]
+    outs = run_workers(tmp, world, fin, env)
     ref_rows, _ = orc.update(ro, gperms, nmb, LR, CR)
     for out in outs:
         close(out["rows"], ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows")
         close(out["theta"], orc.theta, rtol=2e-4, atol=5e-6, msg="weights")
     for k in ("rows", "theta", "adam_m", "adam_v"):
-        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+        for out in outs[1:]:
+            np.testing.assert_array_equal(outs[0][k], out[k])
     assert np.abs(outs[0]["theta"] - theta0).max() > 0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((256, 256), 64, 8, 4, 1), ((384, 256), 128, 16, 4, 2)])
-def test_two_ranks_bf16_path(tmp_path, hidden, E, T, nmb, epochs):
+@pytest.mark.parametrize("world,hidden,E,T,nmb,epochs", [(2, (256, 256), 64, 8, 4, 1), (2, (384, 256), 128, 16, 4, 2), (8, (256, 256), 128, 8, 4, 1)])
+def test_two_ranks_bf16_path(tmp_path, world, hidden, E, T, nmb, epochs):
     """The bf16 matrix-core path under data parallelism (the configuration SURVEY 8e expects DP to pay for): gradient assembly per rank,
     all-reduce, recomputed sums of squares, fold, clip + Adam.  Against the fp32 oracle over the union at the bf16 path's stated
     tolerances (tests/test_bf16_path.py); the replicas must stay bit-identical."""
-    world = 2
     tmp = str(tmp_path)
     fake = build_fake_rccl(tmp)
     orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(13)
@@ -173,18 +179,7 @@ def test_two_ranks_bf16_path(tmp_path, hidden, E, T, nmb, epochs):
     np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
              noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
     env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="0", PPO_TEST_BF16="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), fin, os.path.join(tmp, "out%d.npz" % r)],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    logs = []
-    for p in procs:
-        try:
-            logs.append(p.communicate(timeout=600)[0].decode())
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            pytest.fail("data-parallel workers timed out")
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    outs = [np.load(os.path.join(tmp, "out%d.npz" % r)) for r in range(world)]
+    outs = run_workers(tmp, world, fin, env)
     ref_rows, _ = orc.update(ro, gperms, nmb, LR, CR)
     for out in outs:
         rows = out["rows"]
@@ -197,4 +192,5 @@ def test_two_ranks_bf16_path(tmp_path, hidden, E, T, nmb, epochs):
         assert float(da @ db / (np.linalg.norm(da) * np.linalg.norm(db))) > 0.9           # the run moved the weights the oracle's way
         assert np.abs(out["theta"] - orc.theta).max() <= 2.5 * LR * epochs * nmb
     for k in ("rows", "theta", "adam_m", "adam_v"):
-        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+        for out in outs[1:]:
+            np.testing.assert_array_equal(outs[0][k], out[k])
