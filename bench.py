@@ -26,6 +26,9 @@ CONFIGS = {
     # name: (n_envs, n_steps, hidden, obs, act, nminibatches, noptepochs)   -- SURVEY section 8 table
     "cfg3": dict(n_envs=4096, n_steps=16, hidden=[256, 256], obs=18, act=18, nminibatches=32, noptepochs=10,
                  desc="env_mock-shaped synthetic env, 4096 envs x 16 steps (B=65536), MLP [256,256], 32 minibatches x 10 epochs"),
+    # the reference's OTHER real observation shape (observe_velocities: 36 observations, env/hexapod_closed_loop_env.hpp:20) on configs[2]'s workload
+    "cfg3o36": dict(n_envs=4096, n_steps=16, hidden=[256, 256], obs=36, act=18, nminibatches=32, noptepochs=10,
+                    desc="configs[2]'s workload with the reference's 36-observation hexapod shape: 4096 envs x 16 steps, MLP [256,256], 32 minibatches x 10 epochs"),
     "cfg2": dict(n_envs=1, n_steps=2048, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
                  desc="1 env x 2048 steps, MLP [64,64] (launch-latency bound)"),
     "cfg4": dict(n_envs=1024, n_steps=64, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
@@ -36,7 +39,7 @@ CONFIGS = {
     "cfg5f32": dict(n_envs=8192, n_steps=16, hidden=[1024, 1024, 1024], obs=256, act=64, nminibatches=32, noptepochs=10,
                     desc="synthetic 256-obs/64-act env, 8192 envs x 16 steps, MLP [1024,1024,1024] in exact fp32 (two-tile LDS layout)"),
 }
-BASELINE_INDEX = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4, "cfg5f32": 4}
+BASELINE_INDEX = {"cfg2": 1, "cfg3": 2, "cfg3o36": 2, "cfg4": 3, "cfg5": 4, "cfg5f32": 4}
 LR, CR, GAMMA, LAM = 3.93141e-4, 0.161023, 0.99, 0.95      # README.md:70-81, ppo2.cpp:215-217
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0                              # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparsity figure)
@@ -53,133 +56,109 @@ def flops_per_row(O, A, hidden):
     return 2 * fwd, 2 * dx, 2 * fwd
 
 
-def _cpu_worker(args):
-    """One host core's share of a policy step and of a train step (rows split evenly, as a row-parallel port would)."""
-    cfg, e_rows, m_rows, reps, t_start = args
-    from oracle import oracle as o
-    orc = o.Oracle(cfg["obs"], cfg["act"], cfg["hidden"]); orc.init_orthogonal(0)
-    rng = np.random.RandomState(1)
-    obs = rng.uniform(-1, 1, (e_rows, cfg["obs"])).astype(np.float32); noise = rng.normal(size=(e_rows, cfg["act"])).astype(np.float32)
-    mobs = rng.uniform(-1, 1, (m_rows, cfg["obs"])).astype(np.float32)
-    act, v, nlp = orc.step(mobs, rng.normal(size=(m_rows, cfg["act"])).astype(np.float32))
-    ret = (v + rng.normal(size=m_rows)).astype(np.float32); adv = o.adv_normalize(ret, v)
-    while time.time() < t_start:                             # all workers start together: the cores are loaded at once
-        time.sleep(0.005)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        orc.step(obs, noise)
-    t1 = time.perf_counter()
-    for _ in range(reps):
-        orc.train_step(LR, CR, mobs, act, adv, ret, nlp, v)
-    t2 = time.perf_counter()
-    return (t1 - t0) / reps, (t2 - t1) / reps
-
-
-def cpu_baseline_all_cores(cfg, name, Es, Ms):
-    """The same port with the rows of every call split over all host cores (one child process per core, started
-    together; the cross-core gradient reduction a real multi-threaded port needs is not charged)."""
-    import subprocess
+def granted_cores():
+    """host cores this process may actually use: the affinity mask cut by the cgroup CPU quota (a container often SEES far more)"""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    n = max(1, min(n, 16))                                   # bounded: a container may report far more cores than it may use
-    E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
-    B = E * T; M = B // nmb
-    e_rows, m_rows = max(1, Es // n), max(2, Ms // n)
-    t_start = time.time() + 4.0
-    deadline = time.time() + 45.0
-    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")    # numpy's BLAS pool would oversubscribe
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", name, str(e_rows), str(m_rows), "3", repr(t_start)],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(n)]
-    res = []
-    try:
-        for pr in procs:
-            out, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
-            res.append([float(x) for x in out.split()[-2:]])
-    finally:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
-    t_step = max(r[0] for r in res) * (E / (e_rows * n)); t_train = max(r[1] for r in res) * (M / (m_rows * n))
-    return {"value": B / (T * t_step + ep * nmb * t_train), "unit": "env-steps/s", "cores": n,
-            "sample": "%d processes (capped at 16) x (3 policy steps at %d rows + 3 train steps at %d rows), slowest process, scaled" % (n, e_rows, m_rows)}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
 
 
-def cpu_baseline_vectorised(cfg, budget_s=6.0):
-    """A second CPU leg that is not the double-accumulating scalar port: the dense products of one policy step and one
-    train step (forward, dX, dW of both towers; fp32, tanh included, the O(rows) loss arithmetic left out) on NumPy's
-    BLAS sgemm pinned to ONE thread.  An optimistic stand-in for what TF-Eigen's single-thread contraction could do."""
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:
-        threadpool_limits = None
+def vectorised_update_time(cfg, budget_s):
+    """One WHOLE PPO update of `cfg` on the vectorised CPU port (oracle/numpy_port.py: NumPy expressions over BLAS sgemm; checked
+    against the C oracle in tests/test_oracle.py), with whatever BLAS thread count this process was started with.  Times a bounded
+    sample -- a few policy steps at the full n_envs rows, a few COMPLETE train steps (forward, loss, backward, clip, Adam over all
+    parameters) at the full minibatch rows, one GAE scan, the running-statistics updates -- and extrapolates to T policy steps +
+    epochs x minibatches train steps.  The synthetic env itself is not charged (the GPU side's env kernel is ~1 % of its collect)."""
+    from oracle import oracle as o
+    from oracle import numpy_port as npp
     E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
     B = E * T; M = B // nmb
-    dims = [cfg["obs"]] + list(cfg["hidden"])
+    O, A = cfg["obs"], cfg["act"]
+    orc = o.Oracle(O, A, cfg["hidden"]); orc.init_orthogonal(0)
+    P = npp.NumpyPPO(orc)
     rng = np.random.RandomState(0)
-    Ws = [[(rng.normal(size=(a, b)) / np.sqrt(a)).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])] for _ in range(2)]
-    heads = [(rng.normal(size=(dims[-1], cfg["act"])) * 0.01).astype(np.float32), rng.normal(size=(dims[-1], 1)).astype(np.float32)]
-    f_fwd, f_dx, f_dw = flops_per_row(cfg["obs"], cfg["act"], cfg["hidden"])
-    rows = int(max(64, min(M, 2.0e9 // (f_fwd + f_dx + f_dw))))
-    x = rng.uniform(-1, 1, (rows, cfg["obs"])).astype(np.float32)
+    f_fwd, f_dx, f_dw = flops_per_row(O, A, cfg["hidden"])
+    Es = int(max(1, min(E, 4.0e9 // f_fwd))); Ms = int(max(2, min(M, 4.0e9 // (f_fwd + f_dx + f_dw))))     # (cfg5: 418 / 144 rows; cfg3: all)
+    obs = rng.uniform(-1, 1, (Es, O)).astype(np.float32); noise = rng.normal(size=(Es, A)).astype(np.float32)
 
-    def fwd(keep):
-        acts = []
-        for t in range(2):
-            h = x; hs = [h]
-            for W in Ws[t]:
-                h = np.tanh(h @ W); hs.append(h)
-            out = h @ heads[t]
-            acts.append((hs, out))
-        return acts if keep else None
-
-    def train():
-        acts = fwd(True)
-        for t in range(2):
-            hs, out = acts[t]
-            d = out * np.float32(1e-3)
-            _ = hs[-1].T @ d                                  # head dW
-            dh = (d @ heads[t].T) * (1 - hs[-1] * hs[-1])
-            for l in range(len(Ws[t]) - 1, -1, -1):
-                _ = hs[l].T @ dh                              # dW_l
-                if l:
-                    dh = (dh @ Ws[t][l].T) * (1 - hs[l] * hs[l])
-
-    def timed(fn, share):
+    def timed(fn, share, cap):
+        fn()                                                 # warm: page in, BLAS thread pool up
         t0 = time.perf_counter(); n = 0
-        while n < 1 or (time.perf_counter() - t0 < share * budget_s and n < 50):
+        while n < 1 or (time.perf_counter() - t0 < share * budget_s and n < cap):
             fn(); n += 1
-        return (time.perf_counter() - t0) / n
+        return (time.perf_counter() - t0) / n, n
 
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
-    try:
-        if ctx is not None:
-            ctx.__enter__()
-        t_step = timed(lambda: fwd(False), 0.25) * (E / rows)
-        t_train = timed(train, 0.75) * (M / rows)
-    finally:
-        if ctx is not None:
-            ctx.__exit__(None, None, None)
-    return {"value": B / (T * t_step + ep * nmb * t_train), "unit": "env-steps/s", "cores": 1, "kind": "port (NumPy/BLAS sgemm, 1 thread, dense products + tanh only)",
-            "sample": "policy-step and train-step products at %d rows, scaled to %d / %d rows" % (rows, E, M), "blas_threads_pinned": threadpool_limits is not None}
+    t_step, n_step = timed(lambda: P.step(obs, noise), 0.2, 64)
+    mobs = rng.uniform(-1, 1, (Ms, O)).astype(np.float32)
+    act, v, nlp = P.step(mobs, rng.normal(size=(Ms, A)).astype(np.float32))
+    ret = (v + rng.normal(size=Ms)).astype(np.float32); adv = ((ret - v) - (ret - v).mean()) / ((ret - v).std() + 1e-8)
+    t_train, n_tr = timed(lambda: P.train_step(LR, CR, mobs, act, adv.astype(np.float32), ret, nlp, v), 0.7, 256)
+    Eg = min(E, 8192)
+    rw = rng.normal(size=(T, Eg)).astype(np.float32); dn = (rng.rand(T, Eg) < 0.01).astype(np.float32)
+    t_gae, _ = timed(lambda: npp.gae(rw, rw, dn, rw[0], dn[0], GAMMA, LAM), 0.05, 8)
+    ob = rng.uniform(-1, 1, (Eg, O)).astype(np.float32)
+    t_rs, _ = timed(lambda: npp.running_update(np.zeros(O, np.float32), np.ones(O, np.float32), 1.0, ob), 0.05, 16)
+    t_update = T * (t_step * (E / Es) + t_rs * (E / Eg)) + t_gae * (E / Eg) + ep * nmb * t_train * (M / Ms)
+    return {"value": B / t_update, "unit": "env-steps/s", "update_samples_per_s": ep * B / (ep * nmb * t_train * (M / Ms)),
+            "t_policy_step_ms": 1e3 * t_step * (E / Es), "t_train_step_ms": 1e3 * t_train * (M / Ms),
+            # what the timed statements cover of one update's algorithmic FLOPs (SURVEY section 8 table: dense products of both towers,
+            # forward + dX + dW); the O(rows x A) loss arithmetic, clip and Adam are timed too but are not in that FLOP count
+            "covers": 1.0,
+            "covers_what": "whole update: T policy steps (forward, sample, neglogp), running statistics, GAE, and epochs x minibatches COMPLETE train steps "
+                           "(forward, loss, backward incl. TanhGrad and all weight / bias gradients, global-norm clip, Adam over all %d parameters); the env is not charged" % orc.P,
+            "sample": "%d policy steps at %d rows + %d train steps at %d rows, extrapolated to %d steps + %d train steps per update"
+                      % (n_step, Es, n_tr, Ms, T, ep * nmb) + ("" if (Es, Ms) == (E, M) else " (rows scaled to %d / %d)" % (E, M))}
+
+
+def cpu_vectorised_leg(name, threads, budget_s):
+    """the vectorised port in a CHILD process whose BLAS thread count is fixed before NumPy loads (OPENBLAS / OMP / MKL _NUM_THREADS)"""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", name, str(threads), repr(budget_s)], capture_output=True, text=True,
+                         timeout=60 + 6 * budget_s, env=env, cwd=ROOT)
+    if out.returncode != 0:
+        return {"error": out.stderr[-400:]}
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    r["cores"] = threads
+    return r
 
 
 def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
-    """The oracle's C restatement (a scalar port, 1 thread) timed on a bounded sample of the same workload."""
+    """CPU legs of the same workload on the GPU box's host cores (kind "port": the reference needs TensorFlow-C++ and cannot be built here):
+      value / cores = 1 : the vectorised port (NumPy over BLAS sgemm), ONE thread, a WHOLE update (`covers` 1.0);
+      all_cores          : the same port with BLAS threads = the cores this process is granted (affinity mask cut by the cgroup quota);
+      scalar_port        : the oracle's C restatement (scalar loops, double accumulators), one thread -- the checker itself, on record."""
     from oracle import oracle as o
     E, T, nmb, ep = cfg["n_envs"], cfg["n_steps"], cfg["nminibatches"], cfg["noptepochs"]
     B = E * T; M = B // nmb
-    # bound the sample: about 1.5 GFLOP per call (the scalar port runs ~2-3 GFLOP/s); per-row cost is size independent
+    one = cpu_vectorised_leg(name, 1, 0.5 * budget_s)
+    n = granted_cores()
+    allc = cpu_vectorised_leg(name, n, 0.3 * budget_s) if n > 1 else dict(one)
+    # the scalar port on a bounded sample: about 1 GFLOP per call (it runs ~2-3 GFLOP/s); per-row cost is size independent
     f_fwd, f_dx, f_dw = flops_per_row(cfg["obs"], cfg["act"], cfg["hidden"])
-    Es = int(max(16, min(E, 1.5e9 // f_fwd))); Ms = int(max(16, min(M, 1.5e9 // (f_fwd + f_dx + f_dw))))
+    Es = int(max(16, min(E, 1.0e9 // f_fwd))); Ms = int(max(16, min(M, 1.0e9 // (f_fwd + f_dx + f_dw))))
     orc = o.Oracle(cfg["obs"], cfg["act"], cfg["hidden"])
     orc.init_orthogonal(0)
     rng = np.random.RandomState(0)
     obs = rng.uniform(-1, 1, (Es, cfg["obs"])).astype(np.float32)
     noise = rng.normal(size=(Es, cfg["act"])).astype(np.float32)
     t0 = time.perf_counter(); n_step = 0
-    while n_step < 1 or (time.perf_counter() - t0 < 0.15 * budget_s and n_step < 8):
+    while n_step < 1 or (time.perf_counter() - t0 < 0.03 * budget_s and n_step < 4):
         a, v, nlp = orc.step(obs, noise); n_step += 1
     t_step = (time.perf_counter() - t0) / n_step * (E / Es)
     mobs = rng.uniform(-1, 1, (Ms, cfg["obs"])).astype(np.float32)
@@ -187,32 +166,18 @@ def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
     ret = (v + rng.normal(size=Ms)).astype(np.float32)
     adv = o.adv_normalize(ret, v)
     t0 = time.perf_counter(); n_tr = 0
-    while n_tr < 1 or (time.perf_counter() - t0 < 0.85 * budget_s and n_tr < 64):
+    while n_tr < 1 or (time.perf_counter() - t0 < 0.17 * budget_s and n_tr < 16):
         orc.train_step(LR, CR, mobs, act, adv, ret, nlp, v); n_tr += 1
     t_train = (time.perf_counter() - t0) / n_tr * (M / Ms)
-    t_update = T * t_step + ep * nmb * t_train
-    all_cores = None
-    try:
-        all_cores = cpu_baseline_all_cores(cfg, name, Es, Ms)
-    except Exception as e:                                   # the single-thread leg is the contract; this one is extra
-        all_cores = {"error": repr(e)}
-    try:
-        vect = cpu_baseline_vectorised(cfg)
-    except Exception as e:
-        vect = {"error": repr(e)}
-    scalar = {"value": B / t_update, "unit": "env-steps/s", "cores": 1, "kind": "port (oracle's C restatement: scalar loops, double accumulators)",
-              "sample": "%d policy steps at %d rows + %d train steps at %d rows, extrapolated to %d steps + %d train steps per update"
-                        % (n_step, Es, n_tr, Ms, T, ep * nmb) + ("" if (Es, Ms) == (E, M) else " (rows scaled to %d / %d)" % (E, M)),
-              "update_samples_per_s": ep * B / (ep * nmb * t_train)}
-    # the stated baseline is the FASTER of the two single-thread legs; the other one stays on record beside it
-    best, other, other_key = scalar, vect, "vectorised"
-    if isinstance(vect, dict) and vect.get("value", 0.0) > scalar["value"]:
-        best, other, other_key = dict(vect), scalar, "scalar_port"
-    out = dict(best)
-    out["kind"] = "port" if best is scalar else "port (vectorised: NumPy/BLAS sgemm, 1 thread, dense products + tanh only)"
-    out["kind_detail"] = best["kind"]
-    out[other_key] = other
-    out["all_cores"] = all_cores
+    scalar = {"value": B / (T * t_step + ep * nmb * t_train), "unit": "env-steps/s", "cores": 1,
+              "kind": "port (oracle's C restatement: scalar loops, double accumulators)",
+              "sample": "%d policy steps at %d rows + %d train steps at %d rows, rows scaled to %d / %d" % (n_step, Es, n_tr, Ms, E, M)}
+    out = dict(one) if "value" in one else dict(scalar)
+    out["kind"] = "port"
+    out["kind_detail"] = "vectorised port (oracle/numpy_port.py: NumPy expressions over BLAS sgemm), 1 thread" if "value" in one else scalar["kind"]
+    out["cores"] = 1
+    out["all_cores"] = allc
+    out["scalar_port"] = scalar
     return out
 
 
@@ -254,9 +219,8 @@ def self_launch(n):
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":          # child of cpu_baseline_all_cores: CPU only
-        name, e_rows, m_rows, reps, t_start = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
-        print("%r %r" % _cpu_worker((CONFIGS[name], e_rows, m_rows, reps, t_start)))
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":          # child of cpu_vectorised_leg: CPU only, BLAS threads fixed by its environment
+        print(json.dumps(vectorised_update_time(CONFIGS[sys.argv[2]], float(sys.argv[4]))))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

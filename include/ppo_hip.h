@@ -216,6 +216,10 @@ int ppo_dist_global_shuffle(ppo_handle* h, int on);
 int ppo_prof_enable(ppo_handle* h, int on);
 int ppo_prof_read(ppo_handle* h, int max, char names[][32], double* total_ms, int64_t* launches);
 int ppo_sync(ppo_handle* h);
+/* which kernel VARIANT the calls so far took: the library picks its kernels from the shape, and a caller or a
+ * test can ask which ones were ENQUEUED since ppo_create (a hipGraph capture counts once, its replays do not).  names: e.g.
+ * "train8_kernel", "weight_grad_assemble_kernel", "narrow_train_kernel<static>", "narrow_rollout1_kernel"; returns the count of entries */
+int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueued);
 
 #ifdef __cplusplus
 }

@@ -314,5 +314,11 @@ class PPOHip:
         n = self.lib.ppo_prof_read(self.h, 16, names, ms, cnt)
         return {names[i].value.decode(): (ms[i], cnt[i]) for i in range(n)}
 
+    def kernel_counts(self):
+        """{kernel variant: times enqueued since creation} -- which of the shape-selected kernels the calls so far took"""
+        names = ((C.c_char * 32) * 32)(); cnt = (C.c_int64 * 32)()
+        n = self.lib.ppo_kernel_counts(self.h, 32, names, cnt)
+        return {names[i].value.decode(): cnt[i] for i in range(n)}
+
     def sync(self):
         self._ck(self.lib.ppo_sync(self.h))

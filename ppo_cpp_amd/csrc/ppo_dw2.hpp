@@ -1,15 +1,17 @@
-// ppo_dw2.hpp -- weight gradients AND gradient assembly of one train step in ONE launch, for the 18-obs / [256,256] shape
-// (BASELINE configs[2]; SURVEY 8a rows a13 / a14's inputs: G's .../MatMul_grad/MatMul_1, .../Add_grad/Sum_1 and loss Mean nodes).
+// ppo_dw2.hpp -- weight gradients AND gradient assembly of one train step in ONE launch, for hidden [256,256] behind an observation /
+// action tile of 32 or 64 columns (BASELINE configs[2]: 18 / 18; the reference's 36-observation hexapod, env/hexapod_closed_loop_env.hpp:20)
+// (SURVEY 8a rows a13 / a14's inputs: G's .../MatMul_grad/MatMul_1, .../Add_grad/Sum_1 and loss Mean nodes).
 //
 // What it replaces: weight_grad_kernel (8 row splits, 64x64 tiles, a table of tiles in memory) followed by grad_reduce_kernel
 // (a launch whose only job was to add 8 slabs and 128 per-row-block slots: 4.7 us at its launch + round-trip floor).  Here
 //   * the tile a workgroup owns follows from blockIdx alone (no table read in front of the first operand load);
 //   * 4 row splits x 64 tiles of [64 x 32] (+ one thin strip of the first-layer / policy-head gradient each) = 256 workgroups of
-//     8 waves; a wave's whole share of the rows (64 at M = 2048) is requested before its first matrix instruction and the two
-//     waves of a SIMD cover each other's waits;
+//     8 waves; the rows are walked in 64-row chunks (ANY minibatch that is a whole number of chunks: the host pads the train
+//     kernel's grid to 64 rows, its dead rows are zeros), split s owning chunks [s C / 4, (s + 1) C / 4);
 //   * the split that finishes a tile LAST adds the 4 slabs in split order (bitwise reproducible whoever is last), writes the
 //     finished gradient tile and its sum of squares: the hand-off is the guide's counter form -- slabs stored write-through
-//     (sc1), every wave drains its stores, a workgroup barrier, ONE agent-scope arrival; the last arriver reads with sc1 loads;
+//     (sc1), every wave drains its stores, a workgroup barrier, ONE agent-scope arrival; the last arriver reads with sc1 loads
+//     (why no release / acquire fences: at the arrival below, with the measurement);
 //   * the per-row-block slots of the train kernel (bias / logstd / value-head gradients, loss sums) are spread over the 256
 //     workgroups, requested at kernel entry and finished after the matrix work.
 // clip + Adam (adam_kernel) then reads `grad` and the 64 + 256 partial sums of squares; nothing else changes.
@@ -21,14 +23,18 @@
 #define DW2_TILES 64                        // 2 towers x (4 x 8) tiles of 64 x 32 of the [256 x 256] second-layer gradient
 #define DW2_GRID (DW2_TILES * DW2_SPLITS)
 #define DW2_CH 64                           // minibatch rows per LDS chunk
-// one chunk in LDS (floats): X [64][64] | Y [64][32] | U [64][32] | W [64][16]; a ring of three chunks + 64 words of flags / scratch
-#define DW2_OX 0
-#define DW2_OY (DW2_CH * 64)
-#define DW2_OU (DW2_OY + DW2_CH * 32)
-#define DW2_OW (DW2_OU + DW2_CH * 32)
-#define DW2_BUF (DW2_OW + DW2_CH * 16)
 #define DW2_NBUF 3
-#define DW2_LDS_FLOATS (DW2_NBUF * DW2_BUF + 64)   // 108 KB: one workgroup per CU (the hand-off's measured form)
+#ifndef DW2_MODEL_FENCES
+#define DW2_MODEL_FENCES 0                  // see the arrival below
+#endif
+// one chunk in LDS (floats): X [64][64] | Y [64][32] | U [64][UW] | W [64][16], UW = the wider of the observation and the action tile;
+// a ring of three chunks + 64 words of flags / scratch
+template <int KP0, int AP>
+struct Dw2L {
+    static constexpr int UW = KP0 > AP ? KP0 : AP;
+    static constexpr int OX = 0, OY = DW2_CH * 64, OU = OY + DW2_CH * 32, OW = OU + DW2_CH * UW, BUF = OW + DW2_CH * 16;
+    static constexpr int LDS_FLOATS = DW2_NBUF * BUF + 64;       // 108 KB at 32 / 32, 132 KB with a 64-wide tile: one workgroup per CU (the hand-off's measured form)
+};
 #ifdef PPO_STAMPS
 #define DW2_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = (i) == 15 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
 #else
@@ -39,13 +45,13 @@
 struct SlotJob { int tower; int slot_off; int dst; int in_norm; };
 
 struct Dw2Args {
-    const float* x0g;            // [n][32]  layer-0 input (written by the policy tower's workgroups)
+    const float* x0g;            // [n][KP0] layer-0 input (written by the policy tower's workgroups)
     const float* h1[2];          // [n][256] layer-1 input per tower
     const float* h2pi;           // [n][256] policy head input
     const float* dy0[2];         // [n][256] dLoss/d(pre-activation of layer 0)
     const float* dy1[2];         // [n][256] ... of layer 1
-    const float* dmug;           // [n][32]
-    int n;                       // minibatch rows: a multiple of 512
+    const float* dmug;           // [n][AP]
+    int n;                       // minibatch rows as the train kernel wrote them: a multiple of 64 (rows past the real count are zeros)
     float* slabs; unsigned long long slab_stride;      // [4][P_pad]
     unsigned* counters;          // [DW2_TILES] arrivals; zero between launches (the last arriver resets its word)
     float* grad;                 // [P_pad + 8]
@@ -79,7 +85,35 @@ __device__ __forceinline__ void dw2_dma(const float* src_base, unsigned lane_off
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
 }
 
+// The thin strip a workgroup carries beside its [64 x 32] tile: a UWK-column operand U (layer-0 input / d mu; row pitch UWK in LDS)
+// against 16 columns of a 256-column operand W (layer-0 dY / policy-head input).  Per 64-row chunk wave w owns k-steps 2w, 2w+1.
+// (one register array of the wider form for both kinds: two members selected by `kind` end up in scratch)
+template <int UWK, int NU>
+__device__ __forceinline__ void dw2_read_u(float (&u)[2][NU], const float* ubuf, int wave, int g, int c) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const float* p = ubuf + (8 * wave + 4 * ks + g) * UWK + (UWK / 16) * c;
+        if constexpr (UWK == 32) {
+            const float2 t = *reinterpret_cast<const float2*>(p); u[ks][0] = t.x; u[ks][1] = t.y;
+            if constexpr (NU == 4) { u[ks][2] = 0.f; u[ks][3] = 0.f; }       // (every element defined on both paths: keeps the array in registers)
+        }
+        else { const float4 t = *reinterpret_cast<const float4*>(p); u[ks][0] = t.x; u[ks][1] = t.y; u[ks][2] = t.z; u[ks][3] = t.w; }
+    }
+}
+// U_FIRST: out[U column][W column] (first-layer gradient strip [UWK x 16]); else out[W column][U column] (head strip [16 x UWK])
+template <int UWK, bool U_FIRST, int NU>
+__device__ __forceinline__ void dw2_strip_mma(const float (&u)[2][NU], const float (&ww)[2], f32x4 (&sacc)[NU]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < UWK / 16; ++t)
+            sacc[t] = U_FIRST ? __builtin_amdgcn_mfma_f32_16x16x4f32(u[ks][t], ww[ks], sacc[t], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_16x16x4f32(ww[ks], u[ks][t], sacc[t], 0, 0, 0);
+}
+
+template <int KP0, int AP>
 __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Args a) {
+    typedef Dw2L<KP0, AP> LD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     warm_kernargs<sizeof(Dw2Args)>();
     DW2_STAMP(15); DW2_STAMP(0);
@@ -92,8 +126,8 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     const int split = (b >> 1) & 3, tower = b & 1, tile = b >> 3;
     const int gtile = tower * 32 + tile;
     const int i0 = (tile >> 3) * 64, j0 = (tile & 7) * 32;
-    // strip: kind 0 = [32 x 16] of the first-layer gradient (both towers, tiles 0..15), kind 1 = [16 x 32] of the policy-head
-    // gradient (policy tower, tiles 16..31), kind 2 = none.  Either way a 32-column operand U (layer-0 input / d mu) and 16
+    // strip: kind 0 = [KP0 x 16] of the first-layer gradient (both towers, tiles 0..15), kind 1 = [16 x AP] of the policy-head
+    // gradient (policy tower, tiles 16..31), kind 2 = none.  Either way an operand U of KP0 / AP columns (layer-0 input / d mu) and 16
     // columns [16 s, 16 s + 16) of a 256-column operand W (layer-0 dY / policy-head input).
 #ifdef DW2_NOSTRIP
     const int kind = 2;          // timing experiment only: results are wrong
@@ -101,6 +135,7 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     const int kind = uni(tile < 16 ? 0 : (tower == 0 ? 1 : 2));
 #endif
     const int sidx = tile & 15;
+    const int uwk = kind == 0 ? KP0 : AP;                    // (wave-uniform) columns of this workgroup's U operand
     // the slot-job descriptor of this half-wave: requested first, needed after the first chunk is on its way
     const int jl = tid >> 5, jb = b * a.jobs_per_wg + jl;
     const bool has_job = jl < a.jobs_per_wg && jb < a.n_jobs;
@@ -109,36 +144,43 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     // halves of odd rows are swapped (on the SOURCE address: the destination of a piece is lane-linear), so that the 8-byte
     // fragment reads of rows R and R + 1 (one 32-lane group) cover all 64 banks; 32- and 16-column rows alternate bank halves
     // by themselves
-    const int rows_split = a.n >> 2, nch = rows_split / DW2_CH;
-    const size_t r0 = (size_t)split * rows_split;
+    const int nct = a.n / DW2_CH;                            // chunks of the minibatch; split s owns [s nct / 4, (s + 1) nct / 4)
+    const int cb = (split * nct) >> 2, nch = (((split + 1) * nct) >> 2) - cb;
+    const size_t r0 = (size_t)cb * DW2_CH;
     const float* Xg = uni(a.h1[tower]) + r0 * 256;
     const float* Yg = uni(a.dy1[tower]) + r0 * 256;
-    const float* Ug = uni(kind == 1 ? a.dmug : a.x0g) + r0 * 32;
+    const float* Ug = uni(kind == 1 ? a.dmug : a.x0g) + r0 * uwk;
     const float* Wg = uni(kind == 1 ? a.h2pi : a.dy0[tower]) + r0 * 256;
     const unsigned lx = (unsigned)(((lane >> 4) * 256 + i0 + 4 * ((lane & 15) ^ (((lane >> 4) & 1) << 3))) * 4);
     const unsigned ly = (unsigned)(((lane >> 3) * 256 + j0 + 4 * (lane & 7)) * 4);
-    const unsigned lu = (unsigned)(((lane >> 3) * 32 + 4 * (lane & 7)) * 4);
+    const unsigned lu = (unsigned)(lane * 16);               // U rows are contiguous in memory ([n][uwk]): a piece is 1 KB as it lies
     const unsigned lw = (unsigned)(((lane >> 2) * 256 + 16 * sidx + 4 * (lane & 3)) * 4);
-    // pieces of one 64-row chunk: X 16 (4 rows each), Y 8, U 8 (8 rows each), W 4 (16 rows each); wave w requests X 2w, 2w+1, Y w, U w
-    // and (w < 4) W w: NP pieces per chunk, the count the in-loop waits leave in flight
+    // pieces of one 64-row chunk: X 16 (4 rows each), Y 8, U 8 or 16 (2 KB / 4 KB of rows), W 4 (16 rows each); wave w requests X 2w, 2w+1,
+    // Y w, U w (or 2w, 2w+1) and (w < 4) W w: `np` pieces per chunk and wave, the count the in-loop waits leave in flight
+    const int np = uni(3 + (kind == 2 ? 0 : (uwk >> 5) + (wave < 4 ? 1 : 0)));
     auto stage = [&](int ch) __attribute__((always_inline)) {
-        float* buf = lds + (ch % DW2_NBUF) * DW2_BUF;
+        float* buf = lds + (ch % DW2_NBUF) * LD::BUF;
         const size_t rb = (size_t)ch * DW2_CH;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { const int j = 2 * wave + k; dw2_dma(Xg + (rb + 4 * j) * 256, lx, buf + DW2_OX + j * 256); }
-        dw2_dma(Yg + (rb + 8 * wave) * 256, ly, buf + DW2_OY + wave * 256);
+        for (int k = 0; k < 2; ++k) { const int j = 2 * wave + k; dw2_dma(Xg + (rb + 4 * j) * 256, lx, buf + LD::OX + j * 256); }
+        dw2_dma(Yg + (rb + 8 * wave) * 256, ly, buf + LD::OY + wave * 256);
         if (kind != 2) {
-            dw2_dma(Ug + (rb + 8 * wave) * 32, lu, buf + DW2_OU + wave * 256);
-            if (wave < 4) dw2_dma(Wg + (rb + 16 * wave) * 256, lw, buf + DW2_OW + wave * 256);
+            if (uwk == 32) dw2_dma(Ug + rb * 32 + wave * 256, lu, buf + LD::OU + wave * 256);
+            else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) dw2_dma(Ug + rb * 64 + (2 * wave + k) * 256, lu, buf + LD::OU + (2 * wave + k) * 256);
+            }
+            if (wave < 4) dw2_dma(Wg + (rb + 16 * wave) * 256, lw, buf + LD::OW + wave * 256);
         }
     };
     // wait until at most ONE chunk's pieces of this wave are still in flight (vector-memory operations complete in order)
     auto wait_keep_one = [&]() __attribute__((always_inline)) {
-        if (kind == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (np == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (np == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (np == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     };
-    stage(0);
+    if (nch > 0) stage(0);
     if (nch > 1) stage(1);
     if (nch > 2) stage(2);
     DW2_STAMP(1);
@@ -150,22 +192,26 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     // must have landed at its bottom: two iterations of lead for every piece.
     const int tx = wave & 1, kq = wave >> 1;
     const int ax = (16 * kq + g) * 64 + ((32 * tx + 2 * c) ^ ((g & 1) << 5)), by = (16 * kq + g) * 32 + 2 * c;
-    const int suo = (8 * wave + g) * 32 + 2 * c, swo = (8 * wave + g) * 16 + c;
-    struct Frags { float2 xa[4], yb[4], uu[2]; float ww[2]; };
+    const int swo = (8 * wave + g) * 16 + c;
+    constexpr int NU = LD::UW / 16;
+    struct Frags { float2 xa[4], yb[4]; float u[2][NU]; float ww[2]; };
     auto read_frags = [&](Frags& f, int ch) __attribute__((always_inline)) {
-        const float* buf = lds + (ch % DW2_NBUF) * DW2_BUF;
+        const float* buf = lds + (ch % DW2_NBUF) * LD::BUF;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            f.xa[ks] = *reinterpret_cast<const float2*>(buf + DW2_OX + ax + ks * 256);
-            f.yb[ks] = *reinterpret_cast<const float2*>(buf + DW2_OY + by + ks * 128);
+            f.xa[ks] = *reinterpret_cast<const float2*>(buf + LD::OX + ax + ks * 256);
+            f.yb[ks] = *reinterpret_cast<const float2*>(buf + LD::OY + by + ks * 128);
         }
         if (kind != 2) {
+            if (KP0 == AP || kind == 0) dw2_read_u<KP0, NU>(f.u, buf + LD::OU, wave, g, c); else dw2_read_u<AP, NU>(f.u, buf + LD::OU, wave, g, c);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { f.uu[ks] = *reinterpret_cast<const float2*>(buf + DW2_OU + suo + ks * 128); f.ww[ks] = buf[DW2_OW + swo + ks * 64]; }
+            for (int ks = 0; ks < 2; ++ks) f.ww[ks] = buf[LD::OW + swo + ks * 64];
         }
     };
-    f32x4 acc[2][2], sacc[2];
-    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = sacc[0] = sacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][2], sacc[NU];
+    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NU; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto mma = [&](const Frags& f) __attribute__((always_inline)) {
 #ifdef DW2_NOMFMA
         if (a.n < 0)
@@ -177,25 +223,14 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
             acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].y, f.yb[ks].x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].y, f.yb[ks].y, acc[1][1], 0, 0, 0);
         }
-        if (kind == 0) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.uu[ks].x, f.ww[ks], sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.uu[ks].y, f.ww[ks], sacc[1], 0, 0, 0);
-            }
-        } else if (kind == 1) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ww[ks], f.uu[ks].x, sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ww[ks], f.uu[ks].y, sacc[1], 0, 0, 0);
-            }
-        }
+        if (kind == 0) dw2_strip_mma<KP0, true, NU>(f.u, f.ww, sacc);
+        else if (kind == 1) dw2_strip_mma<AP, false, NU>(f.u, f.ww, sacc);
     };
     // chunks 0 and 1 (and the job descriptor) have landed once at most the pieces of chunk 2 are in flight
     if (nch > 2) wait_keep_one(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     Frags fa, fb;
-    read_frags(fa, 0);
+    if (nch > 0) read_frags(fa, 0);
     // ---- slot jobs: 32 lanes per element, loads issued now, finished after the matrix work ------------------------------------
     float sj[DW2_SLOTK];
     {
@@ -220,23 +255,29 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
         if (i + 1 < nch) iteration(i + 1, fb, fa);
     }
     DW2_STAMP(3);
-    // ---- park: main partials [4 K quarters][64][32], strip partials [8 waves][512]; slot jobs finish here too ----------------------
+    // ---- park: main partials [4 K quarters][64][32], strip partials [8 waves][16 uwk]; slot jobs finish here too --------------------
     float* park = lds;
     float* spark = lds + 4 * 2048;
-    float* red2 = lds + DW2_NBUF * DW2_BUF + 32;
+    static_assert(4 * 2048 + 8 * 16 * LD::UW <= DW2_NBUF * LD::BUF, "park + strip partials fit the chunk ring");
+    float* red2 = lds + DW2_NBUF * LD::BUF + 32;
+    const int sn = 16 * uwk;                                 // elements of this workgroup's strip
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             *reinterpret_cast<float2*>(park + kq * 2048 + (32 * tx + 2 * (4 * g + r) + i) * 32 + 2 * c) = make_float2(acc[i][0][r], acc[i][1][r]);
-    if (kind == 0) {
+    if (kind == 0) {                                         // [KP0 x 16]: instruction t holds U columns (KP0 / 16) m + t
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < KP0 / 16; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) spark[wave * 512 + (2 * (4 * g + r) + t) * 16 + c] = sacc[t][r];                                   // [32 x 16]
-    } else if (kind == 1) {
+            for (int r = 0; r < 4; ++r) spark[wave * sn + ((KP0 / 16) * (4 * g + r) + t) * 16 + c] = sacc[t][r];
+    } else if (kind == 1) {                                  // [16 x AP]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(spark + wave * 512 + (4 * g + r) * 32 + 2 * c) = make_float2(sacc[0][r], sacc[1][r]);   // [16 x 32]
+        for (int r = 0; r < 4; ++r) {
+            float* dst = spark + wave * sn + (4 * g + r) * AP + (AP / 16) * c;
+            if constexpr (AP == 32) *reinterpret_cast<float2*>(dst) = make_float2(sacc[0][r], sacc[1][r]);
+            else *reinterpret_cast<float4*>(dst) = make_float4(sacc[0][r], sacc[1][r], sacc[2][r], sacc[3][r]);
+        }
     }
     {
         float s = ((sj[0] + sj[1]) + (sj[2] + sj[3])) + ((sj[4] + sj[5]) + (sj[6] + sj[7]));
@@ -251,17 +292,17 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
 #pragma unroll
     for (int q = 1; q < 4; ++q) { const float4 p = *reinterpret_cast<const float4*>(park + q * 2048 + 4 * tid); m4.x += p.x; m4.y += p.y; m4.z += p.z; m4.w += p.w; }
     float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool strip_thread = kind != 2 && tid < 128;
+    const bool strip_thread = kind != 2 && 4 * tid < sn;
     if (strip_thread) {
         sv = *reinterpret_cast<const float4*>(spark + 4 * tid);
 #pragma unroll
-        for (int w = 1; w < 8; ++w) { const float4 p = *reinterpret_cast<const float4*>(spark + w * 512 + 4 * tid); sv.x += p.x; sv.y += p.y; sv.z += p.z; sv.w += p.w; }
+        for (int w = 1; w < 8; ++w) { const float4 p = *reinterpret_cast<const float4*>(spark + w * sn + 4 * tid); sv.x += p.x; sv.y += p.y; sv.z += p.z; sv.w += p.w; }
     }
     // element offsets inside the padded parameter vector
     const unsigned moff = (unsigned)(a.w1_off[tower] + (i0 + (tid >> 3)) * 256 + j0 + 4 * (tid & 7));
     unsigned soff = 0;
-    if (kind == 0) soff = (unsigned)(a.w0_off[tower] + (tid >> 2) * 256 + 16 * sidx + 4 * (tid & 3));
-    else if (kind == 1) soff = (unsigned)(a.wmu_off + (16 * sidx + (tid >> 3)) * 32 + 4 * (tid & 7));
+    if (kind == 0) soff = (unsigned)(a.w0_off[tower] + (tid >> 2) * 256 + 16 * sidx + 4 * (tid & 3));                 // W0 [KP0][256]
+    else if (kind == 1) soff = (unsigned)(a.wmu_off + (16 * sidx + (4 * tid) / AP) * AP + (4 * tid) % AP);            // W_mu [256][AP]
     float* slab = a.slabs + (size_t)split * a.slab_stride;
     st_wt4<true>(slab + moff, m4);
     if (strip_thread) st_wt4<true>(slab + soff, sv);
@@ -276,14 +317,30 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                                // ... before the one arrival that signals for all of them
     DW2_STAMP(5);
-    int* flag = reinterpret_cast<int*>(lds + DW2_NBUF * DW2_BUF);
+    int* flag = reinterpret_cast<int*>(lds + DW2_NBUF * LD::BUF);
     if (tid == 0) {
+        // The hand-off is ordered by the HARDWARE's rules for sc1 accesses, not by release / acquire of the language memory model:
+        // every slab store above is `global_store ... sc1` (written through to the memory side, coherent across the XCDs' L2s), every
+        // storing wave has waited `s_waitcnt vmcnt(0)` (its stores are complete at that level), the barrier orders all of them before
+        // this thread, and the last arriver reads with `global_load ... sc1` (never served by its own XCD's L2).  The stores and loads
+        // are volatile inline asm with memory clobbers, so the compiler cannot move them across the atomic either.  The model's form --
+        // an agent-scope RELEASE on this arrival and an ACQUIRE fence in the last arriver (-DDW2_MODEL_FENCES=1) -- was measured: on
+        // gfx950 an agent-scope release is a write-back of the XCD's whole L2 and the acquire an invalidate, 256 + 64 of them per launch:
+        // 15.6 -> 30.8 us per launch (profiles/r04_a_dw2_model_fences_measured_not_kept.txt).  ppo_peer.hpp pays for fences because its
+        // data crosses DEVICES through plain stores; here both sides are sc1 accesses of one device.
+#if DW2_MODEL_FENCES
+        const unsigned old = __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
         const unsigned old = __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         flag[0] = (old == DW2_SPLITS - 1) ? 1 : 0;
     }
     __syncthreads();
     DW2_STAMP(6);
     if (flag[0]) {
+#if DW2_MODEL_FENCES
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         // last arriver: the four slabs in split order (its own included: same bits whoever is last), all loads first
         f32x4 p[DW2_SPLITS], q[DW2_SPLITS];
 #pragma unroll
@@ -303,7 +360,7 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
             sq += (u4[0] * u4[0] + u4[1] * u4[1]) + (u4[2] * u4[2] + u4[3] * u4[3]);
         }
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-        float* red = lds + DW2_NBUF * DW2_BUF + 16;
+        float* red = lds + DW2_NBUF * LD::BUF + 16;
         if (lane == 0) red[wave] = sq;
         __syncthreads();
         if (tid == 0) {

@@ -44,6 +44,14 @@ enum ProfClass { PK_STEP = 0, PK_TRAIN_FB, PK_DW, PK_REDUCE, PK_ADAM, PK_EPOCH, 
 const char* kProfNames[PK_COUNT] = {"policy_step", "train_fwd_bwd", "weight_grad", "grad_reduce", "adam", "epoch_prepare",
                                     "running_stats", "seeded_env", "gae", "allreduce"};
 
+// which kernel VARIANT a call took (ppo_kernel_counts): the fast paths are chosen by shape, and a test must be able to say which one ran
+enum KernelVariant { KV_TRAIN8 = 0, KV_TRAIN_FB, KV_DW2, KV_DW, KV_GRAD_REDUCE, KV_NARROW_TRAIN_STATIC, KV_NARROW_TRAIN, KV_NARROW_STEP_STATIC, KV_NARROW_STEP,
+                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_COUNT };
+const char* kVariantNames[KV_COUNT] = {"train8_kernel", "train_fwd_bwd_kernel", "weight_grad_assemble_kernel", "weight_grad_kernel", "grad_reduce_kernel",
+                                       "narrow_train_kernel<static>", "narrow_train_kernel<runtime>", "narrow_step_kernel<static>", "narrow_step_kernel<runtime>",
+                                       "policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_rollout_coop_kernel", "narrow_collect_kernel",
+                                       "bf16_train_sequence", "bf16_step_sequence"};
+
 // RCCL entry points resolved at run time (the single-GPU path must not depend on librccl being loadable)
 struct Rccl {
     void* lib = nullptr;
@@ -200,6 +208,7 @@ struct ppo_handle {
     size_t ev_next = 0;
     double prof_ms[PK_COUNT]{};
     int64_t prof_n[PK_COUNT]{};
+    int64_t kv[KV_COUNT]{};           // enqueues per kernel variant since ppo_create (a hipGraph capture counts once, its replays do not)
 };
 
 namespace {
@@ -291,6 +300,10 @@ int build_layout(ppo_handle* h) {
     if (h->CT == 4) for (int l = 0; l < n.L; ++l) n.Hp[l] = ru(n.Hp[l], 64);
     const int kq = h->CT == 4 ? 32 : 16;                  // reduction dims must be whole pipeline stages (16*KS)
     n.Kp0 = ru(c.obs_dim, kq); n.Ap = ru(c.act_dim, kq);
+    // the reference's own network family -- two hidden layers of 64 behind up to 64 observations and up to 32 actions (18 / 18 and, with
+    // observed velocities, 36 / 18: env/hexapod_closed_loop_env.hpp:20) -- takes the observation tile as 32 or 64 columns and the action
+    // tile as 32, the two shapes the narrow kernels are instantiated for at compile time (padding weights are zero and stay zero)
+    if (!h->bf.on && n.L == 2 && n.Hp[0] == 64 && n.Hp[1] == 64 && c.obs_dim <= 64 && c.act_dim <= 32) { n.Kp0 = c.obs_dim <= 32 ? 32 : 64; n.Ap = 32; }
     const bool bf = h->bf.on;
     if (bf) {                                             // GEMM path: every dimension is a whole number of 128-wide tiles
         for (int l = 0; l < n.L; ++l) n.Hp[l] = ru(c.hidden[l], GB_PAD);
@@ -444,7 +457,8 @@ void build_narrow_layout(ppo_handle* h) {
     h->nw_stride = ru(h->P_pad + 8, 64);
     // compile-time shape of the reference's own network (18 obs / 18 act padded to 32, [64,64]); anything else runs the
     // runtime-shape instantiation
-    h->nw_static = n.L == 2 && n.Kp0 == 32 && n.Ap == 32 && n.Hp[0] == 64 && n.Hp[1] == 64;
+    { const char* e = getenv("PPO_HIP_NO_NARROW_STATIC");     // (tests: the runtime-shape instantiation on the same shape)
+      h->nw_static = !(e && e[0] == '1') && n.L == 2 && (n.Kp0 == 32 || n.Kp0 == 64) && n.Ap == 32 && n.Hp[0] == 64 && n.Hp[1] == 64; }
     h->narrow = true;
 }
 
@@ -512,7 +526,7 @@ int ensure_train_ws(ppo_handle* h, int rows) {
         h->ws_rows = std::max(h->ws_rows, groups * NW_ROWS);
         return 0;
     }
-    rows = ru(rows, 16);
+    rows = ru(rows, h->dw2 ? DW2_CH : 16);                 // (weight_grad_assemble_kernel walks whole 64-row chunks: the train kernel's grid is padded to them)
     if (rows <= h->ws_rows) return 0;
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -789,21 +803,27 @@ int bf16_weight_grads(ppo_handle* h, const TrainArgs& ta, int Rp) {
 }
 
 // ---- launches -------------------------------------------------------------------------------------------------
+// narrow kernels: compile-time shapes <32, 64, 32, 2> / <64, 64, 32, 2> (observation tile of 32 / 64 columns) or the runtime-shape form;
+// X(KP0, HP, AP, L) is the launch statement
+#define NW_DISPATCH(h, X) do { if (!(h)->nw_static) { X(0, 0, 0, 0); } else if ((h)->net.Kp0 == 32) { X(32, 64, 32, 2); } else { X(64, 64, 32, 2); } } while (0)
+
 template <int CT, int KS, int CTH, bool WIDE>
 void launch_step_t(ppo_handle* h, const StepArgs& a) {
     dim3 grid((a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 2);
     hipLaunchKernelGGL((policy_step_kernel<CT, KS, CTH, WIDE>), grid, dim3(BLOCK_THREADS), (size_t)h->lds_step_total * sizeof(float), h->stream, h->net, a);
 }
 int launch_step(ppo_handle* h, const StepArgs& a) {
-    if (h->bf.on) return launch_step_bf16(h, a);
+    if (h->bf.on) { ++h->kv[KV_BF16_STEP]; return launch_step_bf16(h, a); }
     ProfScope ps(h, PK_STEP);
+    ++h->kv[h->narrow ? (h->nw_static ? KV_NARROW_STEP_STATIC : KV_NARROW_STEP) : KV_POLICY_STEP];
     if (h->narrow) {
         dim3 grid((a.n + NW_ROWS - 1) / NW_ROWS, 2);
         StepArgs sa = a;
         sa.theta = h->nw_img;                                  // the packed weight image stands in for the padded parameter vector
         const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
-        if (h->nw_static) hipLaunchKernelGGL((narrow_step_kernel<32, 64, 32, 2>), grid, dim3(NW_THREADS), lds, h->stream, h->net, h->nw, sa);
-        else hipLaunchKernelGGL((narrow_step_kernel<0, 0, 0, 0>), grid, dim3(NW_THREADS), lds, h->stream, h->net, h->nw, sa);
+#define X(a, b, c, d) hipLaunchKernelGGL((narrow_step_kernel<a, b, c, d>), grid, dim3(NW_THREADS), lds, h->stream, h->net, h->nw, sa)
+        NW_DISPATCH(h, X);
+#undef X
         HIP_OK(h, hipGetLastError());
         return 0;
     }
@@ -885,12 +905,28 @@ int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* p
     return 0;
 }
 
+// the [256,256] pair: one instantiation per (observation tile, action tile) width
+template <int KP0, int AP>
+void launch_train8(ppo_handle* h, dim3 grid, const TrainArgs& ta) {
+    const size_t lds = sizeof(float) * T8L<KP0, AP>::TOTAL;
+    hipLaunchKernelGGL((train8_kernel<KP0, AP>), grid, dim3(T8_THREADS), lds, h->stream, h->net, ta);
+}
+template <int KP0, int AP>
+void launch_dw2(ppo_handle* h, const Dw2Args& da) {
+    const size_t lds = sizeof(float) * Dw2L<KP0, AP>::LDS_FLOATS;
+    hipLaunchKernelGGL((weight_grad_assemble_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da);
+}
+template <int KP0, int AP>
+bool set_lds_pair() {
+    return hipFuncSetAttribute((const void*)train8_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T8L<KP0, AP>::TOTAL) == hipSuccess &&
+           hipFuncSetAttribute((const void*)weight_grad_assemble_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess;
+}
+
 // the per-minibatch launch sequence: fwd+loss+bwd -> weight grads -> reduce [-> all-reduce] -> clip+Adam
 // defer (narrow reference shape, inside ppo_update only): leave this step's clip + Adam to the next train kernel's prologue
 // (flush_pending_adam after the last step)
 int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = false) {
     const NetDev& n = h->net;
-    const int n_rb = (ta.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     ta.theta = h->theta; ta.thetaT = h->thetaT; ta.par = h->par; ta.hyper = h->hyper;
     ta.x0g = h->x0g; ta.dmug = h->dmug;
 #ifdef PPO_STAMPS
@@ -913,6 +949,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
 #endif
             const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
             NwLazyArgs z{};
+            ++h->kv[h->nw_static ? KV_NARROW_TRAIN_STATIC : KV_NARROW_TRAIN];
             if (h->nw_pending) {
                 // the previous step's clip + Adam rides in this launch: read set nw_cur, write the other one
                 float* set[2][3] = {{h->theta, h->adam_m, h->adam_v}, {h->nw_theta1, h->nw_m1, h->nw_v1}};
@@ -922,8 +959,11 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
                 hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
                 h->nw_cur = co; h->nw_pending = false;
             }
-            else if (h->nw_static) hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
-            else hipLaunchKernelGGL((narrow_train_kernel<0, 0, 0, 0>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
+            else {
+#define X(a, b, c, d) hipLaunchKernelGGL((narrow_train_kernel<a, b, c, d>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z)
+                NW_DISPATCH(h, X);
+#undef X
+            }
             HIP_OK(h, hipGetLastError());
         }
         const int n_chunks = h->P_pad / 64;
@@ -940,6 +980,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
     }
     if (h->bf.on) {
         const int Rp = ru(ta.n, GB_PAD);
+        ++h->kv[KV_BF16_TRAIN];
         { ProfScope ps(h, PK_TRAIN_FB); if (bf16_train_fwd_bwd(h, ta, Rp)) return -1; }
         { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, ta, Rp)) return -1; }
         {
@@ -957,19 +998,29 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
         if (h->comm) return enqueue_grad_allreduce(h) ? -1 : enqueue_adam(h, loss_row);      // (the exchange recomputes the per-chunk sums of squares)
         return enqueue_adam(h, loss_row, (h->n_blocks + 1 + BGR_WAVES - 1) / BGR_WAVES);       // one partial per assembly workgroup (adam_kernel keeps the bf16 copy of the weights current)
     }
-    const int n_pad = ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
-    const bool use_dw2 = h->dw2 && n_pad % 512 == 0 && n_rb <= 32 * DW2_SLOTK;
+    // weight_grad_assemble_kernel walks the minibatch in 64-row chunks.  train8_kernel writes zeros for every row >= n of every tile
+    // it is launched on, so its grid is simply padded to whole chunks (ANY row count stays on the fast pair); behind the round-2
+    // train kernel the pair needs a minibatch that is a whole number of chunks by itself.
+    const bool use_dw2 = h->dw2 && (h->t8 || ta.n % DW2_CH == 0) && ru(ta.n, DW2_CH) / ROWS_PER_BLOCK <= 32 * DW2_SLOTK;
+    const int n_pad = use_dw2 ? ru(ta.n, DW2_CH) : ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
+    const int n_rb = n_pad / ROWS_PER_BLOCK;
     ta.xcd_map = use_dw2 ? 1 : 0;
     {
         ProfScope ps(h, PK_TRAIN_FB);
         dim3 grid(n_rb, 2);
         const size_t lds_bytes = (size_t)n.lds_total * sizeof(float);
         const dim3 blk(BLOCK_THREADS);
+        ++h->kv[(h->t8 && !n.wide) ? KV_TRAIN8 : KV_TRAIN_FB];
         if (n.wide) {
             if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, true>), grid, blk, lds_bytes, h->stream, n, ta);
             else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0, true>), grid, blk, lds_bytes, h->stream, n, ta);
         }
-        else if (h->t8) hipLaunchKernelGGL(train8_kernel, grid, dim3(T8_THREADS), (size_t)T8_TOTAL * sizeof(float), h->stream, n, ta);
+        else if (h->t8) {
+            if (n.Kp0 == 32 && n.Ap == 32) launch_train8<32, 32>(h, grid, ta);
+            else if (n.Kp0 == 64 && n.Ap == 32) launch_train8<64, 32>(h, grid, ta);
+            else if (n.Kp0 == 32 && n.Ap == 64) launch_train8<32, 64>(h, grid, ta);
+            else launch_train8<64, 64>(h, grid, ta);
+        }
         else if (h->CT == 4 && h->CTH == 2 && h->early) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2, false, true>), grid, blk, lds_bytes, h->stream, n, ta);
         else if (h->CT == 4 && h->CTH == 2) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 2, false>), grid, blk, lds_bytes, h->stream, n, ta);
         else if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
@@ -989,7 +1040,11 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
             da.stamps = g_stamps + 4096 * 16;
 #endif
             da.n_rowblocks = n_rb; da.slot_w = n.slot_w; da.n_local = (float)ta.n; da.beta_pow = h->beta_pow; da.tail_off = h->P_pad;
-            hipLaunchKernelGGL(weight_grad_assemble_kernel, dim3(DW2_GRID), dim3(DW2_THREADS), (size_t)DW2_LDS_FLOATS * sizeof(float), h->stream, da);
+            ++h->kv[KV_DW2];
+            if (n.Kp0 == 32 && n.Ap == 32) launch_dw2<32, 32>(h, da);
+            else if (n.Kp0 == 64 && n.Ap == 32) launch_dw2<64, 32>(h, da);
+            else if (n.Kp0 == 32 && n.Ap == 64) launch_dw2<32, 64>(h, da);
+            else launch_dw2<64, 64>(h, da);
             HIP_OK(h, hipGetLastError());
         }
         if (h->comm) { if (enqueue_grad_allreduce(h)) return -1; return enqueue_adam(h, loss_row); }
@@ -1004,6 +1059,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
 #endif
         const size_t lds = (h->dw_has_big ? 4 * (64 * 64 + 1024) : 4 * 32 * 32) * sizeof(float);     // 4 waves x (tile + strips)
         const int rows_per_wave = n_pad / split / 4;
+        ++h->kv[KV_DW]; ++h->kv[KV_GRAD_REDUCE];
         if (rows_per_wave % 16 == 0) hipLaunchKernelGGL(weight_grad_kernel<4>, dim3(h->n_dw_tiles * split), dim3(BLOCK_THREADS), lds, h->stream, da);
         else hipLaunchKernelGGL(weight_grad_kernel<1>, dim3(h->n_dw_tiles * split), dim3(BLOCK_THREADS), lds, h->stream, da);
         HIP_OK(h, hipGetLastError());
@@ -1136,12 +1192,13 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     build_narrow_layout(h);
     if (upload_grad_src(h)) return bail(0);
     { const char* e = getenv("PPO_HIP_NO_DW2"); const NetDev& nn = h->net;
-      h->dw2 = !(e && e[0] == '1') && h->early && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256; }
+      h->dw2 = !(e && e[0] == '1') && !nn.wide && h->CT == 4 && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256 && nn.Kp0 <= 64 && nn.Ap <= 64; }
     { const char* e = getenv("PPO_HIP_NO_T8"); const NetDev& nn = h->net;
-      h->t8 = !(e && e[0] == '1') && h->early && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256 && nn.O == 18 && nn.A == 18;
-      if (h->t8 && hipFuncSetAttribute((const void*)train8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T8_TOTAL * 4) != hipSuccess) { fail(h, "hipFuncSetAttribute failed for train8_kernel"); return bail(0); } }
+      // any observation / action width up to 64 (tiles of 32 or 64 columns) in front of hidden [256,256]
+      h->t8 = !(e && e[0] == '1') && !nn.wide && h->CT == 4 && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256 && nn.Kp0 <= 64 && nn.Ap <= 64;
+      if ((h->t8 || h->dw2) && !(set_lds_pair<32, 32>() && set_lds_pair<64, 32>() && set_lds_pair<32, 64>() && set_lds_pair<64, 64>())) {
+          fail(h, "hipFuncSetAttribute failed for train8_kernel / weight_grad_assemble_kernel"); return bail(0); } }
     if (h->dw2) {
-        if (hipFuncSetAttribute((const void*)weight_grad_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS_FLOATS * 4) != hipSuccess) { fail(h, "hipFuncSetAttribute failed for weight_grad_assemble_kernel"); return bail(0); }
         // slot jobs: every element the train kernel leaves as per-row-block partial sums (bias / logstd / value-head gradients), then the loss sums
         const NetDev& nn = h->net;
         std::vector<SlotJob> jobs;
@@ -1170,26 +1227,19 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     }
     if (h->bf.on && bf16_create(h)) return bail(0);
     if (h->narrow) {
-        attr_ok = hipFuncSetAttribute((const void*)narrow_train_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_train_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_train_kernel<32, 64, 32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_collect_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<32, 64, 32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<0, 0, 0, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<32, 64, 32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_kernel<0, 0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_coop_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_rollout_coop_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_host_step_kernel<32, 64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        attr_ok &= hipFuncSetAttribute((const void*)narrow_host_step_kernel<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        attr_ok = true;
+        auto big_lds = [&](const void* f) { attr_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+#define X(a, b, c, d) do { big_lds((const void*)narrow_train_kernel<a, b, c, d>); big_lds((const void*)narrow_step_kernel<a, b, c, d>); big_lds((const void*)narrow_collect_kernel<a, b, c, d>); \
+                           big_lds((const void*)narrow_rollout_kernel<a, b, c, d, false>); big_lds((const void*)narrow_rollout_kernel<a, b, c, d, true>); \
+                           big_lds((const void*)narrow_rollout_coop_kernel<a, b, c, d>); big_lds((const void*)narrow_host_step_kernel<a, b, c, d>); } while (0)
+        X(0, 0, 0, 0); X(32, 64, 32, 2); X(64, 64, 32, 2);
+#undef X
+        big_lds((const void*)narrow_train_kernel<32, 64, 32, 2, true>);
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         { const char* e1 = getenv("PPO_HIP_NO_HOST_FUSED"); const char* e2 = getenv("PPO_HIP_NO_HOST_RESIDENT");
           h->opt_no_host_fused = e1 && e1[0] == '1'; h->opt_no_host_resident = e2 && e2[0] == '1'; }
         const char* nl = getenv("PPO_HIP_NO_LAZY_ADAM");
-        if (h->nw_static && !(nl && nl[0] == '1')) {
+        if (h->nw_static && h->net.Kp0 == 32 && !(nl && nl[0] == '1')) {       // (the deferred form's piece map is the 32-column observation tile's)
             // second parameter / moment set of the deferred Adam (zero-filled: the padding elements are never written and must read 0)
             if (dev_alloc(h, &h->nw_theta1, P) || dev_alloc(h, &h->nw_m1, P) || dev_alloc(h, &h->nw_v1, P)) return bail(0);
             h->nw_lazy = true;
@@ -1722,8 +1772,9 @@ static int enqueue_host_step(ppo_handle* h, int t, bool act, const float* noise_
     q.gamma = h->nz_gamma; q.clip_rew = h->nz_clip_rew; q.clip_obs = h->nz_clip_obs; q.eps = h->nz_eps; q.norm_obs = h->norm_obs_flag; q.norm_rew = h->norm_rew_flag;
     const size_t lds = ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float);
     ProfScope ps(h, PK_STEP);
-    if (h->nw_static) hipLaunchKernelGGL((narrow_host_step_kernel<32, 64, 32, 2>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
-    else hipLaunchKernelGGL((narrow_host_step_kernel<0, 0, 0, 0>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+#define X(a, b, c, d) hipLaunchKernelGGL((narrow_host_step_kernel<a, b, c, d>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q)
+    NW_DISPATCH(h, X);
+#undef X
     HIP_OK(h, hipGetLastError());
     h->host_pending = false;
     return 0;
@@ -1733,18 +1784,19 @@ static void launch_rollout_kernel(ppo_handle* h, const NwRolloutArgs& q, size_t 
     const NetDev& n = h->net;
     const bool multi = q.E > NW_ROWS;
     // ONE environment on the device env, reference shape: the whole rollout in one wave, weights in registers (ppo_rollout1.hpp)
-    static const bool no_r1 = [] { const char* e = getenv("PPO_HIP_NO_ROLLOUT1"); return e && e[0] == '1'; }();
-    if (h->nw_static && q.E == 1 && !q.host_mode && n.O == 18 && n.A == 18 && !no_r1) {
-        hipLaunchKernelGGL(narrow_rollout1_kernel, dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
+    const char* e1 = getenv("PPO_HIP_NO_ROLLOUT1");               // (read per call: the tests compare both forms in one process)
+    const bool no_r1 = e1 && e1[0] == '1';
+    if (h->nw_static && q.E == 1 && !q.host_mode && !no_r1) {      // (any observation width up to 64, any action width up to 32)
+        ++h->kv[KV_ROLLOUT1];
+        if (n.Kp0 == 32) hipLaunchKernelGGL(narrow_rollout1_kernel<32>, dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
+        else hipLaunchKernelGGL(narrow_rollout1_kernel<64>, dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
         return;
     }
-    if (h->nw_static) {
-        if (multi) hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2, true>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
-        else hipLaunchKernelGGL((narrow_rollout_kernel<32, 64, 32, 2, false>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
-    } else {
-        if (multi) hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0, true>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
-        else hipLaunchKernelGGL((narrow_rollout_kernel<0, 0, 0, 0, false>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
-    }
+    ++h->kv[KV_ROLLOUT_PERSISTENT];
+#define X(a, b, c, d) do { if (multi) hipLaunchKernelGGL((narrow_rollout_kernel<a, b, c, d, true>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q); \
+                           else hipLaunchKernelGGL((narrow_rollout_kernel<a, b, c, d, false>), dim3(1), dim3(NW_THREADS), lds, h->stream, n, h->nw, q); } while (0)
+    NW_DISPATCH(h, X);
+#undef X
 }
 
 // ---- resident host-Env rollout kernel (see NwRolloutArgs) -----------------------------------------------------------------------
@@ -2016,9 +2068,11 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
         q.gamma = h->nz_gamma; q.clip_rew = h->nz_clip_rew; q.clip_obs = h->nz_clip_obs; q.eps = h->nz_eps; q.norm_obs = h->norm_obs_flag; q.norm_rew = h->norm_rew_flag;
         q.part = h->nw_coop; q.arrive = ctl; q.err = ctl + 16 * (size_t)coopG; q.spin_limit = 4000000u;
         const size_t lds = ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float);
+        ++h->kv[KV_ROLLOUT_COOP];
         { ProfScope ps(h, PK_STEP);
-          if (h->nw_static) hipLaunchKernelGGL((narrow_rollout_coop_kernel<32, 64, 32, 2>), dim3(coopG), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
-          else hipLaunchKernelGGL((narrow_rollout_coop_kernel<0, 0, 0, 0>), dim3(coopG), dim3(NW_THREADS), lds, h->stream, n, h->nw, q);
+#define X(a, b, c, d) hipLaunchKernelGGL((narrow_rollout_coop_kernel<a, b, c, d>), dim3(coopG), dim3(NW_THREADS), lds, h->stream, n, h->nw, q)
+          NW_DISPATCH(h, X);
+#undef X
           HIP_OK(h, hipGetLastError()); }
         StepArgs va{};
         va.obs = h->ro_obs; va.value = h->ro_val; va.n = E * T; va.nz = no_norm();
@@ -2047,8 +2101,10 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
             NwCollectArgs c{in, st[(t + 1) & 1], seed, step0 + (uint32_t)t + 1u, env0, h->nz_gamma, h->nz_clip_rew, h->nz_eps, h->norm_obs_flag, h->norm_rew_flag,
                             h->ro_rew + (size_t)t * E, h->ro_done + (size_t)t * E};
             ProfScope ps(h, PK_STEP);
-            if (h->nw_static) hipLaunchKernelGGL((narrow_collect_kernel<32, 64, 32, 2>), dim3(1, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, a, c);
-            else hipLaunchKernelGGL((narrow_collect_kernel<0, 0, 0, 0>), dim3(1, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, a, c);
+            ++h->kv[KV_COLLECT_FUSED];
+#define X(p, q_, r, s_) hipLaunchKernelGGL((narrow_collect_kernel<p, q_, r, s_>), dim3(1, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, a, c)
+            NW_DISPATCH(h, X);
+#undef X
             HIP_OK(h, hipGetLastError());
         }
         if (T & 1) {                                           // the live state sits in the second set: bring it home
@@ -2594,6 +2650,12 @@ int ppo_prof_read(ppo_handle* h, int max, char names[][32], double* total_ms, in
         launches[n] = h->prof_n[i];
         ++n;
     }
+    return n;
+}
+
+int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueued) {
+    int n = 0;
+    for (int i = 0; i < KV_COUNT && n < max; ++i) { snprintf(names[n], 32, "%s", kVariantNames[i]); enqueued[n] = h->kv[i]; ++n; }
     return n;
 }
 

@@ -27,16 +27,19 @@
         ACC[(k_ >> 2) & 3] = fmaf(xk_, WREG[k_], ACC[(k_ >> 2) & 3]);                                   \
     }
 
+// KP0 = observation tile (32 or 64 columns); the dense widths O <= KP0 and A <= 32 are uniform run-time values
+template <int KP0>
 __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
-    __shared__ float s_hand[2][64];                          // [parity of t]: 0..17 noise of step t, 32..49 the normalised observation of step t
+    __shared__ float s_hand[2][96];                          // [parity of t]: 0..A-1 noise of step t, 32..32+O-1 the normalised observation of step t
     warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwRolloutArgs)>();
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
-    constexpr int O = 18, A = 18;
-    const bool lj = lane < O;                                 // O == A: observation / action element of this lane
+    const int O = __builtin_amdgcn_readfirstlane(net.O), A = __builtin_amdgcn_readfirstlane(net.A);
+    const bool lj = lane < O;                                 // observation element of this lane
+    const bool la = lane < A;                                 // action element of this lane
     if (role == 1) {
         // ---- noise wave: one step ahead of the main wave ----------------------------------------------------------------------------------
         auto produce = [&](int t) __attribute__((always_inline)) {
-            if (lane < A && !q.noise) s_hand[t & 1][lane] = ctr_normal(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t, lane);
+            if (lane < net.A && !q.noise) s_hand[t & 1][lane] = ctr_normal(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t, lane);
         };
         produce(q.t0);
         for (int t = q.t0; t < q.T; ++t) {
@@ -76,14 +79,17 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
         for (int t = q.t0; t < q.T; ++t) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // block t is complete; the main wave is done with block t + 1's buffer
             // ---- env transition that follows step t (counter hash): new observation, reward, done ------------------------------------------------
-            float tv = 0.f;
-            if (lane < O + 2) {
-                const uint32_t hs = ctr_hash(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t + 1u, (uint32_t)lane);
-                tv = lane <= O ? u32_to_sym_unit(hs) : ((hs % 300u == 0u) ? 1.0f : 0.0f);
+            // (hash lanes 0..O-1 = the observation, O = the reward, O+1 = the done flag: with O up to 64 the last two need lanes of their
+            // own, so lanes 0 and 1 draw them in a second call)
+            float tv = 0.f, tw = 0.f;
+            if (lj) tv = u32_to_sym_unit(ctr_hash(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t + 1u, (uint32_t)lane));
+            if (lane < 2) {
+                const uint32_t hs = ctr_hash(q.seed, (uint32_t)q.env0, q.step0 + (uint32_t)t + 1u, (uint32_t)(O + lane));
+                tw = lane == 0 ? u32_to_sym_unit(hs) : ((hs % 300u == 0u) ? 1.0f : 0.0f);
             }
-            raw = lj ? tv : 0.f;
-            const float rew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), O));
-            done = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), O + 1));
+            raw = tv;
+            const float rew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tw), 0));
+            done = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tw), 1));
             // ---- EnvNormalize::step bookkeeping for a batch of ONE row ----------------------------------------------------------------------------
             if (q.norm_obs) {
                 float sum = 0.f; sum += raw;
@@ -122,11 +128,11 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
         return;
     }
     // ---- main wave: this lane's weight columns and biases ------------------------------------------------------------------------------------
-    float w0[32], w1[64], wm[64];
+    float w0[KP0], w1[64], wm[64];
     {
         const float* img = q.img;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) w0[k] = img[lay.wf[0] + k * lay.wf_ld[0] + lane];
+        for (int k = 0; k < KP0; ++k) w0[k] = img[lay.wf[0] + k * lay.wf_ld[0] + lane];
 #pragma unroll
         for (int k = 0; k < 64; ++k) w1[k] = img[lay.wf[1] + k * lay.wf_ld[1] + lane];
 #pragma unroll
@@ -139,10 +145,11 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // the other waves' block of step t is complete (and they may overwrite the other one)
         const float* hb = s_hand[t & 1];
         float eps = 0.f, x = 0.f;
-        if (lj) { eps = q.noise ? q.noise[(size_t)t * A + lane] : hb[lane]; x = hb[32 + lane]; }
+        if (la) eps = q.noise ? q.noise[(size_t)t * A + lane] : hb[lane];
+        if (lj) x = hb[32 + lane];
         // ---- forward: lane n owns output column n --------------------------------------------------------------------------------------
         float h1, h2, mu;
-        { float c[4] = {0.f, 0.f, 0.f, 0.f}; R1_CHAIN(c, x, w0, 32); h1 = fast_tanh(((c[0] + c[1]) + (c[2] + c[3])) + b0); }
+        { float c[4] = {0.f, 0.f, 0.f, 0.f}; R1_CHAIN(c, x, w0, KP0); h1 = fast_tanh(((c[0] + c[1]) + (c[2] + c[3])) + b0); }
         { float c[4] = {0.f, 0.f, 0.f, 0.f}; R1_CHAIN(c, h1, w1, 64); h2 = fast_tanh(((c[0] + c[1]) + (c[2] + c[3])) + b1); }
         { float c[4] = {0.f, 0.f, 0.f, 0.f}; R1_CHAIN(c, h2, wm, 64); mu = ((c[0] + c[1]) + (c[2] + c[3])) + bmu; }
         // ---- sample + neglogp (G:5894-6672) -----------------------------------------------------------------------------------------------
@@ -150,9 +157,9 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
         const float sigma = expf(logstd);
         const float act = mu + sigma * eps;
         const float z = (act - mu) / sigma;
-        if (lj) q.ro_act[(size_t)t * A + lane] = act;
+        if (la) q.ro_act[(size_t)t * A + lane] = act;
         // the per-step kernels add elements j and j + 16 on lane j of a 16-lane group, then group16_sum: same order here
-        float zz = lj ? z * z : 0.f, sl = lj ? logstd : 0.f;
+        float zz = la ? z * z : 0.f, sl = la ? logstd : 0.f;
         const float zz_hi = __shfl_down(zz, 16), sl_hi = __shfl_down(sl, 16);
         float ssq = 0.f + zz, slog = 0.f + sl;
         if (lane + 16 < A) { ssq += zz_hi; slog += sl_hi; }

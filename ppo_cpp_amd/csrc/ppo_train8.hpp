@@ -1,27 +1,33 @@
-// ppo_train8.hpp -- train model forward + loss + backward of one 16-row tile, 8 waves per workgroup, for the 18-obs / [256,256]
-// shape (BASELINE configs[2]).  Same arithmetic, slots and workspaces as train_fwd_bwd_kernel<4,2,2,false,true> (G:6889-23699
-// minus the weight gradients); what changes is who does what inside the workgroup:
+// ppo_train8.hpp -- train model forward + loss + backward of one 16-row tile, 8 waves per workgroup, for hidden [256,256] with any
+// observation / action width up to 64 (BASELINE configs[2] is 18 / 18; the reference's other hexapod shape is 36 / 18,
+// env/hexapod_closed_loop_env.hpp:20).  Same arithmetic, slots and workspaces as train_fwd_bwd_kernel (G:6889-23699 minus the weight
+// gradients); what changes is who does what inside the workgroup:
 //   * M = 2048 rows give exactly one row tile per CU and tower, so the only latency hiding available is a second wave per SIMD:
 //     the two 256 x 256 products (second layer forward, its transpose backward) are split over K between wave w and wave w + 4
 //     (same SIMD, same 64 output columns, k in [0,128) / [128,256)): one wave's weight stream, LDS reads and waits are covered by
 //     the other's matrix instructions.  The two halves meet in LDS: each wave hands the other the 8 accumulator values it does
 //     not finish, and finishes (bias + tanh / TanhGrad, LDS + workspace stores) the other 8 -- rows {0,1} / {2,3} of every
 //     4-row group, so that the workspace stores stay 16 bytes per lane;
-//   * the three 32-deep products (first layer, policy head transposed; the policy head itself is an 8-way K split) give every
+//   * the three thin products (first layer, policy head transposed; the policy head itself is an 8-way K split) give every
 //     wave 32 output columns: half the epilogue per wave;
-//   * the loss phase has one lane per (row, action) instead of two serial passes over 16 lanes per row.
-// Every loop is compile-time; weights of the small products and the first two ring stages of the second layer are requested at
-// kernel entry behind the input loads (one workgroup of 8 waves per CU: 256 registers per wave).
+//   * the loss phase has one lane per (row, action) (two actions per lane when the action tile is 64 wide) instead of two serial
+//     passes over 16 lanes per row.
+// The padded widths of the observation and action tiles (KP0, AP: 32 or 64) are template parameters -- every loop is compile-time;
+// the dense widths O and A are uniform run-time values.  Weights of the thin products and the first two ring stages of the second
+// layer are requested at kernel entry behind the input loads (one workgroup of 8 waves per CU: 256 registers per wave).
 #pragma once
 #include "ppo_kernels.hpp"
 
 #define T8_THREADS 512
 #define T8_LD 260                 // 256 + LDS_PAD
-#define T8_LD0 36                 // 32 + LDS_PAD
-enum {
-    T8_X0 = 0, T8_H1 = T8_X0 + 16 * T8_LD0, T8_H2 = T8_H1 + 16 * T8_LD, T8_D2 = T8_H2 + 16 * T8_LD, T8_D1 = T8_D2 + 16 * T8_LD,
-    T8_MU = T8_D1 + 16 * T8_LD, T8_PAR = T8_MU + 16 * T8_LD0, T8_ACT = T8_PAR + 840, T8_DLS = T8_ACT + 512, T8_ROWV = T8_DLS + 512,
-    T8_MISC = T8_ROWV + 32, T8_TOTAL = T8_MISC + 128
+// LDS carve (floats) for an observation tile of KP0 and an action tile of AP columns
+template <int KP0, int AP>
+struct T8L {
+    static constexpr int LD0 = KP0 + LDS_PAD, LDM = AP + LDS_PAD;
+    static constexpr int NPAR = 3 * 256 + 2 * AP + 4;                      // biases (2 x 256) | b_mu | logstd | w_v | b_v (NetDev::par_*)
+    static constexpr int X0 = 0, H1 = X0 + 16 * LD0, H2 = H1 + 16 * T8_LD, D2 = H2 + 16 * T8_LD, D1 = D2 + 16 * T8_LD,
+                         MU = D1 + 16 * T8_LD, PAR = MU + 16 * LDM, ACT = PAR + NPAR + 4, DLS = ACT + 16 * AP, ROWV = DLS + 16 * AP,
+                         MISC = ROWV + 32, TOTAL = MISC + 128;
 };
 
 #ifndef T8_WT
@@ -47,17 +53,17 @@ __device__ __forceinline__ void t8_mma_stage(const WFrag<4, 2>& f, f32x4 (&acc)[
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], f.v[4 * q + s][j], acc[j], 0, 0, 0);
     }
 }
-// a 32-deep product into 32 output columns per wave (two interleaved column tiles)
-__device__ __forceinline__ void t8_mma_small(const WFrag<2, 2>& f, const float* Xs, int ldx, int c, int g, f32x4 (&acc)[2]) {
+// a (16 KS)-deep product into 16 CT output columns per wave (CT interleaved column tiles)
+template <int CT, int KS>
+__device__ __forceinline__ void t8_mma_small(const WFrag<CT, KS>& f, const float* Xs, int ldx, int c, int g, f32x4 (&acc)[CT]) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < KS; ++q) {
         const float4 a4 = *reinterpret_cast<const float4*>(Xs + c * ldx + 16 * q + 4 * g);
         const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], f.v[4 * q + s][0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], f.v[4 * q + s][1], acc[1], 0, 0, 0);
-        }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], f.v[4 * q + s][j], acc[j], 0, 0, 0);
     }
 }
 
@@ -115,7 +121,12 @@ __device__ __forceinline__ void t8_exchange(const f32x4 (&acc)[4], float* xch, i
         for (int i = 0; i < 2; ++i) out[j][i] = kh ? th[i][j] + acc[j][keep + i] : acc[j][keep + i] + th[i][j];
 }
 
+template <int KP0, int AP>
 __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArgs a) {
+    typedef T8L<KP0, AP> L8;
+    constexpr int KS0 = KP0 / 16, KSA = AP / 16;       // k-steps of 16 in the first layer / in the head's backward product
+    constexpr int CTA = AP / 16;                       // column tiles of the policy head (all AP columns in every wave)
+    constexpr int NX = KP0 / 32, NA = AP / 32;         // observation / action tile elements per thread ([16][KP0] and [16][AP] over 512 threads)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     warm_kernargs<sizeof(NetDev) + sizeof(TrainArgs)>();
     int tower = blockIdx.y;
@@ -131,18 +142,21 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     const int g = lane >> 4, c = lane & 15;
     const int p = wave & 3, kh = wave >> 2;
     const int rot = uni(rb & 3);
+    const int nO = uni(net.O), nA = uni(net.A);
     float* slot = a.slots[tower] + (size_t)rb * net.slot_w;
-    float* par = lds + T8_PAR;
+    float* par = lds + L8::PAR;
     STAMP(0);
-    // ---- prologue: every input load, then the weights the small products need and the first two ring stages -----------------------
+    // ---- prologue: every input load, then the weights the thin products need and the first two ring stages -------------------------
     const float* par_src = a.par + tower * net.par_total;
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 209) pv = reinterpret_cast<const float4*>(par_src)[tid];                 // 836 floats: biases | b_mu | logstd | w_v | b_v
-    const int er = tid >> 5, ej = tid & 31;                                             // this thread's element of a [16][32] tile
+    if (tid < L8::NPAR / 4) pv = reinterpret_cast<const float4*>(par_src)[tid];         // biases | b_mu | logstd | w_v | b_v
+    const int er = tid >> 5, ej = tid & 31;                                             // this thread's element(s) of a [16][32 q + ej] tile
     const bool erow_live = row0 + er < a.n;
-    float ov = 0.f, av_ = 0.f;
-    if (erow_live && ej < 18) ov = a.obs[(size_t)(row0 + er) * 18 + ej];
-    if (tower == 0 && erow_live && ej < 18) av_ = a.actions[(size_t)(row0 + er) * 18 + ej];
+    float ov[NX], av_[NA];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) { ov[q] = 0.f; if (erow_live && ej + 32 * q < nO) ov[q] = a.obs[(size_t)(row0 + er) * nO + ej + 32 * q]; }
+#pragma unroll
+    for (int q = 0; q < NA; ++q) { av_[q] = 0.f; if (tower == 0 && erow_live && ej + 32 * q < nA) av_[q] = a.actions[(size_t)(row0 + er) * nA + ej + 32 * q]; }
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, s0 = 0.f, s1 = 1.f;
     const bool explicit_adv = a.advs != nullptr;
     if (tid < 16 && row0 + tid < a.n) {
@@ -156,36 +170,41 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     const float* W1 = uni(a.theta + net.w_off[tower][1]) + (size_t)(128 * kh) * 256;
     const float* W1T = uni(a.thetaT + net.wT_off[tower][1]) + (size_t)(128 * kh) * 256;
     const WOff<2> off_big = make_woff<2>(256, g, 64 * p + 4 * c);
-    const WOff<2> off_small = make_woff<2>(256, g, 32 * wave + 2 * c);
-    WFrag<2, 2> wl0, whd, whT;
+    WFrag<2, KS0> wl0;
+    WFrag<CTA, 2> whd;
+    WFrag<2, KSA> whT;
     WFrag<4, 2> fr[3];
-    load_w_stage<2, 2>(wl0, W0, off_small);
+    load_w_stage<2, KS0>(wl0, W0, make_woff<KS0>(256, g, 32 * wave + 2 * c));
     load_w_stage<4, 2>(fr[0], W1 + (size_t)t8_stage_row(0, rot) * 256, off_big);
     load_w_stage<4, 2>(fr[1], W1 + (size_t)t8_stage_row(1, rot) * 256, off_big);
     if (tower == 0) {
-        load_w_stage<2, 2>(whd, uni(a.theta + net.wmu_off) + (size_t)(32 * wave) * 32, make_woff<2>(32, g, 2 * c));     // rows 32w .. 32w+31 of W_mu [256][32]
-        load_w_stage<2, 2>(whT, uni(a.thetaT + net.wmuT_off), off_small);                                             // W_mu^T [32][256]
+        load_w_stage<CTA, 2>(whd, uni(a.theta + net.wmu_off) + (size_t)(32 * wave) * AP, make_woff<2>(AP, g, CTA * c));   // rows 32w .. 32w+31 of W_mu [256][AP]
+        load_w_stage<2, KSA>(whT, uni(a.thetaT + net.wmuT_off), make_woff<KSA>(256, g, 32 * wave + 2 * c));               // W_mu^T [AP][256]
     }
     // consume the inputs
-    if (tid < 209) *reinterpret_cast<float4*>(par + 4 * tid) = pv;
-    lds[T8_X0 + er * T8_LD0 + ej] = ov;
+    if (tid < L8::NPAR / 4) *reinterpret_cast<float4*>(par + 4 * tid) = pv;
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+        lds[L8::X0 + er * L8::LD0 + ej + 32 * q] = ov[q];
+        if (tower == 0) a.x0g[(size_t)(row0 + er) * KP0 + ej + 32 * q] = ov[q];         // rows >= n and padding columns: zeros
+    }
     if (tower == 0) {
-        a.x0g[(size_t)(row0 + er) * 32 + ej] = ov;                                     // rows >= n and padding columns: zeros
-        lds[T8_ACT + er * 32 + ej] = av_;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) lds[L8::ACT + er * AP + ej + 32 * q] = av_[q];
     }
     if (tid < 16) {
         float v0 = r0;
         if (tower == 0 && !explicit_adv) v0 = ((r0 - r1) - s0) / s1;                   // ppo2.hpp:401-406
         const bool live = row0 + tid < a.n;
-        lds[T8_ROWV + 2 * tid] = live ? v0 : 0.f;
-        lds[T8_ROWV + 2 * tid + 1] = live ? r2 : 0.f;
+        lds[L8::ROWV + 2 * tid] = live ? v0 : 0.f;
+        lds[L8::ROWV + 2 * tid + 1] = live ? r2 : 0.f;
     }
     lds_barrier();
     STAMP(1);
     // ---- first layer: h1 = tanh(x W0 + b0), 32 columns per wave ---------------------------------------------------------------------
     {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        t8_mma_small(wl0, lds + T8_X0, T8_LD0, c, g, acc);
+        t8_mma_small<2, KS0>(wl0, lds + L8::X0, L8::LD0, c, g, acc);
         const int col = 32 * wave + 2 * c;
         const float b0 = par[net.par_b[0] + col], b1 = par[net.par_b[0] + col + 1];
 #pragma unroll
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
             const int row = 4 * g + r;
             float y0 = fast_tanh(acc[0][r] + b0), y1 = fast_tanh(acc[1][r] + b1);
             if (row0 + row >= a.n) { y0 = 0.f; y1 = 0.f; }
-            *reinterpret_cast<float2*>(lds + T8_H1 + row * T8_LD + col) = make_float2(y0, y1);
+            *reinterpret_cast<float2*>(lds + L8::H1 + row * T8_LD + col) = make_float2(y0, y1);
             t8_st_wt2(a.hg[tower][0] + (size_t)(row0 + row) * 256 + col, y0, y1);
         }
     }
@@ -202,12 +221,12 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     // ---- second layer: h2 = tanh(h1 W1 + b1), K split over the wave pair -------------------------------------------------------------
     {
         f32x4 acc[4];
-        t8_big_product(fr, W1, off_big, lds + T8_H1 + 128 * kh, c, g, rot, acc);
+        t8_big_product(fr, W1, off_big, lds + L8::H1 + 128 * kh, c, g, rot, acc);
         // the backward product's transposed weights: two stages per wave, in flight through the head and the loss
         load_w_stage<4, 2>(fr[0], W1T + (size_t)t8_stage_row(0, rot) * 256, off_big);
         load_w_stage<4, 2>(fr[1], W1T + (size_t)t8_stage_row(1, rot) * 256, off_big);
         float out[4][2];
-        t8_exchange(acc, lds + T8_D2, p, kh, lane, out);
+        t8_exchange(acc, lds + L8::D2, p, kh, lane, out);
         const int col = 64 * p + 4 * c;
         const float4 b4 = *reinterpret_cast<const float4*>(par + net.par_b[1] + col);
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
@@ -217,45 +236,59 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
             float y[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = (row0 + row < a.n) ? fast_tanh(out[j][i] + bb[j]) : 0.f;
-            *reinterpret_cast<float4*>(lds + T8_H2 + row * T8_LD + col) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(lds + L8::H2 + row * T8_LD + col) = make_float4(y[0], y[1], y[2], y[3]);
             if (tower == 0) st_wt4<T8_WT != 0>(a.hg[0][1] + (size_t)(row0 + row) * 256 + col, make_float4(y[0], y[1], y[2], y[3]));   // (the value head's weight gradient is formed here: nobody reads a copy of its input)
         }
     }
     lds_barrier();
     STAMP(3);
     const float cr = a.hyper[1];
-    const float* h2 = lds + T8_H2;
-    float* d2 = lds + T8_D2;
-    float* misc = lds + T8_MISC;
+    const float* h2 = lds + L8::H2;
+    float* d2 = lds + L8::D2;
+    float* misc = lds + L8::MISC;
     if (tower == 0) {
-        // ---- policy head: mu = h2 W_mu + b_mu, K split 8 ways, partial tiles meet in LDS (the d1 tile is free until the last product)
-        float* scratch = lds + T8_D1;                                                  // [8][16][32]
+        // ---- policy head: mu = h2 W_mu + b_mu, K split 8 ways, partial tiles meet in LDS (the d2 and d1 tiles are free until the
+        // backward products: the exchange of the second layer is behind the barrier above)
+        float* scratch = lds + L8::D2;                                                 // [8][16][AP]: 16 or 32 KB of the 33 KB the two tiles span
+        static_assert(8 * 16 * AP <= 2 * 16 * T8_LD, "split-K scratch of the policy head");
         {
-            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            t8_mma_small(whd, h2 + 32 * wave, T8_LD, c, g, acc);
+            f32x4 acc[CTA];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(scratch + wave * 512 + (4 * g + r) * 32 + 2 * c) = make_float2(acc[0][r], acc[1][r]);
+            for (int j = 0; j < CTA; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            t8_mma_small<CTA, 2>(whd, h2 + 32 * wave, T8_LD, c, g, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* dst = scratch + wave * (16 * AP) + (4 * g + r) * AP + CTA * c;
+                if constexpr (CTA == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[0][r], acc[1][r]);
+                else *reinterpret_cast<float4*>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            }
         }
         lds_barrier();
-        float mu = 0.f;
-        {
-            float s = scratch[er * 32 + ej];
+        float mu[NA];
 #pragma unroll
-            for (int w = 1; w < 8; ++w) s += scratch[w * 512 + er * 32 + ej];
-            mu = s + par[net.par_bmu + ej];
+        for (int q = 0; q < NA; ++q) {
+            float s = scratch[er * AP + ej + 32 * q];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) s += scratch[w * (16 * AP) + er * AP + ej + 32 * q];
+            mu[q] = s + par[net.par_bmu + ej + 32 * q];
         }
-        STAMP(6);
+        STAMP(6);                                                                      // (the scratch lies over d2, which the head's backward product writes: behind the barrier that follows the d mu tile)
         // ---- surrogate loss (G:9428-11290) and its gradient (G:12609-22656): one lane per (row, action) ---------------------------
         const bool live = erow_live;
-        const bool lj = ej < 18;
-        const float logstd = mu * 0.0f + par[net.par_ls + ej];
-        const float sigma = expf(logstd);
-        const float act = live ? lds[T8_ACT + er * 32 + ej] : mu;
-        const float z = (act - mu) / sigma;
-        const float ssq = t8_sum32(lj ? z * z : 0.f), slog = t8_sum32(lj ? logstd : 0.f), sent = t8_sum32(lj ? logstd + HALF_LOG_2PIE : 0.f);
-        const float nlp = 0.5f * ssq + HALF_LOG_2PI * 18.0f + slog;
-        const float adv = live ? lds[T8_ROWV + 2 * er] : 0.f;
-        const float old_nlp = live ? lds[T8_ROWV + 2 * er + 1] : nlp;
+        float z[NA], sigma[NA], zz = 0.f, sl_ = 0.f, se_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const bool lj = ej + 32 * q < nA;
+            const float logstd = mu[q] * 0.0f + par[net.par_ls + ej + 32 * q];
+            sigma[q] = expf(logstd);
+            const float act = live ? lds[L8::ACT + er * AP + ej + 32 * q] : mu[q];
+            z[q] = (act - mu[q]) / sigma[q];
+            zz += lj ? z[q] * z[q] : 0.f; sl_ += lj ? logstd : 0.f; se_ += lj ? logstd + HALF_LOG_2PIE : 0.f;
+        }
+        const float ssq = t8_sum32(zz), slog = t8_sum32(sl_), sent = t8_sum32(se_);
+        const float nlp = 0.5f * ssq + HALF_LOG_2PI * (float)nA + slog;
+        const float adv = live ? lds[L8::ROWV + 2 * er] : 0.f;
+        const float old_nlp = live ? lds[L8::ROWV + 2 * er + 1] : nlp;
         const float lo = 1.0f - cr, hi = 1.0f + cr;
         const float ratio = expf(old_nlp - nlp);
         const float rmin = tf_min(ratio, hi);
@@ -274,32 +307,35 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
             misc[er * 4 + 2] = live ? dk * dk : 0.f;
             misc[er * 4 + 3] = (live && fabsf(ratio - 1.0f) > cr) ? 1.0f : 0.f;
         }
-        float dmu = 0.f, dl = 0.f;
-        if (lj && live) {
-            dl = d_nlp * (1.0f - z * z) - net.ent_coef * gi;                           // AddN_2 G:21299
-            dmu = d_nlp * (-(z / sigma)) + dl * 0.0f;                                  // AddN_3 G:22656
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            float dmu = 0.f, dl = 0.f;
+            if (ej + 32 * q < nA && live) {
+                dl = d_nlp * (1.0f - z[q] * z[q]) - net.ent_coef * gi;                 // AddN_2 G:21299
+                dmu = d_nlp * (-(z[q] / sigma[q])) + dl * 0.0f;                        // AddN_3 G:22656
+            }
+            lds[L8::MU + er * L8::LDM + ej + 32 * q] = dmu;                            // the d mu tile: A operand of the head's backward product
+            lds[L8::DLS + er * AP + ej + 32 * q] = dl;
+            a.dmug[(size_t)(row0 + er) * AP + ej + 32 * q] = dmu;                      // dead rows / padding columns: zeros
         }
-        lds[T8_MU + er * T8_LD0 + ej] = dmu;                                           // the d mu tile: A operand of the head's backward product
-        lds[T8_DLS + er * 32 + ej] = dl;
-        a.dmug[(size_t)(row0 + er) * 32 + ej] = dmu;                                   // dead rows / padding columns: zeros
         lds_barrier();
-        if (tid < 32) {
+        if (tid < AP) {
             float sb = 0.f, sl = 0.f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { sb += lds[T8_MU + q * T8_LD0 + tid]; sl += lds[T8_DLS + q * 32 + tid]; }
+            for (int q = 0; q < 16; ++q) { sb += lds[L8::MU + q * L8::LDM + tid]; sl += lds[L8::DLS + q * AP + tid]; }
             slot[net.slot_head + tid] = sb;
             slot[net.slot_aux + tid] = sl;
-        } else if (tid < 36) {
+        } else if (tid < AP + 4) {
             float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) s += misc[q * 4 + (tid - 32)];
-            slot[net.slot_loss + (tid - 32)] = s;
+            for (int q = 0; q < 16; ++q) s += misc[q * 4 + (tid - AP)];
+            slot[net.slot_loss + (tid - AP)] = s;
         }
         STAMP(7);
         // ---- dY1 = (d mu W_mu^T) .* (1 - h2^2), 32 columns per wave -----------------------------------------------------------------
         {
             f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            t8_mma_small(whT, lds + T8_MU, T8_LD0, c, g, acc);
+            t8_mma_small<2, KSA>(whT, lds + L8::MU, L8::LDM, c, g, acc);
             const int col = 32 * wave + 2 * c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -319,7 +355,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
         const float v = t8_sum32(s) + par[net.par_bv];
         float dv = 0.f, lossv = 0.f;
         if (erow_live) {
-            const float R = lds[T8_ROWV + 2 * er], vo = lds[T8_ROWV + 2 * er + 1];
+            const float R = lds[L8::ROWV + 2 * er], vo = lds[L8::ROWV + 2 * er + 1];
             const float dvo = v - vo;
             const float vmin = tf_min(dvo, cr);
             const float vclip = vo + tf_max(vmin, -cr);
@@ -367,14 +403,14 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
         f32x4 acc[4];
         t8_big_product(fr, W1T, off_big, d2 + 128 * kh, c, g, rot, acc);
         float out[4][2];
-        t8_exchange(acc, lds + T8_H2, p, kh, lane, out);
+        t8_exchange(acc, lds + L8::H2, p, kh, lane, out);
         const int col = 64 * p + 4 * c;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 4 * g + 2 * kh + i;
-            const float4 hh = *reinterpret_cast<const float4*>(lds + T8_H1 + row * T8_LD + col);
+            const float4 hh = *reinterpret_cast<const float4*>(lds + L8::H1 + row * T8_LD + col);
             const float4 y = make_float4(out[0][i] * (1.0f - hh.x * hh.x), out[1][i] * (1.0f - hh.y * hh.y), out[2][i] * (1.0f - hh.z * hh.z), out[3][i] * (1.0f - hh.w * hh.w));
-            *reinterpret_cast<float4*>(lds + T8_D1 + row * T8_LD + col) = y;
+            *reinterpret_cast<float4*>(lds + L8::D1 + row * T8_LD + col) = y;
             st_wt4<T8_WT != 0>(a.dyg[tower][0] + (size_t)(row0 + row) * 256 + col, y);
         }
     }
@@ -383,7 +419,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     // ---- bias gradients: db1 = sum_rows dY1 (threads 0..255), db0 = sum_rows dY0 (threads 256..511)  (.../Add_grad/Sum_1) -------------
     {
         const int k = tid & 255;
-        const float* src = (tid < 256) ? d2 : lds + T8_D1;
+        const float* src = (tid < 256) ? d2 : lds + L8::D1;
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += src[q * T8_LD + k];

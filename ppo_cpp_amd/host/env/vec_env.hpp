@@ -2,9 +2,14 @@
 //
 // The reference spawns one std::thread per sub-environment with a mutex + condition variable per slot
 // (env/vec_env.hpp:33-63, 108-154, 205-277); that cannot scale to the 4096 environments of the benchmark
-// configuration.  Here a fixed pool of workers (<= hardware threads) owns contiguous ranges of environments and is
-// driven by a generation counter: step() publishes the actions, bumps the generation and waits until every worker has
-// finished its range.  Semantics kept from the reference: sub-envs are reset once from the worker threads at
+// configuration.  Here a fixed pool of helper threads (<= usable CPUs - 1) and the CALLING thread share the environments of a
+// step as small chunks claimed from an atomic counter: step() publishes the actions, bumps the generation, starts claiming
+// chunks itself (no wake-up latency in front of the first environment) and returns when the last chunk is finished.  A helper that
+// wakes late or is descheduled simply claims fewer chunks -- the pool adapts to the cores the box really gives it instead of
+// waiting for its slowest fixed share (round 3: 1.44 ms vs 2.70 ms per 16 steps of 4096 mock environments on two boxes that both
+// report 16 cores).  The chunk size is calibrated on the first three steps from the measured time per environment (~25 us of work
+// per chunk, at least 4 chunks per thread); pool_workers() / pool_chunk() / pool_active() report what was chosen and how many
+// threads actually took part.  Semantics kept from the reference: sub-envs are reset once from pool threads at
 // construction; reset() does NOT reset sub-envs but gathers get_original_obs() (env/vec_env.hpp:94-106);
 // get_original_rew() returns the rewards of the last step; the caller's vector of environments is referenced, not
 // copied (env/vec_env.hpp:190).  Conscious fix: get_observation_space_size() returns the OBSERVATION size (the
@@ -12,6 +17,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -56,20 +62,26 @@ inline int usable_cpus() {
 class VecEnv : public virtual Env {
 public:
     explicit VecEnv(const std::vector<std::shared_ptr<Env>>& envs, int max_workers = 0)
-        : envs_(envs), n_(static_cast<int>(envs.size())), generation_(0), pending_(0), terminate_(false), actions_(nullptr),
+        : envs_(envs), n_(static_cast<int>(envs.size())), generation_(0), terminate_(false), actions_(nullptr),
           observations_(Mat::Zero(n_, envs[0]->get_observation_space_size())), rewards_(Mat::Zero(n_, 1)), dones_(Mat::Zero(n_, 1)),
           original_rewards_(Mat::Zero(n_, 1)) {
         assert(!envs.empty());
         const int hw = usable_cpus();
-        int workers = std::min(n_, max_workers > 0 ? max_workers : hw);
-        const int per = (n_ + workers - 1) / workers;
-        workers = (n_ + per - 1) / per;
+        workers_ = std::max(1, std::min(n_, max_workers > 0 ? max_workers : hw));
+        // first guess: 8 chunks per thread; recalibrated from measured time per environment after the first steps
+        chunk_ = std::max(1, n_ / (8 * workers_));
+        claimed_by_.reset(new std::atomic<int>[workers_]);
+        mode_ = RESET;
+        begin_round();
+        for (int w = 1; w < workers_; ++w) threads_.emplace_back(&VecEnv::helper, this, w);
         {
             std::lock_guard<std::mutex> l(m_);
-            pending_ = workers;
+            ++generation_;
         }
-        for (int w = 0; w < workers; ++w) threads_.emplace_back(&VecEnv::worker, this, w * per, std::min(n_, (w + 1) * per));
-        wait_all();                      // every sub-env has been reset once (env/vec_env.hpp:209)
+        go_.notify_all();
+        drain(0);                        // every sub-env is reset once, from the pool (env/vec_env.hpp:209)
+        wait_round();
+        mode_ = STEP;
     }
     VecEnv(const VecEnv&) = delete;
     VecEnv& operator=(const VecEnv&) = delete;
@@ -98,14 +110,20 @@ public:
 
     std::vector<Mat> step(const Mat& actions) override {
         assert(actions.rows() == n_);
-        {
-            std::lock_guard<std::mutex> l(m_);
-            actions_ = &actions;
-            pending_ = static_cast<int>(threads_.size());
-            ++generation_;
+        const auto t0 = std::chrono::steady_clock::now();
+        actions_ = &actions;
+        begin_round();
+        if (workers_ > 1 && n_chunks_ > 1) {
+            {
+                std::lock_guard<std::mutex> l(m_);
+                ++generation_;
+            }
+            go_.notify_all();
         }
-        go_.notify_all();
-        wait_all();
+        drain(0);
+        wait_round();
+        if (steps_ < kCalibrationSteps) calibrate(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        ++steps_;
         return {observations_, rewards_, dones_};
     }
 
@@ -116,24 +134,72 @@ public:
     void render() override { std::cout << "VecEnv::render() not implemented\n"; }
     float get_time() override { std::cout << "VecEnv::get_time() not implemented\n"; return -1.f; }
 
+    // what the pool settled on (not part of the reference's interface): threads incl. the caller, environments per chunk, and how
+    // many threads claimed at least one chunk in the last step
+    int pool_workers() const { return workers_; }
+    int pool_chunk() const { return chunk_; }
+    int pool_active() const { int a = 0; for (int w = 0; w < workers_; ++w) a += claimed_by_[w].load(std::memory_order_relaxed) > 0; return a; }
+
 private:
-    void wait_all() {
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this] { return pending_ == 0; });
+    enum Mode { RESET, STEP };
+    static constexpr int kCalibrationSteps = 3;
+
+    // A round = one pass over the environments.  Everything a claim needs travels in ONE atomic word, so a helper that wakes late
+    // (after the round it was woken for has ended, or while the next one is being set up) can never act on a mix of two rounds:
+    //   ticket = [round : 24][chunks in the round : 20][next chunk : 20]
+    // A claim is valid iff next < chunks; a valid claim means its round is still open, so chunk_ / actions_ / mode_ (published
+    // before the ticket by the release store) are stable while the chunk is processed.
+    static constexpr int kFieldBits = 20;
+    void begin_round() {
+        n_chunks_ = (n_ + chunk_ - 1) / chunk_;
+        if (n_chunks_ >= (1 << (kFieldBits - 1))) { chunk_ = (n_ + (1 << (kFieldBits - 1)) - 2) / ((1 << (kFieldBits - 1)) - 1); n_chunks_ = (n_ + chunk_ - 1) / chunk_; }
+        for (int w = 0; w < workers_; ++w) claimed_by_[w].store(0, std::memory_order_relaxed);
+        remaining_.store(n_chunks_, std::memory_order_relaxed);
+        ++round_;
+        ticket_.store(((round_ & 0xFFFFFFull) << (2 * kFieldBits)) | (static_cast<unsigned long long>(n_chunks_) << kFieldBits), std::memory_order_release);
     }
-    void finish_one() {
-        bool last;
-        {
-            std::lock_guard<std::mutex> l(m_);
-            last = (--pending_ == 0);
-        }
-        if (last) done_.notify_one();
-    }
-    void worker(int begin, int end) {
-        for (int i = begin; i < end; ++i) envs_[i]->reset();
-        unsigned long seen = 0;
+    // claim chunks until none is left; `who` = 0 for the calling thread, 1.. for helpers
+    void drain(int who) {
         Mat a(1, 1);
-        finish_one();
+        for (;;) {
+            const unsigned long long t = ticket_.fetch_add(1, std::memory_order_acq_rel);
+            const int c = static_cast<int>(t & ((1ull << kFieldBits) - 1)), nc = static_cast<int>((t >> kFieldBits) & ((1ull << kFieldBits) - 1));
+            if (c >= nc) break;
+            claimed_by_[who].fetch_add(1, std::memory_order_relaxed);
+            const int begin = c * chunk_, end = std::min(n_, begin + chunk_);
+            if (mode_ == RESET) {
+                for (int i = begin; i < end; ++i) envs_[i]->reset();
+            } else {
+                const int acols = static_cast<int>(actions_->cols());
+                if (a.cols() != acols) a = Mat(1, acols);           // one action row per thread and step, reused for its environments
+                for (int i = begin; i < end; ++i) {
+                    mat_set_row(a, 0, mat_row_ptr(*actions_, i));
+                    const std::vector<Mat> res = envs_[i]->step(a);
+                    mat_set_row(observations_, i, res[0].data());
+                    rewards_(i, 0) = res[1](0, 0);
+                    dones_(i, 0) = res[2](0, 0);
+                    original_rewards_(i, 0) = envs_[i]->get_original_rew()(0, 0);
+                }
+            }
+            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1 && who != 0) {
+                std::lock_guard<std::mutex> l(m_);                  // the caller may be asleep in wait_round()
+                done_.notify_one();
+            }
+        }
+    }
+    // the caller has no chunk left to claim: the last ones are being finished by helpers (a few microseconds: spin, then sleep)
+    void wait_round() {
+        for (int spin = 0; spin < 2000; ++spin) {
+            if (remaining_.load(std::memory_order_acquire) == 0) return;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return remaining_.load(std::memory_order_acquire) == 0; });
+    }
+    void helper(int who) {
+        unsigned long seen = 0;
         for (;;) {
             {
                 std::unique_lock<std::mutex> l(m_);
@@ -141,18 +207,17 @@ private:
                 seen = generation_;
                 if (terminate_) return;
             }
-            const int acols = static_cast<int>(actions_->cols());
-            if (a.cols() != acols) a = Mat(1, acols);               // one action row per worker, reused (not one allocation per env step)
-            for (int i = begin; i < end; ++i) {
-                mat_set_row(a, 0, mat_row_ptr(*actions_, i));
-                const std::vector<Mat> res = envs_[i]->step(a);
-                mat_set_row(observations_, i, res[0].data());
-                rewards_(i, 0) = res[1](0, 0);
-                dones_(i, 0) = res[2](0, 0);
-                original_rewards_(i, 0) = envs_[i]->get_original_rew()(0, 0);
-            }
-            finish_one();
+            drain(who);
         }
+    }
+    // after each of the first steps: time per environment from the step's wall time and the threads that took part -> ~25 us of
+    // work per chunk, but never fewer than 4 chunks per thread (balance) nor more than one chunk per environment
+    void calibrate(double wall_s) {
+        const int active = std::max(1, pool_active());
+        const double per_env = wall_s * active / n_;
+        int c = per_env > 0 ? static_cast<int>(25e-6 / per_env) : chunk_;
+        c = std::min(c, std::max(1, n_ / (4 * workers_)));
+        chunk_ = std::max(1, c);
     }
 
     const std::vector<std::shared_ptr<Env>>& envs_;
@@ -161,8 +226,13 @@ private:
     std::mutex m_;
     std::condition_variable go_, done_;
     unsigned long generation_;
-    int pending_;
     bool terminate_;
     const Mat* actions_;
     Mat observations_, rewards_, dones_, original_rewards_;
+    int workers_ = 1, chunk_ = 1, n_chunks_ = 1, steps_ = 0;
+    Mode mode_ = RESET;
+    std::atomic<int> remaining_{0};
+    std::atomic<unsigned long long> ticket_{0};
+    unsigned long long round_ = 0;
+    std::unique_ptr<std::atomic<int>[]> claimed_by_;
 };

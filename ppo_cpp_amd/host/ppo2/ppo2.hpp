@@ -117,9 +117,10 @@ public:
     void learn(int total_timesteps, int num_saves = 0, const std::string& save_path = "") {
         num_timesteps_ = 0;
         updates_this_learn_ = 0;
-        if (!seeded_ || seeded_with_ != seed) {                    // exploration noise follows PPO2::seed / --seed; a repeated learn() with the
-            check(ppo_seed(h_, seed));                             // same seed continues the generator instead of replaying its draws
-            seeded_ = true; seeded_with_ = seed;
+        if (!seeded_ || seeded_with_ != seed) {                    // exploration noise AND epoch shuffles follow PPO2::seed / --seed; a repeated
+            check(ppo_seed(h_, seed));                             // learn() with the same seed continues both generators instead of replaying
+            seeded_ = true; seeded_with_ = seed;                   // their draws (the shuffle key counts updates since the seed was set)
+            shuffle_updates_ = 0; shuffle_rng_.seed((unsigned)seed);
         }
         const int n_updates = total_timesteps / n_batch_;
         save_interval_ = num_saves > 0 ? static_cast<int>(std::ceil(static_cast<float>(n_updates) / static_cast<float>(num_saves))) : -1;
@@ -175,7 +176,7 @@ private:
             num_timesteps_ += n_batch_;
             UpdateLog log{};
             const int32_t* perms = explicit_perms ? explicit_perms + (size_t)(update - 1) * noptepochs_ * n_batch_ : nullptr;
-            check(ppo_update(h_, learning_rate_, cliprange_, noptepochs_, nminibatches_, perms, seed + (unsigned long long)update, nullptr,
+            check(ppo_update(h_, learning_rate_, cliprange_, noptepochs_, nminibatches_, perms, seed + (unsigned long long)(++shuffle_updates_), nullptr,
                              log.losses));
             const auto t2 = clk::now();
             finish_update(log, t0, t1, t2, rew_view, done_view);
@@ -184,7 +185,7 @@ private:
 
     void learn_reference_loop(int n_updates) {
         Runner runner{env_, act_model_, n_steps_, gamma_, lam_};
-        std::mt19937 rng((unsigned)seed);
+        std::mt19937& rng = shuffle_rng_;                           // (a member: reset only when the seed changes, see learn())
         const int batch_size = n_batch_ / nminibatches_;
         for (int update = 1; update <= n_updates; ++update) {
             const auto t0 = clk::now();
@@ -259,6 +260,8 @@ private:
     int save_interval_ = -1;
     int updates_this_learn_ = 0;
     bool seeded_ = false; unsigned long long seeded_with_ = 0;
+    unsigned long long shuffle_updates_ = 0;                       // updates since the seed was set: key of the on-device epoch shuffles
+    std::mt19937 shuffle_rng_;                                     // the literal loop's std::shuffle generator (ppo2.hpp:288)
     std::string save_path_;
     ckpt::Bundle extra_tensors_;      // q/w, q/b carried through load -> save
     std::vector<UpdateLog> history_;

@@ -396,3 +396,38 @@ def test_graph_golden_regenerates_from_the_reference_graph():
         if k.startswith("meta/op_census"):
             continue
         np.testing.assert_array_equal(np.asarray(v), z[k], err_msg=k)
+
+
+@pytest.mark.parametrize("hidden,n,O,A", [((64, 64), 256, 18, 18), ((256, 256), 300, 18, 18), ((32, 16), 64, 36, 7)])
+def test_vectorised_numpy_port_equals_the_c_oracle(hidden, n, O, A):
+    """oracle/numpy_port.py (bench.py's CPU baseline legs) computes what the C restatement computes: policy step, losses, gradient,
+    clipped norm, three Adam rounds, GAE -- to fp32 rounding (BLAS summation order against double accumulators)."""
+    from oracle import numpy_port as npp
+    orc = o.Oracle(O, A, list(hidden)); orc.init_orthogonal(3)
+    orc.tensor("pi/logstd")[:] = np.random.RandomState(4).uniform(-1.0, 0.2, (1, A))
+    twin = o.Oracle(O, A, list(hidden)); twin.theta[:] = orc.theta
+    P = npp.NumpyPPO(twin)
+    for it in range(3):
+        mb = H.synth_minibatch(orc, n, seed=50 + it)
+        args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+        ref_losses, ref_grad = orc.loss_grad(*args, 0.161)
+        _, ref_norm = orc.clip(ref_grad)
+        orc.train_step(3.9e-4, 0.161, *args)
+        losses, norm = P.train_step(3.9e-4, 0.161, *args)
+        np.testing.assert_allclose(losses[:4], ref_losses[:4], rtol=1e-4, atol=1e-6)
+        assert abs(float(losses[4]) - float(ref_losses[4])) <= 1.01 / n
+        np.testing.assert_allclose(P.grad, ref_grad, rtol=2e-4, atol=2e-6 * float(np.abs(ref_grad).max()))
+        assert norm == pytest.approx(ref_norm, rel=1e-4)
+        np.testing.assert_allclose(twin.theta, orc.theta, rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(twin.v, orc.v, rtol=4e-4, atol=1e-10)
+    np.testing.assert_allclose(twin.pow, orc.pow, rtol=1e-6)
+    rng = np.random.RandomState(1)
+    obs = rng.uniform(-1, 1, (n, O)).astype(np.float32); noise = rng.normal(size=(n, A)).astype(np.float32)
+    for x, y in zip(P.step(obs, noise), twin.step(obs, noise)):
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-5)
+    rw = rng.normal(size=(16, 8)).astype(np.float32); va = (0.3 * rw).astype(np.float32); dn = (rng.rand(16, 8) < 0.1).astype(np.float32)
+    np.testing.assert_allclose(npp.gae(rw, va, dn, va[0], dn[0], 0.99, 0.95), o.gae(rw, va, dn, va[0], dn[0], 0.99, 0.95), rtol=1e-6, atol=1e-6)
+    st = o.RunningStats(O)
+    st.update(obs)
+    m, v, c = npp.running_update(np.zeros(O, np.float32), np.ones(O, np.float32), 1e-6, obs)
+    np.testing.assert_allclose(m, st.mean, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(v, st.var, rtol=1e-5); assert c == st.count
