@@ -140,10 +140,8 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     const int jl = tid >> 5, jb = b * a.jobs_per_wg + jl;
     const bool has_job = jl < a.jobs_per_wg && jb < a.n_jobs;
     const int4 jraw = reinterpret_cast<const int4*>(a.jobs)[has_job ? jb : 0];     // unconditional: the wait sits at the first use, not here
-    // ---- operand staging: LDS-DMA, 1 KB pieces; the image of a chunk is [row][cols]; in the 64-column X image the two 32-column
-    // halves of odd rows are swapped (on the SOURCE address: the destination of a piece is lane-linear), so that the 8-byte
-    // fragment reads of rows R and R + 1 (one 32-lane group) cover all 64 banks; 32- and 16-column rows alternate bank halves
-    // by themselves
+    // ---- operand staging: LDS-DMA, 1 KB pieces; the image of a chunk is [row][cols] (16-byte fragment reads of a 64-column row
+    // cover all 64 banks per 16 lanes; 32- and 16-column rows alternate bank halves by themselves)
     const int nct = a.n / DW2_CH;                            // chunks of the minibatch; split s owns [s nct / 4, (s + 1) nct / 4)
     const int cb = (split * nct) >> 2, nch = (((split + 1) * nct) >> 2) - cb;
     const size_t r0 = (size_t)cb * DW2_CH;
@@ -151,18 +149,23 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     const float* Yg = uni(a.dy1[tower]) + r0 * 256;
     const float* Ug = uni(kind == 1 ? a.dmug : a.x0g) + r0 * uwk;
     const float* Wg = uni(kind == 1 ? a.h2pi : a.dy0[tower]) + r0 * 256;
-    const unsigned lx = (unsigned)(((lane >> 4) * 256 + i0 + 4 * ((lane & 15) ^ (((lane >> 4) & 1) << 3))) * 4);
+    const unsigned lx = (unsigned)(((lane >> 4) * 256 + i0 + 4 * (lane & 15)) * 4);
     const unsigned ly = (unsigned)(((lane >> 3) * 256 + j0 + 4 * (lane & 7)) * 4);
     const unsigned lu = (unsigned)(lane * 16);               // U rows are contiguous in memory ([n][uwk]): a piece is 1 KB as it lies
     const unsigned lw = (unsigned)(((lane >> 2) * 256 + 16 * sidx + 4 * (lane & 3)) * 4);
-    // pieces of one 64-row chunk: X 16 (4 rows each), Y 8, U 8 or 16 (2 KB / 4 KB of rows), W 4 (16 rows each); wave w requests X 2w, 2w+1,
-    // Y w, U w (or 2w, 2w+1) and (w < 4) W w: `np` pieces per chunk and wave, the count the in-loop waits leave in flight
-    const int np = uni(3 + (kind == 2 ? 0 : (uwk >> 5) + (wave < 4 ? 1 : 0)));
-    auto stage = [&](int ch) __attribute__((always_inline)) {
+    // pieces of one 64-row chunk: X 16 (4 rows each), Y 8, U 8 or 16 (2 KB / 4 KB of rows), W 8 half pieces (8 rows x 64 bytes); wave w
+    // requests those of ITS rows 8 w .. 8 w + 7: X 2w, 2w+1, Y w, U w (or 2w, 2w+1), W w: `np` requests per chunk and wave, the count the
+    // in-loop waits leave in flight
+    const int np = uni(3 + (kind == 2 ? 0 : (uwk >> 5) + 1));
+    auto stage_x = [&](int ch) __attribute__((always_inline)) {
         float* buf = lds + (ch % DW2_NBUF) * LD::BUF;
         const size_t rb = (size_t)ch * DW2_CH;
 #pragma unroll
         for (int k = 0; k < 2; ++k) { const int j = 2 * wave + k; dw2_dma(Xg + (rb + 4 * j) * 256, lx, buf + LD::OX + j * 256); }
+    };
+    auto stage_rest = [&](int ch) __attribute__((always_inline)) {
+        float* buf = lds + (ch % DW2_NBUF) * LD::BUF;
+        const size_t rb = (size_t)ch * DW2_CH;
         dw2_dma(Yg + (rb + 8 * wave) * 256, ly, buf + LD::OY + wave * 256);
         if (kind != 2) {
             if (uwk == 32) dw2_dma(Ug + rb * 32 + wave * 256, lu, buf + LD::OU + wave * 256);
@@ -170,9 +173,10 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
 #pragma unroll
                 for (int k = 0; k < 2; ++k) dw2_dma(Ug + rb * 64 + (2 * wave + k) * 256, lu, buf + LD::OU + (2 * wave + k) * 256);
             }
-            if (wave < 4) dw2_dma(Wg + (rb + 16 * wave) * 256, lw, buf + LD::OW + wave * 256);
+            if (lane < 32) dw2_dma(Wg + (rb + 8 * wave) * 256, lw, buf + LD::OW + wave * 128);      // this wave's 8 rows x 16 columns: half a piece
         }
     };
+    auto stage = [&](int ch) __attribute__((always_inline)) { stage_x(ch); stage_rest(ch); };
     // wait until at most ONE chunk's pieces of this wave are still in flight (vector-memory operations complete in order)
     auto wait_keep_one = [&]() __attribute__((always_inline)) {
         if (np == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -184,47 +188,59 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     if (nch > 1) stage(1);
     if (nch > 2) stage(2);
     DW2_STAMP(1);
-    // ---- matrix work: wave w = (X half t = w & 1, K quarter kq = w >> 1) computes the [32 x 32] tile t of the [64 x 32] tile from
-    // rows 16 kq .. 16 kq + 15 of every chunk as 2 x 2 matrix instructions per k-step fed by TWO 8-byte LDS reads (tiles interleaved:
-    // instruction (i, j) covers gradient rows i0 + 32 t + 2 m + i, columns j0 + 2 n + j); the four K quarters meet in LDS at the
-    // end.  Strip: k-steps 2w, 2w+1 of every chunk, summed over the 8 waves at the end.  The fragments of chunk i+1 are read
-    // while the matrix instructions of chunk i run from registers; chunk i+3 is requested at the top of iteration i, chunk i+2
-    // must have landed at its bottom: two iterations of lead for every piece.
-    const int tx = wave & 1, kq = wave >> 1;
-    const int ax = (16 * kq + g) * 64 + ((32 * tx + 2 * c) ^ ((g & 1) << 5)), by = (16 * kq + g) * 32 + 2 * c;
+    // ---- matrix work: wave w owns rows 8 w .. 8 w + 7 of every chunk (the K dimension of the gradient is split 8 ways inside the
+    // workgroup, 4 x more across the row splits) and computes a partial of the WHOLE [64 x 32] tile from them: per 4-row k-step 4 x 2
+    // matrix instructions fed by one 16-byte and one 8-byte LDS read (tiles interleaved: instruction (i, j) covers gradient rows
+    // i0 + 4 m + i, columns j0 + 2 n + j); the eight partials meet in LDS at the end.  Strip: the same rows.  A wave reads exactly the
+    // pieces it requested itself.
+    const int ax = (8 * wave + g) * 64 + 4 * c, by = (8 * wave + g) * 32 + 2 * c;
     const int swo = (8 * wave + g) * 16 + c;
     constexpr int NU = LD::UW / 16;
-    struct Frags { float2 xa[4], yb[4]; float u[2][NU]; float ww[2]; };
-    auto read_frags = [&](Frags& f, int ch) __attribute__((always_inline)) {
+    struct Frags { float4 xa[2]; float2 yb[2]; float u[2][NU]; float ww[2]; };
+    auto read_main = [&](Frags& f, int ch) __attribute__((always_inline)) {
         const float* buf = lds + (ch % DW2_NBUF) * LD::BUF;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            f.xa[ks] = *reinterpret_cast<const float2*>(buf + LD::OX + ax + ks * 256);
+        for (int ks = 0; ks < 2; ++ks) {
+            f.xa[ks] = *reinterpret_cast<const float4*>(buf + LD::OX + ax + ks * 256);
             f.yb[ks] = *reinterpret_cast<const float2*>(buf + LD::OY + by + ks * 128);
         }
+    };
+    auto read_strip = [&](Frags& f, int ch) __attribute__((always_inline)) {
+        const float* buf = lds + (ch % DW2_NBUF) * LD::BUF;
         if (kind != 2) {
             if (KP0 == AP || kind == 0) dw2_read_u<KP0, NU>(f.u, buf + LD::OU, wave, g, c); else dw2_read_u<AP, NU>(f.u, buf + LD::OU, wave, g, c);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) f.ww[ks] = buf[LD::OW + swo + ks * 64];
         }
     };
-    f32x4 acc[2][2], sacc[NU];
-    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto read_frags = [&](Frags& f, int ch) __attribute__((always_inline)) { read_main(f, ch); read_strip(f, ch); };
+    f32x4 acc[4][2], sacc[NU];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NU; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+    auto mma_main = [&](const Frags& f, int ks) __attribute__((always_inline)) {          // one k-step of the [64 x 32] tile: 8 matrix instructions
 #ifdef DW2_NOMFMA
         if (a.n < 0)
 #endif
+        {
+            const float xv[4] = {f.xa[ks].x, f.xa[ks].y, f.xa[ks].z, f.xa[ks].w};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].x, f.yb[ks].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].x, f.yb[ks].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].y, f.yb[ks].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xa[ks].y, f.yb[ks].y, acc[1][1], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], f.yb[ks].x, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], f.yb[ks].y, acc[i][1], 0, 0, 0);
+            }
         }
+    };
+    auto mma_strip = [&](const Frags& f) __attribute__((always_inline)) {
+#ifdef DW2_NOMFMA
+        if (a.n < 0) {
+#endif
         if (kind == 0) dw2_strip_mma<KP0, true, NU>(f.u, f.ww, sacc);
         else if (kind == 1) dw2_strip_mma<AP, false, NU>(f.u, f.ww, sacc);
+#ifdef DW2_NOMFMA
+        }
+#endif
     };
     // chunks 0 and 1 (and the job descriptor) have landed once at most the pieces of chunk 2 are in flight
     if (nch > 2) wait_keep_one(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -240,15 +256,29 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
         for (int k = 0; k < DW2_SLOTK; ++k) { const int rb = ln + 32 * k; sj[k] = (has_job && rb < a.n_rowblocks) ? p[(size_t)rb * a.slot_w] : 0.f; }
     }
     DW2_STAMP(2);
+    // One iteration = the matrix instructions of chunk i from registers; chunk i+3 is requested into the buffer of chunk i (this wave
+    // read its fragments of it in the last iteration), the fragments of chunk i+1 are read (its pieces have landed: the wait at the
+    // bottom of the last iteration).  A wave touches ONLY pieces it requested itself, so there is NO workgroup barrier in the loop: the
+    // per-chunk barrier of the round-3 form cost 470 cycles a chunk -- 3.8 k of an 18.9 k-cycle loop whose matrix instructions take
+    // 10.2 k -- and kept the two waves of a SIMD in phase, their requests and reads under nobody's matrix instructions
+    // (profiles/r04_e_stamps_dw2_loop_experiments.txt).
     auto iteration = [&](int i, Frags& cur, Frags& nxt) __attribute__((always_inline)) {
-#ifndef DW2_NODMA
-        if (i + 3 < nch) stage(i + 3);                 // into the buffer of chunk i: every wave read its fragments of it before the last barrier
+#ifdef DW2_NOREAD
+        const bool st = i + 3 < nch, rd = false;          // timing experiment only: results are wrong
+#else
+        const bool st = i + 3 < nch, rd = i + 1 < nch;
 #endif
-        if (i + 1 < nch) read_frags(nxt, i + 1);
-        mma(cur);
+        mma_main(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef DW2_NODMA
+        if (st) stage(i + 3);
+#endif
+        if (rd) read_frags(nxt, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_main(cur, 1);
+        mma_strip(cur);
         if (i + 3 < nch) wait_keep_one(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk i+2 has landed (this wave's pieces)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          // this wave's reads of chunk i+1 are done
-        __builtin_amdgcn_s_barrier();
     };
     for (int i = 0; i < nch; i += 2) {
         iteration(i, fa, fb);
@@ -256,16 +286,17 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     }
     DW2_STAMP(3);
     // ---- park: main partials [4 K quarters][64][32], strip partials [8 waves][16 uwk]; slot jobs finish here too --------------------
+    __syncthreads();                                          // the partials overlay the chunk ring: every wave is done with it (and its requests have landed)
     float* park = lds;
-    float* spark = lds + 4 * 2048;
-    static_assert(4 * 2048 + 8 * 16 * LD::UW <= DW2_NBUF * LD::BUF, "park + strip partials fit the chunk ring");
+    float* spark = lds + 8 * 2048;
+    static_assert(8 * 2048 + 8 * 16 * LD::UW <= DW2_NBUF * LD::BUF, "park + strip partials fit the chunk ring");
     float* red2 = lds + DW2_NBUF * LD::BUF + 32;
     const int sn = 16 * uwk;                                 // elements of this workgroup's strip
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)                              // instruction (i, j): gradient rows i0 + 4 m + i, columns j0 + 2 n + j
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<float2*>(park + kq * 2048 + (32 * tx + 2 * (4 * g + r) + i) * 32 + 2 * c) = make_float2(acc[i][0][r], acc[i][1][r]);
+            *reinterpret_cast<float2*>(park + wave * 2048 + (4 * (4 * g + r) + i) * 32 + 2 * c) = make_float2(acc[i][0][r], acc[i][1][r]);
     if (kind == 0) {                                         // [KP0 x 16]: instruction t holds U columns (KP0 / 16) m + t
 #pragma unroll
         for (int t = 0; t < KP0 / 16; ++t)
@@ -290,7 +321,7 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     __syncthreads();
     float4 m4 = *reinterpret_cast<const float4*>(park + 4 * tid);
 #pragma unroll
-    for (int q = 1; q < 4; ++q) { const float4 p = *reinterpret_cast<const float4*>(park + q * 2048 + 4 * tid); m4.x += p.x; m4.y += p.y; m4.z += p.z; m4.w += p.w; }
+    for (int q = 1; q < 8; ++q) { const float4 p = *reinterpret_cast<const float4*>(park + q * 2048 + 4 * tid); m4.x += p.x; m4.y += p.y; m4.z += p.z; m4.w += p.w; }
     float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool strip_thread = kind != 2 && 4 * tid < sn;
     if (strip_thread) {

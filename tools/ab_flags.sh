@@ -1,11 +1,12 @@
 #!/bin/bash
-# A/B of compile-time flags at cfg3: tools/r3_abflags.sh <tag> "<flags or empty>" ...   (each variant rebuilt on the box)
+# A/B of compile-time flags on the GPU box: tools/ab_flags.sh <tag> "<flags or empty>" ...   (each variant rebuilt on the box; CONFIG=cfg3 by default)
 tag=$1; shift
+cfg=${CONFIG:-cfg3}
 i=0
 for f in "$@"; do
   touch ppo_cpp_amd/csrc/ppo_hip.hip
   PPO_HIP_EXTRA_FLAGS="$f" python -m ppo_cpp_amd.build > /dev/null 2>&1
-  python bench.py --config cfg3 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > gpurun_out/abf_${tag}_$i.json 2> gpurun_out/abf_${tag}_$i.err
+  python bench.py --config $cfg --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-extra > gpurun_out/abf_${tag}_$i.json 2> gpurun_out/abf_${tag}_$i.err
   python - "$f" gpurun_out/abf_${tag}_$i.json <<'PY'
 import json,sys
 try:

@@ -25,6 +25,13 @@ for tower in (0, 1):
         if (blk[:, i] > 0).all() and (blk[:, j] > 0).all():
             d = blk[:, j] - blk[:, i]
             print("   %-18s median %7.0f  max %7.0f" % (name, np.median(d), d.max()))
+    for i, j, name in [(0, 20, "  kernarg round trip"), (20, 21, "  issue loads"), (21, 22, "  wait + consume"), (22, 1, "  barrier"),
+                       (2, 11, "  fwd L1 product"), (11, 12, "  issue W1T stages"), (12, 13, "  exchange"), (13, 3, "  bias+tanh+stores+barrier"),
+                       (8, 14, "  bwd L1 product"), (14, 15, "  exchange"), (15, 9, "  TanhGrad+stores+barrier")]:
+        if (blk[:, i] > 0).all() and (blk[:, j] > 0).all():
+            d = blk[:, j] - blk[:, i]
+            print("   %-28s median %7.0f  max %7.0f" % (name, np.median(d), d.max()))
+    if os.environ.get("STAMPS_T8_ONLY"): continue
     seq = [16, 20, 21, 22, 23, 24, 25, 26, 27, 17, 18, 19]
     names = ["L1 entry", "st0", "st1", "st2", "st3", "st4", "st5", "st6", "st7", "loop end", "between done", "epilogue done"]
     prev = None
@@ -32,6 +39,7 @@ for tower in (0, 1):
         if (blk[:, idx] > 0).all():
             if prev is not None: print("      %-14s +%6.0f" % (nm, np.median(blk[:, idx] - blk[:, prev])))
             prev = idx
+if os.environ.get('STAMPS_T8_ONLY'): sys.exit(0)
 buf = np.zeros(256 * 8, np.uint64)
 g.lib.ppo_debug_read_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), -buf.size)
 sb = buf.reshape(-1, 8).astype(np.int64)
