@@ -540,27 +540,34 @@ struct SampleArgsB {
     int n, A; uint32_t seed, rng_step, row_base;
 };
 
-__global__ __launch_bounds__(256) void bf16_sample_kernel(SampleArgsB a) {
-    const int r = threadIdx.x >> 4, part = threadIdx.x & 15;
-    const int row = blockIdx.x * 16 + r;
+// one wave per row, one lane per action (two past 64 actions): the row sums take the SAME shape as in bf16_loss_kernel, so the act model's
+// neglogp and the train model's are the same bits on the same weights (first-epoch ratio exactly 1)
+#define BS_ROWS 4
+__global__ __launch_bounds__(64 * BS_ROWS) void bf16_sample_kernel(SampleArgsB a) {
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * BS_ROWS + r;
     const bool live = row < a.n;
     float ssq = 0.f, slog = 0.f;
-    for (int j = part; j < a.A; j += 16) {
-        const float mu = live ? head_sum(a.head[0], (size_t)row * a.ldh + j, a.hsplit, a.hstride) : 0.f;
-        const float logstd = mu * 0.0f + a.logstd[j];
-        const float sigma = expf(logstd);
-        float eps = 0.f;
-        if (live) eps = a.noise ? a.noise[(size_t)row * a.A + j] : ctr_normal(a.seed, a.row_base + row, a.rng_step, j);
-        const float act = mu + sigma * eps;
-        const float z = (act - mu) / sigma;
-        ssq += z * z; slog += logstd;
-        if (live) {
-            if (a.action) a.action[(size_t)row * a.A + j] = act;
-            if (a.det_action) a.det_action[(size_t)row * a.A + j] = mu;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = lane + 64 * e;
+        if (j < a.A) {
+            const float mu = live ? head_sum(a.head[0], (size_t)row * a.ldh + j, a.hsplit, a.hstride) : 0.f;
+            const float logstd = mu * 0.0f + a.logstd[j];
+            const float sigma = expf(logstd);
+            float eps = 0.f;
+            if (live) eps = a.noise ? a.noise[(size_t)row * a.A + j] : ctr_normal(a.seed, a.row_base + row, a.rng_step, j);
+            const float act = mu + sigma * eps;
+            const float z = (act - mu) / sigma;
+            ssq += z * z; slog += logstd;
+            if (live) {
+                if (a.action) a.action[(size_t)row * a.A + j] = act;
+                if (a.det_action) a.det_action[(size_t)row * a.A + j] = mu;
+            }
         }
     }
-    ssq = group16_sum(ssq); slog = group16_sum(slog);
-    if (part == 0 && live) {
+    for (int o = 32; o > 0; o >>= 1) { ssq += __shfl_xor(ssq, o); slog += __shfl_xor(slog, o); }
+    if (lane == 0 && live) {
         if (a.neglogp) a.neglogp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)a.A + slog;
         if (a.value) a.value[row] = head_sum(a.head[1], (size_t)row * a.ldh, a.hsplit, a.hstride);
     }
@@ -580,30 +587,56 @@ struct LossArgsB {
 };
 
 #ifndef BL_ROWS
-#define BL_ROWS 32                 // rows per block of the loss kernel (16 lanes each): one slot row of partial sums per block
+#define BL_ROWS 16                 // rows per block of the loss kernel: one slot row of partial sums per block
 #endif
-__global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
+#define BL_EPT 2                   // action elements per lane: a row is ONE wave (64 lanes), A <= 128
+// One wave per row, one lane per action: every lane requests its element's partial products at once and the row sums are wave
+// reductions.  (Rounds 2-3: 16 lanes per row walking the actions in a loop of dependent loads, 32 rows per block = 128 workgroups of
+// latency: 11.7 us for 8.8 MB.)
+__global__ __launch_bounds__(64 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
     extern __shared__ __attribute__((aligned(16))) float ls[];      // [R][Ap] dmu | [R][Ap] dlogstd | [R][4] pi terms | [R][2] vf terms
     float* dmu_s = ls; float* dls_s = ls + BL_ROWS * a.Ap; float* pt = dls_s + BL_ROWS * a.Ap; float* vt = pt + 4 * BL_ROWS;
-    const int tid = threadIdx.x, r = tid >> 4, part = tid & 15;
+    const int tid = threadIdx.x, r = tid >> 6, lane = tid & 63;
     const int row = blockIdx.x * BL_ROWS + r;
     const bool live = row < a.n;
     const float cr = a.hyper[1];
     const float g = a.inv_n;
-    // policy tower
-    float ssq = 0.f, slog = 0.f, sent = 0.f;
-    for (int j = part; j < a.A; j += 16) {
-        const float mu = head_sum(a.head[0], (size_t)row * a.ldh + j, a.hsplit, a.hstride);
-        dmu_s[r * a.Ap + j] = mu;                            // kept for the gradient pass below (same thread, same element)
-        const float logstd = mu * 0.0f + a.logstd[j];
-        const float act = live ? a.actions[(size_t)row * a.A + j] : mu;
-        const float z = (act - mu) / expf(logstd);
-        ssq += z * z; slog += logstd; sent += logstd + HALF_LOG_2PIE;
+    // every load of the lane first: head partials, actions, the row scalars
+    float hp[BL_EPT][GB_HEAD_SPLIT], act_[BL_EPT], ls_[BL_EPT];
+#pragma unroll
+    for (int e = 0; e < BL_EPT; ++e) {
+        const int j = lane + 64 * e;
+#pragma unroll
+        for (int k = 0; k < GB_HEAD_SPLIT; ++k) hp[e][k] = (j < a.A && k < a.hsplit) ? a.head[0][(size_t)k * a.hstride + (size_t)row * a.ldh + j] : 0.f;
+        act_[e] = (j < a.A && live) ? a.actions[(size_t)row * a.A + j] : 0.f;
+        ls_[e] = j < a.A ? a.logstd[j] : 0.f;
     }
-    ssq = group16_sum(ssq); slog = group16_sum(slog); sent = group16_sum(sent);
-    const float nlp = 0.5f * ssq + HALF_LOG_2PI * (float)a.A + slog;
+    float vp[GB_HEAD_SPLIT];
+#pragma unroll
+    for (int k = 0; k < GB_HEAD_SPLIT; ++k) vp[k] = (lane == 0 && live && k < a.hsplit) ? a.head[1][(size_t)k * a.hstride + (size_t)row * a.ldh] : 0.f;
     const float adv = live ? a.advs[row] : 0.f;
-    const float old_nlp = live ? a.old_neglogp[row] : nlp;
+    const float old_nlp_in = live ? a.old_neglogp[row] : 0.f;
+    float Rv = 0.f, vo = 0.f;
+    if (lane == 0 && live) { Rv = a.returns[row]; vo = a.old_values[row]; }
+    // policy tower
+    float mu[BL_EPT], z[BL_EPT], sigma[BL_EPT];
+    float ssq = 0.f, slog = 0.f, sent = 0.f;
+#pragma unroll
+    for (int e = 0; e < BL_EPT; ++e) {
+        const int j = lane + 64 * e;
+        float m = hp[e][0];
+#pragma unroll
+        for (int k = 1; k < GB_HEAD_SPLIT; ++k) if (k < a.hsplit) m += hp[e][k];       // the partial products in range order (head_sum)
+        mu[e] = m;
+        const float logstd = m * 0.0f + ls_[e];
+        sigma[e] = expf(logstd);
+        const float act = live ? act_[e] : m;
+        z[e] = (act - m) / sigma[e];
+        if (j < a.A) { ssq += z[e] * z[e]; slog += logstd; sent += logstd + HALF_LOG_2PIE; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { ssq += __shfl_xor(ssq, o); slog += __shfl_xor(slog, o); sent += __shfl_xor(sent, o); }
+    const float nlp = 0.5f * ssq + HALF_LOG_2PI * (float)a.A + slog;
+    const float old_nlp = live ? old_nlp_in : nlp;
     const float lo = 1.0f - cr, hi = 1.0f + cr;
     const float ratio = expf(old_nlp - nlp);
     const float rmin = tf_min(ratio, hi);
@@ -614,35 +647,37 @@ __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
     float d_ratio = (-adv) * g * sel;
     d_ratio += (-adv) * g * (1.0f - sel) * pass;
     const float d_nlp = live ? -(d_ratio * ratio) : 0.0f;
-    if (part == 0) {
+    if (lane == 0) {
         const float dk = nlp - old_nlp;
         pt[r * 4 + 0] = live ? tf_max(m1, m2) : 0.f;
         pt[r * 4 + 1] = live ? sent : 0.f;
         pt[r * 4 + 2] = live ? dk * dk : 0.f;
         pt[r * 4 + 3] = (live && fabsf(ratio - 1.0f) > cr) ? 1.0f : 0.f;
     }
-    for (int j = part; j < a.Ap; j += 16) {
-        float dmu = 0.f, dl = 0.f;
-        if (j < a.A && live) {
-            const float mu = dmu_s[r * a.Ap + j];
-            const float sigma = expf(mu * 0.0f + a.logstd[j]);
-            const float z = (a.actions[(size_t)row * a.A + j] - mu) / sigma;
-            dl = d_nlp * (1.0f - z * z) - a.ent_coef * g;                            // AddN_2 G:21299
-            dmu = d_nlp * (-(z / sigma)) + dl * 0.0f;                                // AddN_3 G:22656
+#pragma unroll
+    for (int e = 0; e < BL_EPT; ++e) {
+        const int j = lane + 64 * e;
+        if (j < a.Ap) {
+            float dmu = 0.f, dl = 0.f;
+            if (j < a.A && live) {
+                dl = d_nlp * (1.0f - z[e] * z[e]) - a.ent_coef * g;                      // AddN_2 G:21299
+                dmu = d_nlp * (-(z[e] / sigma[e])) + dl * 0.0f;                          // AddN_3 G:22656
+            }
+            dmu_s[r * a.Ap + j] = dmu; dls_s[r * a.Ap + j] = dl;
+            a.dhead[0][(size_t)row * a.Ap + j] = (bf16_t)dmu;
         }
-        dmu_s[r * a.Ap + j] = dmu; dls_s[r * a.Ap + j] = dl;
-        a.dhead[0][(size_t)row * a.Ap + j] = (bf16_t)dmu;
     }
     // value tower (G:10213-10837, G:14975-19571)
-    if (part == 0) {
+    if (lane == 0) {
         float dv = 0.f, lossv = 0.f;
         if (live) {
-            const float v = head_sum(a.head[1], (size_t)row * a.ldh, a.hsplit, a.hstride);
-            const float R = a.returns[row], vo = a.old_values[row];
+            float v = vp[0];
+#pragma unroll
+            for (int k = 1; k < GB_HEAD_SPLIT; ++k) if (k < a.hsplit) v += vp[k];
             const float dvo = v - vo;
             const float vmin = tf_min(dvo, cr);
             const float vclip = vo + tf_max(vmin, -cr);
-            const float e1 = v - R, e2 = vclip - R;
+            const float e1 = v - Rv, e2 = vclip - Rv;
             const float s1 = e1 * e1, s2 = e2 * e2;
             lossv = tf_max(s1, s2);
             const float gv = a.vf_coef * 0.5f * a.inv_n;
@@ -656,14 +691,15 @@ __global__ __launch_bounds__(16 * BL_ROWS) void bf16_loss_kernel(LossArgsB a) {
     __syncthreads();
     float* s0 = a.slots[0] + (size_t)blockIdx.x * a.slot_w;
     float* s1 = a.slots[1] + (size_t)blockIdx.x * a.slot_w;
-    for (int j = tid; j < a.Ap; j += 16 * BL_ROWS) {
-        float sb = 0.f, sl = 0.f;
-        for (int q = 0; q < BL_ROWS; ++q) { sb += dmu_s[q * a.Ap + j]; sl += dls_s[q * a.Ap + j]; }
-        s0[a.slot_head + j] = sb;                              // db_mu  (fp32 sums of the fp32 values, not of their bf16 roundings)
-        s0[a.slot_aux + j] = sl;                               // dlogstd
+    for (int j = tid; j < 2 * a.Ap; j += 64 * BL_ROWS) {      // threads [0, Ap): db_mu, [Ap, 2 Ap): dlogstd -- fp32 sums of the fp32 values, not of their bf16 roundings
+        const float* src = j < a.Ap ? dmu_s + j : dls_s + (j - a.Ap);
+        float sb = 0.f;
+#pragma unroll
+        for (int q = 0; q < BL_ROWS; ++q) sb += src[q * a.Ap];
+        if (j < a.Ap) s0[a.slot_head + j] = sb; else s0[a.slot_aux + j - a.Ap] = sb;
     }
-    if (tid >= 8 * BL_ROWS && tid < 8 * BL_ROWS + 4) { const int k = tid - 8 * BL_ROWS; float s = 0.f; for (int q = 0; q < BL_ROWS; ++q) s += pt[q * 4 + k]; s0[a.slot_loss + k] = s; }
-    if (tid == 8 * BL_ROWS + 64) { float sb = 0.f, sl = 0.f; for (int q = 0; q < BL_ROWS; ++q) { sb += vt[q * 2]; sl += vt[q * 2 + 1]; } s1[a.slot_head] = sb; s1[a.slot_loss] = sl; }
+    if (tid >= 64 * BL_ROWS - 64 && tid < 64 * BL_ROWS - 60) { const int k = tid - (64 * BL_ROWS - 64); float s = 0.f; for (int q = 0; q < BL_ROWS; ++q) s += pt[q * 4 + k]; s0[a.slot_loss + k] = s; }
+    if (tid == 64 * BL_ROWS - 32) { float sb = 0.f, sl = 0.f; for (int q = 0; q < BL_ROWS; ++q) { sb += vt[q * 2]; sl += vt[q * 2 + 1]; } s1[a.slot_head] = sb; s1[a.slot_loss] = sl; }
 }
 
 // ---- bf16 operand mirror of the fp32 master weights: keeps theta's padded layout (a cast of the whole vector) ----------------

@@ -725,7 +725,8 @@ int launch_step_bf16(ppo_handle* h, const StepArgs& a) {
     sa.head[0] = h->bf.head_out[0]; sa.head[1] = h->bf.head_out[1]; sa.ldh = n.Ap; sa.hsplit = h->bf.head_split; sa.hstride = (size_t)h->bf.Rcap * n.Ap; sa.logstd = h->theta + n.ls_off;
     sa.noise = a.noise; sa.action = a.action; sa.det_action = a.det_action; sa.value = a.value; sa.neglogp = a.neglogp;
     sa.n = a.n; sa.A = n.A; sa.seed = a.seed; sa.rng_step = a.rng_step; sa.row_base = a.row_base;
-    hipLaunchKernelGGL(bf16_sample_kernel, dim3((a.n + 15) / 16), dim3(256), 0, h->stream, sa);
+    if (n.A > 128) return fail(h, "bf16 path: more than 128 actions");
+    hipLaunchKernelGGL(bf16_sample_kernel, dim3((a.n + BS_ROWS - 1) / BS_ROWS), dim3(64 * BS_ROWS), 0, h->stream, sa);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -749,7 +750,8 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
     la.ldh = n.Ap; la.hsplit = b.head_split; la.hstride = (size_t)b.Rcap * n.Ap; la.logstd = h->theta + n.ls_off; la.actions = ta.actions; la.advs = ta.advs; la.returns = ta.returns; la.old_values = ta.old_values;
     la.old_neglogp = ta.old_neglogp; la.hyper = h->hyper; la.n = ta.n; la.A = n.A; la.Ap = n.Ap; la.rows_pad = b.Rcap; la.inv_n = ta.inv_n;
     la.ent_coef = n.ent_coef; la.vf_coef = n.vf_coef; la.slot_w = n.slot_w; la.slot_head = n.slot_head; la.slot_aux = n.slot_aux; la.slot_loss = n.slot_loss;
-    hipLaunchKernelGGL(bf16_loss_kernel, dim3(Rp / BL_ROWS), dim3(16 * BL_ROWS), (size_t)(2 * BL_ROWS * n.Ap + 6 * BL_ROWS) * sizeof(float), h->stream, la);
+    if (n.A > 64 * BL_EPT) return fail(h, "bf16 path: more than %d actions", 64 * BL_EPT);
+    hipLaunchKernelGGL(bf16_loss_kernel, dim3(Rp / BL_ROWS), dim3(64 * BL_ROWS), (size_t)(2 * BL_ROWS * n.Ap + 6 * BL_ROWS) * sizeof(float), h->stream, la);
     HIP_OK(h, hipGetLastError());
     // dY_{L-1} = (d head * W_head^T) .* (1 - h_L^2), then down the hidden layers
     const int HpL = n.Hp[n.L - 1];
