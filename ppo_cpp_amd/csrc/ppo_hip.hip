@@ -197,6 +197,7 @@ struct ppo_handle {
         bool coarse = false, coarse_requested = false;  // the region is plain hipMalloc memory (refused unless asked for: PPO_HIP_PEER_MEM=c)
         void* region = nullptr;                         // mine: [flag block | slots[2][world][cap]] (exported over IPC)
         size_t cap = 0;                                 // floats per slot (multiple of PEER_CHUNK)
+        int scap = 0;                                   // floats per slot of the statistics area behind the slots
         void* mapped[PEER_MAX_WORLD]{};                 // the other ranks' regions as this process sees them
         unsigned* local = nullptr;                      // {seq, arrive, err}
         PeerDev dev{};
@@ -608,7 +609,6 @@ int bf16_refresh_mirrors(ppo_handle* h) {
 
 int bf16_create(ppo_handle* h) {
     ppo_handle::Bf16& b = h->bf;
-    const NetDev& n = h->net;
     if (dev_alloc(h, &b.theta_bf, (size_t)h->P_pad)) return -1;
     bool ok = true;
     auto lds_attr = [&](const void* f, int bytes) { ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
@@ -1608,19 +1608,25 @@ static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, con
     a.part = h->stats_part; a.counter = reinterpret_cast<unsigned*>(h->stats_counter);
     a.world = h->world; a.rank = h->rank;
     const size_t xw = (size_t)(1 + 2 * D) + 3;
+    // over peer-mapped regions the two statistics kernels exchange the table themselves (the last workgroup of each job writes this
+    // rank's moments into every rank's gather area and raises a flag there; norm_finalize_kernel waits for the flags): no memset, no
+    // push / sum launches between them.  PPO_HIP_PEER_STATS=0: the table goes through the general all-reduce as before.
+    static const bool no_peer_stats = [] { const char* e = getenv("PPO_HIP_PEER_STATS"); return e && e[0] == '0'; }();
+    a.use_peer = (h->comm && h->peer.on && h->peer.dev.scap >= (int)xw && !no_peer_stats) ? 1 : 0;
+    if (a.use_peer) a.peer = h->peer.dev;
     if (h->comm) {
         if (!h->stats_xch || h->stats_xch_world != h->world) {
             if (dev_alloc(h, &h->stats_xch, xw * h->world)) return -1;
             h->stats_xch_world = h->world;
         }
         a.xch = h->stats_xch;
-        HIP_OK(h, hipMemsetAsync(h->stats_xch, 0, xw * h->world * sizeof(float), h->stream));
+        if (!a.use_peer) HIP_OK(h, hipMemsetAsync(h->stats_xch, 0, xw * h->world * sizeof(float), h->stream));
     }
     { ProfScope ps(h, PK_STATS);
       hipLaunchKernelGGL(norm_batch_kernel, dim3(a.g_obs + a.g_rew), dim3(NB_THREADS), 0, h->stream, a);
       HIP_OK(h, hipGetLastError()); }
     if (h->comm) {
-        if (allreduce_f32(h, h->stats_xch, xw * h->world)) return -1;
+        if (!a.use_peer && allreduce_f32(h, h->stats_xch, xw * h->world)) return -1;
         ProfScope ps(h, PK_STATS);
         hipLaunchKernelGGL(norm_finalize_kernel, dim3(2), dim3(NB_THREADS), 0, h->stream, a);
         HIP_OK(h, hipGetLastError());
@@ -2487,7 +2493,8 @@ int ppo_dist_peer_export(ppo_handle* h, char handle[64]) {
     ppo_handle::Peer& P = h->peer;
     if (!P.region) {
         P.cap = (size_t)ru(std::max(h->P_pad + 8, 4096), PEER_CHUNK_MAX);
-        const size_t bytes = kPeerFlagBytes + (size_t)2 * h->world * P.cap * sizeof(float);
+        P.scap = ru(2 * h->net.O + 4, 64);                        // a rank's batch moments of an env step: (n, mean[O], M2[O]) + (n, mean, M2) of the returns
+        const size_t bytes = kPeerFlagBytes + (size_t)2 * h->world * (P.cap + P.scap) * sizeof(float);
         // memory kind of the region (other devices write into it): fine-grained = coherent at system scope with the kernels'
         // fences, cached in L2; uncached = every access goes to memory (slowest, needs no fence to be seen); coarse = plain
         // hipMalloc (fastest; coherent across devices only at kernel boundaries by the letter of the memory model)
@@ -2506,6 +2513,7 @@ int ppo_dist_peer_export(ppo_handle* h, char handle[64]) {
             if (kind != 2) fprintf(stderr, "libppo_hip: no fine-grained / uncached device memory for the peer region (rank %d): the peer all-reduce stays off, RCCL is used\n", h->rank);
         }
         HIP_OK(h, hipMemset(P.region, 0, bytes));
+        static_assert((PEER_SFLAG_OFF + 2 * 2 * PEER_MAX_WORLD * PEER_FLAG_STRIDE) * sizeof(unsigned) <= 4096, "statistics flags fit the flag block");
         HIP_OK(h, hipMalloc((void**)&P.local, 64));
         HIP_OK(h, hipMemset(P.local, 0, 64));
         HIP_OK(h, hipDeviceSynchronize());
@@ -2581,8 +2589,9 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
         if (!base) base = (char*)P.region;                         // unmapped peer: the probe fails, nothing is ever sent there afterwards
         d.flags[r] = (unsigned*)base;
         d.slots[r] = (float*)(base + kPeerFlagBytes);
+        d.sslots[r] = d.slots[r] + (size_t)2 * h->world * P.cap;
     }
-    d.seq = P.local; d.arrive = P.local + 1; d.err = P.local + 2;
+    d.seq = P.local; d.arrive = P.local + 1; d.err = P.local + 2; d.sseq = P.local + 4; d.scap = P.scap;
     d.cap = P.cap; d.world = h->world; d.rank = h->rank;
     const char* tm = getenv("PPO_HIP_PEER_TIMEOUT_MS");
     const double ms = tm ? atof(tm) : 10000.0;

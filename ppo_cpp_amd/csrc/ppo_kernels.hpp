@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ppo_peer.hpp"      // PeerDev: the data-parallel statistics exchange rides in norm_batch_kernel / norm_finalize_kernel
+
 #define PPO_MAX_LAYERS 8
 #define ROWS_PER_BLOCK 16          // one 16x16x4 MFMA row tile per workgroup
 #define BLOCK_THREADS 256          // 4 waves, one per SIMD
@@ -1955,6 +1957,8 @@ struct NormBatchArgs {
     unsigned* counter;    // zero between launches
     float* xch;           // data-parallel: [world][(1 + 2D) + 3] slot table (this rank's slot is written here), else null
     int world, rank;
+    int use_peer;         // data-parallel over peer-mapped regions: the table is exchanged by these two kernels themselves (ppo_peer.hpp)
+    PeerDev peer;
 };
 
 __device__ __forceinline__ int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -2173,12 +2177,23 @@ __global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a)
     if (which == 0) norm_finish(a, 0, a.part, a.g_obs, so, publish, sh);
     else norm_finish(a, 1, part_rew, a.g_rew, 3, publish, sh);
     if (tid == 0) a.counter[which] = 0u;
+    if (a.use_peer && publish) {
+        // this rank's batch moments go straight into every rank's gather area: no all-reduce launches between the two statistics kernels.
+        // (a reward job that is not training publishes nothing: its three floats are not read either)
+        __syncthreads();
+        peer_stats_publish(a.peer, which, publish, which ? so : 0, which ? 3 : so);
+    }
 }
 
 // data-parallel second half: combine the ranks' slots (after the all-reduce) and finish; one block
 __global__ __launch_bounds__(NB_THREADS) void norm_finalize_kernel(NormBatchArgs a) {      // grid = 2: block 0 obs, block 1 reward
     __shared__ float sh[3 * NB_THREADS];
     const int so = 1 + 2 * a.D;
+    if (a.use_peer) {                                          // the ranks' slots arrive here: wait for the flags, copy into the local table
+        const int job = blockIdx.x;
+        if ((job == 0 && !a.obs) || (job == 1 && !a.rew)) return;
+        if (!peer_stats_collect(a.peer, job, a.xch, so + 3, job ? so : 0, job ? 3 : so)) return;
+    }
     if (blockIdx.x == 0) { if (a.obs) norm_finish(a, 0, a.xch, a.world, so + 3, nullptr, sh); }
     else if (a.rew) norm_finish(a, 1, a.xch + so, a.world, so + 3, nullptr, sh);
 }

@@ -20,6 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+__device__ __forceinline__ unsigned peer_ld_sys(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void peer_st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 #define PEER_MAX_WORLD 8
 #define PEER_FLAG_STRIDE 16            // unsigned per (parity, source) flag: one 64-byte line each
 
@@ -32,10 +35,65 @@ struct PeerDev {
     unsigned long long cap;            // floats per slot
     int world, rank;
     unsigned spin_limit;               // wait iterations before giving up
+    // running-statistics table of an env step (norm_batch_kernel / norm_finalize_kernel exchange it themselves, no launch of its own):
+    // every region carries a second, small gather area [2 parities][world][scap] behind the slots and flags [2][2 jobs][PEER_MAX_WORLD]
+    // (one 64-byte line each) behind the collective's flags; the sequence numbers of the two jobs (observations, rewards) are local
+    float* sslots[PEER_MAX_WORLD];
+    unsigned* sseq;                    // local: [2] env steps exchanged so far per job
+    int scap;                          // floats per statistics slot (0: the exchange is not available)
 };
+#define PEER_SFLAG_OFF (2 * PEER_MAX_WORLD * PEER_FLAG_STRIDE)       // first statistics flag (unsigned index into a region's flag block)
+__device__ __forceinline__ unsigned* peer_sflag(const PeerDev& p, int at_rank, unsigned par, int job, int from_rank) {
+    return p.flags[at_rank] + PEER_SFLAG_OFF + (((size_t)par * 2 + job) * PEER_MAX_WORLD + from_rank) * PEER_FLAG_STRIDE;
+}
 
-__device__ __forceinline__ unsigned peer_ld_sys(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void peer_st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// the last workgroup of a statistics job: `n` floats at `src` (this rank's batch moments) into slot [rank] of EVERY rank's statistics
+// area, then the flags.  Whole workgroup.
+__device__ __forceinline__ void peer_stats_publish(const PeerDev& p, int job, const float* src, int off, int n) {
+    __shared__ unsigned s_seq;
+    if (threadIdx.x == 0) s_seq = __hip_atomic_load(p.sseq + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __syncthreads();
+    const unsigned s = s_seq, par = s & 1u;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = src[i];
+        for (int k = 0; k < p.world; ++k) {
+            const int r = (p.rank + k) % p.world;
+            p.sslots[r][((size_t)par * p.world + p.rank) * p.scap + off + i] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                // system scope: the slot writes are out before any flag
+    __syncthreads();
+    if (threadIdx.x < (unsigned)p.world) peer_st_sys(peer_sflag(p, threadIdx.x, par, job, p.rank), s);
+    if (threadIdx.x == 0) __hip_atomic_store(p.sseq + job, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read by the NEXT kernel (norm_finalize_kernel)
+}
+
+// norm_finalize_kernel's side: wait for every rank's flag of this job, then copy the `n` floats at `off` of every rank's slot into the
+// local table `dst` ([world][stride], the layout the all-reduced table had).  Whole workgroup; returns false when a peer never answered.
+__device__ __forceinline__ bool peer_stats_collect(const PeerDev& p, int job, float* dst, int stride, int off, int n) {
+    __shared__ unsigned s_bad;
+    const unsigned s = __hip_atomic_load(p.sseq + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), par = s & 1u;
+    if (threadIdx.x == 0) s_bad = 0u;
+    __syncthreads();
+    if (threadIdx.x < (unsigned)p.world) {
+        const unsigned* f = peer_sflag(p, p.rank, par, job, threadIdx.x);
+        unsigned it = 0;
+        while (peer_ld_sys(f) != s) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++it > p.spin_limit) { __hip_atomic_store(p.err, 1u + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_bad = 1u; break; }
+        }
+    }
+    if (threadIdx.x < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __syncthreads();
+    if (s_bad) return false;
+    const float* mine = p.sslots[p.rank] + (size_t)par * p.world * p.scap;
+    for (int i = threadIdx.x; i < n * p.world; i += blockDim.x) {
+        const int r = i / n, e = i - r * n;
+        dst[(size_t)r * stride + off + e] = __hip_atomic_load(mine + (size_t)r * p.scap + off + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    return true;
+}
+
 
 #define PEER_THREADS 256
 // V = float4 per thread of the push kernel = 1024-float pieces per workgroup: fewer, larger workgroups pay fewer system-scope

@@ -194,3 +194,37 @@ def test_two_ranks_bf16_path(tmp_path, world, hidden, E, T, nmb, epochs):
     for k in ("rows", "theta", "adam_m", "adam_v"):
         for out in outs[1:]:
             np.testing.assert_array_equal(outs[0][k], out[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,hidden,E,T", [(2, (64, 64), 16, 12), (8, (256, 256), 64, 6)])
+def test_statistics_exchange_inside_the_statistics_kernels_is_bitwise_the_all_reduce_form(tmp_path, world, hidden, E, T):
+    """Over peer-mapped regions norm_batch_kernel's last workgroups write this rank's batch moments straight into every rank's gather
+    area and norm_finalize_kernel waits for the flags (no push / sum launches between them).  The table that arrives is the table the
+    general all-reduce delivered (PPO_HIP_PEER_STATS=0), so every rollout field and the running statistics must be the same BITS."""
+    tmp = str(tmp_path)
+    fake = build_fake_rccl(tmp)
+    nmb, epochs = 2, 1
+    orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(14)
+    rng = np.random.RandomState(51)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    nz = o.Normalizer(E, 18)
+    ro, _, _ = o.collect(orc, nz, 1234, T, noise, GAMMA, LAM)
+    Bl = (E // world) * T
+    perms = np.stack([np.stack([rng.permutation(Bl).astype(np.int32) for _ in range(epochs)]) for _ in range(world)])
+    res = []
+    for mode in ("1", "0"):
+        sub = os.path.join(tmp, "m" + mode); os.makedirs(sub)
+        uid = np.zeros(128, np.uint8)
+        name = ("/ppo_dp_st_%d_%d_%s" % (os.getpid(), rng.randint(1 << 30), mode)).encode()
+        uid[:len(name)] = np.frombuffer(name, np.uint8)
+        fin = os.path.join(sub, "in.npz")
+        np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=orc.theta, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
+                 noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
+        env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="1", PPO_HIP_PEER_STATS=mode)
+        res.append(run_workers(sub, world, fin, env))
+    for a, b in zip(*res):
+        for k in ("ro_obs", "ro_actions", "ro_values", "ro_neglogp", "ro_rewards", "ro_returns", "ro_dones", "obs_mean", "obs_var", "obs_count", "ret_mean", "ret_var", "ret_count"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    close(res[0][0]["obs_mean"], nz.obs_rms.mean, rtol=1e-5, atol=1e-6)
+    assert float(res[0][0]["obs_count"]) == nz.obs_rms.count
