@@ -371,24 +371,52 @@ def main():
     traffic = traffic_source = rocprof_avg_us = rocprof_source = None
     # kernel names of the dominant class, most specific first (the class "train_fwd_bwd" is train8_kernel on the 18-obs / [256,256] shape,
     # train_fwd_bwd_kernel on other wide fp32 shapes, narrow_train_kernel for nets <= 64 wide, the tanh GEMM on the bf16 path)
-    knames = {"train_fwd_bwd": ["train8_kernel", "train_fwd_bwd_kernel", "narrow_train_kernel", "gemm_nt_bf16_kernel<4, 0>"],
-              "weight_grad": ["weight_grad_assemble_kernel", "weight_grad_kernel", "gemm_dw_bf16_kernel"],
-              "policy_step": ["policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_step_kernel"]}[dom]
+    # The timed class may be ONE kernel (fp32 paths) or a SEQUENCE of launches per train step (bf16 path: L tanh GEMMs, the head GEMM, the loss
+    # kernel, L TanhGrad GEMMs).  `members` = (kernel-name pattern, launches of it per launch of the class); the profile numbers of a
+    # class are the sums over its members x their launches per step, so that traffic / rocprof_avg_us describe the same thing as
+    # flop_per_launch and avg_us.  (For a single-kernel class that is just that kernel's row.)
+    L = len(cfg["hidden"])
+    if bf16:
+        members = {"train_fwd_bwd": [("gemm_nt_bf16_kernel<4, 0>", L), ("gemm_nt_bf16_kernel<4, 2>", 1), ("bf16_loss_kernel", 1), ("gemm_nt_bf16_kernel<4, 1>", L)],
+                   "weight_grad": [("gemm_dw_bf16_kernel", 1)],
+                   "policy_step": [("bf16_stage_kernel", 1), ("gemm_nt_bf16_kernel<4, 0>", L), ("gemm_nt_bf16_kernel<4, 2>", 1), ("bf16_sample_kernel", 1)]}[dom]
+    else:
+        first = {"train_fwd_bwd": ["train8_kernel", "train_fwd_bwd_kernel", "narrow_train_kernel"],
+                 "weight_grad": ["weight_grad_assemble_kernel", "weight_grad_kernel"],
+                 "policy_step": ["policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_step_kernel"]}[dom]
+        members = None                                       # resolved below: the first of these names the profile holds
     try:
         idx = json.load(open(os.path.join(ROOT, "profiles", "current.json"))).get(args.config, {})
+        note = (" [profiled with %s]" % idx["env"]) if idx.get("env") else ""      # e.g. eager launches where the profiler cannot follow the update's graph
         if idx.get("hbm_traffic"):
             kk = json.load(open(os.path.join(ROOT, "profiles", idx["hbm_traffic"])))["kernels"]
-            t = [v for kn in knames for k, v in kk.items() if kn in k][:1]
-            if t:
-                traffic = (2.0 * t[0]["FETCH_SIZE"] + t[0]["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in t[0] else (2.0 * t[0]["FETCH_SIZE_KB"] + t[0]["WRITE_SIZE_KB"]) * 1024.0
-                traffic_source = "profiles/%s (offline rocprofv3 --pmc passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % idx["hbm_traffic"]
+            mem = members or [(n, 1) for n in first if any(n in k for k in kk)][:1]
+            tot, ok = 0.0, bool(mem)
+            for pat, per in mem:
+                hit = [v for k, v in kk.items() if pat in k][:1]
+                if not hit or "FETCH_SIZE" not in hit[0] or "WRITE_SIZE" not in hit[0]:
+                    ok = False
+                    break
+                tot += per * (2.0 * hit[0]["FETCH_SIZE"] + hit[0]["WRITE_SIZE"]) * 1024.0
+            if ok:
+                traffic = tot
+                traffic_source = "profiles/%s (offline rocprofv3 --pmc passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md; %s)%s" % (
+                    idx["hbm_traffic"], " + ".join("%d x %s" % (per, pat) for pat, per in mem), note)
         if idx.get("kernel_stats"):
             import csv
             rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", idx["kernel_stats"]))))
-            hit = [r for kn in knames for r in rows if kn in r["Name"]][:1]
-            if hit:
-                rocprof_avg_us = float(hit[0]["AverageNs"]) / 1e3
-                rocprof_source = "profiles/%s (rocprofv3 --kernel-trace --stats of this command; kernel %s)" % (idx["kernel_stats"], hit[0]["Name"].split("(")[0])
+            mem = members or [(n, 1) for n in first if any(n in r["Name"] for r in rows)][:1]
+            tot, ok = 0.0, bool(mem)
+            for pat, per in mem:
+                hit = [r for r in rows if pat in r["Name"]][:1]
+                if not hit:
+                    ok = False
+                    break
+                tot += per * float(hit[0]["AverageNs"]) / 1e3
+            if ok:
+                rocprof_avg_us = tot
+                rocprof_source = "profiles/%s (rocprofv3 --kernel-trace --stats of this command; %s)%s" % (
+                    idx["kernel_stats"], " + ".join("%d x %s" % (per, pat) for pat, per in mem), note)
     except Exception as e:
         traffic_source = "unavailable: %r" % (e,)
     step_flops = (f_fwd + f_dx + f_dw) * M

@@ -18,7 +18,7 @@
  *   - a non-finite gradient norm poisons the weights with NaN exactly like G:24493-24543; not an error
  *   - there is NO CPU fallback: every call fails loudly when no gfx950 device is usable
  *   - PPO_F32 arithmetic: exact-fp32 matrix instructions (a k-ordered fmaf chain), correctly rounded square root / division in
- *     the clip + Adam step.  ONE stated deviation: a handle of the reference's own [64,64] shape (18 obs / 18 act) applies Adam
+ *     the clip + Adam step.  ONE stated deviation: a handle of the reference's own [64,64] shape (up to 32 observations and 32 actions: 18 / 18) applies Adam
  *     inside the next train kernel's prologue during ppo_update and uses the hardware's 1-ulp reciprocal and square root for the
  *     quotient m * alpha / (sqrt(v) + eps) in ALL its Adam steps (so that both forms agree bit for bit): a 3-ulp error in an update
  *     term that is ~1e-3 of the weight.  PPO_HIP_NO_LAZY_ADAM=1 switches that form, and the deviation, off.

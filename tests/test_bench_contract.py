@@ -48,3 +48,21 @@ def test_cpu_baseline_leg_runs_without_a_gpu_and_covers_a_whole_update():
     r = bench.cpu_vectorised_leg("cfg4", 1, 1.0)
     assert r["value"] > 0 and r["cores"] == 1 and r["covers"] == 1.0 and "train steps" in r["sample"]
     assert bench.granted_cores() >= 1
+
+
+@pytest.mark.gpu
+def test_bench_roofline_of_a_multi_kernel_class_is_consistent_at_cfg5():
+    """bf16 path: the timed class `train_fwd_bwd` is a SEQUENCE of launches per train step; the profile-derived numbers in the roofline
+    block (rocprof_avg_us, traffic) must describe the same sequence as flop_per_launch / avg_us, not one of its kernels."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    r = d["roofline"]
+    assert d["dtype"] == "bf16" and r["kernel"] == "train_fwd_bwd" and r["peak"] == 2500.0
+    if r["rocprof_avg_us"] is not None:
+        assert 0.5 < r["rocprof_avg_us"] / r["avg_us"] < 1.5 and "3 x gemm_nt_bf16_kernel<4, 0>" in r["rocprof_source"] and "PPO_HIP_NO_GRAPH" in r["rocprof_source"]
+    if r["traffic"] is not None:
+        # arithmetic intensity of the class from the two profile-derived numbers: bf16 GEMMs of K = 1024 at 256 x 128 tiles sit at a few
+        # hundred FLOP per HBM byte; one kernel's traffic under the whole class's FLOP (the round-3 mix-up) gave > 1300
+        assert 50.0 < r["flop_per_launch"] / r["traffic"] < 800.0 and "3 x gemm_nt_bf16_kernel<4, 1>" in r["traffic_source"]

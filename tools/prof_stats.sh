@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel-trace stats of bench.py at one config: tools/r3_prof.sh <tag> <config> [ENV=1 ...]  -> gpurun_out/prof_<tag>_stats.csv
+# rocprofv3 kernel-trace stats of bench.py at one config: tools/prof_stats.sh <tag> <config> [ENV=1 ...]  -> gpurun_out/prof_<tag>_stats.csv
 tag=$1; cfg=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out
