@@ -115,15 +115,20 @@ class NumpyPPO:
         return losses, G
 
     def clip_adam(self, grad, lr):
+        """clip_by_global_norm + ApplyAdam over the flat vectors, in place (two scratch vectors, no other temporaries)"""
         o = self.orc
-        norm = np.sqrt(np.dot(grad.astype(np.float64), grad.astype(np.float64))).astype(np.float32)       # sqrt(2 * sum of L2Loss)
+        norm = np.float32(np.sqrt(np.dot(grad, grad)))                                   # sqrt(2 * sum of L2Loss): BLAS sdot
         scale = self.maxn * min(F(1.0) / norm, F(1.0) / self.maxn) if np.isfinite(norm) else F(np.nan)
-        gs = grad * F(scale)
+        if not hasattr(self, "_t0"):
+            self._t0 = np.empty_like(grad); self._t1 = np.empty_like(grad)
+        gs, t = self._t0, self._t1
+        np.multiply(grad, F(scale), out=gs)
         b1p, b2p = o.pow
         alpha = F(lr) * np.sqrt(F(1.0) - b2p) / (F(1.0) - b1p)
-        o.m += (gs - o.m) * (F(1.0) - self.b1)
-        o.v += (gs * gs - o.v) * (F(1.0) - self.b2)
-        o.theta -= (o.m * alpha) / (np.sqrt(o.v) + self.eps)
+        np.subtract(gs, o.m, out=t); t *= (F(1.0) - self.b1); o.m += t                   # m += (g - m)(1 - b1)
+        np.multiply(gs, gs, out=t); t -= o.v; t *= (F(1.0) - self.b2); o.v += t           # v += (g^2 - v)(1 - b2)
+        np.sqrt(o.v, out=t); t += self.eps
+        np.multiply(o.m, alpha, out=gs); gs /= t; o.theta -= gs                          # theta -= alpha m / (sqrt(v) + eps)
         o.pow[0] = b1p * self.b1
         o.pow[1] = b2p * self.b2
         return norm
