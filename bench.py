@@ -567,7 +567,7 @@ def main():
                 g.close()
             r = hostapi.learn(E, T, cfg["hidden"], n_updates=6, nminibatches=nmb, noptepochs=ep, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM)
             out["host_env"] = {"env_steps_per_s": r["env_steps_per_s"], "collect_ms": r["collect_ms"], "update_ms": r["update_ms"],
-                               "collect_phase_ms": r["phase_ms"],
+                               "collect_phase_ms": r["phase_ms"], "vec_env_pool": r["vec_env_pool"],
                                "note": "SeededEnvMock x %d behind the pooled VecEnv on the host cores, PCIe round trip per env step" % E}
         except Exception as e:                               # extra leg: never fatal for the contract line
             out["host_env"] = {"error": repr(e)}

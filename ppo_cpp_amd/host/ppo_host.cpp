@@ -179,6 +179,7 @@ struct ppo_host_result {
     char error[256];
     double obs_count, ret_count;     // running-statistics counts after the run (1e-6 = never updated)
     double phase_env_ms, phase_act_ms, phase_observe_ms;   // host-Env collect split per update: Env::step | ppo_rollout_act (kernel + D2H + sync) | ppo_rollout_observe (pack + H2D enqueue)
+    int pool_workers, pool_chunk, pool_active;              // what the pooled VecEnv settled on: threads incl. the caller, environments per claimed chunk, threads that took part in the last step
 };
 
 // explicit inputs / extra outputs of a parity run (all optional)
@@ -208,7 +209,8 @@ static int run_learn(const ppo_host_args* a, ppo_host_result* out, const ppo_hos
             else envs.push_back(std::make_shared<EnvMock>(i + 1));
         }
         std::unique_ptr<Env> inner;
-        if (a->n_envs > 1) inner.reset(new VecEnv(envs, a->max_workers));
+        VecEnv* pool = nullptr;
+        if (a->n_envs > 1) inner.reset(pool = new VecEnv(envs, a->max_workers));
         else inner.reset(a->seeded_env ? static_cast<Env*>(new SeededEnvMock(1234u, 0)) : static_cast<Env*>(new EnvMock(1)));
         {
             EnvNormalize env{std::move(inner), h, /*training=*/true, a->norm_obs != 0, a->norm_reward != 0, 10.f, 10.f, a->gamma};
@@ -252,6 +254,7 @@ static int run_learn(const ppo_host_args* a, ppo_host_result* out, const ppo_hos
             out->fps_last = hist.back().fps;
             (void)sec;
             out->phase_env_ms = algo.phase_env_ms / n; out->phase_act_ms = algo.phase_act_ms / n; out->phase_observe_ms = algo.phase_observe_ms / n;
+            if (pool) { out->pool_workers = pool->pool_workers(); out->pool_chunk = pool->pool_chunk(); out->pool_active = pool->pool_active(); }
             nlohmann::json j;                                   // serialise round trip of the normaliser
             env.serialize(j);
             out->obs_count = j["obs_rms"]["count"].get<double>(); out->ret_count = j["ret_rms"]["count"].get<double>();

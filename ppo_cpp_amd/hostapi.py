@@ -18,7 +18,8 @@ class HostResult(C.Structure):
     _fields_ = [("env_steps_per_s", C.c_double), ("collect_ms", C.c_double), ("update_ms", C.c_double),
                 ("losses", C.c_float * 5), ("fps_last", C.c_int), ("error", C.c_char * 256),
                 ("obs_count", C.c_double), ("ret_count", C.c_double),
-                ("phase_env_ms", C.c_double), ("phase_act_ms", C.c_double), ("phase_observe_ms", C.c_double)]
+                ("phase_env_ms", C.c_double), ("phase_act_ms", C.c_double), ("phase_observe_ms", C.c_double),
+                ("pool_workers", C.c_int), ("pool_chunk", C.c_int), ("pool_active", C.c_int)]
 
 
 def load_host_library(build=True):
@@ -50,7 +51,8 @@ def learn(n_envs, n_steps, hidden, n_updates, nminibatches=32, noptepochs=10, lr
         raise RuntimeError(r.error.decode())
     return {"env_steps_per_s": r.env_steps_per_s, "collect_ms": r.collect_ms, "update_ms": r.update_ms,
             "losses": [float(x) for x in r.losses], "fps_last": r.fps_last, "obs_count": r.obs_count, "ret_count": r.ret_count,
-            "phase_ms": {"env_step": r.phase_env_ms, "act_kernel_d2h_sync": r.phase_act_ms, "observe_pack_h2d_enqueue": r.phase_observe_ms}}
+            "phase_ms": {"env_step": r.phase_env_ms, "act_kernel_d2h_sync": r.phase_act_ms, "observe_pack_h2d_enqueue": r.phase_observe_ms},
+            "vec_env_pool": {"workers": r.pool_workers, "chunk": r.pool_chunk, "active_in_last_step": r.pool_active}}
 
 
 class HostExplicit(C.Structure):
