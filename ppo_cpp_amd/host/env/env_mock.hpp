@@ -55,10 +55,13 @@ inline float sym_unit(uint32_t h) { return (float)(h >> 8) * (1.0f / 8388608.0f)
 
 class SeededEnvMock : public Env {
 public:
-    SeededEnvMock(uint32_t seed, uint32_t env_id) : seed_(seed), id_(env_id), step_(0), last_rew_(0.f), key_(ppo_detail::ctr_key(seed, env_id)) {}
+    // obs_dim / act_dim: 18 / 18 like EnvMock; 36 / 18 stands in for the hexapod that also observes its velocities
+    // (reference env/hexapod_closed_loop_env.hpp:20).  Hash lanes 0 .. obs_dim-1 = the observation, obs_dim = reward, obs_dim + 1 = done.
+    SeededEnvMock(uint32_t seed, uint32_t env_id, int obs_dim = 18, int act_dim = 18)
+        : seed_(seed), id_(env_id), step_(0), last_rew_(0.f), key_(ppo_detail::ctr_key(seed, env_id)), kDim(obs_dim), kAct(act_dim) {}
     std::string get_action_space() override { return Env::SPACE_CONTINOUS; }
     std::string get_observation_space() override { return Env::SPACE_CONTINOUS; }
-    int get_action_space_size() override { return kDim; }
+    int get_action_space_size() override { return kAct; }
     int get_observation_space_size() override { return kDim; }
     Mat reset() override { step_ = 0; return obs_at(0); }
     std::vector<Mat> step(const Mat& /*actions*/) override {
@@ -80,9 +83,9 @@ public:
     float get_time() override { return 0.f; }
 
 private:
-    static constexpr int kDim = 18;
     Mat obs_at(uint32_t step) const { Mat m(1, kDim); for (int j = 0; j < kDim; ++j) m(0, j) = ppo_detail::sym_unit(ppo_detail::ctr_hash_keyed(key_, step, (uint32_t)j)); return m; }
     uint32_t seed_, id_, step_;
     float last_rew_;
     uint64_t key_;                  // splitmix64(seed, env id): the step-independent half of the counter hash
+    int kDim, kAct;
 };

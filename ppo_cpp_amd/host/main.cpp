@@ -26,7 +26,7 @@ const char* kAliases[][2] = {{"-d", "dir"}, {"--dir", "dir"}, {"-p", "path"}, {"
                              {"-c", "cr"}, {"--cr", "cr"}, {"--clip_range", "cr"}, {"--cliprange", "cr"}, {"--saves", "saves"}, {"--num_saves", "saves"},
                              {"--epochs", "epochs"}, {"--num_epochs", "epochs"}, {"--batch_steps", "batch_steps"}, {"--n_steps", "batch_steps"},
                              {"-j", "threads"}, {"--threads", "threads"}, {"--jobs", "threads"}, {"--num_threads", "threads"}, {"--hidden", "hidden"},
-                             {"--minibatches", "minibatches"}, {"--seed", "seed"}, {"-g", "graph"}, {"--graph", "graph"}, {"--graph_path", "graph"}};
+                             {"--minibatches", "minibatches"}, {"--seed", "seed"}, {"-g", "graph"}, {"--graph", "graph"}, {"--graph_path", "graph"}, {"--obs", "obs"}};
 const char* kSwitches[][2] = {{"-r", "resume"}, {"--resume", "resume"}, {"-v", "verbose"}, {"--verbose", "verbose"}, {"--seeded", "seeded"}};
 }  // namespace
 
@@ -37,7 +37,8 @@ int main(int argc, char** argv) {
         bool ok = false;
         if (a == "-h" || a == "--help") {
             std::printf("usage: ppo_cpp_hip [--steps N] [--lr X] [--ent X] [--cr X] [--epochs N] [--batch_steps N] [--threads N_ENVS] [--minibatches N]\n"
-                        "                   [--hidden 256,256] [--saves N --dir DIR --id ID] [--path CKPT_PREFIX] [--resume] [--seeded] [--seed N]\n");
+                        "                   [--hidden 256,256] [--saves N --dir DIR --id ID] [--path CKPT_PREFIX] [--resume] [--seeded] [--seed N]\n"
+                        "                   [--obs 36   (with --seeded: observation width of the mock environment; 36 = the hexapod that observes its velocities)]\n");
             return 0;
         }
         for (auto& al : kAliases) if (a == al[0] && i + 1 < argc) { f.kv[al[1]] = argv[++i]; ok = true; break; }
@@ -50,7 +51,9 @@ int main(int argc, char** argv) {
     const bool training = !f.has("path") || f.has("resume");                  // ppo2.cpp:171
     ppo_handle* h = nullptr;
     ppo_config cfg;
-    ppo_config_default(&cfg, 18, 18, (int)hidden.size(), hidden.data());
+    const int obs_dim = (int)f.num("obs", 18);                                  // (the reference's closed-loop hexapod: 18, or 36 with observe_velocities, hexapod_closed_loop_env.hpp:20)
+    if (obs_dim != 18 && !f.has("seeded")) { std::fprintf(stderr, "--obs needs --seeded (EnvMock, the reference's stub, is 18 / 18)\n"); return 1; }
+    ppo_config_default(&cfg, obs_dim, 18, (int)hidden.size(), hidden.data());
     cfg.ent_coef = (float)f.num("ent", 0.0);                                    // live here (the reference bakes it into the graph)
     int rc = 0;
     try {
@@ -64,12 +67,12 @@ int main(int argc, char** argv) {
         }
         std::vector<std::shared_ptr<Env>> envs;
         for (int i = 0; i < n_envs; ++i) {
-            if (f.has("seeded")) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i));
+            if (f.has("seeded")) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i, obs_dim, 18));
             else envs.push_back(std::make_shared<EnvMock>(i + 1));
         }
         std::unique_ptr<Env> inner;
         if (n_envs > 1) inner.reset(new VecEnv(envs));                           // ppo2.cpp:188-201
-        else inner.reset(f.has("seeded") ? static_cast<Env*>(new SeededEnvMock(1234u, 0)) : static_cast<Env*>(new EnvMock(1)));
+        else inner.reset(f.has("seeded") ? static_cast<Env*>(new SeededEnvMock(1234u, 0, obs_dim, 18)) : static_cast<Env*>(new EnvMock(1)));
         EnvNormalize env{std::move(inner), h, training};                          // ppo2.cpp:207
         PPO2 algorithm{h, env, 0.99f, n_steps, cfg.ent_coef, (float)f.num("lr", 1e-3), 0.5f, 0.5f, 0.95f, (int)f.num("minibatches", 32),
                        (int)f.num("epochs", 10), (float)f.num("cr", 0.2)};         // ppo2.cpp:215-217

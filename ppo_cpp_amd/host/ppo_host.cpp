@@ -171,6 +171,7 @@ struct ppo_host_args {
     int reference_loop;      // 1: force the literal reference loop (Runner::run + host shuffle + _train_step)
     int norm_obs, norm_reward;   // EnvNormalize constructor flags (env_normalize.hpp:24-27)
     unsigned long long seed;     // PPO2::seed (exploration noise + epoch shuffles)
+    int obs_dim, act_dim;        // SeededEnvMock's shape (0 = 18): 36 / 18 is the hexapod with observed velocities (hexapod_closed_loop_env.hpp:20)
 };
 struct ppo_host_result {
     double env_steps_per_s, collect_ms, update_ms;
@@ -198,20 +199,22 @@ static int run_learn(const ppo_host_args* a, ppo_host_result* out, const ppo_hos
     ppo_handle* h = nullptr;
     try {
         ppo_config cfg;
-        ppo_config_default(&cfg, 18, 18, a->n_hidden, a->hidden);
+        const int O = a->obs_dim > 0 ? a->obs_dim : 18, A = a->act_dim > 0 ? a->act_dim : 18;
+        if ((O != 18 || A != 18) && !a->seeded_env) throw std::runtime_error("EnvMock (the reference's stub) is 18 / 18");
+        ppo_config_default(&cfg, O, A, a->n_hidden, a->hidden);
         cfg.device = a->device;
         if (ppo_create(&cfg, &h) != 0) throw std::runtime_error(ppo_last_error(nullptr));
         if (ppo_init_orthogonal(h, 0) != 0) throw std::runtime_error(ppo_last_error(h));
         if (x && x->theta_in && ppo_set_flat(h, 0, x->theta_in, ppo_num_params(h)) != 0) throw std::runtime_error(ppo_last_error(h));
         std::vector<std::shared_ptr<Env>> envs;
         for (int i = 0; i < a->n_envs; ++i) {
-            if (a->seeded_env) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i));
+            if (a->seeded_env) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i, O, A));
             else envs.push_back(std::make_shared<EnvMock>(i + 1));
         }
         std::unique_ptr<Env> inner;
         VecEnv* pool = nullptr;
         if (a->n_envs > 1) inner.reset(pool = new VecEnv(envs, a->max_workers));
-        else inner.reset(a->seeded_env ? static_cast<Env*>(new SeededEnvMock(1234u, 0)) : static_cast<Env*>(new EnvMock(1)));
+        else inner.reset(a->seeded_env ? static_cast<Env*>(new SeededEnvMock(1234u, 0, O, A)) : static_cast<Env*>(new EnvMock(1)));
         {
             EnvNormalize env{std::move(inner), h, /*training=*/true, a->norm_obs != 0, a->norm_reward != 0, 10.f, 10.f, a->gamma};
             PPO2 algorithm{h, env, a->gamma, a->n_steps, cfg.ent_coef, a->lr, 0.5f, 0.5f, a->lam, a->nminibatches, a->noptepochs, a->cliprange};

@@ -11,7 +11,7 @@ class HostArgs(C.Structure):
                 ("nminibatches", C.c_int), ("noptepochs", C.c_int), ("n_updates", C.c_int),
                 ("lr", C.c_float), ("cliprange", C.c_float), ("gamma", C.c_float), ("lam", C.c_float),
                 ("seeded_env", C.c_int), ("device", C.c_int), ("max_workers", C.c_int), ("reference_loop", C.c_int),
-                ("norm_obs", C.c_int), ("norm_reward", C.c_int), ("seed", C.c_ulonglong)]
+                ("norm_obs", C.c_int), ("norm_reward", C.c_int), ("seed", C.c_ulonglong), ("obs_dim", C.c_int), ("act_dim", C.c_int)]
 
 
 class HostResult(C.Structure):
@@ -36,7 +36,7 @@ def load_host_library(build=True):
 
 
 def learn(n_envs, n_steps, hidden, n_updates, nminibatches=32, noptepochs=10, lr=3.93141e-4, cliprange=0.161023, gamma=0.99,
-          lam=0.95, seeded_env=True, device=-1, max_workers=0, reference_loop=False, norm_obs=True, norm_reward=True, seed=0):
+          lam=0.95, seeded_env=True, device=-1, max_workers=0, reference_loop=False, norm_obs=True, norm_reward=True, seed=0, obs_dim=18, act_dim=18):
     lib = load_host_library()
     a = HostArgs()
     a.n_envs, a.n_steps, a.n_hidden = n_envs, n_steps, len(hidden)
@@ -46,6 +46,7 @@ def learn(n_envs, n_steps, hidden, n_updates, nminibatches=32, noptepochs=10, lr
     a.lr, a.cliprange, a.gamma, a.lam = lr, cliprange, gamma, lam
     a.seeded_env, a.device, a.max_workers, a.reference_loop = int(seeded_env), device, max_workers, int(reference_loop)
     a.norm_obs, a.norm_reward, a.seed = int(norm_obs), int(norm_reward), seed
+    a.obs_dim, a.act_dim = obs_dim, act_dim
     r = HostResult()
     if lib.ppo_host_learn(C.byref(a), C.byref(r)) != 0:
         raise RuntimeError(r.error.decode())
@@ -62,7 +63,7 @@ class HostExplicit(C.Structure):
 
 
 def learn_explicit(n_envs, n_steps, hidden, theta, noise, perms, nminibatches, lr=3.93141e-4, cliprange=0.161023, gamma=0.99, lam=0.95,
-                   reference_loop=False, device=-1):
+                   reference_loop=False, device=-1, obs_dim=18, act_dim=18):
     """PPO2::learn for perms.shape[0] updates with explicit weights, exploration noise [U,T,E,A] and epoch permutations [U,epochs,B]
     on SeededEnvMock x n_envs behind VecEnv + EnvNormalize.  Returns per-update mean losses [U,5], final weights, obs_rms, ret_rms."""
     import numpy as np
@@ -78,8 +79,10 @@ def learn_explicit(n_envs, n_steps, hidden, theta, noise, perms, nminibatches, l
     a.lr, a.cliprange, a.gamma, a.lam = lr, cliprange, gamma, lam
     a.seeded_env, a.device, a.max_workers, a.reference_loop = 1, device, 0, int(reference_loop)
     a.norm_obs, a.norm_reward, a.seed = 1, 1, 0
+    a.obs_dim, a.act_dim = obs_dim, act_dim
+    assert noise.shape[3] == act_dim
     out = {"losses": np.zeros((U, 5), np.float32), "theta": np.zeros(theta.size, np.float32),
-           "obs_mean": np.zeros(18, np.float32), "obs_var": np.zeros(18, np.float32), "obs_count": np.zeros(1, np.float64),
+           "obs_mean": np.zeros(obs_dim, np.float32), "obs_var": np.zeros(obs_dim, np.float32), "obs_count": np.zeros(1, np.float64),
            "ret_mean": np.zeros(1, np.float32), "ret_var": np.zeros(1, np.float32), "ret_count": np.zeros(1, np.float64)}
     x = HostExplicit(theta.ctypes.data, noise.ctypes.data, perms.ctypes.data, out["losses"].ctypes.data, out["theta"].ctypes.data,
                      out["obs_mean"].ctypes.data, out["obs_var"].ctypes.data, out["obs_count"].ctypes.data,

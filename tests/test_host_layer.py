@@ -21,8 +21,11 @@ def test_host_utilities():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("reference_loop", [False, True])
-@pytest.mark.parametrize("hidden,E,T,nmb,epochs", [((64, 64), 8, 32, 4, 2), ((256, 256), 8, 16, 4, 2)])
-def test_learn_matches_the_oracle_update_by_update(hidden, E, T, nmb, epochs, reference_loop):
+@pytest.mark.parametrize("hidden,E,T,nmb,epochs,O,A", [((64, 64), 8, 32, 4, 2, 18, 18), ((256, 256), 8, 16, 4, 2, 18, 18),
+                                                       # the reference's other real shape: the hexapod that also observes its velocities (36 observations,
+                                                       # env/hexapod_closed_loop_env.hpp:20,61-72), with ONE environment like its shipped command line and with 8
+                                                       ((64, 64), 1, 64, 4, 2, 36, 18), ((256, 256), 8, 16, 4, 2, 36, 18)])
+def test_learn_matches_the_oracle_update_by_update(hidden, E, T, nmb, epochs, O, A, reference_loop):
     """PPO2::learn end to end against the oracle (reference ppo2/ppo2.hpp:264-349 driving ppo2/runner.hpp:56-191): SeededEnvMock x 8
     behind VecEnv + EnvNormalize, two updates with EXPLICIT exploration noise and epoch permutations, through the HBM-resident
     loop and through the literal reference loop (Runner::run, host-side row permutation and slicing, _train_step per minibatch).
@@ -32,18 +35,19 @@ def test_learn_matches_the_oracle_update_by_update(hidden, E, T, nmb, epochs, re
     from oracle import oracle as o
     LR, CR, GAMMA, LAM = 0.000393141177482903, 0.16102319955825806, 0.99, 0.95
     U, B = 2, E * T
-    orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(3)
-    orc.tensor("pi/logstd")[:] = np.random.RandomState(4).uniform(-1.0, 0.2, (1, 18))
+    orc = o.Oracle(O, A, list(hidden)); orc.init_orthogonal(3)
+    orc.tensor("pi/logstd")[:] = np.random.RandomState(4).uniform(-1.0, 0.2, (1, A))
     theta0 = orc.theta.copy()
     rng = np.random.RandomState(77)
-    noise = rng.normal(size=(U, T, E, 18)).astype(np.float32)
+    noise = rng.normal(size=(U, T, E, A)).astype(np.float32)
     perms = np.empty((U, epochs, B), np.int32)
     for u in range(U):
         perm = np.arange(B, dtype=np.int32)                        # identity per update, shuffled cumulatively per epoch (ppo2.hpp:274-288)
         for e in range(epochs):
             rng.shuffle(perm); perms[u, e] = perm
-    got = hostapi.learn_explicit(E, T, list(hidden), theta0, noise, perms, nmb, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM, reference_loop=reference_loop)
-    nz = o.Normalizer(E, 18, gamma=GAMMA)
+    got = hostapi.learn_explicit(E, T, list(hidden), theta0, noise, perms, nmb, lr=LR, cliprange=CR, gamma=GAMMA, lam=LAM, reference_loop=reference_loop,
+                                 obs_dim=O, act_dim=A)
+    nz = o.Normalizer(E, O, gamma=GAMMA)
     state = None
     for u in range(U):
         ro, state, _ = o.collect(orc, nz, 1234, T, noise[u], GAMMA, LAM, step0=u * T, state=state)
@@ -97,6 +101,13 @@ def test_command_line_driver_trains_saves_and_plays_back(tmp_path):
     play = subprocess.run([exe, "--path", str(tmp_path / "run.pkl.1"), "--hidden", "64,64", "--seeded"], capture_output=True, text=True, timeout=120)
     assert play.returncode == 0, play.stderr
     assert play.stdout.count("action[0..3]") == 5
+    # the hexapod's other shape from the command line: 36 observations (observe_velocities), ONE environment like the reference's shipped run
+    out = subprocess.run([exe, "--steps", "1024", "--batch_steps", "256", "--threads", "1", "--hidden", "64,64", "--epochs", "2", "--minibatches", "4",
+                          "--seeded", "--obs", "36"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.count(",") == 6]
+    assert len(lines) == 4 and np.isfinite([float(x) for x in lines[-1].split(",")[:6]]).all()
+    assert subprocess.run([exe, "--obs", "36"], capture_output=True, text=True, timeout=60).returncode == 1        # (EnvMock is 18 / 18)
 
 
 @pytest.mark.gpu
