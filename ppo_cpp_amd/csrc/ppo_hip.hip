@@ -85,6 +85,7 @@ struct ppo_handle {
     float* hyper = nullptr;           // {lr, cliprange}
     float* norm_out = nullptr;        // [1]
     GradSrc* grad_src = nullptr;
+    int n_tiled = 0; AdamArgs::Tiled tiled[ADAM_MAX_TILED]{};   // matrices whose transposed copy adam_kernel writes tile by tile
     // train workspaces (sized for ws_rows minibatch rows)
     int ws_rows = 0;
     float* x0g = nullptr;
@@ -275,7 +276,9 @@ void prof_collect(ppo_handle* h) {
 }
 
 // ---- layout -------------------------------------------------------------------------------------------------
-void add_tensor(ppo_handle* h, const char* name, int rows, int cols, int prow, int pcol, int& od, int& op) {
+void add_tensor(ppo_handle* h, const char* name, int rows, int cols, int prow, int pcol, int& od, int& op, bool tile_align = false) {
+    // a matrix with a transposed copy starts on a 1024-element boundary when it can be walked in 32 x 32 tiles (adam_kernel's tiled form)
+    if (tile_align && prow % 32 == 0 && pcol % 32 == 0) op = ru(op, 1024);
     Tensor t{};
     snprintf(t.name, sizeof t.name, "%s", name);
     t.rows = rows; t.cols = cols; t.prow = prow; t.pcol = pcol;
@@ -318,9 +321,10 @@ int build_layout(ppo_handle* h) {
     char nm[32];
     for (int l = 0; l < n.L; ++l) {
         const int in = l ? n.H[l - 1] : n.O, inp = l ? n.Hp[l - 1] : n.Kp0;
-        snprintf(nm, sizeof nm, "pi_fc%d/w", l); n.w_off[0][l] = op; add_tensor(h, nm, in, n.H[l], inp, n.Hp[l], od, op);
+        const bool ta = !bf && l >= 1;                          // (layers >= 1 and the policy head have transposed copies on the fp32 paths)
+        snprintf(nm, sizeof nm, "pi_fc%d/w", l); add_tensor(h, nm, in, n.H[l], inp, n.Hp[l], od, op, ta); n.w_off[0][l] = h->tensors.back().off_pad;
         snprintf(nm, sizeof nm, "pi_fc%d/b", l); n.b_off[0][l] = op; add_tensor(h, nm, n.H[l], 0, 1, n.Hp[l], od, op);
-        snprintf(nm, sizeof nm, "vf_fc%d/w", l); n.w_off[1][l] = op; add_tensor(h, nm, in, n.H[l], inp, n.Hp[l], od, op);
+        snprintf(nm, sizeof nm, "vf_fc%d/w", l); add_tensor(h, nm, in, n.H[l], inp, n.Hp[l], od, op, ta); n.w_off[1][l] = h->tensors.back().off_pad;
         snprintf(nm, sizeof nm, "vf_fc%d/b", l); n.b_off[1][l] = op; add_tensor(h, nm, n.H[l], 0, 1, n.Hp[l], od, op);
     }
     const int HL = n.H[n.L - 1], HpL = n.Hp[n.L - 1];
@@ -328,7 +332,7 @@ int build_layout(ppo_handle* h) {
     // run through the same batched GEMM launches (the padding columns are zero and provably stay zero)
     n.wv_off = op;  add_tensor(h, "vf/w", HL, 1, HpL, bf ? n.Ap : 1, od, op);
     n.bv_off = op;  add_tensor(h, "vf/b", 1, 0, 1, bf ? n.Ap : 1, od, op);
-    n.wmu_off = op; add_tensor(h, "pi/w", HL, n.A, HpL, n.Ap, od, op);
+    add_tensor(h, "pi/w", HL, n.A, HpL, n.Ap, od, op, !bf); n.wmu_off = h->tensors.back().off_pad;
     n.bmu_off = op; add_tensor(h, "pi/b", n.A, 0, 1, n.Ap, od, op);
     n.ls_off = op;  add_tensor(h, "pi/logstd", 1, n.A, 1, n.Ap, od, op);
     h->P_dense = od; h->P_pad = op; h->n_blocks = op / 256;
@@ -465,7 +469,11 @@ void build_narrow_layout(ppo_handle* h) {
 
 int upload_grad_src(ppo_handle* h) {
     const NetDev& n = h->net;
-    std::vector<GradSrc> src(h->n_blocks);
+    // chunks no tensor covers (alignment gaps): no gradient, no mirrors
+    GradSrc none{2, 0, 0, 0, 0, -1, 0, 0, -1, 0, -1, 0, -1, 0, -1, -1};
+    std::vector<GradSrc> src(h->n_blocks, none);
+    for (size_t b = 0; b < src.size(); ++b) src[b].base = (int)b * 256;
+    h->n_tiled = 0;
     for (const Tensor& t : h->tensors) {
         GradSrc g{2, 0, 0, 0, t.off_pad, -1, t.prow, t.pcol, -1, 0, -1, 0, -1, 0, -1, -1};
         const std::string nm = t.name;
@@ -505,6 +513,8 @@ int upload_grad_src(ppo_handle* h) {
             } else if (nm == "pi/w") { g.i_off = lay.wh; g.i_ld = lay.wh_ld; g.it_off = lay.wht; g.it_ld = lay.wht_ld; }
             else if (g.p_off >= 0) g.ip_off = ib + lay.par + (g.p_off - tower * n.par_total);
         }
+        if (g.t_off >= 0 && t.off_pad % 1024 == 0 && t.prow % 32 == 0 && t.pcol % 32 == 0 && h->n_tiled < ADAM_MAX_TILED)
+            h->tiled[h->n_tiled++] = AdamArgs::Tiled{t.off_pad, t.prow * t.pcol, t.pcol, t.prow, g.t_off};
         const int nb = ru(t.prow * t.pcol, 256) / 256;
         for (int b = 0; b < nb; ++b) src[t.off_pad / 256 + b] = g;
     }
@@ -898,7 +908,10 @@ int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* p
     }
     AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
                 h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out, parts, n_parts,
-                h->bf.on ? h->bf.theta_bf : nullptr, h->narrow ? h->nw_img : nullptr, nullptr, nullptr, nullptr};
+                0, {}, h->bf.on ? h->bf.theta_bf : nullptr, h->narrow ? h->nw_img : nullptr, nullptr, nullptr, nullptr};
+    { const char* e = getenv("PPO_HIP_ADAM_NO_TILES");           // (read per call: the test compares both forms in one process)
+      const bool no_tiles = e && e[0] == '1';
+      if (!no_tiles) { aa.n_tiled = h->n_tiled; for (int q = 0; q < h->n_tiled; ++q) aa.tiled[q] = h->tiled[q]; } }
     if (h->nw_cur == 1) { aa.theta_in = h->nw_theta1; aa.m_in = h->nw_m1; aa.v_in = h->nw_v1; h->nw_cur = 0; }   // (always writes set 0)
     // (the handle whose train kernels may apply Adam in their prologue uses the same 1-ulp quotient in its launches: bit-identical forms)
     if (h->adam_fast) hipLaunchKernelGGL(adam_kernel<true>, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);

@@ -1521,6 +1521,7 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* grad, floa
 // Every block re-derives the norm from the per-block partials in the same fixed order -> identical on all
 // blocks (and on all ranks after the all-reduce).  Block 0 also writes the loss row and the next beta powers.
 // ------------------------------------------------------------------------------------------------------------
+#define ADAM_MAX_TILED 8
 struct AdamArgs {
     float* theta; float* m; float* v; const float* grad; const float* sumsq; int n_blocks;
     float* thetaT; float* par; const GradSrc* src;
@@ -1530,6 +1531,11 @@ struct AdamArgs {
     float* loss_row;             // [5] destination for this train step (may be null)
     float* norm_out;             // [1] (may be null)
     const float* norm_parts; int n_parts;   // what the norm is summed from: sumsq itself, or its 1024-wide folds for very large nets
+    // matrices whose transposed copy is written as whole 32 x 32 tiles (their region starts on a 1024-element boundary and both padded
+    // dimensions are multiples of 32): a block of adam_kernel then takes ONE tile of the matrix instead of 1024 consecutive elements,
+    // and the transposed tile leaves through LDS as 128-byte rows.  (Element by element the transposed copy is a scatter of 4-byte
+    // stores 1 KB apart -- 64 cache lines per store instruction: 1.7 us of a 40 us train step at BASELINE configs[2].)
+    int n_tiled; struct Tiled { int base, count, pcol, prow, t_off; } tiled[ADAM_MAX_TILED];
     __bf16* theta_bf;            // bf16 path: straight bf16 copy of theta kept current here (null otherwise)
     float* img;                  // narrow path: packed LDS images kept current here (null otherwise)
     const float* theta_in; const float* m_in; const float* v_in;   // read from another parameter set (narrow path's deferred Adam); null = in place
@@ -1573,10 +1579,25 @@ __device__ __forceinline__ void adam_element(float gscaled, float m, float v, fl
 template <bool FAST>
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     __shared__ float red[4];
+    __shared__ float tt[32][33];
     const int tid = threadIdx.x;
-    const size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
+    size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
     const int chunk = (int)(idx >> 8);
     const bool live = chunk < a.n_blocks;
+    // a block inside a tiled matrix takes tile (ti, tj): thread t = row t / 8, columns 4 (t % 8) .. + 3 of the tile (wave-uniform lookup in the
+    // kernel arguments: no memory round trip in front of the element loads)
+    int tiled = -1, ti = 0, tj = 0;
+    {
+        const int b0 = (int)blockIdx.x * 1024;
+#pragma unroll
+        for (int q = 0; q < ADAM_MAX_TILED; ++q)
+            if (q < a.n_tiled && b0 >= a.tiled[q].base && b0 < a.tiled[q].base + a.tiled[q].count) tiled = q;
+        if (tiled >= 0) {
+            const int k = (b0 - a.tiled[tiled].base) >> 10, tpr = a.tiled[tiled].pcol >> 5;
+            ti = k / tpr; tj = k - ti * tpr;
+            idx = (size_t)a.tiled[tiled].base + (size_t)(32 * ti + (tid >> 3)) * a.tiled[tiled].pcol + 32 * tj + 4 * (tid & 7);
+        }
+    }
     // issue this thread's element loads BEFORE the norm reduction: both memory round trips overlap
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = g4, v4 = g4, t4 = g4;
     GradSrc gs{};
@@ -1624,7 +1645,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
             *reinterpret_cast<bf16x4_t*>(a.theta_bf + idx) = o4;
         }
         const int e0 = (int)(idx - (size_t)gs.base);
-        if (gs.t_off >= 0) {                               // keep the backward pass's transposed copy current
+        if (gs.t_off >= 0 && tiled < 0) {                  // keep the backward pass's transposed copy current (element by element: small / unaligned matrices)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int e = e0 + k;
@@ -1639,6 +1660,16 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) write_images(gs, a.img, e0 + k, to[k]);
         }
+        if (tiled >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[4 * (tid & 7) + k][tid >> 3] = to[k];
+        }
+    }
+    if (tiled >= 0) {                                      // (block-uniform) the transposed tile: row r' = column 32 tj + r' of the matrix, 128 bytes per row
+        __syncthreads();
+        const int rp = tid >> 3, q4 = 4 * (tid & 7);
+        const float4 o = make_float4(tt[rp][q4], tt[rp][q4 + 1], tt[rp][q4 + 2], tt[rp][q4 + 3]);
+        st_wt4<PPO_WT_C2>(a.thetaT + a.tiled[tiled].t_off + (size_t)(32 * tj + rp) * a.tiled[tiled].prow + 32 * ti + q4, o);
     }
     if (blockIdx.x == 0) {
         if (tid == 0) {

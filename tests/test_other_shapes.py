@@ -155,3 +155,28 @@ def test_one_environment_rollout_kernel_on_other_widths(O, A, monkeypatch):
     for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
         close(g.rollout_get(f), ro[f], rtol=2e-4, atol=2e-5, msg=f)
     g.close()
+
+
+@pytest.mark.parametrize("hidden,O,A", [((256, 256), 18, 18), ((256, 256), 36, 18), ((64, 64), 18, 18), ((512, 256, 256), 18, 18)])
+def test_tiled_transposed_copies_equal_the_element_wise_form(hidden, O, A, monkeypatch):
+    """adam_kernel writes the transposed copies the backward pass streams (W_l^T, W_mu^T) as whole 32 x 32 tiles through LDS when the
+    matrix allows it; PPO_HIP_ADAM_NO_TILES=1 writes them element by element as rounds 1-3 did.  Same Adam arithmetic either way: after
+    three train steps (each backward pass reads the copies the previous step wrote) weights and both moments must be the same BITS."""
+    outs = []
+    orc = o.Oracle(O, A, list(hidden)); orc.init_orthogonal(21)
+    mbs = [H.synth_minibatch(orc, 512, seed=90 + it) for it in range(3)]
+    for tiles in (True, False):
+        if tiles:
+            monkeypatch.delenv("PPO_HIP_ADAM_NO_TILES", raising=False)
+        else:
+            monkeypatch.setenv("PPO_HIP_ADAM_NO_TILES", "1")
+        import ppo_cpp_amd
+        g = ppo_cpp_amd.PPOHip(O, A, list(hidden))
+        g.set_flat(orc.theta)
+        losses = []
+        for mb in mbs:
+            losses.append(g.train_step(LR, CR, mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"]))
+        outs.append((np.stack(losses), g.get_flat(0), g.get_flat(1), g.get_flat(2)))
+        g.close()
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
