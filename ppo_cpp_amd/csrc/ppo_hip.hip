@@ -2210,6 +2210,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             hipLaunchKernelGGL(invert_perm_kernel, dim3((Bp + 255) / 256), dim3(256), 0, h->stream, h->d_perms + (size_t)ep * Bp, h->d_inv, Bp);
             HIP_OK(h, hipGetLastError());
         }
+        bool merged = false;
         {
             ProfScope ps(h, PK_EPOCH);
             EpochArgs ea{};
@@ -2227,8 +2228,19 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
                 HIP_OK(h, hipGetLastError());
             } else if (!h->comm) {
                 ea.phase = 0;
-                hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(EP_THREADS), 0, h->stream, ea);
-                HIP_OK(h, hipGetLastError());
+                const char* em = getenv("PPO_HIP_NO_EPOCH_MERGE");       // (read when the update is captured: the test compares both forms)
+                const bool no_merge = em && em[0] == '1';
+                if (!h->bf.on && M <= EPG_MAX_M && !no_merge) {
+                    // index map, advantage statistics AND the gather of the epoch in one launch (fp32 paths; the bf16 path stages its epoch separately)
+                    GatherArgs ga{h->d_gidx, h->d_advstats, B, M, h->net.O, h->net.A, h->ro_obs, h->ro_act, h->ro_ret, h->ro_val, h->ro_nlp,
+                                  h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};
+                    hipLaunchKernelGGL(epoch_prepare_gather_kernel, dim3(nmb * EPG_SPLIT), dim3(EP_THREADS), 0, h->stream, ea, ga);
+                    HIP_OK(h, hipGetLastError());
+                    merged = true;
+                } else {
+                    hipLaunchKernelGGL(epoch_prepare_kernel, dim3(nmb), dim3(EP_THREADS), 0, h->stream, ea);
+                    HIP_OK(h, hipGetLastError());
+                }
             } else {
                 // the advantage statistics are over the whole (all-rank) minibatch (ppo2.hpp:401-406)
                 for (int phase = 1; phase <= 3; ++phase) {
@@ -2240,7 +2252,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
                 }
             }
         }
-        {
+        if (!merged) {
             ProfScope ps(h, PK_EPOCH);
             GatherArgs ga{h->d_gidx, h->d_advstats, B, M, h->net.O, h->net.A, h->ro_obs, h->ro_act, h->ro_ret, h->ro_val, h->ro_nlp,
                           h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};

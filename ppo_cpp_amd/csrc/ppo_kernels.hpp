@@ -1863,6 +1863,78 @@ __global__ __launch_bounds__(256) void epoch_gather_kernel(GatherArgs a) {
     }
 }
 
+// epoch_prepare_kernel (single rank, local shuffle) AND epoch_gather_kernel in one launch: EPG_SPLIT workgroups per minibatch each derive the
+// minibatch's index map and advantage statistics (the same statements in the same order: every one of them holds the same bits; the redundant
+// work is a few thousand integer hashes) and then copy their 1 / EPG_SPLIT share of its rows.  One launch and one dependent round trip through
+// memory (the index map) per epoch less: the map never leaves the workgroup's LDS except as this epoch's `gidx` record.
+#define EPG_SPLIT 8
+#define EPG_MAX_M 8192              // rows of a minibatch the LDS copy of the index map holds (32 KB)
+__global__ __launch_bounds__(EP_THREADS) void epoch_prepare_gather_kernel(EpochArgs a, GatherArgs ga) {
+    __shared__ float red[EP_THREADS / 64];
+    __shared__ float s_mean, s_den;
+    __shared__ int s_idx[EPG_MAX_M];
+    const int k = blockIdx.x / EPG_SPLIT, part = blockIdx.x % EPG_SPLIT, tid = threadIdx.x;
+    const uint32_t mask = (a.bits >= 32) ? 0xFFFFFFFFu : ((1u << a.bits) - 1u);
+    float sum = 0.f;
+    for (int i = tid; i < a.M; i += EP_THREADS) {
+        const int pos = k * a.M + i;
+        int r;
+        if (a.inv_perm) r = a.inv_perm[pos];
+        else {
+            uint32_t x = (uint32_t)pos;
+            do { x = keyed_bijection(x, a.bits, mask, a.keys[0], a.keys[1]); } while (x >= (uint32_t)a.B);
+            r = (int)x;
+        }
+        const int s = (r % a.T) * a.E + (r / a.T);
+        s_idx[i] = s;
+        if (part == 0) a.gidx[pos] = s;
+        sum += a.returns[s] - a.values[s];
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < EP_THREADS / 64; ++w) tot += red[w];           // fixed order
+        s_mean = tot / (float)a.M;
+    }
+    __syncthreads();
+    const float mean = s_mean;
+    float sq = 0.f;
+    for (int i = tid; i < a.M; i += EP_THREADS) {
+        const int s = s_idx[i];
+        const float d = (a.returns[s] - a.values[s]) - mean;
+        sq += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < EP_THREADS / 64; ++w) tot += red[w];
+        const float var = tot / (float)a.M;
+        s_den = (float)((double)sqrtf(var) + 1e-8);
+        if (part == 0) { a.stats[2 * k] = mean; a.stats[2 * k + 1] = s_den; }
+    }
+    __syncthreads();
+    const float den = s_den;
+    // ---- this workgroup's rows of the minibatch: [r0, r1) --------------------------------------------------------------------------------
+    const int per = (a.M + EPG_SPLIT - 1) / EPG_SPLIT, r0 = part * per, r1 = min(a.M, r0 + per);
+    const int W = ga.O + ga.A;
+    for (int i = tid; i < (r1 - r0) * W; i += EP_THREADS) {
+        const int r = r0 + i / W, j = i % W, p = k * a.M + r, s = s_idx[r];
+        if (j < ga.O) ga.mb_obs[(size_t)p * ga.O + j] = ga.obs[(size_t)s * ga.O + j];
+        else ga.mb_act[(size_t)p * ga.A + (j - ga.O)] = ga.act[(size_t)s * ga.A + (j - ga.O)];
+    }
+    for (int r = r0 + tid; r < r1; r += EP_THREADS) {
+        const int p = k * a.M + r, s = s_idx[r];
+        const float R = ga.ret[s], V = ga.val[s];
+        ga.mb_ret[p] = R; ga.mb_val[p] = V; ga.mb_nlp[p] = ga.nlp[s];
+        ga.mb_adv[p] = ((R - V) - mean) / den;                                  // ppo2.hpp:401-406
+    }
+}
+
 // inv[perm[i]] = i   (out.row(perm[i]) = in.row(i), ppo2.hpp:291-296)
 __global__ void invert_perm_kernel(const int* perm, int* inv, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

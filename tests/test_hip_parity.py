@@ -829,3 +829,27 @@ def test_full_size_config4_single_rank_properties():
     close(rows3[:, :4], ref_rows[:, :4], rtol=2e-4, atol=2e-6, msg="loss rows")
     assert np.abs(rows3[:, 4] - ref_rows[:, 4]).max() <= 2.01 / (E * T // nmb)          # clipfrac: a count (see test_train_step...)
     close(g.get_flat(0), orc.theta, rtol=2e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("hidden,E,T,nmb,explicit", [((256, 256), 256, 16, 8, False), ((64, 64), 16, 24, 4, True), ((256, 256), 100, 10, 5, True)])
+def test_merged_epoch_kernel_is_bitwise_the_two_launch_form(hidden, E, T, nmb, explicit, monkeypatch):
+    """epoch_prepare_gather_kernel (index map, advantage statistics and the gather of an epoch in ONE launch, EPG_SPLIT workgroups per minibatch
+    each re-deriving the map) against epoch_prepare_kernel + epoch_gather_kernel (PPO_HIP_NO_EPOCH_MERGE=1): loss rows, weights and the Adam
+    moments of a two-epoch update must be the same BITS, with the on-device shuffle and with explicit permutations."""
+    rng = np.random.RandomState(31)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    perms = np.stack([rng.permutation(E * T).astype(np.int32) for _ in range(2)]) if explicit else None
+    outs = []
+    for merged in (True, False):
+        if merged:
+            monkeypatch.delenv("PPO_HIP_NO_EPOCH_MERGE", raising=False)
+        else:
+            monkeypatch.setenv("PPO_HIP_NO_EPOCH_MERGE", "1")
+        g = hip(hidden); g.init_orthogonal(2)
+        g.norm_init(E); g.rollout_alloc(E, T)
+        g.collect_synthetic(55, GAMMA, LAM, noise)
+        rows, mean = g.update(LR, CR, 2, nmb, perms, seed=9)
+        outs.append((rows, g.get_flat(0), g.get_flat(1), g.get_flat(2)))
+        g.close()
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
