@@ -70,15 +70,11 @@ public:
         workers_ = std::max(1, std::min(n_, max_workers > 0 ? max_workers : hw));
         // first guess: 8 chunks per thread; recalibrated from measured time per environment after the first steps
         chunk_ = std::max(1, n_ / (8 * workers_));
-        claimed_by_.reset(new std::atomic<int>[workers_]);
+        per_.reset(new PerThread[workers_]);
         mode_ = RESET;
         begin_round();
         for (int w = 1; w < workers_; ++w) threads_.emplace_back(&VecEnv::helper, this, w);
-        {
-            std::lock_guard<std::mutex> l(m_);
-            ++generation_;
-        }
-        go_.notify_all();
+        wake_helpers();
         drain(0);                        // every sub-env is reset once, from the pool (env/vec_env.hpp:209)
         wait_round();
         mode_ = STEP;
@@ -113,13 +109,7 @@ public:
         const auto t0 = std::chrono::steady_clock::now();
         actions_ = &actions;
         begin_round();
-        if (workers_ > 1 && n_chunks_ > 1) {
-            {
-                std::lock_guard<std::mutex> l(m_);
-                ++generation_;
-            }
-            go_.notify_all();
-        }
+        wake_helpers();
         drain(0);
         wait_round();
         if (steps_ < kCalibrationSteps) calibrate(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -138,7 +128,7 @@ public:
     // many threads claimed at least one chunk in the last step
     int pool_workers() const { return workers_; }
     int pool_chunk() const { return chunk_; }
-    int pool_active() const { int a = 0; for (int w = 0; w < workers_; ++w) a += claimed_by_[w].load(std::memory_order_relaxed) > 0; return a; }
+    int pool_active() const { int a = 0; for (int w = 0; w < workers_; ++w) a += per_[w].claimed.load(std::memory_order_relaxed) > 0; return a; }
 
 private:
     enum Mode { RESET, STEP };
@@ -150,10 +140,22 @@ private:
     // A claim is valid iff next < chunks; a valid claim means its round is still open, so chunk_ / actions_ / mode_ (published
     // before the ticket by the release store) are stable while the chunk is processed.
     static constexpr int kFieldBits = 20;
+    // only as many helpers as there are chunks beyond the caller's first one are woken (a helper that sleeps through a round simply joins
+    // the next one it is woken for): a step of a few hundred cheap environments costs one or two wake-ups, not fifteen
+    void wake_helpers() {
+        const int want = std::min(workers_ - 1, n_chunks_ - 1);
+        if (want <= 0) return;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            ++generation_;
+        }
+        if (want >= workers_ - 1) go_.notify_all();
+        else for (int i = 0; i < want; ++i) go_.notify_one();
+    }
     void begin_round() {
         n_chunks_ = (n_ + chunk_ - 1) / chunk_;
         if (n_chunks_ >= (1 << (kFieldBits - 1))) { chunk_ = (n_ + (1 << (kFieldBits - 1)) - 2) / ((1 << (kFieldBits - 1)) - 1); n_chunks_ = (n_ + chunk_ - 1) / chunk_; }
-        for (int w = 0; w < workers_; ++w) claimed_by_[w].store(0, std::memory_order_relaxed);
+        for (int w = 0; w < workers_; ++w) per_[w].claimed.store(0, std::memory_order_relaxed);
         remaining_.store(n_chunks_, std::memory_order_relaxed);
         ++round_;
         ticket_.store(((round_ & 0xFFFFFFull) << (2 * kFieldBits)) | (static_cast<unsigned long long>(n_chunks_) << kFieldBits), std::memory_order_release);
@@ -161,11 +163,18 @@ private:
     // claim chunks until none is left; `who` = 0 for the calling thread, 1.. for helpers
     void drain(int who) {
         Mat a(1, 1);
+        int mine = 0;
+        bool timing = false;
+        std::chrono::steady_clock::time_point t0;
         for (;;) {
             const unsigned long long t = ticket_.fetch_add(1, std::memory_order_acq_rel);
             const int c = static_cast<int>(t & ((1ull << kFieldBits) - 1)), nc = static_cast<int>((t >> kFieldBits) & ((1ull << kFieldBits) - 1));
             if (c >= nc) break;
-            claimed_by_[who].fetch_add(1, std::memory_order_relaxed);
+            if (++mine == 1) {
+                // (read only behind a valid claim: steps_ / mode_ change between rounds, on the caller's thread, before the ticket's release store)
+                timing = steps_ < kCalibrationSteps && mode_ == STEP;
+                if (timing) t0 = std::chrono::steady_clock::now();
+            }
             const int begin = c * chunk_, end = std::min(n_, begin + chunk_);
             if (mode_ == RESET) {
                 for (int i = begin; i < end; ++i) envs_[i]->reset();
@@ -181,11 +190,22 @@ private:
                     original_rewards_(i, 0) = envs_[i]->get_original_rew()(0, 0);
                 }
             }
-            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1 && who != 0) {
-                std::lock_guard<std::mutex> l(m_);                  // the caller may be asleep in wait_round()
-                done_.notify_one();
+            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                // the round's last chunk: publish this thread's share first (the caller reads the shares after it has seen remaining_ == 0 ...
+                // through this thread's later release below, or its own), then wake the caller if it may be asleep in wait_round()
+                finish_share(who, mine, timing, t0);
+                mine = -1;
+                if (who != 0) {
+                    std::lock_guard<std::mutex> l(m_);
+                    done_.notify_one();
+                }
             }
         }
+        if (mine > 0) finish_share(who, mine, timing, t0);
+    }
+    void finish_share(int who, int mine, bool timing, std::chrono::steady_clock::time_point t0) {
+        per_[who].claimed.store(mine, std::memory_order_relaxed);
+        if (timing) per_[who].busy_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
     }
     // the caller has no chunk left to claim: the last ones are being finished by helpers (a few microseconds: spin, then sleep)
     void wait_round() {
@@ -210,14 +230,17 @@ private:
             drain(who);
         }
     }
-    // after each of the first steps: time per environment from the step's wall time and the threads that took part -> ~25 us of
-    // work per chunk, but never fewer than 4 chunks per thread (balance) nor more than one chunk per environment
-    void calibrate(double wall_s) {
-        const int active = std::max(1, pool_active());
-        const double per_env = wall_s * active / n_;
-        int c = per_env > 0 ? static_cast<int>(25e-6 / per_env) : chunk_;
-        c = std::min(c, std::max(1, n_ / (4 * workers_)));
-        chunk_ = std::max(1, c);
+    // after each of the first steps: time per environment from the threads' own busy time (not the step's wall time, which is mostly wake-up
+    // latency for cheap environments) -> ~12 us of work per chunk, at most 8 chunks per thread, at least one environment per chunk; rounds
+    // with fewer chunks than threads wake fewer helpers
+    void calibrate(double /*wall_s*/) {
+        long long busy = 0;
+        for (int w = 0; w < workers_; ++w) busy += per_[w].busy_ns.exchange(0, std::memory_order_relaxed);
+        if (busy <= 0) return;
+        const double per_env = 1e-9 * (double)busy / n_;
+        int c = static_cast<int>(12e-6 / per_env);
+        c = std::max(c, (n_ + 8 * workers_ - 1) / (8 * workers_));
+        chunk_ = std::max(1, std::min(c, n_));
     }
 
     const std::vector<std::shared_ptr<Env>>& envs_;
@@ -231,8 +254,10 @@ private:
     Mat observations_, rewards_, dones_, original_rewards_;
     int workers_ = 1, chunk_ = 1, n_chunks_ = 1, steps_ = 0;
     Mode mode_ = RESET;
-    std::atomic<int> remaining_{0};
-    std::atomic<unsigned long long> ticket_{0};
+    // the two words every thread hammers live on cache lines of their own; so does each thread's share record
+    alignas(64) std::atomic<unsigned long long> ticket_{0};
+    alignas(64) std::atomic<int> remaining_{0};
+    struct alignas(64) PerThread { std::atomic<int> claimed{0}; std::atomic<long long> busy_ns{0}; };
+    std::unique_ptr<PerThread[]> per_;
     unsigned long long round_ = 0;
-    std::unique_ptr<std::atomic<int>[]> claimed_by_;
 };
