@@ -9,7 +9,10 @@
 // waiting for its slowest fixed share (round 3: 1.44 ms vs 2.70 ms per 16 steps of 4096 mock environments on two boxes that both
 // report 16 cores).  The chunk size is calibrated on the first three steps from the measured time per environment (~25 us of work
 // per chunk, at least 4 chunks per thread); pool_workers() / pool_chunk() / pool_active() report what was chosen and how many
-// threads actually took part.  Semantics kept from the reference: sub-envs are reset once from pool threads at
+// threads actually took part.  Between two steps of a rollout (~100 us: the policy's act call) a helper does not go back to sleep at once: it
+// watches the claim word for up to PPO_VECENV_SPIN_US (default 250 us; 0 = never; only while rounds have lately followed each other within half of that) and starts on the
+// next round by itself -- a futex wake-up per helper and step (5-10 us each, issued one after the other by the caller) is what a step of a few
+// thousand cheap environments otherwise mostly consists of; step() then only wakes as many helpers as are really asleep.  Semantics kept from the reference: sub-envs are reset once from pool threads at
 // construction; reset() does NOT reset sub-envs but gathers get_original_obs() (env/vec_env.hpp:94-106);
 // get_original_rew() returns the rewards of the last step; the caller's vector of environments is referenced, not
 // copied (env/vec_env.hpp:190).  Conscious fix: get_observation_space_size() returns the OBSERVATION size (the
@@ -71,6 +74,7 @@ public:
         // first guess: 8 chunks per thread; recalibrated from measured time per environment after the first steps
         chunk_ = std::max(1, n_ / (8 * workers_));
         per_.reset(new PerThread[workers_]);
+        if (const char* e = std::getenv("PPO_VECENV_SPIN_US")) spin_cap_ns_ = std::max(0ll, std::atoll(e)) * 1000;
         mode_ = RESET;
         begin_round();
         for (int w = 1; w < workers_; ++w) threads_.emplace_back(&VecEnv::helper, this, w);
@@ -140,17 +144,23 @@ private:
     // A claim is valid iff next < chunks; a valid claim means its round is still open, so chunk_ / actions_ / mode_ (published
     // before the ticket by the release store) are stable while the chunk is processed.
     static constexpr int kFieldBits = 20;
+    static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     // only as many helpers as there are chunks beyond the caller's first one are woken (a helper that sleeps through a round simply joins
     // the next one it is woken for): a step of a few hundred cheap environments costs one or two wake-ups, not fifteen
     void wake_helpers() {
         const int want = std::min(workers_ - 1, n_chunks_ - 1);
         if (want <= 0) return;
+        int asleep;
         {
             std::lock_guard<std::mutex> l(m_);
             ++generation_;
+            asleep = sleepers_;
         }
-        if (want >= workers_ - 1) go_.notify_all();
-        else for (int i = 0; i < want; ++i) go_.notify_one();
+        // helpers that are not asleep are watching the ticket and have the round already
+        const int need = std::min(asleep, want - (workers_ - 1 - asleep));
+        if (need <= 0) return;
+        if (need >= asleep) go_.notify_all();
+        else for (int i = 0; i < need; ++i) go_.notify_one();
     }
     void begin_round() {
         n_chunks_ = (n_ + chunk_ - 1) / chunk_;
@@ -165,16 +175,16 @@ private:
         Mat a(1, 1);
         int mine = 0;
         bool timing = false;
-        std::chrono::steady_clock::time_point t0;
+        long long busy = 0;
         for (;;) {
             const unsigned long long t = ticket_.fetch_add(1, std::memory_order_acq_rel);
             const int c = static_cast<int>(t & ((1ull << kFieldBits) - 1)), nc = static_cast<int>((t >> kFieldBits) & ((1ull << kFieldBits) - 1));
             if (c >= nc) break;
-            if (++mine == 1) {
-                // (read only behind a valid claim: steps_ / mode_ change between rounds, on the caller's thread, before the ticket's release store)
-                timing = steps_ < kCalibrationSteps && mode_ == STEP;
-                if (timing) t0 = std::chrono::steady_clock::now();
-            }
+            // (read only behind a valid claim: steps_ / mode_ change between rounds, on the caller's thread, before the ticket's release store)
+            if (++mine == 1) timing = steps_ < kCalibrationSteps && mode_ == STEP;
+            // calibration steps: the time inside the environments only (claims and waiting excluded: with the first guess of tiny chunks they would
+            // be most of it, and the chunk derived from it would stay tiny)
+            const long long ta = timing ? now_ns() : 0;
             const int begin = c * chunk_, end = std::min(n_, begin + chunk_);
             if (mode_ == RESET) {
                 for (int i = begin; i < end; ++i) envs_[i]->reset();
@@ -190,22 +200,23 @@ private:
                     original_rewards_(i, 0) = envs_[i]->get_original_rew()(0, 0);
                 }
             }
+            if (timing) busy += now_ns() - ta;
             if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 // the round's last chunk: publish this thread's share first (the caller reads the shares after it has seen remaining_ == 0 ...
                 // through this thread's later release below, or its own), then wake the caller if it may be asleep in wait_round()
-                finish_share(who, mine, timing, t0);
-                mine = -1;
+                finish_share(who, mine, busy);
+                mine = -1; busy = 0;
                 if (who != 0) {
                     std::lock_guard<std::mutex> l(m_);
                     done_.notify_one();
                 }
             }
         }
-        if (mine > 0) finish_share(who, mine, timing, t0);
+        if (mine > 0) finish_share(who, mine, busy);
     }
-    void finish_share(int who, int mine, bool timing, std::chrono::steady_clock::time_point t0) {
+    void finish_share(int who, int mine, long long busy) {
         per_[who].claimed.store(mine, std::memory_order_relaxed);
-        if (timing) per_[who].busy_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+        if (busy) per_[who].busy_ns.fetch_add(busy, std::memory_order_relaxed);
     }
     // the caller has no chunk left to claim: the last ones are being finished by helpers (a few microseconds: spin, then sleep)
     void wait_round() {
@@ -220,14 +231,37 @@ private:
     }
     void helper(int who) {
         unsigned long seen = 0;
+        unsigned long long last_round = 0;                      // round of this thread's last drain
+        // `credit` > 0: the next round lately came within half the spin budget, so watching for it beats sleeping.  One long pause (the update
+        // between two rollouts) costs one credit, not the habit; environments whose steps are always far apart run it down to 0 and sleep at once.
+        int credit = 2;
+        long long idle_since = now_ns();
         for (;;) {
-            {
+            bool go = false;
+            const long long budget = spin_cap_ns_;
+            if (spin_cap_ns_ > 0 && credit > 0) {
+                for (;;) {
+                    if ((ticket_.load(std::memory_order_acquire) >> (2 * kFieldBits)) != last_round) { go = true; break; }
+#if defined(__x86_64__)
+                    for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+#endif
+                    if (now_ns() - idle_since > budget) break;
+                }
+            }
+            if (!go) {
                 std::unique_lock<std::mutex> l(m_);
-                go_.wait(l, [&] { return generation_ != seen; });
+                if (generation_ == seen) {
+                    ++sleepers_;
+                    go_.wait(l, [&] { return generation_ != seen; });
+                    --sleepers_;
+                }
                 seen = generation_;
                 if (terminate_) return;
             }
+            credit = (now_ns() - idle_since) * 2 <= spin_cap_ns_ ? std::min(credit + 1, 4) : std::max(credit - 1, 0);
+            last_round = ticket_.load(std::memory_order_acquire) >> (2 * kFieldBits);
             drain(who);
+            idle_since = now_ns();
         }
     }
     // after each of the first steps: time per environment from the threads' own busy time (not the step's wall time, which is mostly wake-up
@@ -249,6 +283,8 @@ private:
     std::mutex m_;
     std::condition_variable go_, done_;
     unsigned long generation_;
+    int sleepers_ = 0;                 // helpers inside go_.wait (guarded by m_)
+    long long spin_cap_ns_ = 250000;
     bool terminate_;
     const Mat* actions_;
     Mat observations_, rewards_, dones_, original_rewards_;
