@@ -30,11 +30,6 @@ struct T8L {
                          MISC = ROWV + 32, TOTAL = MISC + 128;
 };
 
-#ifndef T8_RES
-#define T8_RES 0                  // 1: the whole [128 x 64] weight block of a wave in registers before each 256 x 256 product (four stages, no in-loop loads):
-                                  // measured 42.4 us per train step against 40.5 -- requesting 32 KB per wave at once stalls the waves on the request queue
-                                  // for longer than the in-loop requests cost (profiles/r04_f_train8_experiments.txt)
-#endif
 #ifndef T8_PRO
 #define T8_PRO 1                  // where the second layer's first two ring stages are requested: 0 both in the prologue, 1 the second one behind the prologue's
                                   // barrier (it lands while the first layer runs; the prologue's request burst is 32 KB per wave shorter: 41.7 -> 40.6 us per
@@ -116,25 +111,6 @@ __device__ __forceinline__ void t8_big_product(WFrag<4, 2> (&fr)[3], const float
     }
 }
 
-// T8_RES: all four stages of the wave's [128 x 64] weight block are requested BEFORE the product (a ring of four register stages,
-// nothing is loaded inside the loop): the product runs at the matrix pipe's pace as far as the block has arrived
-__device__ __forceinline__ void t8_big_product_res(WFrag<4, 2> (&fr)[4], const float* Xs /* tile + 128 kh */, int c, int g, f32x4 (&acc)[4]) {
-    auto load_a = [&](WFrag<4, 2>& f, int st) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) f.a[q] = *reinterpret_cast<const float4*>(Xs + c * T8_LD + 32 * st + 16 * q + 4 * g);
-    };
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    load_a(fr[0], 0);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 < 4) load_a(fr[st + 1], st + 1);
-        t8_mma_stage(fr[st], acc);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // the two K halves meet: wave kh hands rows {2,3} (kh = 0) / {0,1} (kh = 1) of every 4-row group to its partner and returns the
 // finished values of the rows it keeps: out[j][i] = row 4g + 2 kh + i, column 64 p + 4 c + j  (kh0 + kh1 in that order on both sides)
 __device__ __forceinline__ void t8_exchange(const f32x4 (&acc)[4], float* xch, int p, int kh, int lane, float (&out)[4][2]) {
@@ -209,11 +185,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     WFrag<2, KS0> wl0;
     WFrag<CTA, 2> whd;
     WFrag<2, KSA> whT;
-#if T8_RES
-    WFrag<4, 2> fr[4];
-#else
     WFrag<4, 2> fr[3];
-#endif
     load_w_stage<2, KS0>(wl0, W0, make_woff<KS0>(256, g, 32 * wave + 2 * c));
 #if T8_PRO < 2
     load_w_stage<4, 2>(fr[0], W1 + (size_t)t8_stage_row(0, rot) * 256, off_big);
@@ -253,11 +225,6 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
 #if T8_PRO >= 1
     load_w_stage<4, 2>(fr[1], W1 + (size_t)t8_stage_row(1, rot) * 256, off_big);       // behind the barrier: lands while the first layer runs
 #endif
-#if T8_RES
-    load_w_stage<4, 2>(fr[2], W1 + (size_t)64 * 256, off_big);
-    load_w_stage<4, 2>(fr[3], W1 + (size_t)96 * 256, off_big);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     // ---- first layer: h1 = tanh(x W0 + b0), 32 columns per wave ---------------------------------------------------------------------
     {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -278,11 +245,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     // ---- second layer: h2 = tanh(h1 W1 + b1), K split over the wave pair -------------------------------------------------------------
     {
         f32x4 acc[4];
-#if T8_RES
-        t8_big_product_res(fr, lds + L8::H1 + 128 * kh, c, g, acc);
-#else
         t8_big_product(fr, W1, off_big, lds + L8::H1 + 128 * kh, c, g, rot, acc);
-#endif
         STAMP(11);
         // the backward product's transposed weights: two stages per wave, in flight through the head and the loss
 #if T8_W1T == 0
@@ -317,11 +280,6 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     STAMP(3);
 #if T8_W1T == 2
     load_w_stage<4, 2>(fr[1], W1T + (size_t)t8_stage_row(1, rot) * 256, off_big);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#if T8_RES
-    load_w_stage<4, 2>(fr[2], W1T + (size_t)64 * 256, off_big);                        // the rest of the backward block: in flight through the head and the loss
-    load_w_stage<4, 2>(fr[3], W1T + (size_t)96 * 256, off_big);
     __builtin_amdgcn_sched_barrier(0);
 #endif
     const float cr = a.hyper[1];
@@ -483,11 +441,7 @@ __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArg
     // ---- dY0 = (dY1 W1^T) .* (1 - h1^2), K split over the wave pair (the h2 tile is free now: exchange scratch) ------------------------
     {
         f32x4 acc[4];
-#if T8_RES
-        t8_big_product_res(fr, d2 + 128 * kh, c, g, acc);
-#else
         t8_big_product(fr, W1T, off_big, d2 + 128 * kh, c, g, rot, acc);
-#endif
         STAMP(14);
         float out[4][2];
         t8_exchange(acc, lds + L8::H2, p, kh, lane, out);
