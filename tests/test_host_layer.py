@@ -128,7 +128,9 @@ def test_learn_honours_the_normaliser_flags():
 def test_pooled_vecenv_is_clean_under_thread_sanitizer(tmp_path):
     """SURVEY section 5 (race detection): the pooled VecEnv (worker pool, generation counter, chunked env ranges) stepped
     from the main thread under -fsanitize=thread -- construction, 300 steps over 16 environments with 3 workers, reset,
-    destruction -- with the reference test's expectations on the rows (test/vecenv_test.cpp:36-47)."""
+    destruction -- with the reference test's expectations on the rows (test/vecenv_test.cpp:36-47); then 200 environments on 4 threads with
+    pauses of 0 / 50 / 400 us between the steps, so that helpers are caught watching the claim word, timing out into their sleep and being
+    woken from it; once with the default spin budget and once with PPO_VECENV_SPIN_US=0 (helpers always sleep)."""
     import os
     import subprocess
     host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ppo_cpp_amd", "host")
@@ -136,9 +138,22 @@ def test_pooled_vecenv_is_clean_under_thread_sanitizer(tmp_path):
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <unistd.h>
 #include "env/env_mock.hpp"
 #include "env/vec_env.hpp"
 int main() {
+    {
+        std::vector<std::shared_ptr<Env>> envs;
+        for (int i = 0; i < 200; ++i) envs.push_back(std::make_shared<EnvMock>(i + 1));
+        VecEnv ve{envs, 4};
+        Mat actions = Mat::Zero(ve.get_num_envs(), ve.get_action_space_size());
+        for (int s = 0; s < 120; ++s) {
+            const std::vector<Mat> r = ve.step(actions);
+            for (int e = 0; e < 200; ++e) if (r[1](e, 0) != (float)(e + 1) || r[0](e, 17) != (float)(e + 1)) return 6;
+            if (s % 7 == 3) usleep(400); else if (s % 5 == 1) usleep(50);
+        }
+        if (ve.pool_workers() != 4 || ve.pool_chunk() < 1) return 7;
+    }
     for (int workers : {0, 1, 3}) {
         std::vector<std::shared_ptr<Env>> envs;
         for (int i = 0; i < 16; ++i) envs.push_back(std::make_shared<EnvMock>(i + 1));
@@ -166,5 +181,10 @@ int main() {
         pytest.skip("this toolchain has no ThreadSanitizer runtime")
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I", host, "-o", str(exe), str(cpp)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
-    assert run.returncode == 0 and "ok" in run.stdout and "ThreadSanitizer" not in run.stderr, run.stdout[-500:] + run.stderr[-3000:]
+    for spin in (None, "0"):
+        env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1")
+        env.pop("PPO_VECENV_SPIN_US", None)
+        if spin is not None:
+            env["PPO_VECENV_SPIN_US"] = spin
+        run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=env)
+        assert run.returncode == 0 and "ok" in run.stdout and "ThreadSanitizer" not in run.stderr, run.stdout[-500:] + run.stderr[-3000:]
