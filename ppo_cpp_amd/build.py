@@ -46,7 +46,7 @@ def build_host(force=False, verbose=False):
         return None
     deps = _sources(host, (".cpp", ".hpp", ".h")) + [os.path.join(ROOT, "include", "ppo_hip.h")]
     if force or _newer(HOST_SO, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"),
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-DPPO_MAT_NO_BOUNDS", "-I", os.path.join(ROOT, "include"),
                "-I", host, "-o", HOST_SO, src, "-L", PKG, "-lppo_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
@@ -63,7 +63,7 @@ def build_driver(force=False, verbose=False):
         return None
     deps = _sources(host, (".cpp", ".hpp", ".h")) + [os.path.join(ROOT, "include", "ppo_hip.h")]
     if force or _newer(exe, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", host, "-o", exe, src,
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-DPPO_MAT_NO_BOUNDS", "-I", os.path.join(ROOT, "include"), "-I", host, "-o", exe, src,
                "-L", PKG, "-lppo_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

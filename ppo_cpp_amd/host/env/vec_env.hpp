@@ -66,8 +66,7 @@ class VecEnv : public virtual Env {
 public:
     explicit VecEnv(const std::vector<std::shared_ptr<Env>>& envs, int max_workers = 0)
         : envs_(envs), n_(static_cast<int>(envs.size())), generation_(0), terminate_(false), actions_(nullptr),
-          observations_(Mat::Zero(n_, envs[0]->get_observation_space_size())), rewards_(Mat::Zero(n_, 1)), dones_(Mat::Zero(n_, 1)),
-          original_rewards_(Mat::Zero(n_, 1)) {
+          obs_dim_(envs[0]->get_observation_space_size()), original_rewards_(Mat::Zero(n_, 1)) {
         assert(!envs.empty());
         const int hw = usable_cpus();
         workers_ = std::max(1, std::min(n_, max_workers > 0 ? max_workers : hw));
@@ -112,13 +111,22 @@ public:
         assert(actions.rows() == n_);
         const auto t0 = std::chrono::steady_clock::now();
         actions_ = &actions;
+        // the results leave by MOVE: the threads fill fresh matrices (their storage is the block the caller's previous result gave back,
+        // mat.hpp) -- copying 300 KB out of members was half of a step at 4096 environments
+        if (observations_.rows() != n_) observations_ = Mat::Zero(n_, obs_dim_);
+        if (rewards_.rows() != n_) rewards_ = Mat::Zero(n_, 1);
+        if (dones_.rows() != n_) dones_ = Mat::Zero(n_, 1);
         begin_round();
         wake_helpers();
         drain(0);
         wait_round();
         if (steps_ < kCalibrationSteps) calibrate(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         ++steps_;
-        return {observations_, rewards_, dones_};
+        std::vector<Mat> out;
+        out.reserve(3);
+        out.push_back(std::move(observations_)); out.push_back(std::move(rewards_)); out.push_back(std::move(dones_));
+        observations_ = Mat(); rewards_ = Mat(); dones_ = Mat();             // (a moved-from matrix keeps its shape fields: make them empty again)
+        return out;
     }
 
     Mat get_original_obs() override { std::cout << "VecEnv::get_original_obs() not implemented\n"; return Mat::Zero(n_, get_observation_space_size()); }
@@ -287,6 +295,7 @@ private:
     long long spin_cap_ns_ = 250000;
     bool terminate_;
     const Mat* actions_;
+    const int obs_dim_;
     Mat observations_, rewards_, dones_, original_rewards_;
     int workers_ = 1, chunk_ = 1, n_chunks_ = 1, steps_ = 0;
     Mode mode_ = RESET;

@@ -25,10 +25,63 @@ typedef Eigen::Matrix<float, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> Ma
 #include <cassert>
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
+#include <new>
 #include <ostream>
 #include <vector>
 
+// element-access bounds checks: on wherever assert() is, unless the build defines PPO_MAT_NO_BOUNDS (the product libraries do: the host loop walks
+// 4096-row columns element by element every env step; shape checks elsewhere stay asserts)
+#if defined(PPO_MAT_NO_BOUNDS)
+#define PPO_MAT_BOUNDS(x) ((void)0)
+#else
+#define PPO_MAT_BOUNDS(x) assert(x)
+#endif
+
 namespace Eigen {
+
+// Storage of the stand-in matrix.  The host loop hands whole batches around BY VALUE (std::vector<Mat> Env::step(const Mat&) is the
+// reference's interface): at 4096 environments every env step allocates and frees several buffers of 16 - 300 KB, which glibc serves with
+// mmap / munmap and fresh page faults each time (measured: 70 us of a 145 us VecEnv::step).  Buffers of 16 KB .. 64 MB therefore go through
+// a small per-thread cache: a freed block is kept (at most 8, at most 128 MB per thread) and handed to the next request of exactly its size.
+namespace mat_detail {
+struct BlockCache {
+    static constexpr int kSlots = 8;
+    static constexpr size_t kMin = 16u << 10, kMax = 64u << 20, kCap = 128u << 20;
+    void* p[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t n[kSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t held = 0;
+    ~BlockCache() { for (int i = 0; i < kSlots; ++i) if (p[i]) ::operator delete(p[i]); }
+    void* take(size_t bytes) {
+        for (int i = 0; i < kSlots; ++i) if (p[i] && n[i] == bytes) { void* q = p[i]; p[i] = nullptr; held -= bytes; return q; }
+        return nullptr;
+    }
+    bool give(void* q, size_t bytes) {
+        if (held + bytes > kCap) return false;
+        for (int i = 0; i < kSlots; ++i) if (!p[i]) { p[i] = q; n[i] = bytes; held += bytes; return true; }
+        return false;
+    }
+    static BlockCache& mine() { static thread_local BlockCache c; return c; }
+};
+template <class T>
+struct RecyclingAllocator {
+    typedef T value_type;
+    RecyclingAllocator() = default;
+    template <class U> RecyclingAllocator(const RecyclingAllocator<U>&) {}
+    T* allocate(size_t count) {
+        const size_t bytes = count * sizeof(T);
+        if (bytes >= BlockCache::kMin && bytes <= BlockCache::kMax) if (void* q = BlockCache::mine().take(bytes)) return static_cast<T*>(q);
+        return static_cast<T*>(::operator new(bytes));
+    }
+    void deallocate(T* q, size_t count) {
+        const size_t bytes = count * sizeof(T);
+        if (bytes >= BlockCache::kMin && bytes <= BlockCache::kMax && BlockCache::mine().give(q, bytes)) return;
+        ::operator delete(q);
+    }
+    template <class U> bool operator==(const RecyclingAllocator<U>&) const { return true; }
+    template <class U> bool operator!=(const RecyclingAllocator<U>&) const { return false; }
+};
+}  // namespace mat_detail
 
 const int Dynamic = -1;
 enum StorageOptions { ColMajor = 0, RowMajor = 1 };
@@ -59,8 +112,8 @@ public:
     const float* data() const { return v_.data(); }
     void resize(long rows, long cols) { r_ = rows; c_ = cols; v_.assign((size_t)rows * cols, 0.f); }
     void setZero() { for (auto& e : v_) e = 0.f; }
-    float& operator()(long i, long j) { assert(i >= 0 && i < r_ && j >= 0 && j < c_); return v_[(size_t)i * c_ + j]; }
-    float operator()(long i, long j) const { assert(i >= 0 && i < r_ && j >= 0 && j < c_); return v_[(size_t)i * c_ + j]; }
+    float& operator()(long i, long j) { PPO_MAT_BOUNDS(i >= 0 && i < r_ && j >= 0 && j < c_); return v_[(size_t)i * c_ + j]; }
+    float operator()(long i, long j) const { PPO_MAT_BOUNDS(i >= 0 && i < r_ && j >= 0 && j < c_); return v_[(size_t)i * c_ + j]; }
     // reductions (double accumulation, rounded once)
     float squaredNorm() const { double s = 0; for (float e : v_) s += (double)e * e; return (float)s; }
     float norm() const { return std::sqrt(squaredNorm()); }
@@ -142,7 +195,7 @@ public:
 
 private:
     long r_, c_;
-    std::vector<float> v_;
+    std::vector<float, mat_detail::RecyclingAllocator<float>> v_;
 };
 
 class ConstBlockRef {

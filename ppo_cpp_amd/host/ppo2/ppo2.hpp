@@ -11,6 +11,7 @@
 //     from the clock, ppo2.hpp:288 / ppo2.cpp:159-162, i.e. it is not reproducible either way).
 #pragma once
 #include <chrono>
+#include <cstring>
 #include <cmath>
 #include <cstdio>
 #include <numeric>
@@ -153,24 +154,28 @@ private:
         const int E = n_envs_, T = n_steps_;
         check(ppo_rollout_alloc(h_, E, T));
         check(ppo_rollout_reset(h_, raw.reset().data()));                  // EnvNormalize::reset + Runner ctor
-        Mat actions(E, raw.get_action_space_size()), rew_view(E, T), done_view(E, T), dones = Mat::Zero(E, 1);
+        // the logger's env-major [E, T] views are filled once per update from time-major rows (a row per env step is one copy; writing a
+        // column of an [E, T] matrix touches E cache lines)
+        Mat actions(E, raw.get_action_space_size()), rew_view(E, T), done_view(E, T), rew_tm(T, E), done_tm(T, E), dones = Mat::Zero(E, 1);
         for (int update = 1; update <= n_updates; ++update) {
             const auto t0 = clk::now();
             for (int t = 0; t < T; ++t) {
-                for (int e = 0; e < E; ++e) done_view(e, t) = dones(e, 0);
+                std::memcpy(done_tm.data() + (size_t)t * E, dones.data(), sizeof(float) * (size_t)E);
                 const auto p0 = clk::now();
                 const float* eps = explicit_noise ? explicit_noise + ((size_t)(update - 1) * T + t) * E * actions.cols() : nullptr;
                 check(ppo_rollout_act(h_, t, eps, actions.data()));
                 const auto p1 = clk::now();
-                const std::vector<Mat> r = raw.step(actions);
+                std::vector<Mat> r = raw.step(actions);
                 const auto p2 = clk::now();
                 check(ppo_rollout_observe(h_, t, r[0].data(), r[1].data(), r[2].data()));
                 const auto p3 = clk::now();
                 if (update > 2) { phase_act_ms += ms(p0, p1); phase_env_ms += ms(p1, p2); phase_observe_ms += ms(p2, p3); }
-                dones = r[2];
+                dones = std::move(r[2]);
                 const Mat orig = raw.get_original_rew();
-                for (int e = 0; e < E; ++e) rew_view(e, t) = orig(e, 0);
+                std::memcpy(rew_tm.data() + (size_t)t * E, orig.data(), sizeof(float) * (size_t)E);
             }
+            for (int e = 0; e < E; ++e)
+                for (int t = 0; t < T; ++t) { rew_view(e, t) = rew_tm(t, e); done_view(e, t) = done_tm(t, e); }
             check(ppo_rollout_finish(h_, gamma_, lam_));
             const auto t1 = clk::now();
             num_timesteps_ += n_batch_;
