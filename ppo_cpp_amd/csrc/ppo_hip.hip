@@ -1635,6 +1635,10 @@ static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, con
         a.xch = h->stats_xch;
         if (!a.use_peer) HIP_OK(h, hipMemsetAsync(h->stats_xch, 0, xw * h->world * sizeof(float), h->stream));
     }
+#ifdef PPO_STAMPS
+    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+    a.stamps = g_stamps + 4096 * 32;
+#endif
     { ProfScope ps(h, PK_STATS);
       hipLaunchKernelGGL(norm_batch_kernel, dim3(a.g_obs + a.g_rew), dim3(NB_THREADS), 0, h->stream, a);
       HIP_OK(h, hipGetLastError()); }
@@ -2698,7 +2702,10 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
 #ifdef PPO_STAMPS
 int ppo_debug_read_stamps(ppo_handle* h, unsigned long long* dst, int n) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    HIP_OK(h, hipMemcpy(dst, g_stamps + (n < 0 ? 4096 * 16 : 0), (size_t)(n < 0 ? -n : n) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // n > 0: the train kernels' area; n < 0: the second area (weight gradients); n < -(1 << 20): the third (statistics kernel), count = -n - (1 << 20)
+    const bool third = n < -(1 << 20);
+    const int cnt = third ? -n - (1 << 20) : (n < 0 ? -n : n);
+    HIP_OK(h, hipMemcpy(dst, g_stamps + (third ? 4096 * 32 : (n < 0 ? 4096 * 16 : 0)), (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

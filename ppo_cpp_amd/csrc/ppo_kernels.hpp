@@ -2038,8 +2038,8 @@ __global__ __launch_bounds__(GAE_LONG_THREADS) void gae_long_kernel(const float*
 //   obs job   : obs_rms.update(raw_obs)   (:94-98; scale + clip are fused into the next policy step's input staging)
 //   reward job: ret = ret*gamma + r ; ret_rms.update(ret) ; out = clip(r / sqrt(var + eps)) ; ret *= 1 - done   (:64-92)
 // Every workgroup reduces a chunk of rows to (n, mean, M2) with the reference's two passes (mean, then squared
-// deviations: common/running_statistics.hpp:26-54).  The workgroup that finishes LAST (device-scope counter; release /
-// acquire fences around it) combines the chunks in index order with M2 = sum_k M2_k + sum_k n_k (mean_k - mean)^2 --
+// deviations: common/running_statistics.hpp:26-54).  The workgroup that finishes LAST (device-scope counter; write-through
+// partials, see NB_ST) combines the chunks in index order with M2 = sum_k M2_k + sum_k n_k (mean_k - mean)^2 --
 // algebraically the two-pass result over the whole batch, deterministic, and better conditioned than one long fp32
 // sum -- and applies RunningStatistics::update's merge (:88-104; count is double, every matrix op fp32).
 // Data-parallel: the last workgroup instead publishes this rank's (n, mean, M2) in its slot of `xch`; ONE all-reduce
@@ -2062,16 +2062,33 @@ struct NormBatchArgs {
     int world, rank;
     int use_peer;         // data-parallel over peer-mapped regions: the table is exchanged by these two kernels themselves (ppo_peer.hpp)
     PeerDev peer;
+#ifdef PPO_STAMPS
+    unsigned long long* stamps;   // diagnostic builds only: [block][8] cycle stamps
+#endif
 };
+#ifdef PPO_STAMPS
+#define NSTAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NSTAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
+// The chunks' partial sets travel from their workgroups to the last arriver of the job like weight_grad_assemble_kernel's slabs: stored
+// write-through (agent-scope relaxed atomic stores = sc1), every storing thread drains its stores before the workgroup barrier in front of the
+// ONE relaxed arrival, and the last arriver reads them with agent-scope loads (sc1: lines it has not touched in this launch, never served
+// from its own XCD's L2).  The language model's pair -- a release fence in every workgroup, an acquire in the last -- costs a write-back of the
+// whole L2 per workgroup: 3.3 - 3.8 k cycles of this 28 k-cycle kernel (tools/stamps_norm.py).
+__device__ __forceinline__ void NB_ST(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float NB_LD(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // (n, mean[D], M2[D]) of rows [r0, r1) of a row-major [*, D] matrix -> out[0], out[1 .. D], out[1+D .. 2D].
 // A thread's first 8 values stay in registers between the two passes (one memory round trip for the usual chunk size).
-__device__ __forceinline__ void chunk_moments(const float* __restrict__ x, int r0, int r1, int D, float* out, float* sh /* 2*NB_THREADS */) {
+// pre != null (D == 1 only): the thread's first 8 values, rows r0 + tid + 256 u, are handed over in registers instead of being re-read.
+__device__ __forceinline__ void chunk_moments(const float* __restrict__ x, int r0, int r1, int D, float* out, float* sh /* 2*NB_THREADS */, const float* pre = nullptr) {
     const int tid = threadIdx.x;
     const float n = (float)(r1 - r0);
-    if (tid == 0) out[0] = n;
+    if (tid == 0) NB_ST(out, n);
     float* cm = sh + NB_THREADS;                         // chunk means of the current column group
     constexpr int U = 8;
     for (int cbase = 0; cbase < D; cbase += NB_THREADS) {
@@ -2082,7 +2099,7 @@ __device__ __forceinline__ void chunk_moments(const float* __restrict__ x, int r
         const int top = pow2_ceil(rpp) >> 1;
         float v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int r = r0 + rsub + u * rpp; v[u] = (act && r < r1) ? x[(size_t)r * D + col] : 0.f; }
+        for (int u = 0; u < U; ++u) { const int r = r0 + rsub + u * rpp; v[u] = (act && r < r1) ? (pre ? pre[u] : x[(size_t)r * D + col]) : 0.f; }
         for (int pass = 0; pass < 2; ++pass) {
             const float bm = pass ? cm[tid % Dg] : 0.f;
             float t[U];
@@ -2102,7 +2119,7 @@ __device__ __forceinline__ void chunk_moments(const float* __restrict__ x, int r
             }
             if (tid < Dg) {
                 if (pass == 0) cm[tid] = sh[tid] / n;    // colwise().mean()
-                else { out[1 + cbase + tid] = cm[tid]; out[1 + D + cbase + tid] = sh[tid]; }
+                else { NB_ST(out + 1 + cbase + tid, cm[tid]); NB_ST(out + 1 + D + cbase + tid, sh[tid]); }
             }
             __syncthreads();
         }
@@ -2112,6 +2129,32 @@ __device__ __forceinline__ void chunk_moments(const float* __restrict__ x, int r
 // Whole block: combine K <= NB_THREADS (n, mean[D], M2[D]) sets (stride floats apart) for the column group
 // [cbase, cbase + Dg).  NB_THREADS / Dg threads share a column (strided over the sets) and meet in a fixed-shape tree,
 // so the result does not depend on scheduling.  Threads tid < Dg return their column's batch (n, mean, M2).
+// One column, K <= 64 sets (the reward job: its chunks are at most NB_MAX_REW_BLOCKS): the same sums in ONE wave.  The block-wide form puts set
+// k in thread k and adds in a tree of strides 128 .. 1 over 256 slots of which only the first K are non-zero; strides 32 .. 1 over the 64 lanes
+// of a wave pair the same values in the same order (the upper levels only ever add zeros), so the bits are the same -- without its 20
+// workgroup barriers.  Every thread of the block returns the result (through sh).
+__device__ __forceinline__ void combine_single_column(const float* sets, int K, int stride, float* sh, float& n, float& mean, float& M2) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid < 64) {
+        const bool have = tid < K;
+        const float nk = have ? NB_LD(sets + (size_t)tid * stride) : 0.f;
+        const float mk = have ? NB_LD(sets + (size_t)tid * stride + 1) : 0.f;
+        const float qk = have ? NB_LD(sets + (size_t)tid * stride + 2) : 0.f;
+        float nn = 0.f;
+        for (int k = 0; k < K; ++k) nn += __shfl(nk, k);                         // index order, like the block-wide form
+        float s = have ? nk * mk : 0.f;
+        for (int h = 32; h > 0; h >>= 1) s += __shfl_down(s, h);
+        const float bm = __shfl(s, 0) / nn;
+        const float d = mk - bm;
+        float q = have ? qk + nk * (d * d) : 0.f;
+        for (int h = 32; h > 0; h >>= 1) q += __shfl_down(q, h);
+        if (tid == 0) { sh[0] = nn; sh[1] = bm; sh[2] = q; }
+    }
+    __syncthreads();
+    n = sh[0]; mean = sh[1]; M2 = sh[2];
+}
+
 __device__ __forceinline__ void combine_group(const float* sets, int K, int stride, int D, int cbase, int Dg, float* sh /* 3*NB_THREADS */,
                                               float& n, float& mean, float& M2) {
     const int tid = threadIdx.x;
@@ -2121,8 +2164,19 @@ __device__ __forceinline__ void combine_group(const float* sets, int K, int stri
     const int cg = tid % Dg, col = cbase + cg, ksub = tid / Dg;
     const bool act = ksub < rpp;
     const int top = pow2_ceil(rpp) >> 1;
+    // everything this thread will need of its first CG sets is requested up front, together with the sets' row counts: ONE trip to the
+    // memory side (the sets were written through by other workgroups) instead of one per pass
+    constexpr int CG = 4;
+    float pm[CG], pq[CG];
+#pragma unroll
+    for (int j = 0; j < CG; ++j) {
+        const int k = ksub + j * rpp;
+        const bool ok = act && k < K;
+        pm[j] = ok ? NB_LD(sets + (size_t)k * stride + 1 + col) : 0.f;
+        pq[j] = ok ? NB_LD(sets + (size_t)k * stride + 1 + D + col) : 0.f;
+    }
     __syncthreads();
-    if (tid < K) shn[tid] = sets[(size_t)tid * stride];
+    if (tid < K) shn[tid] = NB_LD(sets + (size_t)tid * stride);
     __syncthreads();
     float nn = 0.f;
     for (int k = 0; k < K; ++k) nn += shn[k];
@@ -2131,11 +2185,19 @@ __device__ __forceinline__ void combine_group(const float* sets, int K, int stri
         const float bm = pass ? cm[cg] : 0.f;
         float s = 0.f;
         if (act) {
-#pragma unroll 4
-            for (int k = ksub; k < K; k += rpp) {
-                const float nk = shn[k], mk = sets[(size_t)k * stride + 1 + col];
+#pragma unroll
+            for (int j = 0; j < CG; ++j) {
+                const int k = ksub + j * rpp;
+                if (k < K) {
+                    const float nk = shn[k], mk = pm[j];
+                    if (pass == 0) s += nk * mk;
+                    else { const float d = mk - bm; s += pq[j] + nk * (d * d); }
+                }
+            }
+            for (int k = ksub + CG * rpp; k < K; k += rpp) {
+                const float nk = shn[k], mk = NB_LD(sets + (size_t)k * stride + 1 + col);
                 if (pass == 0) s += nk * mk;
-                else { const float d = mk - bm; s += sets[(size_t)k * stride + 1 + D + col] + nk * (d * d); }
+                else { const float d = mk - bm; s += NB_LD(sets + (size_t)k * stride + 1 + D + col) + nk * (d * d); }
             }
         }
         __syncthreads();
@@ -2152,13 +2214,14 @@ __device__ __forceinline__ void combine_group(const float* sets, int K, int stri
 }
 
 // RunningStatistics::update's merge of a batch (mean, M2, n) into column c (common/running_statistics.hpp:88-104)
-__device__ __forceinline__ float merge_column(NormDev st, int c, double cnt, float bmean, float bM2, float nbf) {
+// (old_mean / old_var: the column's statistics before the merge, read by the caller ahead of the combine)
+__device__ __forceinline__ float merge_column(NormDev st, int c, double cnt, float bmean, float bM2, float nbf, float old_mean, float old_var) {
     const double nb = (double)nbf;
     const double tot = cnt + nb;
     const float bvar = bM2 / (float)nb;                                        // :51-54
-    const float delta = bmean - st.mean[c];                                    // :90
-    const float new_mean = st.mean[c] + (delta * (float)nb) / (float)tot;      // :94
-    const float m_a = st.var[c] * (float)cnt;                                  // :97
+    const float delta = bmean - old_mean;                                      // :90
+    const float new_mean = old_mean + (delta * (float)nb) / (float)tot;        // :94
+    const float m_a = old_var * (float)cnt;                                    // :97
     const float m_b = bvar * (float)nb;                                        // :98
     const float M2 = m_a + m_b + (((delta * delta) * (float)cnt) * (float)nb) / (float)tot;  // :100
     const float v = M2 / (float)tot;                                           // :101
@@ -2178,12 +2241,13 @@ __device__ __forceinline__ void norm_finish(const NormBatchArgs& a, int which, c
         float ntot = 0.f;
         for (int cbase = 0; cbase < D; cbase += NB_THREADS) {
             const int Dg = min(NB_THREADS, D - cbase);
-            float n, mean, M2;
+            float n, mean, M2, om = 0.f, ov = 0.f;
+            if (!publish && tid < Dg) { om = a.obs_st.mean[cbase + tid]; ov = a.obs_st.var[cbase + tid]; }      // in flight during the combine
             combine_group(sets, K, stride, D, cbase, Dg, sh, n, mean, M2);
             if (tid < Dg) {
                 const int c = cbase + tid;
                 if (publish) { publish[0] = n; publish[1 + c] = mean; publish[1 + D + c] = M2; }
-                else merge_column(a.obs_st, c, cnt, mean, M2, n);
+                else merge_column(a.obs_st, c, cnt, mean, M2, n, om, ov);
             }
             ntot = n;
         }
@@ -2191,26 +2255,28 @@ __device__ __forceinline__ void norm_finish(const NormBatchArgs& a, int which, c
         if (tid == 0 && !publish) *a.obs_st.count = (double)ntot + cnt;        // :103
         return;
     }
-    // reward branch: the first batch of the apply pass is in flight while the statistics are combined
-    constexpr int U = 8;
+    // reward branch: the first batch of the apply pass (4096 rows) is in flight while the statistics are combined
+    constexpr int U = 16;
     float dn[U], rw[U], rt[U];
     if (!publish) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = tid + NB_THREADS * u;
             const bool ok = i < a.rew_rows;
-            dn[u] = ok ? a.dones[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; rt[u] = ok ? a.ret[i] : 0.f;
+            dn[u] = ok ? a.dones[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; rt[u] = ok ? NB_LD(a.ret + i) : 0.f;
         }
     }
     float var = a.ret_st.var[0];
+    const float old_ret_mean = a.ret_st.mean[0];
     if (a.training_rew) {
         const double cnt = *a.ret_st.count;
         float n, mean, M2;
-        combine_group(sets, K, stride, 1, 0, 1, sh, n, mean, M2);
+        if (K <= 64) combine_single_column(sets, K, stride, sh, n, mean, M2);
+        else combine_group(sets, K, stride, 1, 0, 1, sh, n, mean, M2);
         if (tid == 0) {
             if (publish) { publish[0] = n; publish[1] = mean; publish[2] = M2; }
             else {
-                var = merge_column(a.ret_st, 0, cnt, mean, M2, n);
+                var = merge_column(a.ret_st, 0, cnt, mean, M2, n, old_ret_mean, var);
                 *a.ret_st.count = (double)n + cnt;
             }
         }
@@ -2226,7 +2292,7 @@ __device__ __forceinline__ void norm_finish(const NormBatchArgs& a, int which, c
             for (int u = 0; u < U; ++u) {
                 const int i = base + tid + NB_THREADS * u;
                 const bool ok = i < a.rew_rows;
-                dn[u] = ok ? a.dones[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; rt[u] = ok ? a.ret[i] : 0.f;
+                dn[u] = ok ? a.dones[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; rt[u] = ok ? NB_LD(a.ret + i) : 0.f;
             }
         }
 #pragma unroll
@@ -2249,36 +2315,56 @@ __global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a)
     const int so = 1 + 2 * a.D;
     float* part_rew = a.part + (size_t)a.g_obs * so;
     const int which = b < a.g_obs ? 0 : 1;
+    NSTAMP(0);
+#ifdef PPO_STAMPS
+    if (a.stamps && threadIdx.x == 0) { a.stamps[(size_t)blockIdx.x * 8 + 4] = 0; a.stamps[(size_t)blockIdx.x * 8 + 5] = 0; a.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)which; }
+#endif
     if (which == 0) {
         const int r0 = b * a.rows_per_obs_block, r1 = min(a.rows, r0 + a.rows_per_obs_block);
         chunk_moments(a.obs, r0, r1, a.D, a.part + (size_t)b * so, sh);
     } else {
         const int k = b - a.g_obs;
         const int r0 = k * a.rows_per_rew_block, r1 = min(a.rew_rows, r0 + a.rows_per_rew_block);
+        // ret = ret * gamma + r (:66).  A thread's first 8 rows (r0 + tid + 256 u) stay in registers for the statistics below.
+        float nv[8];
+        {
+            float rt[8], rw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = r0 + tid + NB_THREADS * u; const bool ok = i < r1; rt[u] = ok ? a.ret[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = r0 + tid + NB_THREADS * u;
+                nv[u] = rt[u] * a.gamma + rw[u];
+                if (i < r1) NB_ST(a.ret + i, nv[u]);                                   // (written through: the job's last arriver reads every chunk's rows)
+            }
+        }
         constexpr int U = 4;
-        for (int base = r0; base < r1; base += NB_THREADS * U) {               // :66 (the same thread re-reads its elements below)
+        for (int base = r0 + 8 * NB_THREADS; base < r1; base += NB_THREADS * U) {
             float rt[U], rw[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { const int i = base + tid + NB_THREADS * u; const bool ok = i < r1; rt[u] = ok ? a.ret[i] : 0.f; rw[u] = ok ? a.rew[i] : 0.f; }
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const int i = base + tid + NB_THREADS * u; if (i < r1) a.ret[i] = rt[u] * a.gamma + rw[u]; }
+            for (int u = 0; u < U; ++u) { const int i = base + tid + NB_THREADS * u; if (i < r1) NB_ST(a.ret + i, rt[u] * a.gamma + rw[u]); }
         }
-        if (a.training_rew) chunk_moments(a.ret, r0, r1, 1, part_rew + (size_t)k * 3, sh);
+        if (a.training_rew) chunk_moments(a.ret, r0, r1, 1, part_rew + (size_t)k * 3, sh, nv);
     }
-    // last-block-done, one counter per job: release our partials, count, and let the final arrival acquire everyone's.
+    // last-block-done, one counter per job: the partials (and the reward job's returns) are written through, every thread drains its stores, the
+    // barrier orders them before the ONE relaxed arrival, and the job's last arriver reads them with agent-scope loads (NB_ST / NB_LD above).
     // The two jobs finish independently (two workgroups run the two tails side by side).
-    // (release only before the arrival, acquire only in the last arriver: __threadfence() is both -- a write-back AND an
-    // invalidate of the whole L2 -- in every workgroup)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    NSTAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores (partials; the reward job's `ret`) are complete
     __syncthreads();
+    NSTAMP(2);
     const unsigned total = which == 0 ? (unsigned)a.g_obs : (unsigned)a.g_rew;
     if (tid == 0) is_last = (__hip_atomic_fetch_add(a.counter + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) ? 1 : 0;
     __syncthreads();
+    NSTAMP(3);
     if (!is_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    NSTAMP(4);
     float* publish = a.xch ? a.xch + (size_t)a.rank * (so + 3) + (which ? so : 0) : nullptr;
     if (which == 0) norm_finish(a, 0, a.part, a.g_obs, so, publish, sh);
     else norm_finish(a, 1, part_rew, a.g_rew, 3, publish, sh);
+    NSTAMP(5);
     if (tid == 0) a.counter[which] = 0u;
     if (a.use_peer && publish) {
         // this rank's batch moments go straight into every rank's gather area: no all-reduce launches between the two statistics kernels.
