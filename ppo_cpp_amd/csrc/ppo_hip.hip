@@ -2238,6 +2238,10 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
                     // index map, advantage statistics AND the gather of the epoch in one launch (fp32 paths; the bf16 path stages its epoch separately)
                     GatherArgs ga{h->d_gidx, h->d_advstats, B, M, h->net.O, h->net.A, h->ro_obs, h->ro_act, h->ro_ret, h->ro_val, h->ro_nlp,
                                   h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};
+#ifdef PPO_STAMPS
+                    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+                    ga.stamps = g_stamps + 4096 * 32;
+#endif
                     hipLaunchKernelGGL(epoch_prepare_gather_kernel, dim3(nmb * EPG_SPLIT), dim3(EP_THREADS), 0, h->stream, ea, ga);
                     HIP_OK(h, hipGetLastError());
                     merged = true;
