@@ -912,6 +912,10 @@ int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* p
     { const char* e = getenv("PPO_HIP_ADAM_NO_TILES");           // (read per call: the test compares both forms in one process)
       const bool no_tiles = e && e[0] == '1';
       if (!no_tiles) { aa.n_tiled = h->n_tiled; for (int q = 0; q < h->n_tiled; ++q) aa.tiled[q] = h->tiled[q]; } }
+#ifdef PPO_STAMPS
+    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+    aa.stamps = g_stamps + 4096 * 40;
+#endif
     if (h->nw_cur == 1) { aa.theta_in = h->nw_theta1; aa.m_in = h->nw_m1; aa.v_in = h->nw_v1; h->nw_cur = 0; }   // (always writes set 0)
     // (the handle whose train kernels may apply Adam in their prologue uses the same 1-ulp quotient in its launches: bit-identical forms)
     if (h->adam_fast) hipLaunchKernelGGL(adam_kernel<true>, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
@@ -2707,9 +2711,10 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
 int ppo_debug_read_stamps(ppo_handle* h, unsigned long long* dst, int n) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
     // n > 0: the train kernels' area; n < 0: the second area (weight gradients); n < -(1 << 20): the third (statistics kernel), count = -n - (1 << 20)
-    const bool third = n < -(1 << 20);
-    const int cnt = third ? -n - (1 << 20) : (n < 0 ? -n : n);
-    HIP_OK(h, hipMemcpy(dst, g_stamps + (third ? 4096 * 32 : (n < 0 ? 4096 * 16 : 0)), (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // ... n < -(2 << 20): the fourth (adam_kernel), count = -n - (2 << 20)
+    const bool fourth = n < -(2 << 20), third = !fourth && n < -(1 << 20);
+    const int cnt = fourth ? -n - (2 << 20) : third ? -n - (1 << 20) : (n < 0 ? -n : n);
+    HIP_OK(h, hipMemcpy(dst, g_stamps + (fourth ? 4096 * 40 : third ? 4096 * 32 : (n < 0 ? 4096 * 16 : 0)), (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -1539,7 +1539,15 @@ struct AdamArgs {
     __bf16* theta_bf;            // bf16 path: straight bf16 copy of theta kept current here (null otherwise)
     float* img;                  // narrow path: packed LDS images kept current here (null otherwise)
     const float* theta_in; const float* m_in; const float* v_in;   // read from another parameter set (narrow path's deferred Adam); null = in place
+#ifdef PPO_STAMPS
+    unsigned long long* stamps;  // diagnostic builds only: [block][8]
+#endif
 };
+#ifdef PPO_STAMPS
+#define ASTAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
 
 // second-level partial sums of the per-chunk sums of squares: with millions of parameters every Adam block re-reading
 // every chunk's partial is hundreds of MB of L2 traffic per step; 1024-wide folds in a fixed order keep the norm
@@ -1580,22 +1588,25 @@ template <bool FAST>
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     __shared__ float red[4];
     __shared__ float tt[32][33];
+    ASTAMP(0);
     const int tid = threadIdx.x;
     size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
     const int chunk = (int)(idx >> 8);
     const bool live = chunk < a.n_blocks;
     // a block inside a tiled matrix takes tile (ti, tj): thread t = row t / 8, columns 4 (t % 8) .. + 3 of the tile (wave-uniform lookup in the
     // kernel arguments: no memory round trip in front of the element loads)
-    int tiled = -1, ti = 0, tj = 0;
+    int tiled = -1, ti = 0, tj = 0, t_base = 0, t_pcol = 32, t_prow = 0, t_toff = 0;
     {
         const int b0 = (int)blockIdx.x * 1024;
 #pragma unroll
         for (int q = 0; q < ADAM_MAX_TILED; ++q)
-            if (q < a.n_tiled && b0 >= a.tiled[q].base && b0 < a.tiled[q].base + a.tiled[q].count) tiled = q;
+            if (q < a.n_tiled && b0 >= a.tiled[q].base && b0 < a.tiled[q].base + a.tiled[q].count) {
+                tiled = q; t_base = a.tiled[q].base; t_pcol = a.tiled[q].pcol; t_prow = a.tiled[q].prow; t_toff = a.tiled[q].t_off;
+            }
         if (tiled >= 0) {
-            const int k = (b0 - a.tiled[tiled].base) >> 10, tpr = a.tiled[tiled].pcol >> 5;
+            const int k = (b0 - t_base) >> 10, tpr = t_pcol >> 5;
             ti = k / tpr; tj = k - ti * tpr;
-            idx = (size_t)a.tiled[tiled].base + (size_t)(32 * ti + (tid >> 3)) * a.tiled[tiled].pcol + 32 * tj + 4 * (tid & 7);
+            idx = (size_t)t_base + (size_t)(32 * ti + (tid >> 3)) * t_pcol + 32 * tj + 4 * (tid & 7);
         }
     }
     // issue this thread's element loads BEFORE the norm reduction: both memory round trips overlap
@@ -1609,6 +1620,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         t4 = *reinterpret_cast<const float4*>((a.theta_in ? a.theta_in : a.theta) + idx);
         gs = a.src[chunk];
     }
+    ASTAMP(1);
     const float b1p = a.beta_pow[0], b2p = a.beta_pow[1], lr = a.hyper[0];
     // global norm from the per-chunk partial sums, same fixed order in every block (and on every rank)
     float s = 0.f;
@@ -1624,9 +1636,11 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     } else {
         for (int i = tid; i < a.n_parts; i += 256) s += a.norm_parts[i];
     }
+    ASTAMP(2);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
+    ASTAMP(3);
     const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
     float scale = a.max_norm * tf_min(1.0f / norm, 1.0f / a.max_norm);          // G:24289-24472
     if (!isfinite(norm)) scale = __builtin_nanf("");                            // G:24493-24543
@@ -1665,12 +1679,18 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
             for (int k = 0; k < 4; ++k) tt[4 * (tid & 7) + k][tid >> 3] = to[k];
         }
     }
+    ASTAMP(4);
     if (tiled >= 0) {                                      // (block-uniform) the transposed tile: row r' = column 32 tj + r' of the matrix, 128 bytes per row
         __syncthreads();
         const int rp = tid >> 3, q4 = 4 * (tid & 7);
         const float4 o = make_float4(tt[rp][q4], tt[rp][q4 + 1], tt[rp][q4 + 2], tt[rp][q4 + 3]);
-        st_wt4<PPO_WT_C2>(a.thetaT + a.tiled[tiled].t_off + (size_t)(32 * tj + rp) * a.tiled[tiled].prow + 32 * ti + q4, o);
+        st_wt4<PPO_WT_C2>(a.thetaT + t_toff + (size_t)(32 * tj + rp) * t_prow + 32 * ti + q4, o);
     }
+    ASTAMP(5);
+#ifdef PPO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASTAMP(6);
+#endif
     if (blockIdx.x == 0) {
         if (tid == 0) {
             a.beta_pow[2] = b1p * a.beta1;                                      // G:31217-31342 (after the applies)
