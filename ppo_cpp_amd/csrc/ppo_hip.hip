@@ -820,8 +820,13 @@ int bf16_weight_grads(ppo_handle* h, const TrainArgs& ta, int Rp) {
 #define NW_DISPATCH(h, X) do { if (!(h)->nw_static) { X(0, 0, 0, 0); } else if ((h)->net.Kp0 == 32) { X(32, 64, 32, 2); } else { X(64, 64, 32, 2); } } while (0)
 
 template <int CT, int KS, int CTH, bool WIDE>
-void launch_step_t(ppo_handle* h, const StepArgs& a) {
+void launch_step_t(ppo_handle* h, const StepArgs& a0) {
+    StepArgs a = a0;
     dim3 grid((a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 2);
+#ifdef PPO_STAMPS
+    if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+    a.stamps = grid.x <= 256 ? g_stamps + 4096 * 44 : nullptr;
+#endif
     hipLaunchKernelGGL((policy_step_kernel<CT, KS, CTH, WIDE>), grid, dim3(BLOCK_THREADS), (size_t)h->lds_step_total * sizeof(float), h->stream, h->net, a);
 }
 int launch_step(ppo_handle* h, const StepArgs& a) {
@@ -2711,10 +2716,10 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
 int ppo_debug_read_stamps(ppo_handle* h, unsigned long long* dst, int n) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
     // n > 0: the train kernels' area; n < 0: the second area (weight gradients); n < -(1 << 20): the third (statistics kernel), count = -n - (1 << 20)
-    // ... n < -(2 << 20): the fourth (adam_kernel), count = -n - (2 << 20)
-    const bool fourth = n < -(2 << 20), third = !fourth && n < -(1 << 20);
-    const int cnt = fourth ? -n - (2 << 20) : third ? -n - (1 << 20) : (n < 0 ? -n : n);
-    HIP_OK(h, hipMemcpy(dst, g_stamps + (fourth ? 4096 * 40 : third ? 4096 * 32 : (n < 0 ? 4096 * 16 : 0)), (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // ... n < -(2 << 20): the fourth (adam_kernel), count = -n - (2 << 20); n < -(3 << 20): the fifth (policy_step_kernel), count = -n - (3 << 20)
+    const bool fifth = n < -(3 << 20), fourth = !fifth && n < -(2 << 20), third = !fifth && !fourth && n < -(1 << 20);
+    const int cnt = fifth ? -n - (3 << 20) : fourth ? -n - (2 << 20) : third ? -n - (1 << 20) : (n < 0 ? -n : n);
+    HIP_OK(h, hipMemcpy(dst, g_stamps + (fifth ? 4096 * 44 : fourth ? 4096 * 40 : third ? 4096 * 32 : (n < 0 ? 4096 * 16 : 0)), (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

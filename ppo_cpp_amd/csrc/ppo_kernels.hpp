@@ -749,11 +749,20 @@ struct StepArgs {
     ObsNorm nz;
     int n;
     uint32_t seed, rng_step, row_base;
+#ifdef PPO_STAMPS
+    unsigned long long* stamps;   // diagnostic builds only: [tower][block][8]
+#endif
 };
+#ifdef PPO_STAMPS
+#define PSTAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
 
 template <int CT, int KS, int CTH, bool WIDE>
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void policy_step_kernel(NetDev net, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    PSTAMP(0);
     warm_kernargs<sizeof(NetDev) + sizeof(StepArgs)>();
     const int tower = blockIdx.y;
     if (tower == 1 && !a.value) return;
@@ -767,6 +776,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void policy_step_kernel(NetDev ne
     stage_block_inputs(net, a.par + tower * net.par_total, par, lds + net.lds_h[0], ld0, a.obs, row0, a.n, a.nz,
                        tower == 0 ? a.obs_out : nullptr, nullptr, RowScalars{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, nullptr);
     lds_barrier();
+    PSTAMP(1);
     int K = net.Kp0, ldx = ld0;
     for (int l = 0; l < net.L; ++l) {
         const int Np = net.Hp[l], ldy = Np + LDS_PAD;
@@ -776,16 +786,20 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void policy_step_kernel(NetDev ne
                                              else if constexpr (CTH > 0) head_prefetch<CTH>(hpre.w, a.theta + net.wmu_off, net.Ap, Np);   // (both towers: uniform code)
                                          });
         lds_barrier();
+        if (l == 0) PSTAMP(2);
         K = Np; ldx = ldy;
     }
+    PSTAMP(3);
     const float* hL = lds + net.lds_h[net.L];
     if (tower == 1) {
         const float v = value_head(hL, ldx, K, par + net.par_wv, par[net.par_bv]);
         const int row = row0 + (threadIdx.x >> 4);
         if ((threadIdx.x & 15) == 0 && row < a.n) a.value[row] = v;
+        PSTAMP(5);
         return;
     }
     policy_head<CTH>(net, a.theta, hpre, hL, ldx, K, lds);
+    PSTAMP(4);
     const float* mus = lds + net.lds_mu;
     const int ldm = net.Ap + LDS_PAD;
     // sampling + neglogp (G:5894-6672): 16 lanes per row, each lane owns actions j = part, part+16, ...
@@ -810,6 +824,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void policy_step_kernel(NetDev ne
     ssq = group16_sum(ssq);
     slog = group16_sum(slog);
     if (part == 0 && row < a.n && a.neglogp) a.neglogp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
+    PSTAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------------------
