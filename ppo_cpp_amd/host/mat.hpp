@@ -45,23 +45,33 @@ namespace Eigen {
 // mmap / munmap and fresh page faults each time (measured: 70 us of a 145 us VecEnv::step).  Buffers of 16 KB .. 64 MB therefore go through
 // a small per-thread cache: a freed block is kept (at most 8, at most 128 MB per thread) and handed to the next request of exactly its size.
 namespace mat_detail {
-struct BlockCache {
+struct BlockCache {                    // plain data (no destructor): stays addressable for matrices that die after the thread's guard below
     static constexpr int kSlots = 8;
     static constexpr size_t kMin = 16u << 10, kMax = 64u << 20, kCap = 128u << 20;
-    void* p[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t n[kSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
-    size_t held = 0;
-    ~BlockCache() { for (int i = 0; i < kSlots; ++i) if (p[i]) ::operator delete(p[i]); }
+    void* p[kSlots];
+    size_t n[kSlots];
+    size_t held;
+    bool dead;                         // the thread is past its guard (static / thread-local destruction): no more caching
     void* take(size_t bytes) {
+        if (dead) return nullptr;
         for (int i = 0; i < kSlots; ++i) if (p[i] && n[i] == bytes) { void* q = p[i]; p[i] = nullptr; held -= bytes; return q; }
         return nullptr;
     }
     bool give(void* q, size_t bytes) {
-        if (held + bytes > kCap) return false;
+        if (dead || held + bytes > kCap) return false;
         for (int i = 0; i < kSlots; ++i) if (!p[i]) { p[i] = q; n[i] = bytes; held += bytes; return true; }
         return false;
     }
-    static BlockCache& mine() { static thread_local BlockCache c; return c; }
+    struct Guard {                     // frees what the thread still holds when it ends
+        BlockCache* c;
+        ~Guard() { for (int i = 0; i < kSlots; ++i) if (c->p[i]) { ::operator delete(c->p[i]); c->p[i] = nullptr; } c->held = 0; c->dead = true; }
+    };
+    static BlockCache& mine() {
+        static thread_local BlockCache c = {};
+        static thread_local Guard g{&c};
+        (void)g;
+        return c;
+    }
 };
 template <class T>
 struct RecyclingAllocator {
