@@ -137,7 +137,7 @@ def test_gae_and_advantage_normalisation_kernels():
         close(g.adv_normalize(r, v), o.adv_normalize(r, v), rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("E", [1, 7, 64, 4096])
+@pytest.mark.parametrize("E", [1, 7, 64, 4096, 5000, 150000])      # 5000: the reward job's apply pass takes a second batch; 150000: chunks longer than a thread keeps in registers
 def test_running_statistics_and_normalisation(E):
     _, g = pair((4, 5), "ginit")
     g.norm_init(E)
