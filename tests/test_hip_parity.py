@@ -831,7 +831,8 @@ def test_full_size_config4_single_rank_properties():
     close(g.get_flat(0), orc.theta, rtol=2e-4, atol=5e-6)
 
 
-@pytest.mark.parametrize("hidden,E,T,nmb,explicit", [((256, 256), 256, 16, 8, False), ((64, 64), 16, 24, 4, True), ((256, 256), 100, 10, 5, True)])
+@pytest.mark.parametrize("hidden,E,T,nmb,explicit", [((256, 256), 256, 16, 8, False), ((64, 64), 16, 24, 4, True), ((256, 256), 100, 10, 5, True),
+                                                      ((64, 64), 2048, 16, 4, False), ((64, 64), 77, 13, 7, True)])      # 8192-row minibatches (the most the merged kernel takes); 143 rows: ragged shares
 def test_merged_epoch_kernel_is_bitwise_the_two_launch_form(hidden, E, T, nmb, explicit, monkeypatch):
     """epoch_prepare_gather_kernel (index map, advantage statistics and the gather of an epoch in ONE launch, EPG_SPLIT workgroups per minibatch
     each re-deriving the map) against epoch_prepare_kernel + epoch_gather_kernel (PPO_HIP_NO_EPOCH_MERGE=1): loss rows, weights and the Adam
