@@ -35,6 +35,14 @@ public:
     }
 
     struct UpdateLog { int fps; float losses[5]; double collect_ms, update_ms; };
+    // Data parallel (no reference counterpart): this PPO2 is rank `rank` of `world` processes, one per GPU, whose handles share a
+    // communicator (ppo_dist_init, see dist.hpp).  `env` holds THIS rank's share of the environments; n_batch, total_timesteps, the fps of the
+    // CSV line and the checkpoint's n_envs are job-wide quantities.  The replicas stay bit-identical, so rank 0 alone prints and saves
+    // (replica_saves: the others also save, under <path>.rank<r>, for the tests that compare them byte for byte).
+    void set_distributed(int world, int rank) { world_ = world < 1 ? 1 : world; rank_ = rank; if (rank_ != 0) quiet = true; }
+    int world() const { return world_; }
+    int rank() const { return rank_; }
+    bool replica_saves = false;
     const std::vector<UpdateLog>& history() const { return history_; }
     std::vector<std::pair<int, float>>& episode_rewards() { return episodes_; }
     bool quiet = false;
@@ -51,6 +59,7 @@ public:
     // (<path>[.<id>].index / .data-00000-of-00001, names "model/<tensor>"; the untrained q/w, q/b ride along so that the
     // reference's restore_all finds every variable) and the JSON side-car with hyper-parameters + Env::serialize.
     void save(std::string save_path, int save_id = -1) {
+        if (rank_ != 0) { if (!replica_saves) return; save_path += ".rank" + std::to_string(rank_); }
         if (save_id >= 0) save_path += "." + std::to_string(save_id);
         ckpt::Bundle b = extra_tensors_;
         const int nt = ppo_num_tensors(h_);
@@ -78,7 +87,7 @@ public:
         json["max_grad_norm"] = max_grad_norm_; json["learning_rate"] = learning_rate_; json["lam"] = lam_;
         json["nminibatches"] = nminibatches_; json["noptepochs"] = noptepochs_; json["cliprange"] = cliprange_;
         json["cliprange_vf"] = cliprange_vf_; json["observation_space"] = env_.get_observation_space();
-        json["action_space"] = env_.get_action_space(); json["n_envs"] = n_envs_; json["model_filename"] = model_filename;
+        json["action_space"] = env_.get_action_space(); json["n_envs"] = n_envs_ * world_; json["model_filename"] = model_filename;
         std::ofstream f(save_path + ".json");
         if (!f) throw std::runtime_error("PPO2::save: unable to open " + save_path + ".json");
         f << json.dump();
@@ -123,13 +132,15 @@ public:
             seeded_ = true; seeded_with_ = seed;                   // their draws (the shuffle key counts updates since the seed was set)
             shuffle_updates_ = 0; shuffle_rng_.seed((unsigned)seed);
         }
-        const int n_updates = total_timesteps / n_batch_;
+        const int n_updates = total_timesteps / (n_batch_ * world_);
         save_interval_ = num_saves > 0 ? static_cast<int>(std::ceil(static_cast<float>(n_updates) / static_cast<float>(num_saves))) : -1;
         save_path_ = save_path;
         if (num_saves > 0 && save_path.empty()) throw std::runtime_error("PPO2::learn: num_saves > 0 needs a save path");
         if (n_batch_ % nminibatches_ != 0) throw std::runtime_error("PPO2: n_batch must be divisible by nminibatches");
         EnvNormalize* nz = dynamic_cast<EnvNormalize*>(&env_);
         if (nz && nz->training()) learn_resident(*nz, n_updates);
+        else if (world_ > 1) throw std::runtime_error("PPO2::learn: data parallel needs the HBM-resident loop (an EnvNormalize in training mode): the literal loop's "
+                                                      "host-side advantage normalisation sees one rank's rows only");
         else learn_reference_loop(n_updates);
         if (num_saves > 0 && save_interval_ > 0 && (n_updates % save_interval_) != 0) save(save_path, n_updates / save_interval_);
     }
@@ -178,11 +189,12 @@ private:
                 for (int t = 0; t < T; ++t) { rew_view(e, t) = rew_tm(t, e); done_view(e, t) = done_tm(t, e); }
             check(ppo_rollout_finish(h_, gamma_, lam_));
             const auto t1 = clk::now();
-            num_timesteps_ += n_batch_;
+            num_timesteps_ += n_batch_ * world_;
             UpdateLog log{};
             const int32_t* perms = explicit_perms ? explicit_perms + (size_t)(update - 1) * noptepochs_ * n_batch_ : nullptr;
-            check(ppo_update(h_, learning_rate_, cliprange_, noptepochs_, nminibatches_, perms, seed + (unsigned long long)(++shuffle_updates_), nullptr,
-                             log.losses));
+            // every rank shuffles its OWN rows (include/ppo_hip.h, ppo_dist_global_shuffle 0): the rank is part of the key
+            check(ppo_update(h_, learning_rate_, cliprange_, noptepochs_, nminibatches_, perms,
+                             seed + (unsigned long long)(++shuffle_updates_) + ((unsigned long long)rank_ << 40), nullptr, log.losses));
             const auto t2 = clk::now();
             finish_update(log, t0, t1, t2, rew_view, done_view);
         }
@@ -236,14 +248,16 @@ private:
         log.collect_ms = ms(t0, t1);
         log.update_ms = ms(t1, t2);
         const double total = std::max(ms(t0, t2), 1e-3);
-        log.fps = static_cast<int>(n_batch_ * 1000.0 / total);            // ppo2.hpp:337-341
+        // ppo2.hpp:337-341; data parallel: the job's env steps over THIS rank's wall time (the ranks meet in a collective every minibatch,
+        // so their update times differ by less than one exchange)
+        log.fps = static_cast<int>((double)n_batch_ * world_ * 1000.0 / total);
         if (!quiet) {
             std::printf("%d,", log.fps);
             for (int i = 0; i < 5; ++i) std::printf("%g,", log.losses[i]);
             std::printf("\n");
         }
         episode_reward_ = Utils::total_episode_reward_logger(
-            episode_reward_, rew_view, done_view, [this](int step, const char*, float v) { episodes_.push_back({step, v}); }, num_timesteps_ - n_batch_);
+            episode_reward_, rew_view, done_view, [this](int step, const char*, float v) { episodes_.push_back({step, v}); }, num_timesteps_ - n_batch_ * world_);
         history_.push_back(log);
         const int update = ++updates_this_learn_;                   // save ids / cadence count from the start of THIS learn() call
         if (save_interval_ > 0 && update % save_interval_ == 0) save(save_path_, update / save_interval_ - 1);
@@ -253,6 +267,7 @@ private:
 
     ppo_handle* h_;
     Env& env_;
+    int world_ = 1, rank_ = 0;
     float gamma_;
     int n_steps_;
     float ent_coef_, learning_rate_, vf_coef_, max_grad_norm_, lam_;
