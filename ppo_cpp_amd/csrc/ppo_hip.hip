@@ -1561,7 +1561,7 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
     h->nz_envs = n_envs; h->nz_gamma = gamma; h->nz_clip_obs = clip_obs; h->nz_clip_rew = clip_rew; h->nz_eps = epsilon;
     if (norm_alloc_stats(h, h->obs_rms, h->net.O) || norm_alloc_stats(h, h->ret_rms, 1)) return -1;
     if (dev_alloc(h, &h->nz_ret, n_envs) || dev_alloc(h, &h->stats_counter, 4) ||
-        dev_alloc(h, &h->stats_part, (size_t)NB_MAX_OBS_BLOCKS * (1 + 2 * h->net.O) + (size_t)NB_MAX_REW_BLOCKS * 3)) return -1;
+        dev_alloc(h, &h->stats_part, (size_t)NB_MAX_OBS_BLOCKS * ru(1 + 2 * h->net.O, 32) + (size_t)NB_MAX_REW_BLOCKS * NB_REW_STRIDE)) return -1;
     // raw observations | raw rewards | dones of the current env step in ONE block (one H2D copy per env step on the
     // host-Env path) with a pinned host mirror owned by the handle (replaces the pageable Utils::convert_* copies of
     // ppo2/utils.hpp:17-73)
@@ -1623,11 +1623,13 @@ static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, con
     a.rew_rows = rows; a.training_rew = (training_rew && h->norm_rew_flag) ? 1 : 0; a.scale_rew = h->norm_rew_flag;
     if (rew_dev) {
         a.g_rew = std::max(1, std::min(NB_MAX_REW_BLOCKS, (rows + 1023) / 1024));
-        a.rows_per_rew_block = (rows + a.g_rew - 1) / a.g_rew;
+        // whole multiples of 32 rows: a chunk owner rewrites its rows of `ret` for the job's last arriver to read, and no 128-byte line of
+        // that hand-off may belong to two workgroups (NB_ST in ppo_kernels.hpp)
+        a.rows_per_rew_block = ru((rows + a.g_rew - 1) / a.g_rew, 32);
         a.g_rew = (rows + a.rows_per_rew_block - 1) / a.rows_per_rew_block;
     }
     a.gamma = h->nz_gamma; a.clip_rew = h->nz_clip_rew; a.eps = h->nz_eps;
-    a.part = h->stats_part; a.counter = reinterpret_cast<unsigned*>(h->stats_counter);
+    a.part = h->stats_part; a.part_stride = ru(1 + 2 * D, 32); a.counter = reinterpret_cast<unsigned*>(h->stats_counter);
     a.world = h->world; a.rank = h->rank;
     const size_t xw = (size_t)(1 + 2 * D) + 3;
     // over peer-mapped regions the two statistics kernels exchange the table themselves (the last workgroup of each job writes this

@@ -2122,6 +2122,7 @@ __global__ __launch_bounds__(GAE_LONG_THREADS) void gae_long_kernel(const float*
 #define NB_THREADS 256
 #define NB_MAX_OBS_BLOCKS 256
 #define NB_MAX_REW_BLOCKS 64
+#define NB_REW_STRIDE 32      // floats between the reward chunks' (n, mean, M2) sets: one 128-byte line each
 
 struct NormBatchArgs {
     const float* obs; int rows; int D; NormDev obs_st; int g_obs; int rows_per_obs_block;      // obs == null: no obs job
@@ -2129,7 +2130,8 @@ struct NormBatchArgs {
     int rew_rows; int training_rew; int g_rew; int rows_per_rew_block;
     int scale_rew;        // EnvNormalize::norm_reward (env_normalize.hpp:75): 0 = rewards pass through unscaled and unclipped
     float gamma, clip_rew, eps;
-    float* part;          // [g_obs][1 + 2D] then [g_rew][3]
+    float* part;          // [g_obs][part_stride] then [g_rew][NB_REW_STRIDE]: every chunk's set on 128-byte lines of its own
+    int part_stride;      // 1 + 2D rounded up to 32 floats
     unsigned* counter;    // zero between launches
     float* xch;           // data-parallel: [world][(1 + 2D) + 3] slot table (this rank's slot is written here), else null
     int world, rank;
@@ -2152,6 +2154,9 @@ __device__ __forceinline__ int pow2_ceil(int x) { int p = 1; while (p < x) p <<=
 // ONE relaxed arrival, and the last arriver reads them with agent-scope loads (sc1: lines it has not touched in this launch, never served
 // from its own XCD's L2).  The language model's pair -- a release fence in every workgroup, an acquire in the last -- costs a write-back of the
 // whole L2 per workgroup: 3.3 - 3.8 k cycles of this 28 k-cycle kernel (tools/stamps_norm.py).
+// "Has not touched" is made true by the layout, not assumed: no 128-byte line of the hand-off is shared between two workgroups -- the sets are
+// part_stride / NB_REW_STRIDE floats apart (multiples of 32 on a 256-byte-aligned base) and the reward chunks are whole multiples of 32 rows of
+// `ret` (enqueue_norm_batch), so the plain load a chunk owner makes of its OWN rows of `ret` never brings a neighbour's rows into its XCD's L2.
 __device__ __forceinline__ void NB_ST(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float NB_LD(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -2385,8 +2390,8 @@ __global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a)
     __shared__ float sh[3 * NB_THREADS];
     __shared__ int is_last;
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int so = 1 + 2 * a.D;
-    float* part_rew = a.part + (size_t)a.g_obs * so;
+    const int so = 1 + 2 * a.D, ps = a.part_stride;
+    float* part_rew = a.part + (size_t)a.g_obs * ps;
     const int which = b < a.g_obs ? 0 : 1;
     NSTAMP(0);
 #ifdef PPO_STAMPS
@@ -2394,7 +2399,7 @@ __global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a)
 #endif
     if (which == 0) {
         const int r0 = b * a.rows_per_obs_block, r1 = min(a.rows, r0 + a.rows_per_obs_block);
-        chunk_moments(a.obs, r0, r1, a.D, a.part + (size_t)b * so, sh);
+        chunk_moments(a.obs, r0, r1, a.D, a.part + (size_t)b * ps, sh);
     } else {
         const int k = b - a.g_obs;
         const int r0 = k * a.rows_per_rew_block, r1 = min(a.rew_rows, r0 + a.rows_per_rew_block);
@@ -2419,7 +2424,7 @@ __global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a)
 #pragma unroll
             for (int u = 0; u < U; ++u) { const int i = base + tid + NB_THREADS * u; if (i < r1) NB_ST(a.ret + i, rt[u] * a.gamma + rw[u]); }
         }
-        if (a.training_rew) chunk_moments(a.ret, r0, r1, 1, part_rew + (size_t)k * 3, sh, nv);
+        if (a.training_rew) chunk_moments(a.ret, r0, r1, 1, part_rew + (size_t)k * NB_REW_STRIDE, sh, nv);
     }
     // last-block-done, one counter per job: the partials (and the reward job's returns) are written through, every thread drains its stores, the
     // barrier orders them before the ONE relaxed arrival, and the job's last arriver reads them with agent-scope loads (NB_ST / NB_LD above).
@@ -2435,8 +2440,8 @@ __global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a)
     if (!is_last) return;
     NSTAMP(4);
     float* publish = a.xch ? a.xch + (size_t)a.rank * (so + 3) + (which ? so : 0) : nullptr;
-    if (which == 0) norm_finish(a, 0, a.part, a.g_obs, so, publish, sh);
-    else norm_finish(a, 1, part_rew, a.g_rew, 3, publish, sh);
+    if (which == 0) norm_finish(a, 0, a.part, a.g_obs, ps, publish, sh);
+    else norm_finish(a, 1, part_rew, a.g_rew, NB_REW_STRIDE, publish, sh);
     NSTAMP(5);
     if (tid == 0) a.counter[which] = 0u;
     if (a.use_peer && publish) {

@@ -48,6 +48,22 @@ def main():
         time.sleep(float(os.environ.get("PPO_TEST_DRILL_SLEEP", "4")))
         g.close()
         return
+    iters = int(os.environ.get("PPO_TEST_ITERS", "0"))
+    if iters:
+        # determinism soak (tests/test_race_guards.py): many collect + update iterations with the library's own generators; everything that
+        # crosses ranks (statistics table per env step, advantage moments per epoch, gradient per minibatch) is exercised `iters` times over
+        means = []
+        for i in range(iters):
+            g.collect_synthetic(int(d["seed"]), float(d["gamma"]), float(d["lam"]), None, env0=rank * El, step0=i * T, first=(i == 0))
+            means.append(g.update(float(d["lr"]), float(d["cr"]), epochs, nmb, None, seed=500 + i, want_rows=False)[1].copy())
+        out = {"means": np.array(means), "theta": g.get_flat(0), "adam_m": g.get_flat(1), "adam_v": g.get_flat(2), "ro_returns": g.rollout_get("returns")}
+        for which, nm in ((0, "obs"), (1, "ret")):
+            m, v, c = g.norm_stats(which)
+            out[nm + "_mean"], out[nm + "_var"], out[nm + "_count"] = m, v, np.float64(c)
+        out["peer"] = np.int32(g.dist_peer_active())
+        g.close()
+        np.savez(fout, **out)
+        return
     g.collect_synthetic(int(d["seed"]), float(d["gamma"]), float(d["lam"]), d["noise"][:, sl], env0=rank * El, step0=0, first=True)
     out = {"ro_" + f: g.rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones")}
     for which, nm in ((0, "obs"), (1, "ret")):

@@ -1,0 +1,157 @@
+"""Race / determinism guards for the hand-offs that deliberately bypass the language memory model's release / acquire pair.
+
+Three places pass data between workgroups of ONE launch through write-through (sc1) stores, a drained store queue, a workgroup barrier, one
+relaxed agent-scope arrival and sc1 loads in the last arriver (the model's fences measured 2x on these kernels, profiles/r04_a_*):
+  * weight_grad_assemble_kernel's per-tile slab sums (ppo_dw2.hpp: the last of a tile's 4 row splits adds the slabs),
+  * norm_batch_kernel's chunk moments and the reward job's discounted returns (ppo_kernels.hpp, NB_ST / NB_LD),
+  * the narrow path's partial gradient vectors and the cooperative rollout's step words (ppo_narrow.hpp),
+and the data-parallel peer exchange passes slots between PROCESSES with system-scope stores and flags (ppo_peer.hpp).  Every sum on these
+paths has a fixed order, so a correct run is a pure function of its inputs: the tests below run the same workload several times -- hipGraph
+replay, again, and with eager launches (different timing between the kernels) -- and require every weight, Adam slot, loss row and running
+statistic to come out with the SAME BITS.  A stale or torn read in any hand-off shows up as a bitwise mismatch between two runs (it would move a
+gradient tile or a chunk moment by a whole partial sum, not by rounding); the reference has no counterpart (one thread issues one
+Session::Run per train step, ppo2/ppo2.hpp:430-468).  Iteration counts are sized for a few seconds per test; tools/soak*.py run the same
+bodies for as long as one likes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ppo_cpp_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LR, CR, GAMMA, LAM = 3.93141e-4, 0.161023, 0.99, 0.95
+
+
+def _run(monkeypatch, obs, act, hidden, E, T, nmb, epochs, iters, eager, bf16=False):
+    if eager:
+        monkeypatch.setenv("PPO_HIP_NO_GRAPH", "1")
+    else:
+        monkeypatch.delenv("PPO_HIP_NO_GRAPH", raising=False)
+    g = ppo_cpp_amd.PPOHip(obs, act, list(hidden), compute_dtype=1 if bf16 else 0)
+    g.init_orthogonal(0); g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+    means = []
+    for i in range(iters):
+        g.collect_synthetic(1234, GAMMA, LAM, None, env0=0, step0=i * T, first=(i == 0))
+        means.append(g.update(LR, CR, epochs, nmb, None, seed=1000 + i, want_rows=False)[1].copy())
+    out = {"theta": g.get_flat(0), "adam_m": g.get_flat(1), "adam_v": g.get_flat(2), "means": np.array(means), "returns": g.rollout_get("returns")}
+    for which, nm in ((0, "obs"), (1, "ret")):
+        m, v, c = g.norm_stats(which)
+        out[nm + "_mean"], out[nm + "_var"], out[nm + "_count"] = m, v, np.float64(c)
+    counts = g.kernel_counts()
+    g.close()
+    monkeypatch.delenv("PPO_HIP_NO_GRAPH", raising=False)
+    return out, counts
+
+
+def _same_bits(a, b, what):
+    assert np.isfinite(a["theta"]).all(), what
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg="%s: %s differs between two runs of the same workload" % (what, k))
+
+
+def test_headline_shape_tile_and_statistics_hand_offs(monkeypatch):
+    """BASELINE configs[2] exactly (4096 envs x 16 steps, [256,256], 32 minibatches x 10 epochs), 40 collect + update iterations = 12 800 train
+    steps x 64 tile hand-offs (weight_grad_assemble_kernel) and 640 statistics launches per run: hipGraph replay twice and eager launches once."""
+    a, counts = _run(monkeypatch, 18, 18, (256, 256), 4096, 16, 32, 10, 40, eager=False)
+    assert counts.get("weight_grad_assemble_kernel", 0) > 0 and counts.get("train8_kernel", 0) > 0, counts
+    b, _ = _run(monkeypatch, 18, 18, (256, 256), 4096, 16, 32, 10, 40, eager=False)
+    c, _ = _run(monkeypatch, 18, 18, (256, 256), 4096, 16, 32, 10, 40, eager=True)
+    _same_bits(a, b, "graph replay, run vs run")
+    _same_bits(a, c, "graph replay vs eager launches")
+    assert np.abs(a["means"][0] - a["means"][-1]).max() > 0             # (the run trained: the losses moved)
+
+
+@pytest.mark.parametrize("E,T", [(5000, 24), (4097, 24), (150000, 2)])
+def test_statistics_hand_off_at_row_counts_that_do_not_fill_lines(monkeypatch, E, T):
+    """norm_batch_kernel at environment counts whose chunks do not end on 128-byte lines (5000 rows used to give 1000-row reward chunks; 4097 leaves
+    a one-row chunk): the reward chunks are now whole multiples of 32 rows and every chunk's partial set sits on lines of its own, so the last
+    arriver reads no line another workgroup shared with it.  30 rollouts (720 statistics launches) twice on the launch-per-kernel path: same bits;
+    the first rollout's statistics against the oracle's two-pass moments."""
+    from oracle import oracle as o
+    monkeypatch.setenv("PPO_HIP_NO_PERSISTENT_COLLECT", "1")
+    iters = 30 if E < 100000 else 6
+    runs = []
+    for _ in range(2):
+        g = ppo_cpp_amd.PPOHip(18, 18, [64, 64]); g.init_orthogonal(0); g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+        first = None
+        for i in range(iters):
+            g.collect_synthetic(1234, GAMMA, LAM, None, env0=0, step0=i * T, first=(i == 0))
+            if i == 0:
+                first = (g.norm_stats(0), g.norm_stats(1), g.rollout_get("rewards"))
+        out = {"returns": g.rollout_get("returns"), "rewards": g.rollout_get("rewards"), "obs": g.rollout_get("obs")}
+        for which, nm in ((0, "obs"), (1, "ret")):
+            m, v, c = g.norm_stats(which)
+            out[nm + "_mean"], out[nm + "_var"], out[nm + "_count"] = m, v, np.float64(c)
+        kc = g.kernel_counts()                                           # the launch-per-kernel path: norm_batch_kernel per env step, no resident rollout
+        assert kc["narrow_rollout_coop_kernel"] == 0 and kc["narrow_rollout_kernel"] == 0 and kc["narrow_collect_kernel"] == 0, kc
+        g.close()
+        runs.append((out, first))
+    for k in runs[0][0]:
+        np.testing.assert_array_equal(runs[0][0][k], runs[1][0][k], err_msg=k)
+    if E <= 5000:                                                        # (the scalar oracle's rollout: seconds at these sizes)
+        orc = o.Oracle(18, 18, [64, 64]); orc.init_orthogonal(0)
+        nz = o.Normalizer(E, 18)
+        noise = np.zeros((T, E, 18), np.float32)                        # the statistics do not depend on the actions of the seeded env
+        ro, _, _ = o.collect(orc, nz, 1234, T, noise, GAMMA, LAM)
+        (m, v, c), (rm, rv, rc), rew = runs[0][1]
+        np.testing.assert_allclose(m, nz.obs_rms.mean, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(v, nz.obs_rms.var, rtol=1e-5)
+        np.testing.assert_allclose(rv, nz.ret_rms.var, rtol=1e-5); assert c == nz.obs_rms.count and rc == nz.ret_rms.count
+        np.testing.assert_allclose(rew, ro["rewards"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("E,T,nmb,iters", [(1024, 64, 32, 100), (48, 32, 4, 300), (1, 512, 8, 150)])
+def test_narrow_path_partial_vectors_and_cooperative_rollout(monkeypatch, E, T, nmb, iters):
+    """The reference's [64,64] shape: narrow_train_kernel's per-workgroup partial gradient vectors (write-through, summed by narrow_reduce_kernel),
+    the deferred Adam reading the other parameter set, and -- at 1024 environments, BASELINE configs[3]'s count -- the cooperative persistent rollout
+    whose workgroups meet once per env step through step words: graph replay twice, eager once."""
+    a, counts = _run(monkeypatch, 18, 18, (64, 64), E, T, nmb, 4, iters, eager=False)
+    assert any(k.startswith("narrow_train_kernel") and v > 0 for k, v in counts.items()), counts
+    b, _ = _run(monkeypatch, 18, 18, (64, 64), E, T, nmb, 4, iters, eager=False)
+    c, _ = _run(monkeypatch, 18, 18, (64, 64), E, T, nmb, 4, iters, eager=True)
+    _same_bits(a, b, "graph replay, run vs run")
+    _same_bits(a, c, "graph replay vs eager launches")
+
+
+def test_bf16_path_slabs_and_split_k(monkeypatch):
+    """configs[4]'s shape (256 / 64 / [1024]^3, bf16): the work-balanced weight-gradient GEMM's 2-3 partial slabs per tile, the split-K heads
+    and the column-sum slots are all added in a fixed order: 4 iterations of 2 epochs x 8 minibatches of 4096 rows, graph replay twice + eager."""
+    a, _ = _run(monkeypatch, 256, 64, (1024, 1024, 1024), 2048, 16, 8, 2, 4, eager=False, bf16=True)
+    b, _ = _run(monkeypatch, 256, 64, (1024, 1024, 1024), 2048, 16, 8, 2, 4, eager=False, bf16=True)
+    c, _ = _run(monkeypatch, 256, 64, (1024, 1024, 1024), 2048, 16, 8, 2, 4, eager=True, bf16=True)
+    _same_bits(a, b, "graph replay, run vs run")
+    _same_bits(a, c, "graph replay vs eager launches")
+
+
+@pytest.mark.parametrize("world,hidden,E,T,nmb,epochs,iters", [(8, (256, 256), 64, 8, 4, 4, 12), (8, (64, 64), 128, 16, 4, 4, 12)])
+def test_peer_exchange_between_eight_processes_is_deterministic(tmp_path, world, hidden, E, T, nmb, epochs, iters):
+    """World 8 on the one-shot peer path (slots pushed into every peer's region, a flag per source, rank-ordered sums: ppo_peer.hpp; the statistics
+    table pushed by norm_batch_kernel's last workgroups): 12 collect + update iterations = 192 gradient exchanges, 48 advantage-moment exchanges
+    and ~100 statistics exchanges between 8 processes, run TWICE: every rank of both runs must hold the same bits (a slot read before its flag's
+    data had landed, or a parity slot reused too early, would change a whole rank's contribution)."""
+    from tests.test_dp_two_ranks import build_fake_rccl, run_workers
+    fake = build_fake_rccl(str(tmp_path))
+    import ppo_cpp_amd as pk                                             # noqa: F401  (the workers import the same build)
+    from oracle import oracle as o
+    orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(21)
+    res = []
+    for run in range(2):
+        sub = os.path.join(str(tmp_path), "run%d" % run); os.makedirs(sub)
+        uid = np.zeros(128, np.uint8)
+        name = ("/ppo_dp_soak_%d_%d" % (os.getpid(), run)).encode()
+        uid[:len(name)] = np.frombuffer(name, np.uint8)
+        fin = os.path.join(sub, "in.npz")
+        np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=orc.theta, uid=uid, gamma=GAMMA, lam=LAM, seed=1234, lr=LR, cr=CR)
+        env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="1", PPO_TEST_ITERS=str(iters))
+        res.append(run_workers(sub, world, fin, env))
+    keys = ("means", "theta", "adam_m", "adam_v", "obs_mean", "obs_var", "obs_count", "ret_mean", "ret_var", "ret_count")
+    for out in res[0] + res[1]:
+        assert int(out["peer"]) == 1
+        for k in keys:
+            np.testing.assert_array_equal(res[0][0][k], out[k], err_msg=k)          # replicas of one run AND the two runs: one set of bits
+    for r in range(world):
+        np.testing.assert_array_equal(res[0][r]["ro_returns"], res[1][r]["ro_returns"])
+    assert np.isfinite(res[0][0]["theta"]).all() and np.abs(res[0][0]["theta"] - orc.theta).max() > 0
