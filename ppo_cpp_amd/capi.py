@@ -26,7 +26,10 @@ def load_library(build=True):
     if _LIB is not None:
         return _LIB
     so = os.path.join(_PKG, "libppo_hip.so")
-    if build and os.path.exists("/opt/rocm/bin/hipcc"):
+    alt = os.environ.get("PPO_HIP_LIBRARY")                  # a diagnostic build (tools/stamps*.py: -DPPO_STAMPS) kept OUTSIDE the package directory
+    if alt:
+        so = alt
+    elif build and os.path.exists("/opt/rocm/bin/hipcc"):
         from . import build as _b
         so = _b.build_hip()
     if not os.path.exists(so):

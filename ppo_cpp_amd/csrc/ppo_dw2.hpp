@@ -111,18 +111,17 @@ __device__ __forceinline__ void dw2_strip_mma(const float (&u)[2][NU], const flo
                               : __builtin_amdgcn_mfma_f32_16x16x4f32(ww[ks], u[ks][t], sacc[t], 0, 0, 0);
 }
 
+// The kernel's body; b = the workgroup's linear index 0 .. DW2_GRID - 1 (blockIdx.x of the standalone launch; also called as the second phase
+// of train8_dw2_fused_kernel, ppo_fused_ab.hpp).
 template <int KP0, int AP>
-__global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Args a) {
+__device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int b) {
     typedef Dw2L<KP0, AP> LD;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    warm_kernargs<sizeof(Dw2Args)>();
     DW2_STAMP(15); DW2_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
     // workgroups are dealt round-robin over the 8 XCDs: XCD x takes row split x >> 1 of tower x & 1, so the rows x 2 operands
     // of that split (1 MB at M = 2048) are fetched from the fabric once per XCD and shared by its 32 tiles through the L2, and
     // they are exactly the rows the train kernel's workgroups on XCD x wrote (its xcd_map 1).  Speed only.
-    const int b = blockIdx.x;
     const int split = (b >> 1) & 3, tower = b & 1, tile = b >> 3;
     const int gtile = tower * 32 + tile;
     const int i0 = (tile >> 3) * 64, j0 = (tile & 7) * 32;
@@ -404,4 +403,11 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
         __syncthreads();
     }
     DW2_STAMP(7);
+}
+
+template <int KP0, int AP>
+__global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(Dw2Args)>();
+    dw2_body<KP0, AP>(a, lds, (int)blockIdx.x);
 }

@@ -9,6 +9,7 @@
 #include "ppo_peer.hpp"
 #include "ppo_dw2.hpp"
 #include "ppo_train8.hpp"
+#include "ppo_fused_ab.hpp"
 #include "ppo_rollout1.hpp"
 
 #include <dlfcn.h>
@@ -46,11 +47,11 @@ const char* kProfNames[PK_COUNT] = {"policy_step", "train_fwd_bwd", "weight_grad
 
 // which kernel VARIANT a call took (ppo_kernel_counts): the fast paths are chosen by shape, and a test must be able to say which one ran
 enum KernelVariant { KV_TRAIN8 = 0, KV_TRAIN_FB, KV_DW2, KV_DW, KV_GRAD_REDUCE, KV_NARROW_TRAIN_STATIC, KV_NARROW_TRAIN, KV_NARROW_STEP_STATIC, KV_NARROW_STEP,
-                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_COUNT };
+                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_FUSED_AB, KV_COUNT };
 const char* kVariantNames[KV_COUNT] = {"train8_kernel", "train_fwd_bwd_kernel", "weight_grad_assemble_kernel", "weight_grad_kernel", "grad_reduce_kernel",
                                        "narrow_train_kernel<static>", "narrow_train_kernel<runtime>", "narrow_step_kernel<static>", "narrow_step_kernel<runtime>",
                                        "policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_rollout_coop_kernel", "narrow_collect_kernel",
-                                       "bf16_train_sequence", "bf16_step_sequence"};
+                                       "bf16_train_sequence", "bf16_step_sequence", "train8_dw2_fused_kernel"};
 
 // RCCL entry points resolved at run time (the single-GPU path must not depend on librccl being loadable)
 struct Rccl {
@@ -102,6 +103,8 @@ struct ppo_handle {
     // weight gradients + gradient assembly in one launch (ppo_dw2.hpp; 18-obs / [256,256] shape)
     bool dw2 = false;
     bool t8 = false;                  // 8-wave train kernel with K-split wave pairs (ppo_train8.hpp; same shape as dw2)
+    bool fuse_ab = false;             // PPO_HIP_FUSE_AB=1: train8 + weight_grad_assemble as ONE launch around a grid-wide meeting (ppo_fused_ab.hpp; measured, not the default)
+    unsigned* fab_meet = nullptr;     // the meeting's table: [FAB_GRID] per-workgroup epoch words, [FAB_GRID] raised when a wait timed out
     unsigned* dw2_counters = nullptr; float* dw2_parts = nullptr; SlotJob* dw2_jobs = nullptr; int dw2_n_jobs = 0, dw2_jpw = 0;
     // staging for host-pointer calls
     int st_rows = 0;
@@ -895,6 +898,21 @@ int peer_check(ppo_handle* h) {
     return 0;
 }
 
+// after a stream synchronisation: did the fused train kernel's grid-wide meeting time out (its workgroups were not all resident)?
+int fab_check(ppo_handle* h) {
+    if (!h->fab_meet || !h->fuse_ab) return 0;
+    unsigned e = 0;
+    HIP_OK(h, hipMemcpy(&e, h->fab_meet + FAB_GRID, sizeof e, hipMemcpyDeviceToHost));
+    if (e) {
+        (void)hipMemset(h->fab_meet, 0, (FAB_GRID + 32) * sizeof e);
+        h->fuse_ab = false;
+        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        return fail(h, "train8_dw2_fused_kernel: its 256 workgroups were not resident together within 0.5 s (is another process using this GPU?); this "
+                       "step's results are invalid.  The handle now runs the two-launch form (the default without PPO_HIP_FUSE_AB=1)");
+    }
+    return 0;
+}
+
 int pick_split(ppo_handle* h, int n) {
     int s = h->max_split;
     while (s > 1 && (n % (16 * s) != 0)) s >>= 1;
@@ -941,8 +959,14 @@ void launch_dw2(ppo_handle* h, const Dw2Args& da) {
     hipLaunchKernelGGL((weight_grad_assemble_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da);
 }
 template <int KP0, int AP>
+void launch_fused_ab(ppo_handle* h, const TrainArgs& ta, const Dw2Args& da, int n_rb) {
+    const size_t lds = sizeof(float) * FabL<KP0, AP>::FLOATS;
+    hipLaunchKernelGGL((train8_dw2_fused_kernel<KP0, AP>), dim3(DW2_GRID), dim3(FAB_THREADS), lds, h->stream, h->net, ta, da, h->fab_meet, n_rb);
+}
+template <int KP0, int AP>
 bool set_lds_pair() {
-    return hipFuncSetAttribute((const void*)train8_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T8L<KP0, AP>::TOTAL) == hipSuccess &&
+    return hipFuncSetAttribute((const void*)train8_dw2_fused_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * FabL<KP0, AP>::FLOATS) == hipSuccess &&
+           hipFuncSetAttribute((const void*)train8_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T8L<KP0, AP>::TOTAL) == hipSuccess &&
            hipFuncSetAttribute((const void*)weight_grad_assemble_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess;
 }
 
@@ -1029,6 +1053,29 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
     const int n_pad = use_dw2 ? ru(ta.n, DW2_CH) : ru(ta.n, ROWS_PER_BLOCK);            // the train kernel zero-fills the rows of its last partial tile
     const int n_rb = n_pad / ROWS_PER_BLOCK;
     ta.xcd_map = use_dw2 ? 1 : 0;
+    Dw2Args da{};
+    if (use_dw2) {
+        da.x0g = h->x0g; da.h2pi = h->hg[0][1]; da.dmug = h->dmug;
+        for (int t = 0; t < 2; ++t) { da.h1[t] = h->hg[t][0]; da.dy0[t] = h->dyg[t][0]; da.dy1[t] = h->dyg[t][1]; da.w0_off[t] = n.w_off[t][0]; da.w1_off[t] = n.w_off[t][1]; da.slots[t] = h->slots[t]; }
+        da.wmu_off = n.wmu_off; da.n = n_pad; da.slabs = h->slabs; da.slab_stride = (unsigned long long)h->P_pad; da.counters = h->dw2_counters;
+        da.grad = h->grad; da.parts = h->dw2_parts; da.jobs = h->dw2_jobs; da.n_jobs = h->dw2_n_jobs; da.jobs_per_wg = h->dw2_jpw;
+#ifdef PPO_STAMPS
+        da.stamps = g_stamps + 4096 * 16;
+#endif
+        da.n_rowblocks = n_rb; da.slot_w = n.slot_w; da.n_local = (float)ta.n; da.beta_pow = h->beta_pow; da.tail_off = h->P_pad;
+    }
+    // one launch for both kernels when every workgroup of both phases is resident at once (<= 2048 rows: 2 n_rb <= 256 = one workgroup per CU)
+    if (use_dw2 && h->t8 && h->fuse_ab && 2 * n_rb <= DW2_GRID && n_rb % 4 == 0) {
+        ProfScope ps(h, PK_TRAIN_FB);
+        ++h->kv[KV_FUSED_AB];
+        if (n.Kp0 == 32 && n.Ap == 32) launch_fused_ab<32, 32>(h, ta, da, n_rb);
+        else if (n.Kp0 == 64 && n.Ap == 32) launch_fused_ab<64, 32>(h, ta, da, n_rb);
+        else if (n.Kp0 == 32 && n.Ap == 64) launch_fused_ab<32, 64>(h, ta, da, n_rb);
+        else launch_fused_ab<64, 64>(h, ta, da, n_rb);
+        HIP_OK(h, hipGetLastError());
+        if (h->comm) { if (enqueue_grad_allreduce(h)) return -1; return enqueue_adam(h, loss_row); }
+        return enqueue_adam(h, loss_row, DW2_TILES + DW2_GRID, h->dw2_parts);
+    }
     {
         ProfScope ps(h, PK_TRAIN_FB);
         dim3 grid(n_rb, 2);
@@ -1055,15 +1102,6 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
         // weight gradients + slab / slot sums + partial sums of squares in ONE launch (ppo_dw2.hpp): no grad_reduce_kernel
         {
             ProfScope ps(h, PK_DW);
-            Dw2Args da{};
-            da.x0g = h->x0g; da.h2pi = h->hg[0][1]; da.dmug = h->dmug;
-            for (int t = 0; t < 2; ++t) { da.h1[t] = h->hg[t][0]; da.dy0[t] = h->dyg[t][0]; da.dy1[t] = h->dyg[t][1]; da.w0_off[t] = n.w_off[t][0]; da.w1_off[t] = n.w_off[t][1]; da.slots[t] = h->slots[t]; }
-            da.wmu_off = n.wmu_off; da.n = n_pad; da.slabs = h->slabs; da.slab_stride = (unsigned long long)h->P_pad; da.counters = h->dw2_counters;
-            da.grad = h->grad; da.parts = h->dw2_parts; da.jobs = h->dw2_jobs; da.n_jobs = h->dw2_n_jobs; da.jobs_per_wg = h->dw2_jpw;
-#ifdef PPO_STAMPS
-            da.stamps = g_stamps + 4096 * 16;
-#endif
-            da.n_rowblocks = n_rb; da.slot_w = n.slot_w; da.n_local = (float)ta.n; da.beta_pow = h->beta_pow; da.tail_off = h->P_pad;
             ++h->kv[KV_DW2];
             if (n.Kp0 == 32 && n.Ap == 32) launch_dw2<32, 32>(h, da);
             else if (n.Kp0 == 64 && n.Ap == 32) launch_dw2<64, 32>(h, da);
@@ -1222,6 +1260,11 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
       h->t8 = !(e && e[0] == '1') && !nn.wide && h->CT == 4 && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256 && nn.Kp0 <= 64 && nn.Ap <= 64;
       if ((h->t8 || h->dw2) && !(set_lds_pair<32, 32>() && set_lds_pair<64, 32>() && set_lds_pair<32, 64>() && set_lds_pair<64, 64>())) {
           fail(h, "hipFuncSetAttribute failed for train8_kernel / weight_grad_assemble_kernel"); return bail(0); } }
+    { const char* e = getenv("PPO_HIP_FUSE_AB");
+      // OPT-IN (measured slower than the two launches, profiles/r05_a_*: 40.7 vs 39.85 us per train step).  The fused form's grid-wide meeting
+      // needs all DW2_GRID workgroups resident at once: one per CU (each takes > 80 KB of LDS)
+      h->fuse_ab = (e && e[0] == '1') && h->t8 && h->dw2 && prop.multiProcessorCount >= DW2_GRID;
+      if (h->fuse_ab && dev_alloc(h, &h->fab_meet, FAB_GRID + 32)) return bail(0); }
     if (h->dw2) {
         // slot jobs: every element the train kernel leaves as per-row-block partial sums (bias / logstd / value-head gradients), then the loss sums
         const NetDev& nn = h->net;
@@ -1297,6 +1340,7 @@ void ppo_destroy(ppo_handle* h) {
     for (float* p : {h->gs_obs, h->gs_act, h->gs_ret, h->gs_val, h->gs_nlp}) if (p) (void)hipFree(p);
     if (h->dw2_jobs) (void)hipFree(h->dw2_jobs);
     if (h->dw2_counters) (void)hipFree(h->dw2_counters);
+    if (h->fab_meet) (void)hipFree(h->fab_meet);
     if (h->dw2_parts) (void)hipFree(h->dw2_parts);
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->sumsq2, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
@@ -1499,7 +1543,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
     HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    return 0;
+    return fab_check(h);
 }
 
 int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm) {
@@ -2417,6 +2461,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
+    if (fab_check(h)) return -1;
     return peer_check(h);
 }
 
@@ -2465,6 +2510,28 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
     if (rc) return fail(h, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
     h->world = world; h->rank = rank;
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    if (h->fuse_ab && world > 1) {
+        // Do two ranks share a device (N processes on one GPU: the tests' dry runs)?  Then kernels whose workgroups wait for each other while
+        // holding a CU each (train8_dw2_fused_kernel's grid-wide meeting) could starve one another: every rank publishes its device's PCI
+        // location in its slot of a table, one all-reduce, and the handles of a job with a shared device fall back to the two-launch form.
+        int dom = 0, bus = 0, dv = 0;
+        (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, h->device);
+        (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, h->device);
+        (void)hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, h->device);
+        std::vector<float> tab((size_t)world, 0.f);
+        tab[(size_t)rank] = (float)(1 + (((dom & 0xff) << 16) | ((bus & 0xff) << 8) | (dv & 0xff)));      // exact in fp32 (< 2^24)
+        float* dt = nullptr;
+        bool shared = true;                                     // (unknown counts as shared)
+        if (hipMalloc((void**)&dt, world * sizeof(float)) == hipSuccess &&
+            hipMemcpy(dt, tab.data(), world * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+            h->rccl.AllReduce(dt, dt, (size_t)world, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream) == 0 &&
+            hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(tab.data(), dt, world * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) {
+            shared = false;
+            for (int i = 0; i < world; ++i) for (int j = i + 1; j < world; ++j) if (tab[(size_t)i] == tab[(size_t)j]) shared = true;
+        }
+        if (dt) (void)hipFree(dt);
+        if (shared) h->fuse_ab = false;
+    }
     // Collectives inside the update's hipGraph: with a communicator the eager sequence is 5-6 launches and up to three
     // collectives per train step issued from the host, which at narrow networks is slower than the GPU runs them.  Whether
     // this RCCL build can be stream-captured is PROBED here, collectively (every rank runs the same probe in the same order):

@@ -180,3 +180,30 @@ def test_tiled_transposed_copies_equal_the_element_wise_form(hidden, O, A, monke
         g.close()
     for x, y in zip(*outs):
         np.testing.assert_array_equal(x, y)
+
+
+def test_fused_train_and_weight_gradient_launch_is_bitwise_the_two_launches(monkeypatch):
+    """PPO_HIP_FUSE_AB=1 (ppo_fused_ab.hpp; measured and not the default, profiles/r05_a_*): train8_kernel's and weight_grad_assemble_kernel's bodies in
+    ONE launch around a grid-wide meeting.  Same arithmetic in the same order: losses, gradient, weights and Adam slots of three train steps must be the
+    same BITS as the two launches give, at a full (2048) and a partial (1000 rows: workgroups that skip phase A) minibatch."""
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PPO_HIP_FUSE_AB", mode)
+        for n in (2048, 1000):
+            orc, g = pair((256, 256), O=18, A=18, seed=9)
+            k0 = g.kernel_counts()
+            acc = []
+            for it in range(3):
+                mb = H.synth_minibatch(orc, n, seed=90 + it)
+                args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+                acc.append(np.asarray(g.train_step(LR, CR, *args)).copy())
+                acc.append(g.last_grad()[0].copy())
+            acc += [g.get_flat(0), g.get_flat(1), g.get_flat(2)]
+            ran = delta(g.kernel_counts(), k0)
+            assert ran == ({"train8_dw2_fused_kernel": 3} if mode == "1" else {"train8_kernel": 3, "weight_grad_assemble_kernel": 3}), ran
+            outs[(mode, n)] = acc
+            g.close()
+    for n in (2048, 1000):
+        for a, b in zip(outs[("0", n)], outs[("1", n)]):
+            np.testing.assert_array_equal(a, b)
+
