@@ -150,6 +150,9 @@ struct ppo_handle {
     // through sequence words in pinned memory (pin_flag[PCTL_*])
     bool opt_no_host_fused = false, opt_no_host_resident = false;     // PPO_HIP_NO_HOST_FUSED / _RESIDENT, read once in ppo_create
     float* pin_in_dev = nullptr; float* pin_out_dev = nullptr; unsigned* pin_flag_dev = nullptr;   // the pinned blocks as the device sees them
+    // general host-Env path: policy_step_kernel's policy-tower workgroups store their 16 rows of actions into pin_out themselves and raise their
+    // word of this pinned table to wg_seq; ppo_rollout_act watches the table (PPO_HIP_NO_DIRECT_ACT=1: D2H copy + stream query as in round 4)
+    unsigned* pin_wgflag = nullptr; unsigned* pin_wgflag_dev = nullptr; int pin_wgflag_n = 0; unsigned wg_seq = 0; bool opt_no_direct_act = false;
     bool host_proto = false;          // the last ppo_rollout_act used the resident / fused form: observe only posts the transition
     bool hp_active = false;           // a resident kernel may be running
     int hp_posted = 0;                // transitions posted in this rollout
@@ -1359,6 +1362,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_flag) (void)hipHostFree(h->pin_flag);
+    if (h->pin_wgflag) (void)hipHostFree(h->pin_wgflag);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1617,8 +1621,14 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
     HIP_OK(h, hipHostMalloc((void**)&h->pin_in, in_n * sizeof(float), hipHostMallocDefault));
     HIP_OK(h, hipHostMalloc((void**)&h->pin_out, (size_t)n_envs * h->net.A * sizeof(float), hipHostMallocDefault));
     if (!h->pin_flag) { HIP_OK(h, hipHostMalloc((void**)&h->pin_flag, 1024, hipHostMallocDefault)); memset(h->pin_flag, 0, 1024); h->act_seq = 0; }
+    if (h->pin_wgflag) { (void)hipHostFree(h->pin_wgflag); h->pin_wgflag = nullptr; }
+    h->pin_wgflag_n = (n_envs + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    HIP_OK(h, hipHostMalloc((void**)&h->pin_wgflag, (size_t)h->pin_wgflag_n * sizeof(unsigned), hipHostMallocDefault));
+    memset(h->pin_wgflag, 0, (size_t)h->pin_wgflag_n * sizeof(unsigned)); h->wg_seq = 0;
+    { const char* e = getenv("PPO_HIP_NO_DIRECT_ACT"); h->opt_no_direct_act = e && e[0] == '1'; }
     {
         void* d = nullptr;
+        HIP_OK(h, hipHostGetDevicePointer(&d, h->pin_wgflag, 0)); h->pin_wgflag_dev = (unsigned*)d;
         HIP_OK(h, hipHostGetDevicePointer(&d, h->pin_in, 0)); h->pin_in_dev = (float*)d;
         HIP_OK(h, hipHostGetDevicePointer(&d, h->pin_out, 0)); h->pin_out_dev = (float*)d;
         HIP_OK(h, hipHostGetDevicePointer(&d, h->pin_flag, 0)); h->pin_flag_dev = (unsigned*)d;
@@ -1793,7 +1803,8 @@ int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
 static ObsNorm obs_norm(ppo_handle* h) { return ObsNorm{h->obs_rms.mean, h->obs_rms.var, h->nz_eps, h->nz_clip_obs, h->norm_obs_flag}; }
 
 // policy step on the current observations -> rollout[t]
-static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uint32_t seed, uint32_t rng_step, uint32_t row_base) {
+// direct: the policy tower also publishes the actions to the host itself (StepArgs::host_action)
+static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uint32_t seed, uint32_t rng_step, uint32_t row_base, bool direct = false) {
     const NetDev& n = h->net;
     const size_t E = h->E;
     if (h->done_staged != t) HIP_OK(h, hipMemcpyAsync(h->ro_done + t * E, h->cur_done, E * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
@@ -1801,6 +1812,7 @@ static int enqueue_rollout_act(ppo_handle* h, int t, const float* noise_dev, uin
     a.theta = h->theta; a.par = h->par; a.obs = h->raw_obs; a.noise = noise_dev; a.action = h->ro_act + t * E * n.A; a.det_action = nullptr;
     a.value = h->ro_val + t * E; a.neglogp = h->ro_nlp + t * E; a.obs_out = h->ro_obs + t * E * n.O; a.nz = obs_norm(h); a.n = (int)E;
     a.seed = seed; a.rng_step = rng_step; a.row_base = row_base;
+    if (direct) { a.host_action = h->pin_out_dev; a.host_flags = h->pin_wgflag_dev; a.host_seq = ++h->wg_seq; }
     return launch_step(h, a);
 }
 
@@ -2020,7 +2032,38 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
         memcpy(actions_out, h->pin_out, cnt * sizeof(float));
         return 0;
     }
-    if (enqueue_rollout_act(h, t, nd, h->rng_seed, h->rng_calls++, (uint32_t)(h->rank * h->E))) return -1;
+    // policy_step_kernel (the fp32 families wider than 64) can hand the actions over itself: no copy command, no wait for the value tower.  Used for
+    // up to 64 environments only: shader stores into host memory cost ~1 us per 16-row block once more than a few workgroups publish (measured per
+    // env step, direct | copy engine: 64 envs 25.4 | 31.6 us, 256: 45 | 43, 1024: 55 | 49, 4096: 80 | 66 -- profiles/r05_b_*).
+    // PPO_HIP_DIRECT_ACT_MAX_BLOCKS overrides the limit (tests run the form at 256 blocks).
+    const char* dme = getenv("PPO_HIP_DIRECT_ACT_MAX_BLOCKS");                   // (read per call: a test switches it inside one process)
+    const int direct_max = dme ? atoi(dme) : 4;
+    const bool direct = !h->opt_no_direct_act && !h->narrow && !h->bf.on && h->pin_wgflag && (h->E + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK <= direct_max;
+    if (enqueue_rollout_act(h, t, nd, h->rng_seed, h->rng_calls++, (uint32_t)(h->rank * h->E), direct)) return -1;
+    if (direct) {
+        // Watch the table: block b's 16 rows are copied out as soon as its word shows this call's sequence number (the copy of the early blocks
+        // hides under the kernel's tail).  The policy kernel is stream-ordered behind the H2D copy of the last observation and the statistics
+        // kernel, so once its last block has published, the pinned input block is free again -- without a stream synchronisation.
+        const unsigned want = h->wg_seq;
+        const int G = (h->E + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+        const size_t blk = (size_t)ROWS_PER_BLOCK * n.A;
+        unsigned long spins = 0;
+        for (int b = 0; b < G; ) {
+            if (__atomic_load_n(h->pin_wgflag + b, __ATOMIC_ACQUIRE) == want) {
+                const size_t off = (size_t)b * blk, cntb = std::min(blk, cnt - off);
+                memcpy(actions_out + off, h->pin_out + off, cntb * sizeof(float));
+                ++b;
+                continue;
+            }
+            if ((++spins & 0x3ffff) == 0) {                     // every ~quarter million polls: is the stream still alive?
+                const hipError_t qe = hipStreamQuery(h->stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) return fail(h, "ppo_rollout_act: %s", hipGetErrorString(qe));
+                if (qe == hipSuccess && __atomic_load_n(h->pin_wgflag + b, __ATOMIC_ACQUIRE) != want) return fail(h, "ppo_rollout_act: the policy kernel finished without publishing block %d", b);
+            }
+        }
+        h->pin_in_busy = false;
+        return 0;
+    }
     // one D2H into the handle's pinned landing buffer and the ONLY stream synchronisation of an env step: the statistics
     // kernel of the previous ppo_rollout_observe, this policy step and the copy drain together
     HIP_OK(h, hipMemcpyAsync(h->pin_out, h->ro_act + (size_t)t * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));

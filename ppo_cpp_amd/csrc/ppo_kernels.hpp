@@ -749,6 +749,12 @@ struct StepArgs {
     ObsNorm nz;
     int n;
     uint32_t seed, rng_step, row_base;
+    // host-Env rollouts (ppo_rollout_act): the policy tower's workgroup ALSO stores its 16 rows of actions into the handle's pinned landing buffer
+    // (16-byte stores) and then raises its own word of a pinned flag table to host_seq; the host watches the table -- no D2H copy command, no
+    // stream synchronisation, and the value tower's workgroups are not waited for.  null: off
+    float* host_action;      // pinned host memory as the device sees it, [n,A]
+    unsigned* host_flags;    // pinned, one word per 16-row block
+    unsigned host_seq;
 #ifdef PPO_STAMPS
     unsigned long long* stamps;   // diagnostic builds only: [tower][block][8]
 #endif
@@ -820,10 +826,35 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void policy_step_kernel(NetDev ne
             if (a.action) a.action[(size_t)row * net.A + j] = act;
             if (a.det_action) a.det_action[(size_t)row * net.A + j] = mu;
         }
+        if (a.host_action) lds[net.lds_mu + r * ldm + j] = act;      // (this lane owns element (r, j): mu has been read)
     }
     ssq = group16_sum(ssq);
     slog = group16_sum(slog);
     if (part == 0 && row < a.n && a.neglogp) a.neglogp[row] = 0.5f * ssq + HALF_LOG_2PI * (float)net.A + slog;
+    if (a.host_action) {
+        // The block's rows are contiguous in the landing buffer ([16][A] floats from byte 64 A blockIdx.x): whole 16-byte pieces, the last rows' odd
+        // elements one by one.  Pinned host memory is uncached on the device: a store leaves for the host at once.  Every storing thread waits for
+        // its stores to be acknowledged, the barrier collects the waves, then ONE word: the host reads the block only after that word shows host_seq.
+        lds_barrier();
+        const int live = min(ROWS_PER_BLOCK, a.n - row0) * net.A;       // elements of this block
+        float* dst = a.host_action + (size_t)row0 * net.A;
+        const float* tile = lds + net.lds_mu;
+        for (int k = threadIdx.x; 4 * k < live; k += BLOCK_THREADS) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = min(4 * k + i, live - 1); v[i] = tile[(e / net.A) * ldm + e % net.A]; }
+            if (4 * k + 3 < live) {
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                const f32x4_t q = {v[0], v[1], v[2], v[3]};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst + 4 * k), "v"(q) : "memory");
+            } else {
+                for (int i = 0; 4 * k + i < live; ++i) __hip_atomic_store(dst + 4 * k + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.host_flags + blockIdx.x, a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     PSTAMP(5);
 }
 

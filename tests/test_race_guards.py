@@ -155,3 +155,43 @@ def test_peer_exchange_between_eight_processes_is_deterministic(tmp_path, world,
     for r in range(world):
         np.testing.assert_array_equal(res[0][r]["ro_returns"], res[1][r]["ro_returns"])
     assert np.isfinite(res[0][0]["theta"]).all() and np.abs(res[0][0]["theta"] - orc.theta).max() > 0
+
+
+@pytest.mark.parametrize("hidden,E,T", [((256, 256), 4096, 48), ((256, 256), 4093, 24), ((128, 96), 77, 40), ((256, 256), 1, 40)])
+def test_actions_published_by_the_policy_kernel_are_the_rollout_rows(monkeypatch, hidden, E, T):
+    """Host-Env path for nets wider than 64 (ppo_rollout_act, reference ppo2/runner.hpp:75-116): the policy tower's workgroups store their 16 rows of
+    actions straight into pinned memory and raise one word each; the host copies a block out as soon as its word shows the call's sequence number.
+    No fence, no stream synchronisation: what orders the bytes before the word is `s_waitcnt vmcnt(0)` on uncached stores.  A block read before
+    its bytes had landed would differ from the rollout buffer's row: every env step's returned actions must be the SAME BITS as rollout field
+    `actions`, over T steps x several rollouts, at a block count of 256, at ragged last blocks (4093: 13 rows; 77; 1), and equal to the
+    copy-engine form (PPO_HIP_NO_DIRECT_ACT=1) including the fields the still-running value tower writes."""
+    # (the library uses this form up to 64 environments -- beyond that the copy engine is faster; the override lets the test run it at 256 blocks)
+    monkeypatch.setenv("PPO_HIP_DIRECT_ACT_MAX_BLOCKS", "4096")
+    rng = np.random.RandomState(5)
+    trans = [(rng.uniform(-1, 1, (E, 18)).astype(np.float32), rng.uniform(-1, 1, E).astype(np.float32), (rng.uniform(size=E) < 0.05).astype(np.float32))
+             for _ in range(2 * T + 1)]
+    outs = {}
+    for form in ("direct", "copy"):
+        if form == "copy":
+            monkeypatch.setenv("PPO_HIP_NO_DIRECT_ACT", "1")
+        else:
+            monkeypatch.delenv("PPO_HIP_NO_DIRECT_ACT", raising=False)
+        g = ppo_cpp_amd.PPOHip(18, 18, list(hidden)); g.init_orthogonal(2); g.seed(7); g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+        g.rollout_reset(trans[0][0])
+        got = []
+        k = 1
+        for ro in range(2):
+            acts = []
+            for t in range(T):
+                a = g.rollout_act(t, None)
+                acts.append(a.copy())
+                g.rollout_observe(t, *trans[k]); k += 1
+            g.rollout_finish(GAMMA, LAM)
+            np.testing.assert_array_equal(np.stack(acts), g.rollout_get("actions"), err_msg="%s: returned actions vs rollout rows (rollout %d)" % (form, ro))
+            got.append({f: g.rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns", "dones")})
+        g.close()
+        outs[form] = got
+    monkeypatch.delenv("PPO_HIP_NO_DIRECT_ACT", raising=False)
+    for a, b in zip(outs["direct"], outs["copy"]):
+        for f in a:
+            np.testing.assert_array_equal(a[f], b[f], err_msg=f)
