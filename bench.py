@@ -33,13 +33,18 @@ CONFIGS = {
                  desc="1 env x 2048 steps, MLP [64,64] (launch-latency bound)"),
     "cfg4": dict(n_envs=1024, n_steps=64, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
                  desc="1024 envs x 64 steps, MLP [64,64]"),
+    # configs[1] / configs[3] with the hexapod's 36-observation shape (observe_velocities, env/hexapod_closed_loop_env.hpp:20,61-72)
+    "cfg2o36": dict(n_envs=1, n_steps=2048, hidden=[64, 64], obs=36, act=18, nminibatches=32, noptepochs=10,
+                    desc="1 env x 2048 steps, MLP [64,64], 36 observations"),
+    "cfg4o36": dict(n_envs=1024, n_steps=64, hidden=[64, 64], obs=36, act=18, nminibatches=32, noptepochs=10,
+                    desc="1024 envs x 64 steps, MLP [64,64], 36 observations"),
     "cfg5": dict(n_envs=8192, n_steps=16, hidden=[1024, 1024, 1024], obs=256, act=64, nminibatches=32, noptepochs=10,
                  dtype="bf16",
                  desc="synthetic 256-obs/64-act env, 8192 envs x 16 steps, MLP [1024,1024,1024], bf16 MFMA operands / fp32 accumulate, master weights and Adam"),
     "cfg5f32": dict(n_envs=8192, n_steps=16, hidden=[1024, 1024, 1024], obs=256, act=64, nminibatches=32, noptepochs=10,
                     desc="synthetic 256-obs/64-act env, 8192 envs x 16 steps, MLP [1024,1024,1024] in exact fp32 (two-tile LDS layout)"),
 }
-BASELINE_INDEX = {"cfg2": 1, "cfg3": 2, "cfg3o36": 2, "cfg4": 3, "cfg5": 4, "cfg5f32": 4}
+BASELINE_INDEX = {"cfg2": 1, "cfg2o36": 1, "cfg3": 2, "cfg3o36": 2, "cfg4": 3, "cfg4o36": 3, "cfg5": 4, "cfg5f32": 4}
 LR, CR, GAMMA, LAM = 3.93141e-4, 0.161023, 0.99, 0.95      # README.md:70-81, ppo2.cpp:215-217
 PEAK_F32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0                              # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparsity figure)

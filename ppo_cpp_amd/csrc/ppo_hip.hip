@@ -1007,7 +1007,8 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
                 const int ci = h->nw_cur, co = ci ^ 1;
                 z = NwLazyArgs{h->grad, h->sumsq, h->nw_pending_parts, set[ci][0], set[ci][1], set[ci][2], set[co][0], set[co][1], set[co][2], h->beta_pow,
                                h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, h->nw_pending_loss, h->norm_out};
-                hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
+                if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
+                else hipLaunchKernelGGL((narrow_train_kernel<64, 64, 32, 2, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
                 h->nw_cur = co; h->nw_pending = false;
             }
             else {
@@ -1304,12 +1305,12 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
                            big_lds((const void*)narrow_rollout_coop_kernel<a, b, c, d>); big_lds((const void*)narrow_host_step_kernel<a, b, c, d>); } while (0)
         X(0, 0, 0, 0); X(32, 64, 32, 2); X(64, 64, 32, 2);
 #undef X
-        big_lds((const void*)narrow_train_kernel<32, 64, 32, 2, true>);
+        big_lds((const void*)narrow_train_kernel<32, 64, 32, 2, true>); big_lds((const void*)narrow_train_kernel<64, 64, 32, 2, true>);
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         { const char* e1 = getenv("PPO_HIP_NO_HOST_FUSED"); const char* e2 = getenv("PPO_HIP_NO_HOST_RESIDENT");
           h->opt_no_host_fused = e1 && e1[0] == '1'; h->opt_no_host_resident = e2 && e2[0] == '1'; }
         const char* nl = getenv("PPO_HIP_NO_LAZY_ADAM");
-        if (h->nw_static && h->net.Kp0 == 32 && !(nl && nl[0] == '1')) {       // (the deferred form's piece map is the 32-column observation tile's)
+        if (h->nw_static && !(nl && nl[0] == '1')) {       // (the static shapes: [64,64] behind a 32- or 64-column observation tile -- 18 / 36 observations -- and 32 action columns)
             // second parameter / moment set of the deferred Adam (zero-filled: the padding elements are never written and must read 0)
             if (dev_alloc(h, &h->nw_theta1, P) || dev_alloc(h, &h->nw_m1, P) || dev_alloc(h, &h->nw_v1, P)) return bail(0);
             h->nw_lazy = true;

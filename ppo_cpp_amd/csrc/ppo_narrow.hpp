@@ -209,10 +209,13 @@ struct NwLazyArgs {
     float* loss_row; float* norm_out;
 };
 
-struct NwLazyRegs { float4 g[5], m[5], v[5], t[5]; float part, b1p, b2p, lr; };
+// pieces per thread: 5 behind a 32-column observation tile, 6 behind a 64-column one (the first-layer matrix [64][64] is two 512-piece blocks)
+template <int KP0> struct NwLazyN { static constexpr int N = KP0 == 64 ? 6 : 5; };
+template <int NP> struct NwLazyRegs { float4 g[NP], m[NP], v[NP], t[NP]; float part, b1p, b2p, lr; };
 
-// Thread -> 16-byte piece.  Pieces 0,1 = second-layer matrix [64][64], 2 = first-layer matrix [32][64], 3 = policy head matrix
-// [64][32], 4 = one float4 of a vector (threads 0..48).  Matrix pieces in memory order (fully coalesced loads: the prologue is
+// Thread -> 16-byte piece.  Pieces 0,1 = second-layer matrix [64][64], 2 = first-layer matrix rows 0..31 ([32][64]), 3 = policy head matrix
+// [64][32], 4 = one float4 of a vector (threads 0..48), 5 (64-column observation tile only: the 36-observation hexapod,
+// env/hexapod_closed_loop_env.hpp:20) = first-layer matrix rows 32..63.  Matrix pieces in memory order (fully coalesced loads: the prologue is
 // bound by the bytes it pulls through the L1, 160 KB per workgroup; a row-spread dealing that would make the transposed LDS
 // copy conflict-free costs more in the loads than it saves in LDS).  The transposed copy (element (r, c) -> [c][r], row pitch
 // = 16 mod 64 banks) is written with lane-rotated elements -- the j-th write of a lane stores its element (j + c4) & 3 -- which
@@ -233,6 +236,11 @@ __device__ __forceinline__ NwPiece nw_lazy_piece(const NetDev& net, int tower, i
         p.r = tid >> 3; p.c = 4 * (tid & 7); p.off = net.wmu_off + 4 * tid;    // [64][32]: 8 float4 per row
         return p;
     }
+    if (k == 5) {                                                               // W0 rows 32..63 of a [64][64] first layer
+        const int idx = tid + 512;
+        p.r = idx >> 4; p.c = 4 * (idx & 15); p.off = net.w_off[tower][0] + 4 * idx;
+        return p;
+    }
     if (tid < 16) p.off = net.b_off[tower][0] + 4 * tid;
     else if (tid < 32) p.off = net.b_off[tower][1] + 4 * (tid - 16);
     else if (tower == 0) { if (tid < 40) p.off = net.bmu_off + 4 * (tid - 32); else if (tid < 48) p.off = net.ls_off + 4 * (tid - 40); }
@@ -241,11 +249,12 @@ __device__ __forceinline__ NwPiece nw_lazy_piece(const NetDev& net, int tower, i
     return p;
 }
 
-__device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArgs& z, const float* hyper, int tower, NwLazyRegs& R) {
+template <int NP>
+__device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArgs& z, const float* hyper, int tower, NwLazyRegs<NP>& R) {
     const int tid = threadIdx.x;
     R.b1p = z.beta_pow[0]; R.b2p = z.beta_pow[1]; R.lr = hyper[0];             // requested with everything else: one round trip
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < NP; ++k) {
         const int off = nw_lazy_piece(net, tower, k, tid).off;
         R.g[k] = R.m[k] = R.v[k] = R.t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (off >= 0) {
@@ -261,8 +270,9 @@ __device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArg
 }
 
 // `red`: 4 floats of LDS scratch.  Ends with the image complete in LDS (caller synchronises).
+template <int NP>
 __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout& lay, const NwLazyArgs& z, int tower, int grp, int n_groups,
-                                              NwLazyRegs& R, float* lds, float* red, unsigned long long* st = nullptr) {
+                                              NwLazyRegs<NP>& R, float* lds, float* red, unsigned long long* st = nullptr) {
     const int tid = threadIdx.x;
 #ifdef PPO_STAMPS
 #define LSTAMP(i) do { if (st && tid == 0) st[i] = __builtin_readcyclecounter(); } while (0)
@@ -295,7 +305,7 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
         }
     };
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < NP; ++k) {
         const NwPiece pc = nw_lazy_piece(net, tower, k, tid);
         if (pc.off < 0) continue;
         const float gv[4] = {R.g[k].x, R.g[k].y, R.g[k].z, R.g[k].w}, mv[4] = {R.m[k].x, R.m[k].y, R.m[k].z, R.m[k].w};
@@ -309,7 +319,7 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
             *reinterpret_cast<float4*>(lds + lay.wf[1] + pc.r * lay.wf_ld[1] + pc.c) = t4;
             put_t(lds + lay.wt[1], lay.wt_ld[1], pc.r, pc.c, to, tid & 3);
             mine = own;
-        } else if (k == 2) {                                                    // W0 [32][64]
+        } else if (k == 2 || k == 5) {                                          // W0 rows 0..31 / 32..63 (forward copy only: no dX of the first layer)
             *reinterpret_cast<float4*>(lds + lay.wf[0] + pc.r * lay.wf_ld[0] + pc.c) = t4;
             mine = own;
         } else if (k == 3) {                                                    // W_mu [64][32]
@@ -362,9 +372,9 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
     const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
     NSTAMP(0);
     if constexpr (LAZY) {
-        static_assert(KP0 == 32 && HP == 64 && AP == 32 && LL == 2, "deferred Adam: reference shape only");
+        static_assert((KP0 == 32 || KP0 == 64) && HP == 64 && AP == 32 && LL == 2, "deferred Adam: the reference's shapes only (18 or 36 observations)");
         float* lazy_red = lds + lay.w_total + lay.misc;      // 4 floats of pipe 0's loss scratch (no static LDS: the launch may ask for all 160 KB)
-        NwLazyRegs R;
+        NwLazyRegs<NwLazyN<KP0>::N> R;
         nw_lazy_issue(net, z, a.hyper, tower, R);
         NSTAMP(12);
         nw_stage<S>(net, lay, nullptr, 0, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,

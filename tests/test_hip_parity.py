@@ -163,11 +163,11 @@ def test_running_statistics_and_normalisation(E):
     np.testing.assert_array_equal(m, np.float32(st["obs_rms"]["mean"])); assert c == st["obs_rms"]["count"]
 
 
-def _rollout_pair(hidden, E, T, seed, src="orth"):
-    orc, g = pair(hidden, src)
+def _rollout_pair(hidden, E, T, seed, src="orth", O=18):
+    orc, g = pair(hidden, src, O=O) if O != 18 else pair(hidden, src)
     rng = np.random.RandomState(seed)
     noise = rng.normal(size=(T, E, 18)).astype(np.float32)
-    nz = o.Normalizer(E, 18)
+    nz = o.Normalizer(E, O)
     ro, state, last_v = o.collect(orc, nz, 1234, T, noise, GAMMA, LAM)
     g.norm_init(E)
     g.rollout_alloc(E, T)
@@ -422,9 +422,11 @@ def test_persistent_rollout_is_bitwise_the_per_step_launches(hidden, E, T, expli
         np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
 
 
+@pytest.mark.parametrize("O", [18, 36])
 @pytest.mark.parametrize("E,T,nmb,epochs", [(16, 16, 4, 3), (64, 64, 32, 1), (3, 100, 4, 2), (16, 16, 1, 1)])
-def test_deferred_adam_is_bitwise_the_adam_launch(E, T, nmb, epochs, monkeypatch):
-    """Reference shape ([64,64]): inside ppo_update the clip + Adam of step k is applied by the prologue of step k+1's train
+def test_deferred_adam_is_bitwise_the_adam_launch(E, T, nmb, epochs, O, monkeypatch):
+    """Reference shapes ([64,64] behind 18 observations, and behind 36 -- the hexapod that observes its velocities, env/hexapod_closed_loop_env.hpp:20,61-72:
+    a 64-column observation tile whose first-layer matrix is two 512-piece blocks of the prologue's piece map): inside ppo_update the clip + Adam of step k is applied by the prologue of step k+1's train
     kernel (ping-pong parameter sets, weights written straight into the LDS image).  Same expression, same norm order: loss
     rows, weights, both moments, beta powers, the reported norm and the act model after the update must equal the run with
     an adam_kernel launch per step (PPO_HIP_NO_LAZY_ADAM=1, with the deferred form's 1-ulp quotient: PPO_HIP_ADAM_FAST=1) bit for
@@ -433,17 +435,19 @@ def test_deferred_adam_is_bitwise_the_adam_launch(E, T, nmb, epochs, monkeypatch
     for lazy in (True, False):
         monkeypatch.setenv("PPO_HIP_NO_LAZY_ADAM", "0" if lazy else "1")
         monkeypatch.setenv("PPO_HIP_ADAM_FAST", "0" if lazy else "1")
-        orc, g, nz, ro, noise = _rollout_pair((64, 64), E, T, 23)
+        orc, g, nz, ro, noise = _rollout_pair((64, 64), E, T, 23, O=O)
         for f in ("obs", "actions", "values", "neglogp", "returns"):
             g.rollout_set(f, ro[f])
         rng = np.random.RandomState(99)
         perms = np.stack([rng.permutation(E * T).astype(np.int32) for _ in range(epochs)])
         got = {}
+        k0 = g.kernel_counts()
         for it in range(2):
             got["rows%d" % it], got["mean%d" % it] = g.update(LR, CR, epochs, nmb, perms)
+        assert g.kernel_counts()["narrow_train_kernel<static>"] > k0["narrow_train_kernel<static>"]       # (the compile-time shape ran, both widths)
         got["theta"], got["m"], got["v"], got["pow"] = g.get_flat(0), g.get_flat(1), g.get_flat(2), g.beta_powers()
         got["norm"] = np.float32(g.last_grad()[1])
-        obs = np.random.RandomState(3).uniform(-2, 2, (40, 18)).astype(np.float32)
+        obs = np.random.RandomState(3).uniform(-2, 2, (40, O)).astype(np.float32)
         got["value"] = g.value(obs); got["mu"] = g.act_deterministic(obs)       # the packed image the act kernels read
         mb = H.synth_minibatch(orc, 64, seed=9)                                  # a plain train step afterwards: set 0 holds the weights
         got["step"] = g.train_step(LR, CR, mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
