@@ -726,7 +726,8 @@ int bf16_stage(ppo_handle* h, const float* obs, int nrows, int Rp, ObsNorm nz, f
     const NetDev& n = h->net;
     StageArgsB sa{obs, nrows, n.O, n.Kp0, Rp, nz, obs_out, b.x0};
     const size_t cnt = (size_t)Rp * n.Kp0;
-    hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
+    if (n.O % 4 == 0 && n.Kp0 % 4 == 0) hipLaunchKernelGGL(bf16_stage4_kernel, dim3(bf16_stage4_grid(n.Kp0, cnt / 4)), dim3(256), 0, h->stream, sa);
+    else hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -1609,8 +1610,8 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
     if (n_envs < 1) return fail(h, "ppo_norm_init: n_envs must be positive");
     h->nz_envs = n_envs; h->nz_gamma = gamma; h->nz_clip_obs = clip_obs; h->nz_clip_rew = clip_rew; h->nz_eps = epsilon;
     if (norm_alloc_stats(h, h->obs_rms, h->net.O) || norm_alloc_stats(h, h->ret_rms, 1)) return -1;
-    if (dev_alloc(h, &h->nz_ret, n_envs) || dev_alloc(h, &h->stats_counter, 4) ||
-        dev_alloc(h, &h->stats_part, (size_t)NB_MAX_OBS_BLOCKS * ru(1 + 2 * h->net.O, 32) + (size_t)NB_MAX_REW_BLOCKS * NB_REW_STRIDE)) return -1;
+    if (dev_alloc(h, &h->nz_ret, n_envs) || dev_alloc(h, &h->stats_counter, 2 + 256) ||
+        dev_alloc(h, &h->stats_part, std::max((size_t)NB_MAX_OBS_BLOCKS * ru(1 + 2 * h->net.O, 32), (size_t)NB_CG_MAX_WG * NB_CG_STRIDE) + (size_t)NB_MAX_REW_BLOCKS * NB_REW_STRIDE)) return -1;
     // raw observations | raw rewards | dones of the current env step in ONE block (one H2D copy per env step on the
     // host-Env path) with a pinned host mirror owned by the handle (replaces the pageable Utils::convert_* copies of
     // ppo2/utils.hpp:17-73)
@@ -1666,7 +1667,16 @@ static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, con
     NormBatchArgs a{};
     const int D = h->net.O;
     a.D = D; a.obs = obs_dev; a.rows = rows; a.obs_st = h->obs_rms;
-    if (obs_dev) {
+    static const bool no_strips = [] { const char* e = getenv("PPO_HIP_NO_OBS_STRIPS"); return e && e[0] == '1'; }();
+    if (obs_dev && !no_strips && D % 64 == 0 && D <= 64 * 254 && rows >= 256) {
+        // wide observations: 64-column groups x row splits (obs_cgroup_job): splits of 128 rows (a thread's 8 rows stay in registers) where the table
+        // of sets allows it (<= NB_CG_MAX_WG workgroups, <= 256 splits for the combine)
+        a.n_strips = D / 64;
+        int S = std::min((rows + 127) / 128, std::min(16 * NB_CG_KP, NB_CG_MAX_WG / a.n_strips));
+        a.rows_per_obs_block = (rows + S - 1) / S;
+        a.n_splits = (rows + a.rows_per_obs_block - 1) / a.rows_per_obs_block;
+        a.g_obs = a.n_strips * a.n_splits;
+    } else if (obs_dev) {
         // ~2048 values per workgroup: 8 independent loads per thread and pass
         const int cap = D <= 32 ? NB_MAX_OBS_BLOCKS : 64;       // wide rows: the final combine walks the chunks per column
         a.g_obs = std::max(1, std::min(cap, (int)(((int64_t)rows * D + 2047) / 2048)));
@@ -2373,7 +2383,8 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
                 if (bb.epoch_staged) {
                     StageArgsB sa{h->mb_obs, B, h->net.O, h->net.Kp0, B, no_norm(), nullptr, bb.xe};
                     const size_t cnt = (size_t)B * h->net.Kp0;
-                    hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
+                    if (h->net.O % 4 == 0 && h->net.Kp0 % 4 == 0) hipLaunchKernelGGL(bf16_stage4_kernel, dim3(bf16_stage4_grid(h->net.Kp0, cnt / 4)), dim3(256), 0, h->stream, sa);
+                    else hipLaunchKernelGGL(bf16_stage_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, sa);
                     HIP_OK(h, hipGetLastError());
                 }
             }

@@ -2168,6 +2168,9 @@ struct NormBatchArgs {
     int world, rank;
     int use_peer;         // data-parallel over peer-mapped regions: the table is exchanged by these two kernels themselves (ppo_peer.hpp)
     PeerDev peer;
+    // wide observations (D a multiple of 64: BASELINE configs[4] has 256): the obs job is dealt as n_strips = D / 64 column groups x n_splits row
+    // splits (g_obs = n_strips * n_splits workgroups of rows_per_obs_block rows), see obs_cgroup_job.  0: the row-chunk form above
+    int n_strips, n_splits;
 #ifdef PPO_STAMPS
     unsigned long long* stamps;   // diagnostic builds only: [block][8] cycle stamps
 #endif
@@ -2274,8 +2277,9 @@ __device__ __forceinline__ void combine_group(const float* sets, int K, int stri
     const bool act = ksub < rpp;
     const int top = pow2_ceil(rpp) >> 1;
     // everything this thread will need of its first CG sets is requested up front, together with the sets' row counts: ONE trip to the
-    // memory side (the sets were written through by other workgroups) instead of one per pass
-    constexpr int CG = 4;
+    // memory side (the sets were written through by other workgroups) instead of one per pass.  (16: the column-group form of wide observations
+    // combines 64 sets over 4 threads per column; with 4 the other 12 were 48 dependent round trips, 21.8 k cycles -- tools/stamps_norm_wide.py)
+    constexpr int CG = 16;
     float pm[CG], pq[CG];
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
@@ -2417,17 +2421,167 @@ __device__ __forceinline__ void norm_finish(const NormBatchArgs& a, int which, c
     }
 }
 
+// ---- obs job for WIDE observations ----------------------------------------------------------------------------------------------------
+// The row-chunk form gives a workgroup whole rows: at D = 256 a sweep of 256 threads is ONE row, a thread walks its chunk row by row, and the
+// last arriver combines every chunk's 2 D floats through one CU (hence at most 64 chunks for wide rows): 75.7 us for 8192 x 256 observations,
+// 0.22 TB/s (profiles/r04_z_kernel_stats_cfg5.csv).  Here (D a multiple of 64) workgroup b owns the 64-COLUMN GROUP b % n_cg of the rows of split
+// b / n_cg: thread (q, rs) = 16-byte strip q of the group in rows rs, rs + 16, ... -- a wave reads 4 rows x 256 contiguous bytes per instruction
+// (a first version with one 4-column strip per workgroup had every lane of a load on its own cache line: 23.7 k cycles for 8 loads per thread,
+// tools/stamps_norm_wide.py) -- 8 rows per thread stay in registers (ONE trip to memory for splits of up to 128 rows), the two passes of
+// common/running_statistics.hpp:26-54 run out of registers, the 16 row-subs of a strip meet in a fixed tree (two lane exchanges inside a wave,
+// then the four waves through LDS).  What crosses workgroups is a (n, mean[64], M2[64]) set per (group, split); the LAST split of a group combines
+// the group's sets with the row-chunk form's Chan combine (combine_group: index order) and merges / publishes its 64 columns; the last GROUP to
+// finish writes the count (every group's merge has read the old one by then).  Same hand-off as the row-chunk form: write-through sets on lines of
+// their own (NB_CG_STRIDE floats apart), drained stores, barrier, one relaxed arrival, agent-scope loads.  Fixed orders: bitwise reproducible.
+// counter[2 + group]: the groups' arrival words.
+#define NB_CG_STRIDE 160                  // 1 + 2 * 64 floats rounded up to whole 128-byte lines
+#define NB_CG_MAX_WG 1024                 // workgroups of the column-group form (the table of sets is sized for it)
+#define NB_CG_KP 8                        // sets a thread of the group's last arriver combines: at most 16 * NB_CG_KP row splits
+// 16-byte write-through load of bytes another workgroup of this launch stored write-through; the caller waits with nb_wait8 before the first use
+__device__ __forceinline__ f32x4 nb_ld4_sc1(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void nb_wait8(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e, f32x4& f, f32x4& g, f32x4& h) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) :: "memory");
+}
+__device__ __forceinline__ void obs_cgroup_job(const NormBatchArgs& a, int b, float* sh, int* flag) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_cg = a.n_strips, cg = b % n_cg, split = b / n_cg, D = a.D;
+    const int q = tid & 15, rs = tid >> 4, c0 = 64 * cg + 4 * q;
+    const int r0 = split * a.rows_per_obs_block, r1 = min(a.rows, r0 + a.rows_per_obs_block);
+    const float n = (float)(r1 - r0);
+    constexpr int U = 8;
+    float4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int r = r0 + rs + 16 * u; x[u] = r < r1 ? *reinterpret_cast<const float4*>(a.obs + (size_t)r * D + c0) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, M2[4];
+    float* red = sh;                                               // [4 waves][16 strips][4]
+    for (int pass = 0; pass < 2; ++pass) {
+        float t[4][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = r0 + rs + 16 * u < r1;
+            const float v[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[j] - mean[j]; t[j][u] = ok ? (pass ? d * d : d) : 0.f; }
+        }
+        float s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = ((t[j][0] + t[j][1]) + (t[j][2] + t[j][3])) + ((t[j][4] + t[j][5]) + (t[j][6] + t[j][7]));
+        for (int r = r0 + rs + 16 * U; r < r1; r += 16) {                                  // splits longer than 128 rows: the rest from memory, both passes
+            const float4 w = *reinterpret_cast<const float4*>(a.obs + (size_t)r * D + c0);
+            const float v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[j] - mean[j]; s[j] += pass ? d * d : d; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += __shfl_xor(s[j], 16); s[j] += __shfl_xor(s[j], 32); }      // the wave's four row-subs: (0 + 1) + (2 + 3)
+        __syncthreads();                                                                   // (red is free again)
+        if (lane < 16) { *reinterpret_cast<float4*>(red + (wave * 16 + q) * 4) = make_float4(s[0], s[1], s[2], s[3]); }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float tot = (red[(0 * 16 + q) * 4 + j] + red[(1 * 16 + q) * 4 + j]) + (red[(2 * 16 + q) * 4 + j] + red[(3 * 16 + q) * 4 + j]);
+            if (pass == 0) mean[j] = tot / n; else M2[j] = tot;                            // colwise().mean() ; sum of squared deviations
+        }
+    }
+    NSTAMP(1);
+    float* out = a.part + (size_t)b * NB_CG_STRIDE;                 // set layout of this form: [mean 64 | M2 64]; its row count follows from the split index
+    if (tid < 16) {
+        st_wt4<true>(out + 4 * q, make_float4(mean[0], mean[1], mean[2], mean[3]));
+        st_wt4<true>(out + 64 + 4 * q, make_float4(M2[0], M2[1], M2[2], M2[3]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    NSTAMP(2);
+    if (tid == 0) *flag = (__hip_atomic_fetch_add(a.counter + 2 + cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.n_splits - 1u) ? 1 : 0;
+    __syncthreads();
+    NSTAMP(3);
+    if (!*flag) return;
+    // ---- last split of this column group: combine the splits (index order), then merge (or publish) columns 64 cg .. 64 cg + 63 ----------
+    float* publish = a.xch ? a.xch + (size_t)a.rank * (1 + 2 * D + 3) : nullptr;
+    const double cnt = *a.obs_st.count;
+    float om = 0.f, ov = 0.f;
+    if (!publish && tid < 64) { om = a.obs_st.mean[64 * cg + tid]; ov = a.obs_st.var[64 * cg + tid]; }       // in flight during the combine
+    // Thread (q, ks): strip q of the group, sets ks, ks + 16, ... (at most NB_CG_KP of them: n_splits <= 16 NB_CG_KP), every 16-byte piece of them requested
+    // in ONE trip to the memory side (write-through loads; 4-byte agent-scope loads of the same 64 sets took 18 k cycles: ~75 per wave instruction).
+    // Chan's combine in a fixed shape: a thread adds its sets in index order, the 16 set-subs of a strip meet like the row-subs above.
+    const int ks = tid >> 4;
+    f32x4 pm[NB_CG_KP], pq[NB_CG_KP];
+    float nk[NB_CG_KP];
+#pragma unroll
+    for (int j = 0; j < NB_CG_KP; ++j) {
+        const int k = min(ks + 16 * j, a.n_splits - 1);              // (past the end: a valid address, weight 0)
+        const float* st = a.part + ((size_t)k * n_cg + cg) * NB_CG_STRIDE;
+        pm[j] = nb_ld4_sc1(st + 4 * q); pq[j] = nb_ld4_sc1(st + 64 + 4 * q);
+        const int kk = ks + 16 * j;
+        nk[j] = kk < a.n_splits ? (float)(min(a.rows, (kk + 1) * a.rows_per_obs_block) - kk * a.rows_per_obs_block) : 0.f;
+    }
+    nb_wait8(pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], pm[6], pm[7]);
+    nb_wait8(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
+    const float nn = (float)a.rows;
+    float bmv[4] = {0.f, 0.f, 0.f, 0.f}, bqv[4];
+    for (int pass = 0; pass < 2; ++pass) {
+        float sc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NB_CG_KP; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (pass == 0) sc[c] += nk[j] * pm[j][c];
+                else { const float d = pm[j][c] - bmv[c]; sc[c] += nk[j] > 0.f ? pq[j][c] + nk[j] * (d * d) : 0.f; }
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sc[c] += __shfl_xor(sc[c], 16); sc[c] += __shfl_xor(sc[c], 32); }
+        __syncthreads();
+        if (lane < 16) *reinterpret_cast<float4*>(red + (wave * 16 + q) * 4) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float tot = (red[(0 * 16 + q) * 4 + c] + red[(1 * 16 + q) * 4 + c]) + (red[(2 * 16 + q) * 4 + c] + red[(3 * 16 + q) * 4 + c]);
+            if (pass == 0) bmv[c] = tot / nn; else bqv[c] = tot;
+        }
+    }
+    NSTAMP(7);
+    __syncthreads();
+    if (tid < 16) { *reinterpret_cast<float4*>(sh + 64 + 4 * tid) = make_float4(bmv[0], bmv[1], bmv[2], bmv[3]); *reinterpret_cast<float4*>(sh + 128 + 4 * tid) = make_float4(bqv[0], bqv[1], bqv[2], bqv[3]); }
+    __syncthreads();
+    if (tid < 64) {
+        const int c = 64 * cg + tid;
+        const float bm = sh[64 + tid], bq = sh[128 + tid];
+        if (publish) { if (c == 0) NB_ST(publish, nn); NB_ST(publish + 1 + c, bm); NB_ST(publish + 1 + D + c, bq); }
+        else merge_column(a.obs_st, c, cnt, bm, bq, nn, om, ov);
+    }
+    NSTAMP(4);
+    if (tid == 0) __hip_atomic_store(a.counter + 2 + cg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // ready for the next launch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the old count has been read, the published columns are out
+    __syncthreads();
+    NSTAMP(5);
+    if (tid == 0) *flag = (__hip_atomic_fetch_add(a.counter + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)n_cg - 1u) ? 1 : 0;
+    __syncthreads();
+    NSTAMP(6);
+    if (!*flag) return;
+    // ---- last group: every group has read the old count ------------------------------------------------------------------------------------
+    if (tid == 0) {
+        if (!publish) *a.obs_st.count = (double)(float)a.rows + cnt; // :103
+        a.counter[0] = 0u;
+    }
+    if (a.use_peer && publish) { __syncthreads(); peer_stats_publish(a.peer, 0, publish, 0, 1 + 2 * D); }
+}
+
 __global__ __launch_bounds__(NB_THREADS) void norm_batch_kernel(NormBatchArgs a) {
     __shared__ float sh[3 * NB_THREADS];
     __shared__ int is_last;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int so = 1 + 2 * a.D, ps = a.part_stride;
-    float* part_rew = a.part + (size_t)a.g_obs * ps;
+    float* part_rew = a.part + (size_t)a.g_obs * (a.n_strips ? NB_CG_STRIDE : ps);
     const int which = b < a.g_obs ? 0 : 1;
     NSTAMP(0);
 #ifdef PPO_STAMPS
     if (a.stamps && threadIdx.x == 0) { a.stamps[(size_t)blockIdx.x * 8 + 4] = 0; a.stamps[(size_t)blockIdx.x * 8 + 5] = 0; a.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)which; }
 #endif
+    if (which == 0 && a.n_strips) { obs_cgroup_job(a, b, sh, &is_last); return; }
     if (which == 0) {
         const int r0 = b * a.rows_per_obs_block, r1 = min(a.rows, r0 + a.rows_per_obs_block);
         chunk_moments(a.obs, r0, r1, a.D, a.part + (size_t)b * ps, sh);

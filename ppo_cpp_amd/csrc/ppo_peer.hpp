@@ -55,7 +55,7 @@ __device__ __forceinline__ void peer_stats_publish(const PeerDev& p, int job, co
     __syncthreads();
     const unsigned s = s_seq, par = s & 1u;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float v = src[i];
+        const float v = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the strip form: other workgroups of this launch wrote parts of it, write-through)
         for (int k = 0; k < p.world; ++k) {
             const int r = (p.rank + k) % p.world;
             p.sslots[r][((size_t)par * p.world + p.rank) * p.scap + off + i] = v;

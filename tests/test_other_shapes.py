@@ -7,7 +7,7 @@ import pytest
 
 from oracle import oracle as o
 from tests import helpers as H
-from tests.test_hip_parity import pair, close, CR, LR, GAMMA, LAM
+from tests.test_hip_parity import pair, hip, close, CR, LR, GAMMA, LAM
 
 pytestmark = pytest.mark.gpu
 
@@ -207,3 +207,37 @@ def test_fused_train_and_weight_gradient_launch_is_bitwise_the_two_launches(monk
         for a, b in zip(outs[("0", n)], outs[("1", n)]):
             np.testing.assert_array_equal(a, b)
 
+
+
+@pytest.mark.parametrize("O,E", [(256, 4096), (256, 8192), (256, 150000), (64, 300), (192, 5000), (100, 5000)])
+def test_running_statistics_of_wide_observations(O, E):
+    """EnvNormalize / RunningStatistics (env/env_normalize.hpp:64-116, common/running_statistics.hpp:26-104) for WIDE observations (BASELINE configs[4]: 256):
+    norm_batch_kernel deals the observation job as 64-column groups x row splits (obs_cgroup_job; widths that are multiples of 64) instead of row chunks
+    (100 columns: the row-chunk form).  Six batches -- a frozen step, a
+    clipped value -- against the oracle's two-pass moments at the tolerances of test_running_statistics_and_normalisation; the count exact; then the same
+    six batches again on a fresh handle: same bits (fixed combine order), and against the row-chunk form (PPO_HIP_NO_OBS_STRIPS is read once per process,
+    so that comparison is to the oracle only)."""
+    def run():
+        g = hip((256, 256), O, 18)
+        g.norm_init(E)
+        nz = o.Normalizer(E, O)
+        rng = np.random.RandomState(7)
+        for it in range(6):
+            raw = rng.normal(loc=0.5, scale=2.0, size=(E, O)).astype(np.float32)
+            if it == 3:
+                raw[0, 0] = 1e4
+            training = it != 4
+            nz.training = training
+            got = g.norm_obs(raw, training)
+            if E <= 8192 or it in (0, 5):
+                close(got, nz.obs(raw), rtol=2e-5, atol=2e-6, msg="obs it=%d" % it)
+            else:
+                nz.obs(raw)
+        m, v, c = g.norm_stats(0)
+        close(m, nz.obs_rms.mean, rtol=1e-5, atol=1e-6); close(v, nz.obs_rms.var, rtol=1e-5); assert c == nz.obs_rms.count
+        g.close()
+        return m, v
+    a = run()
+    if E <= 8192:
+        b = run()
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
