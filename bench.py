@@ -142,7 +142,10 @@ def _rows_worker(cfg, n_proc, budget_s, t_start):
     P = npp.NumpyPPO(orc)
     rng = np.random.RandomState(1)
     f_fwd, f_dx, f_dw = flops_per_row(O, A, cfg["hidden"])
-    e_rows = int(max(1, min(E // n_proc, 4.0e9 // f_fwd))); m_rows = int(max(2, min(M // n_proc, 4.0e9 // (f_fwd + f_dx + f_dw))))
+    # a worker's share of a call: ceil(rows / n_proc) -- never less than ONE environment / two minibatch rows (with fewer rows than processes the
+    # slowest process still does a whole row: no credit for splitting what cannot be split)
+    e_share = max(1, -(-E // n_proc)); m_share = max(2, -(-M // n_proc))
+    e_rows = int(max(1, min(e_share, 4.0e9 // f_fwd))); m_rows = int(max(2, min(m_share, 4.0e9 // (f_fwd + f_dx + f_dw))))
     obs = rng.uniform(-1, 1, (e_rows, O)).astype(np.float32); noise = rng.normal(size=(e_rows, A)).astype(np.float32)
     mobs = rng.uniform(-1, 1, (m_rows, O)).astype(np.float32)
     act, v, nlp = P.step(mobs, rng.normal(size=(m_rows, A)).astype(np.float32))
@@ -157,8 +160,8 @@ def _rows_worker(cfg, n_proc, budget_s, t_start):
             fn(); n += 1
         return (time.perf_counter() - t0) / n
 
-    t_step = timed(lambda: P.step(obs, noise), 0.25, 64) * ((E / n_proc) / e_rows)
-    t_lg = timed(lambda: P.loss_grad(mobs, act, adv, ret, nlp, v, CR), 0.75, 256) * ((M / n_proc) / m_rows)
+    t_step = timed(lambda: P.step(obs, noise), 0.25, 64) * (e_share / e_rows)
+    t_lg = timed(lambda: P.loss_grad(mobs, act, adv, ret, nlp, v, CR), 0.75, 256) * (m_share / m_rows)
     return {"t_step": t_step, "t_loss_grad": t_lg, "e_rows": e_rows, "m_rows": m_rows}
 
 
@@ -193,7 +196,13 @@ def cpu_all_cores_leg(cfg, name, n_proc, budget_s):
     t_red = (time.perf_counter() - t0) / 20
     t_step = max(r["t_step"] for r in res); t_lg = max(r["t_loss_grad"] for r in res)
     t_update = T * t_step + ep * nmb * (t_lg + t_red)
+    # how evenly the box served the workers (a process that shares its core with somebody else's job is several times slower: `value` counts the
+    # slowest, as a synchronous row-parallel step must; the median tells what the cores could do)
+    import statistics
+    per_worker = sorted(B / (T * r["t_step"] + ep * nmb * (r["t_loss_grad"] + t_red)) for r in res)
     return {"value": B / t_update, "unit": "env-steps/s", "cores": n_proc, "covers": 1.0,
+            "workers_env_steps_per_s": {"min": per_worker[0], "median": statistics.median(per_worker), "max": per_worker[-1]},
+            "note": "box-dependent (cores granted vs cores busy elsewhere cannot be known): the single-thread leg is the stable figure",
             "t_policy_step_ms": 1e3 * t_step, "t_train_step_ms": 1e3 * (t_lg + t_red), "t_reduce_clip_adam_ms": 1e3 * t_red,
             "sample": "%d processes x 1 BLAS thread, each 1/%d of the rows (%d policy-step rows, %d minibatch rows), slowest process; gradient sum + clip + Adam timed in one process"
                       % (n_proc, n_proc, res[0]["e_rows"], res[0]["m_rows"])}
@@ -259,6 +268,29 @@ def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
     return out
 
 
+def count_gpus_from_sysfs():
+    """GPU nodes of /sys/class/kfd/kfd/topology (a node with simd_count > 0 is a GPU; CPUs have 0), cut by ROCR_VISIBLE_DEVICES /
+    HIP_VISIBLE_DEVICES when they are plain index lists; None when the topology cannot be read"""
+    import glob
+    n = 0
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        return None
+    try:
+        for f in files:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except OSError:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and all(x.strip().isdigit() for x in v.split(",") if x.strip()):
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves -- `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` -- as a CHILD process (never exec: this
@@ -271,12 +303,9 @@ def self_launch(n):
         port = sk.getsockname()[1]
     if not os.environ.get("PPO_RCCL_LIBRARY"):
         # RCCL takes ONE rank per device.  (PPO_RCCL_LIBRARY = a stand-in such as tests/fake_rccl lets N ranks share a device: a dry
-        # run of the flow, not a measurement.)  Counting devices does not initialise the GPU in this process.
-        try:
-            import torch
-            ndev = torch.cuda.device_count()
-        except Exception:
-            ndev = None
+        # run of the flow, not a measurement.)  The devices are counted from the kernel driver's topology files -- no HIP / torch call, so this
+        # parent really never touches the GPU; when the files are not there the ranks report a shortage themselves.
+        ndev = count_gpus_from_sysfs()
         if ndev is not None and ndev < n:
             print(json.dumps({"error": "bench.py --gpus %d: this node exposes %d HIP device(s); RCCL needs one device per rank" % (n, ndev)}), flush=True)
             return 2

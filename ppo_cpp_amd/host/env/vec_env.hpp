@@ -183,7 +183,6 @@ private:
         Mat a(1, 1);
         int mine = 0;
         bool timing = false;
-        long long busy = 0;
         for (;;) {
             const unsigned long long t = ticket_.fetch_add(1, std::memory_order_acq_rel);
             const int c = static_cast<int>(t & ((1ull << kFieldBits) - 1)), nc = static_cast<int>((t >> kFieldBits) & ((1ull << kFieldBits) - 1));
@@ -208,23 +207,15 @@ private:
                     original_rewards_(i, 0) = envs_[i]->get_original_rew()(0, 0);
                 }
             }
-            if (timing) busy += now_ns() - ta;
-            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-                // the round's last chunk: publish this thread's share first (the caller reads the shares after it has seen remaining_ == 0 ...
-                // through this thread's later release below, or its own), then wake the caller if it may be asleep in wait_round()
-                finish_share(who, mine, busy);
-                mine = -1; busy = 0;
-                if (who != 0) {
-                    std::lock_guard<std::mutex> l(m_);
-                    done_.notify_one();
-                }
+            // this chunk's share is published BEFORE the decrement that may end the round: the caller reads the shares (calibrate, pool_active) after it
+            // has seen remaining_ == 0, and the acq_rel decrement orders these relaxed adds in front of that read -- whichever thread finished last
+            per_[who].claimed.fetch_add(1, std::memory_order_relaxed);
+            if (timing) per_[who].busy_ns.fetch_add(now_ns() - ta, std::memory_order_relaxed);
+            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1 && who != 0) {
+                std::lock_guard<std::mutex> l(m_);               // the round's last chunk: wake the caller if it may be asleep in wait_round()
+                done_.notify_one();
             }
         }
-        if (mine > 0) finish_share(who, mine, busy);
-    }
-    void finish_share(int who, int mine, long long busy) {
-        per_[who].claimed.store(mine, std::memory_order_relaxed);
-        if (busy) per_[who].busy_ns.fetch_add(busy, std::memory_order_relaxed);
     }
     // the caller has no chunk left to claim: the last ones are being finished by helpers (a few microseconds: spin, then sleep)
     void wait_round() {
@@ -282,6 +273,9 @@ private:
         const double per_env = 1e-9 * (double)busy / n_;
         int c = static_cast<int>(12e-6 / per_env);
         c = std::max(c, (n_ + 8 * workers_ - 1) / (8 * workers_));
+        // never fewer than two chunks per thread: an estimate that came out low (a step timed while helpers were still waking) must not leave threads
+        // without work for the lifetime of the pool
+        c = std::min(c, (n_ + 2 * workers_ - 1) / (2 * workers_));
         chunk_ = std::max(1, std::min(c, n_));
     }
 
