@@ -113,8 +113,13 @@ __device__ __forceinline__ void dw2_strip_mma(const float (&u)[2][NU], const flo
 
 // The kernel's body; b = the workgroup's linear index 0 .. DW2_GRID - 1 (blockIdx.x of the standalone launch; also called as the second phase
 // of train8_dw2_fused_kernel, ppo_fused_ab.hpp).
-template <int KP0, int AP>
-__device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int b) {
+// PEER (data parallel over peer-mapped regions, ppo_peer.hpp): the workgroup that finishes a tile LAST holds the assembled tile -- it also stores it,
+// its strip and the 24-odd slot-job results of the tile's four workgroups into slot [rank] of EVERY rank's gather region (16-byte stores), takes ONE
+// system-scope release, and arrives on the local counter; the last of the 64 finishers raises this rank's flag at every peer.  No push launch; the
+// sum over the ranks happens inside adam_kernel<.., 2>.  (Round 2 pushed from every workgroup that wrote gradient elements -- 590 of them, each with
+// its own fence -- and lost; here at most 64 workgroups fence.)
+template <int KP0, int AP, bool PEER = false>
+__device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int b, const PeerDev* pp = nullptr) {
     typedef Dw2L<KP0, AP> LD;
     DW2_STAMP(15); DW2_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
@@ -313,7 +318,7 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
         float s = ((sj[0] + sj[1]) + (sj[2] + sj[3])) + ((sj[4] + sj[5]) + (sj[6] + sj[7]));
         for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);                                       // within the 32 lanes of the job
         if ((tid & 31) == 0) {
-            if (has_job) a.grad[jraw.z] = s;
+            if (has_job) st_wt<PEER>(a.grad + jraw.z, s);          // (PEER: the tile's finisher reads it back with a write-through load and pushes it)
             red2[tid >> 5] = (has_job && jraw.w) ? s * s : 0.f;
         }
     }
@@ -341,7 +346,7 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
         for (int j = 0; j < 16; ++j) q += red2[j];
         a.parts[DW2_TILES + b] = q;
     }
-    if (b == 0 && tid == 64) a.grad[a.tail_off + 5] = a.n_local;
+    if (b == 0 && tid == 64) st_wt<PEER>(a.grad + a.tail_off + 5, a.n_local);
     if (b == 0 && tid == 65) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }    // cur <- next (adam writes next)
     DW2_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // EVERY storing wave drains its write-through stores ...
@@ -401,6 +406,42 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
             __hip_atomic_store(a.counters + gtile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
         }
         __syncthreads();
+        if constexpr (PEER) {
+            const PeerDev& p = *pp;
+            const unsigned sq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, par = sq & 1u;     // (published by the LAST finisher only, below)
+            // the slot-job results of this tile's four workgroups (their stores were write-through and drained before their arrival)
+            float jv = 0.f; int jdst = -1;
+            if (tid < DW2_SPLITS * a.jobs_per_wg) {
+                const int sp = tid / a.jobs_per_wg, jl2 = tid - sp * a.jobs_per_wg;
+                const int jb2 = ((tile << 3) | (sp << 1) | tower) * a.jobs_per_wg + jl2;
+                if (jb2 < a.n_jobs) { jdst = a.jobs[jb2].dst; jv = __hip_atomic_load(a.grad + jdst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            const bool has_n = gtile == 0 && tid == 511;                                     // workgroup 0 (tile 0 of the policy tower) wrote the row count
+            const float nloc = has_n ? __hip_atomic_load(a.grad + a.tail_off + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll 1
+            for (int k = 0; k < p.world; ++k) {
+                const int r = (p.rank + k) % p.world;                                        // every rank starts at a different peer: the links share the load
+                float* dst = p.slots[r] + ((unsigned long long)par * p.world + p.rank) * p.cap;
+                // system-scope WRITE-THROUGH stores (sc0 sc1): nothing of the slots stays dirty in this XCD's L2, so the finisher needs no cache-wide
+                // release -- a system-scope release fence here walks the whole L2 (64 of them per launch: 54.6 -> 72.4 us per train step, measured)
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst + moff), "v"(t4) : "memory");
+                if (strip_thread) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst + soff), "v"(u4) : "memory");
+                if (jdst >= 0) __hip_atomic_store(dst + jdst, jv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (has_n) __hip_atomic_store(dst + a.tail_off + 5, nloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's slot writes are complete at system scope (what a release waits for, too)
+            __syncthreads();
+            if (tid == 0) flag[0] = (__hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DW2_TILES - 1u) ? 1 : 0;
+            __syncthreads();
+            if (flag[0]) {                                              // the last finisher: every tile of this rank is out -> the flags (peer_push_kernel's tail)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+                if (tid < (unsigned)p.world) peer_st_sys(p.flags[tid] + ((size_t)par * PEER_MAX_WORLD + p.rank) * PEER_FLAG_STRIDE, sq);
+                if (tid == 0) {
+                    __hip_atomic_store(p.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.seq, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read by the NEXT kernel (adam_kernel<.., 2>): the kernel boundary orders it
+                }
+            }
+        }
     }
     DW2_STAMP(7);
 }
@@ -410,4 +451,11 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     extern __shared__ __attribute__((aligned(16))) float lds[];
     warm_kernargs<sizeof(Dw2Args)>();
     dw2_body<KP0, AP>(a, lds, (int)blockIdx.x);
+}
+
+template <int KP0, int AP>
+__global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_peer_kernel(Dw2Args a, PeerDev p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(Dw2Args) + sizeof(PeerDev)>();
+    dw2_body<KP0, AP, true>(a, lds, (int)blockIdx.x, &p);
 }

@@ -104,6 +104,9 @@ struct ppo_handle {
     bool dw2 = false;
     bool t8 = false;                  // 8-wave train kernel with K-split wave pairs (ppo_train8.hpp; same shape as dw2)
     bool fuse_ab = false;             // PPO_HIP_FUSE_AB=1: train8 + weight_grad_assemble as ONE launch around a grid-wide meeting (ppo_fused_ab.hpp; measured, not the default)
+    // data-parallel adam_kernel<.., MEET>: the meeting's epoch words (+ error word) and the workgroups' partial sums of squares; PPO_HIP_NO_ADAM_MEET=1:
+    // the round-4 sequence (all-reduce + grad_sumsq_kernel / push + sum kernels, then the plain adam_kernel)
+    unsigned* adam_meet_words = nullptr; float* adam_meet_parts = nullptr; bool adam_meet = false;
     unsigned* fab_meet = nullptr;     // the meeting's table: [FAB_GRID] per-workgroup epoch words, [FAB_GRID] raised when a wait timed out
     unsigned* dw2_counters = nullptr; float* dw2_parts = nullptr; SlotJob* dw2_jobs = nullptr; int dw2_n_jobs = 0, dw2_jpw = 0;
     // staging for host-pointer calls
@@ -917,14 +920,36 @@ int fab_check(ppo_handle* h) {
     return 0;
 }
 
+// after a stream synchronisation: did adam_kernel<.., MEET>'s grid-wide meeting time out?
+int adam_meet_check(ppo_handle* h) {
+    if (!h->adam_meet_words || !h->comm) return 0;
+    unsigned e = 0;
+    HIP_OK(h, hipMemcpy(&e, h->adam_meet_words + ADAM_MEET_MAX_GRID, sizeof e, hipMemcpyDeviceToHost));
+    if (e) {
+        (void)hipMemset(h->adam_meet_words, 0, (ADAM_MEET_MAX_GRID + 32) * sizeof e);
+        h->adam_meet = false;
+        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        return fail(h, "adam_kernel: the workgroups of its data-parallel form were not resident together within ~0.5 s; this step's results are invalid.  "
+                       "The handle now uses the launches that need no meeting (PPO_HIP_NO_ADAM_MEET=1 selects them from the start)");
+    }
+    return 0;
+}
+
 int pick_split(ppo_handle* h, int n) {
     int s = h->max_split;
     while (s > 1 && (n % (16 * s) != 0)) s >>= 1;
     return s;
 }
 
+// data parallel: may adam_kernel take the sums of squares (and, over peer regions, the ranks' sum) into its own launch?  Every workgroup of the launch
+// has to be resident at once; the bf16 path's 20 k workgroups are not.
+bool adam_can_meet(const ppo_handle* h) { return h->comm && h->adam_meet && (h->n_blocks + 3) / 4 <= ADAM_MEET_MAX_GRID && !h->bf.on; }
+
 // clip + Adam on the assembled gradient (after the optional all-reduce)
-int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* parts_from = nullptr) {      // n_sumsq: entries of h->sumsq / parts_from (0 = one per 256-element chunk)
+// meet (data parallel, see adam_kernel): 2 = the ranks' tiles sit in the peer slots (weight_grad_assemble_kernel<.., PEER> pushed them).  (1 = `grad` is
+// reduced but its sums of squares are not formed -- measured on the RCCL path against the grad_sumsq_kernel launch it would replace: 43.1 vs 42.2 us per
+// train step at configs[2], the meeting costs more than the launch; not instantiated)
+int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* parts_from = nullptr, int meet = 0) {      // n_sumsq: entries of h->sumsq / parts_from (0 = one per 256-element chunk)
     ProfScope ps(h, PK_ADAM);
     const float* parts = parts_from ? parts_from : h->sumsq; int n_parts = n_sumsq ? n_sumsq : h->n_blocks;
     if (!n_sumsq && h->n_blocks > 2048) {                  // very large nets: fold the per-chunk partials first
@@ -944,9 +969,18 @@ int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* p
     aa.stamps = g_stamps + 4096 * 40;
 #endif
     if (h->nw_cur == 1) { aa.theta_in = h->nw_theta1; aa.m_in = h->nw_m1; aa.v_in = h->nw_v1; h->nw_cur = 0; }   // (always writes set 0)
+    const dim3 grid((h->n_blocks + 3) / 4);
+    if (meet) {
+        aa.meet_words = h->adam_meet_words; aa.meet_parts = h->adam_meet_parts; aa.meet_grid = (int)grid.x;
+        aa.peer = h->peer.dev;
+        if (h->adam_fast) hipLaunchKernelGGL((adam_kernel<true, 2>), grid, dim3(256), 0, h->stream, aa);
+        else hipLaunchKernelGGL((adam_kernel<false, 2>), grid, dim3(256), 0, h->stream, aa);
+        HIP_OK(h, hipGetLastError());
+        return 0;
+    }
     // (the handle whose train kernels may apply Adam in their prologue uses the same 1-ulp quotient in its launches: bit-identical forms)
-    if (h->adam_fast) hipLaunchKernelGGL(adam_kernel<true>, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
-    else hipLaunchKernelGGL(adam_kernel<false>, dim3((h->n_blocks + 3) / 4), dim3(256), 0, h->stream, aa);
+    if (h->adam_fast) hipLaunchKernelGGL(adam_kernel<true>, grid, dim3(256), 0, h->stream, aa);
+    else hipLaunchKernelGGL(adam_kernel<false>, grid, dim3(256), 0, h->stream, aa);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -963,13 +997,19 @@ void launch_dw2(ppo_handle* h, const Dw2Args& da) {
     hipLaunchKernelGGL((weight_grad_assemble_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da);
 }
 template <int KP0, int AP>
+void launch_dw2_peer(ppo_handle* h, const Dw2Args& da) {
+    const size_t lds = sizeof(float) * Dw2L<KP0, AP>::LDS_FLOATS;
+    hipLaunchKernelGGL((weight_grad_assemble_peer_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da, h->peer.dev);
+}
+template <int KP0, int AP>
 void launch_fused_ab(ppo_handle* h, const TrainArgs& ta, const Dw2Args& da, int n_rb) {
     const size_t lds = sizeof(float) * FabL<KP0, AP>::FLOATS;
     hipLaunchKernelGGL((train8_dw2_fused_kernel<KP0, AP>), dim3(DW2_GRID), dim3(FAB_THREADS), lds, h->stream, h->net, ta, da, h->fab_meet, n_rb);
 }
 template <int KP0, int AP>
 bool set_lds_pair() {
-    return hipFuncSetAttribute((const void*)train8_dw2_fused_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * FabL<KP0, AP>::FLOATS) == hipSuccess &&
+    return hipFuncSetAttribute((const void*)weight_grad_assemble_peer_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess &&
+           hipFuncSetAttribute((const void*)train8_dw2_fused_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * FabL<KP0, AP>::FLOATS) == hipSuccess &&
            hipFuncSetAttribute((const void*)train8_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T8L<KP0, AP>::TOTAL) == hipSuccess &&
            hipFuncSetAttribute((const void*)weight_grad_assemble_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess;
 }
@@ -1102,6 +1142,21 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
         else if (h->CT == 4) hipLaunchKernelGGL((train_fwd_bwd_kernel<4, 2, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
         else hipLaunchKernelGGL((train_fwd_bwd_kernel<1, 1, 0, false>), grid, blk, lds_bytes, h->stream, n, ta);
         HIP_OK(h, hipGetLastError());
+    }
+    // data parallel over peer regions: the tiles' finishers push to the peers themselves and adam_kernel adds the ranks up (no push / sum launches)
+    const char* npt = getenv("PPO_HIP_NO_PEER_TILES");           // (read per call: a test compares the two forms in one process; a graph keeps what it captured)
+    const bool no_peer_tiles = npt && npt[0] == '1';
+    if (use_dw2 && h->comm && h->peer.on && !no_peer_tiles && adam_can_meet(h) && (size_t)h->P_pad + 8 <= h->peer.cap) {
+        {
+            ProfScope ps(h, PK_DW);
+            ++h->kv[KV_DW2];
+            if (n.Kp0 == 32 && n.Ap == 32) launch_dw2_peer<32, 32>(h, da);
+            else if (n.Kp0 == 64 && n.Ap == 32) launch_dw2_peer<64, 32>(h, da);
+            else if (n.Kp0 == 32 && n.Ap == 64) launch_dw2_peer<32, 64>(h, da);
+            else launch_dw2_peer<64, 64>(h, da);
+            HIP_OK(h, hipGetLastError());
+        }
+        return enqueue_adam(h, loss_row, 0, nullptr, 2);
     }
     if (use_dw2) {
         // weight gradients + slab / slot sums + partial sums of squares in ONE launch (ppo_dw2.hpp): no grad_reduce_kernel
@@ -1346,6 +1401,8 @@ void ppo_destroy(ppo_handle* h) {
     if (h->dw2_jobs) (void)hipFree(h->dw2_jobs);
     if (h->dw2_counters) (void)hipFree(h->dw2_counters);
     if (h->fab_meet) (void)hipFree(h->fab_meet);
+    if (h->adam_meet_words) (void)hipFree(h->adam_meet_words);
+    if (h->adam_meet_parts) (void)hipFree(h->adam_meet_parts);
     if (h->dw2_parts) (void)hipFree(h->dw2_parts);
     void* ptrs[] = {h->par, h->thetaT, h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->sumsq2, h->beta_pow, h->hyper, h->norm_out, h->grad_src, h->x0g, h->dmug,
                     h->slots[0], h->slots[1], h->slabs, h->dw_tiles, h->st_obs, h->st_act, h->st_noise, h->st_loss, h->obs_rms.mean,
@@ -1549,7 +1606,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
     HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    return fab_check(h);
+    return fab_check(h) || adam_meet_check(h) ? -1 : 0;
 }
 
 int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm) {
@@ -2516,7 +2573,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    if (fab_check(h)) return -1;
+    if (fab_check(h) || adam_meet_check(h)) return -1;
     return peer_check(h);
 }
 
@@ -2565,6 +2622,10 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
     if (rc) return fail(h, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
     h->world = world; h->rank = rank;
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    { const char* e = getenv("PPO_HIP_NO_ADAM_MEET");
+      h->adam_meet = !(e && e[0] == '1');
+      if (h->adam_meet && (dev_alloc(h, &h->adam_meet_words, ADAM_MEET_MAX_GRID + 32) || dev_alloc(h, &h->adam_meet_parts, ADAM_MEET_MAX_GRID))) return -1;
+      HIP_OK(h, hipStreamSynchronize(h->stream)); }
     if (h->fuse_ab && world > 1) {
         // Do two ranks share a device (N processes on one GPU: the tests' dry runs)?  Then kernels whose workgroups wait for each other while
         // holding a CU each (train8_dw2_fused_kernel's grid-wide meeting) could starve one another: every rank publishes its device's PCI
@@ -2768,6 +2829,12 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
     // the verdict must be COMMON: a rank that could not map a peer, or whose probe failed, takes everybody back to RCCL
     bool ok = wanted && mapped && (!P.coarse || P.coarse_requested);
     if (wanted) ok = peer_probe(h) && ok;
+    // My slots go back to zero before I join the agreement below: the probe's patterns must not stay in elements that a later collective leaves
+    // unwritten (the padding of the parameter vector, which weight_grad_assemble_kernel<.., PEER>'s tile pushes never touch and adam_kernel<.., 2>
+    // adds up with everything else).  Nobody writes into my slots between my probe's last sum and that agreement: every peer's next push comes
+    // after IT has passed the agreement, which needs me.
+    HIP_OK(h, hipMemset((char*)P.region + kPeerFlagBytes, 0, (size_t)2 * h->world * P.cap * sizeof(float)));
+    HIP_OK(h, hipDeviceSynchronize());
     float* flag = nullptr;
     HIP_OK(h, hipMalloc((void**)&flag, sizeof(float)));
     const float mine = ok ? 1.f : 0.f;

@@ -1585,6 +1585,10 @@ struct AdamArgs {
     __bf16* theta_bf;            // bf16 path: straight bf16 copy of theta kept current here (null otherwise)
     float* img;                  // narrow path: packed LDS images kept current here (null otherwise)
     const float* theta_in; const float* m_in; const float* v_in;   // read from another parameter set (narrow path's deferred Adam); null = in place
+    // data parallel, MEET > 0 (see adam_kernel): the grid-wide meeting's table -- one epoch word and one partial sum of squares per workgroup, an
+    // error word behind the epoch words -- and, MEET == 2, the peer regions whose slots this kernel adds up itself
+    unsigned* meet_words; float* meet_parts; int meet_grid;
+    PeerDev peer;
 #ifdef PPO_STAMPS
     unsigned long long* stamps;  // diagnostic builds only: [block][8]
 #endif
@@ -1630,12 +1634,32 @@ __device__ __forceinline__ void adam_element(float gscaled, float m, float v, fl
 
 // One block = 1024 consecutive parameters (4 per thread, 16-byte accesses); n_blocks counts the 256-element chunks the
 // gradient-source table and the partial sums of squares are indexed by.
-template <bool FAST>
+// MEET (data parallel only; the single-GPU launch is MEET = 0 and unchanged):
+//   2: nobody has added the ranks' gradients yet: the finishers of weight_grad_assemble_kernel<.., PEER> pushed this rank's tiles straight into
+//      every peer's slot (ppo_dw2.hpp).  Every workgroup waits for the W flags, adds the W slots of its elements in RANK order (the same order on
+//      every rank: bit-identical replicas), writes the sum to `grad`, adds up the squares of ITS elements, publishes the partial, the workgroups
+//      meet, and everybody derives the norm from the partials in workgroup order -- no push launch, no sum launch (tools/peer_overhead.py, one
+//      rank, configs[2]: 54.9 -> 50.1 us per train step; 39.4 without a communicator).
+//   1: `grad` already holds the all-reduced gradient, only its sums of squares are missing (what the RCCL path launches grad_sumsq_kernel for).
+//      Measured: 43.1 us per train step against 42.2 with the launch -- the meeting costs more than the launch it replaces.  Not instantiated.
+// The meeting: every workgroup of the launch must be resident together (the host uses these forms up to ADAM_MEET_MAX_GRID workgroups of this
+// 256-thread, 4 KB kernel).  No read-modify-write on a shared word: workgroup b reads its own epoch word e at entry, stores e + 1 behind its partial,
+// and 256 threads watch the table.  The wait is bounded: on a time-out the error word is raised, the step's result is garbage and the next
+// synchronising call reports it.
+#define ADAM_MEET_MAX_GRID 1024
+__device__ __forceinline__ f32x4 adam_ld4_sys(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <bool FAST, int MEET = 0>
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     __shared__ float red[4];
     __shared__ float tt[32][33];
     ASTAMP(0);
     const int tid = threadIdx.x;
+    unsigned epoch = 0;
+    if constexpr (MEET > 0) epoch = __hip_atomic_load(a.meet_words + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;   // (only this workgroup writes its word)
     size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
     const int chunk = (int)(idx >> 8);
     const bool live = chunk < a.n_blocks;
@@ -1660,7 +1684,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     GradSrc gs{};
     gs.t_off = -1; gs.p_off = -1;
     if (live) {
-        g4 = *reinterpret_cast<const float4*>(a.grad + idx);
+        if constexpr (MEET != 2) g4 = *reinterpret_cast<const float4*>(a.grad + idx);
         m4 = *reinterpret_cast<const float4*>((a.m_in ? a.m_in : a.m) + idx);
         v4 = *reinterpret_cast<const float4*>((a.v_in ? a.v_in : a.v) + idx);
         t4 = *reinterpret_cast<const float4*>((a.theta_in ? a.theta_in : a.theta) + idx);
@@ -1668,9 +1692,63 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
     ASTAMP(1);
     const float b1p = a.beta_pow[0], b2p = a.beta_pow[1], lr = a.hyper[0];
+    if constexpr (MEET == 2) {
+        // the ranks' slots of this workgroup's elements, added in rank order (peer_sum_kernel's arithmetic) and left in `grad`
+        __shared__ unsigned s_seq;
+        if (tid == 0) s_seq = __hip_atomic_load(a.peer.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned sq = s_seq, par = sq & 1u;
+        if (tid < (unsigned)a.peer.world) {
+            const unsigned* f = a.peer.flags[a.peer.rank] + ((size_t)par * PEER_MAX_WORLD + tid) * PEER_FLAG_STRIDE;
+            unsigned it = 0;
+            while (peer_ld_sys(f) != sq) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++it > a.peer.spin_limit) { __hip_atomic_store(a.peer.err, 1u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();
+        const float* mine = a.peer.slots[a.peer.rank] + (unsigned long long)par * a.peer.world * a.peer.cap;
+        f32x4 sv[PEER_MAX_WORLD];
+#pragma unroll
+        for (int r = 0; r < PEER_MAX_WORLD; ++r) sv[r] = adam_ld4_sys(mine + (unsigned long long)(r < a.peer.world ? r : 0) * a.peer.cap + (live ? idx : 0));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]) :: "memory");
+        f32x4 acc = sv[0];
+#pragma unroll
+        for (int r = 1; r < PEER_MAX_WORLD; ++r) if (r < a.peer.world) acc += sv[r];
+        g4 = live ? make_float4(acc[0], acc[1], acc[2], acc[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) *reinterpret_cast<float4*>(const_cast<float*>(a.grad) + idx) = g4;       // (ppo_get_last_grad reads it)
+        if (blockIdx.x == 0 && tid < 8) {                                                   // the loss sums + row count ride behind the gradient
+            float t = 0.f;
+            for (int r = 0; r < a.peer.world; ++r) { const float x = __hip_atomic_load(mine + (unsigned long long)r * a.peer.cap + (size_t)a.n_blocks * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); t = r ? t + x : x; }
+            const_cast<float*>(a.grad)[(size_t)a.n_blocks * 256 + tid] = t;
+        }
+    }
     // global norm from the per-chunk partial sums, same fixed order in every block (and on every rank)
     float s = 0.f;
+    if constexpr (MEET > 0) {
+        // this workgroup's partial: the squares of its 1024 elements in a fixed tree, published behind a write-through store; then the meeting
+        float q = (g4.x * g4.x + g4.y * g4.y) + (g4.z * g4.z + g4.w * g4.w);
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        if ((tid & 63) == 0) red[tid >> 6] = q;
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(a.meet_parts + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(a.meet_words + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned polls = 0;
+        for (;;) {
+            bool ok = true;
+            for (int i = tid; i < a.meet_grid; i += 256) ok = ok && (int)(__hip_atomic_load(a.meet_words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0;
+            if (__syncthreads_and(ok ? 1 : 0)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > (1u << 20)) { if (tid == 0) __hip_atomic_store(a.meet_words + ADAM_MEET_MAX_GRID, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        for (int i = tid; i < a.meet_grid; i += 256) s += __hip_atomic_load(a.meet_parts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
     if (a.n_parts > 512) {
+
         // many partials (the bf16 path's one per assembly workgroup): a thread's first eight are requested together -- one memory round
         // trip, not one per partial -- and added in the same index order
         float pv[8];

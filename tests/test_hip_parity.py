@@ -547,15 +547,22 @@ def test_rccl_plumbing_single_rank_communicator():
 
 
 @pytest.mark.parametrize("hidden", [(64, 64), (256, 256)])
-def test_peer_allreduce_single_rank_is_bitwise_the_rccl_path(hidden):
+def test_peer_allreduce_single_rank_is_bitwise_the_rccl_path(hidden, monkeypatch):
     """The one-shot peer all-reduce (push into the gather slot, flag, rank-ordered sum + sums of squares) with a one-rank
     communicator: the region is this process's own, so the kernels, the sequence / parity protocol, the probe of
     ppo_dist_peer_attach and the hipGraph capture of the peer kernels all run -- and, one slot being added to nothing, the
-    rollout and the update must be BIT-identical to the same run over ncclAllReduce."""
+    rollout and the update must be BIT-identical to the same run over ncclAllReduce.
+    [256,256] (round 5): by default the tiles' finishers push and adam_kernel<.., 2> adds the ranks up and forms the norm from one partial per
+    Adam workgroup instead of one per 256-element chunk -- the same gradient bits, a norm that may differ in its last place: that form is held
+    to the push / sum form (PPO_HIP_NO_PEER_TILES=1, which stays bitwise the RCCL path) at 1e-5 relative / 1e-6 of each field's largest value."""
     import ppo_cpp_amd
     E, T, nmb, epochs = 16, 16, 4, 2
     outs = []
-    for peer in (False, True):
+    forms = [("rccl", None), ("peer", "1")] + ([("peer", "0")] if hidden == (256, 256) else [])
+    for form, no_tiles in forms:
+        peer = form == "peer"
+        if no_tiles is not None:
+            monkeypatch.setenv("PPO_HIP_NO_PEER_TILES", no_tiles)
         orc, g, nz, ro, noise = _rollout_pair(hidden, E, T, 31)
         g.dist_init(1, 0, ppo_cpp_amd.PPOHip.dist_unique_id())
         if peer:
@@ -579,9 +586,14 @@ def test_peer_allreduce_single_rank_is_bitwise_the_rccl_path(hidden):
             got["rows2"], _ = g.update(LR, CR, epochs, nmb, perms)
         outs.append(got)
         g.close()
+    monkeypatch.delenv("PPO_HIP_NO_PEER_TILES", raising=False)
     assert np.abs(outs[0]["rows0"]).max() > 0
     for k in outs[0]:
         np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+    if len(outs) == 3:
+        for k in outs[1]:
+            np.testing.assert_allclose(outs[2][k], outs[1][k], rtol=1e-5, atol=1e-6 * float(np.abs(outs[1][k]).max()), err_msg="tile push vs push / sum kernels: " + k)
+        assert not np.array_equal(outs[2]["theta"], np.zeros_like(outs[2]["theta"]))
 
 
 @pytest.mark.parametrize("hidden,O,A,n", [((512, 512), 18, 18, 64), ((1024, 1024, 1024), 256, 64, 48), ((1024,), 256, 64, 40), ((1100,), 18, 18, 20),
