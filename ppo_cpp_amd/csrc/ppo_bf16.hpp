@@ -332,19 +332,10 @@ __device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a
 #endif
 }
 
+// one output tile of C = epilogue(A B): tower tw, rows i0 .., columns j0 .., reduction range ks (F32 only)
 template <int WM, int EPI>
-__global__ __launch_bounds__(GB_THREADS(WM)) void gemm_nt_bf16_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char gb_lds[];
-    const int tw = blockIdx.y;
-    const int ks = EPI == GEPI_F32 ? blockIdx.x / a.tiles_ij : 0, bt = EPI == GEPI_F32 ? blockIdx.x % a.tiles_ij : blockIdx.x;
-    const int ti = bt % a.tiles_i, tj = bt / a.tiles_i;
-    const int i0 = ti * GB_BM(WM), j0 = tj * GB_N;
+__device__ __forceinline__ void gemm_nt_tile(const GemmArgs& a, int tw, int i0, int j0, int ks, char* gb_lds, unsigned long long* gst) {
     GemmAcc acc;
-#ifdef PPO_STAMPS
-    unsigned long long* gst = a.stamps ? a.stamps + ((size_t)(EPI * 2 + tw) * 256 + blockIdx.x) * 8 : nullptr;
-#else
-    unsigned long long* gst = nullptr;
-#endif
     GSTAMP(0);
     float4 bias4[4];                                         // this lane's 16 bias values: requested before the loop, used after it
 #pragma unroll
@@ -376,6 +367,76 @@ __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_nt_bf16_kernel(GemmArgs a
 #else
         if (acc.v[0][0][0] == 123.456f) a.C[tw][0] = (bf16_t)acc.v[1][1][1];
 #endif
+    }
+}
+
+template <int WM, int EPI>
+__global__ __launch_bounds__(GB_THREADS(WM)) void gemm_nt_bf16_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char gb_lds[];
+    const int tw = blockIdx.y;
+    const int ks = EPI == GEPI_F32 ? blockIdx.x / a.tiles_ij : 0, bt = EPI == GEPI_F32 ? blockIdx.x % a.tiles_ij : blockIdx.x;
+    const int ti = bt % a.tiles_i, tj = bt / a.tiles_i;
+#ifdef PPO_STAMPS
+    unsigned long long* gst = a.stamps ? a.stamps + ((size_t)(EPI * 2 + tw) * 256 + blockIdx.x) * 8 : nullptr;
+#else
+    unsigned long long* gst = nullptr;
+#endif
+    gemm_nt_tile<WM, EPI>(a, tw, ti * GB_BM(WM), tj * GB_N, ks, gb_lds, gst);
+}
+
+// ---- a CHAIN of layers in one launch ---------------------------------------------------------------------------------------------------
+// The hidden layers of a pass depend on each other only inside a ROW tile: tile (ti, tj) of layer l + 1 needs rows ti of ALL column tiles of layer l,
+// i.e. the outputs of the tiles_j workgroups that share (tower, ti).  One launch per layer makes that a chip-wide barrier plus a launch: of the
+// 24.6 us of a [4096 x 1024 x 1024] x 2 launch only ~18 us are a workgroup's life (tools/step_sequence.py against the in-kernel stamps), and the
+// 8 GEMM launches of a train step carry ~50 us of that.  Here the layers of a pass run in ONE launch of tiles_i x tiles_j x 2 workgroups (one per
+// CU: 144 KB of LDS each, all resident -- the host only uses this form when they fit the device); after its epilogue a workgroup raises its word of
+// a table, and before the next layer it waits for the tiles_j words of its row group only.
+// Visibility WITHOUT cache-wide fences: the tiles_j workgroups of a row group are dealt to ONE XCD (workgroup b runs on XCD b % 8), so the layer's
+// output tile a workgroup wrote with plain stores (complete in that XCD's L2 once the stores are acknowledged: s_waitcnt vmcnt(0)) is what the
+// group's other workgroups read through the same L2; a CU's L1 holds no line of it (it has not been read in this launch).  That DOES rest on the
+// dealing, so it is CHECKED, not assumed: every word carries the hardware's XCC id of its writer (s_getreg HW_REG_XCC_ID) and a reader that finds a
+// producer on another XCD raises the error word -- the host call that synchronises next returns an error and the handle goes back to one launch per
+// layer.  Waits are bounded the same way (a workgroup that never became resident).
+#define GB_CHAIN_MAX 4
+struct ChainArgs {
+    int n;                                    // links: link l + 1 reads link l's C as its A
+    int tiles_i, tiles_j;                     // of every link (same output shape)
+    unsigned* words;                          // [GB_CHAIN_MAX][2 * tiles_i groups][16]: (epoch << 4) | xcc per workgroup; then the error word at [GB_CHAIN_WORDS]
+    GemmArgs link[GB_CHAIN_MAX];
+};
+#define GB_CHAIN_WORDS (GB_CHAIN_MAX * 64 * 16)           // up to 64 row groups
+
+template <int EPI>
+__global__ __launch_bounds__(GB_THREADS(4)) void gemm_chain_bf16_kernel(ChainArgs ca) {
+    extern __shared__ __attribute__((aligned(16))) char gb_lds[];
+    const unsigned b = blockIdx.x, x = b & 7u, q = b >> 3;
+    const int G = 2 * ca.tiles_i, gpx = G >> 3;                          // row groups; per XCD
+    const int gidx = (int)x * gpx + (int)q / ca.tiles_j, tj = (int)q % ca.tiles_j;
+    const int tw = gidx / ca.tiles_i, ti = gidx % ca.tiles_i;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    unsigned* mine = ca.words + ((size_t)gidx * 16 + tj);               // + l * G * 16 for link l
+    const unsigned epoch = (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 4) + 1u;      // (only this workgroup writes its words)
+    for (int l = 0; l < ca.n; ++l) {
+        if (l > 0) {
+            // (requesting the next layer's weights BEFORE this wait was measured: no gain -- the group's workgroups finish together, there is no
+            // idle time to fill; profiles/r05_e_*)
+            if (threadIdx.x < (unsigned)ca.tiles_j) {
+                const unsigned* w = ca.words + ((size_t)(l - 1) * G + gidx) * 16 + threadIdx.x;
+                unsigned polls = 0, v;
+                while ((int)(((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) - epoch) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > (1u << 21)) { __hip_atomic_store(ca.words + GB_CHAIN_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                if ((v & 15u) != xcc) __hip_atomic_store(ca.words + GB_CHAIN_WORDS, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        gemm_nt_tile<4, EPI>(ca.link[l], tw, ti * GB_BM(4), tj * GB_N, 0, gb_lds, nullptr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's stores of the output tile are acknowledged by the L2
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(mine + (size_t)l * G * 16, (epoch << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -177,7 +177,10 @@ struct ppo_handle {
         float* dbias = nullptr; int db_off[2][PPO_MAX_LAYERS]{}; int n_dbias = 0;
         DwTileB* dw_tiles = nullptr; int n_dw_tiles = 0; int dw_wm = 4;
         int tile0[2][PPO_MAX_LAYERS + 1]{};             // first weight-gradient tile of every matrix ([L] = the head), in the order of the tile table
+        // the hidden layers of a pass as ONE launch (gemm_chain_bf16_kernel): its word tables (forward, backward); PPO_HIP_NO_BF16_CHAIN=1: a launch per layer
+        bool chain = false; unsigned* chain_words[2]{}; int n_cu = 0;
     } bf;
+    bool dev_shared = false;          // data parallel: another rank of the job runs on this device (kernels whose workgroups wait for each other are not used then)
     // narrow-network path (every hidden width <= 64; kernels in ppo_narrow.hpp)
     bool narrow = false;
     NwLayout nw{};
@@ -635,7 +638,48 @@ int bf16_create(ppo_handle* h) {
     lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_TANHGRAD>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_TANHGRAD>, GB_LDS_BYTES(2));
     lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_F32>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_F32>, GB_LDS_BYTES(2));
     lds_attr((const void*)gemm_dw_bf16_kernel<4>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_dw_bf16_kernel<2>, GB_LDS_BYTES(2));
+    lds_attr((const void*)gemm_chain_bf16_kernel<GEPI_TANH>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_chain_bf16_kernel<GEPI_TANHGRAD>, GB_LDS_BYTES(4));
     if (!ok) return fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 GEMM kernels");
+    { const char* e = getenv("PPO_HIP_NO_BF16_CHAIN");
+      b.chain = !(e && e[0] == '1');
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) b.n_cu = prop.multiProcessorCount;
+      for (int d = 0; d < 2 && b.chain; ++d) if (dev_alloc(h, &b.chain_words[d], GB_CHAIN_WORDS + 32)) return -1; }
+    return 0;
+}
+
+// The layers of a pass in one launch (gemm_chain_bf16_kernel): `n` links of the same output shape [I][J]; false when the shape does not qualify
+// (256-row tiles, every row group of tiles_j workgroups on one XCD, all workgroups resident at once) -- the caller then launches layer by layer.
+template <int EPI>
+bool bf16_chain(ppo_handle* h, const GemmArgs* links, int n, int I, int J, int which) {
+    ppo_handle::Bf16& b = h->bf;
+    if (!b.chain || h->dev_shared || n < 2 || n > GB_CHAIN_MAX || I % 256 != 0 || J % GB_N != 0) return false;
+    const int tiles_i = I / 256, tiles_j = J / GB_N, G = 2 * tiles_i;
+    if (G % 8 != 0 || G > 64 || tiles_j > 16 || G * tiles_j > b.n_cu) return false;
+    ChainArgs ca{};
+    ca.n = n; ca.tiles_i = tiles_i; ca.tiles_j = tiles_j; ca.words = b.chain_words[which];
+    for (int l = 0; l < n; ++l) { ca.link[l] = links[l]; ca.link[l].ksplit = 1; ca.link[l].tiles_i = tiles_i; ca.link[l].tiles_ij = tiles_i * tiles_j; }
+    hipLaunchKernelGGL((gemm_chain_bf16_kernel<EPI>), dim3(G * tiles_j), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, ca);
+    return hipGetLastError() == hipSuccess;
+}
+
+// after a stream synchronisation: did a chained launch time out or find a row group spread over two XCDs?
+int bf16_chain_check(ppo_handle* h) {
+    ppo_handle::Bf16& b = h->bf;
+    if (!b.on || !b.chain) return 0;
+    for (int d = 0; d < 2; ++d) {
+        unsigned e = 0;
+        if (!b.chain_words[d]) continue;
+        HIP_OK(h, hipMemcpy(&e, b.chain_words[d] + GB_CHAIN_WORDS, sizeof e, hipMemcpyDeviceToHost));
+        if (e) {
+            for (int k = 0; k < 2; ++k) (void)hipMemset(b.chain_words[k], 0, (GB_CHAIN_WORDS + 32) * sizeof e);
+            b.chain = false;
+            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            return fail(h, "gemm_chain_bf16_kernel: %s; this call's results are invalid.  The handle now launches layer by layer (PPO_HIP_NO_BF16_CHAIN=1 selects "
+                           "that from the start)", e == 2 ? "a row group's workgroups were not on one XCD (the launch's workgroup dealing is not round-robin over the XCDs here)"
+                                                          : "its workgroups were not resident together within ~1 s (is another process using this GPU?)");
+        }
+    }
     return 0;
 }
 
@@ -699,6 +743,8 @@ int bf16_gemm(ppo_handle* h, const GemmArgs& a, int I, int J) {
 int bf16_forward(ppo_handle* h, int Rp, const bf16_t* x0_override = nullptr) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
+    GemmArgs fl[PPO_MAX_LAYERS];
+    bool same_j = true;
     for (int l = 0; l < n.L; ++l) {
         GemmArgs a{};
         const int Kp = l ? n.Hp[l - 1] : n.Kp0;
@@ -707,7 +753,8 @@ int bf16_forward(ppo_handle* h, int Rp, const bf16_t* x0_override = nullptr) {
             a.C[t] = b.hb[t][l];
         }
         a.lda = Kp; a.ldb = n.Hp[l]; a.K = Kp; a.ldc = n.Hp[l];
-        if (bf16_gemm<GEPI_TANH>(h, a, Rp, n.Hp[l])) return -1;
+        fl[l] = a;
+        same_j = same_j && n.Hp[l] == n.Hp[0];
     }
     GemmArgs a{};
     const int HpL = n.Hp[n.L - 1];
@@ -715,6 +762,11 @@ int bf16_forward(ppo_handle* h, int Rp, const bf16_t* x0_override = nullptr) {
         a.A[t] = b.hb[t][n.L - 1]; a.B[t] = b.theta_bf + (t ? n.wv_off : n.wmu_off); a.bias[t] = h->theta + (t ? n.bv_off : n.bmu_off); a.F[t] = b.head_out[t];
     }
     a.lda = HpL; a.ldb = n.Ap; a.K = HpL; a.ldf = n.Ap;
+    // every hidden layer in ONE launch when the shape qualifies, else a launch per layer.  (The heads riding behind the last layer of the chained launch --
+    // a workgroup's own column tile is one 128-deep reduction range -- was measured: -4.2 us on the pass, +1.8 us in the loss kernel for twice the
+    // partial products, and +16 us per env step on the act path, which has to cut its heads the same way to give the same bits; not kept.)
+    if (!(same_j && n.L <= GB_CHAIN_MAX && bf16_chain<GEPI_TANH>(h, fl, n.L, Rp, n.Hp[0], 0)))
+        for (int l = 0; l < n.L; ++l) if (bf16_gemm<GEPI_TANH>(h, fl[l], Rp, n.Hp[l])) return -1;
     // the heads are few tiles (Ap = 128 columns): cut the reduction so that the launch covers the chip; the partial products are
     // added by the consumers (bf16_sample_kernel / bf16_loss_kernel) in range order
     const int tiles = 2 * (Rp / (Rp % 256 == 0 ? 256 : 128)) * (n.Ap / GB_N);
@@ -775,6 +827,9 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
     HIP_OK(h, hipGetLastError());
     // dY_{L-1} = (d head * W_head^T) .* (1 - h_L^2), then down the hidden layers
     const int HpL = n.Hp[n.L - 1];
+    GemmArgs bl[PPO_MAX_LAYERS];
+    int outw[PPO_MAX_LAYERS];
+    bool same_j = true;
     {
         GemmArgs a{};
         for (int t = 0; t < 2; ++t) {
@@ -783,7 +838,7 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
         a.lda = n.Ap; a.ldb = n.Ap; a.K = n.Ap; a.ldh = HpL; a.ldc = HpL;
         for (int t = 0; t < 2; ++t) a.bsum[t] = b.dbias + b.db_off[t][n.L - 1];
         a.bsum_ld = b.n_dbias;
-        if (bf16_gemm<GEPI_TANHGRAD>(h, a, Rp, HpL)) return -1;
+        bl[0] = a; outw[0] = HpL;
     }
     for (int l = n.L - 1; l >= 1; --l) {
         GemmArgs a{};
@@ -793,8 +848,11 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
         a.lda = n.Hp[l]; a.ldb = n.Hp[l]; a.K = n.Hp[l]; a.ldh = n.Hp[l - 1]; a.ldc = n.Hp[l - 1];
         for (int t = 0; t < 2; ++t) a.bsum[t] = b.dbias + b.db_off[t][l - 1];
         a.bsum_ld = b.n_dbias;
-        if (bf16_gemm<GEPI_TANHGRAD>(h, a, Rp, n.Hp[l - 1])) return -1;
+        bl[n.L - l] = a; outw[n.L - l] = n.Hp[l - 1];
+        same_j = same_j && n.Hp[l - 1] == HpL;
     }
+    if (!(same_j && n.L <= GB_CHAIN_MAX && bf16_chain<GEPI_TANHGRAD>(h, bl, n.L, Rp, HpL, 1)))
+        for (int k = 0; k < n.L; ++k) if (bf16_gemm<GEPI_TANHGRAD>(h, bl[k], Rp, outw[k])) return -1;
     return 0;
 }
 
@@ -1401,6 +1459,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->dw2_jobs) (void)hipFree(h->dw2_jobs);
     if (h->dw2_counters) (void)hipFree(h->dw2_counters);
     if (h->fab_meet) (void)hipFree(h->fab_meet);
+    for (int d = 0; d < 2; ++d) if (h->bf.chain_words[d]) (void)hipFree(h->bf.chain_words[d]);
     if (h->adam_meet_words) (void)hipFree(h->adam_meet_words);
     if (h->adam_meet_parts) (void)hipFree(h->adam_meet_parts);
     if (h->dw2_parts) (void)hipFree(h->dw2_parts);
@@ -1606,7 +1665,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
     HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    return fab_check(h) || adam_meet_check(h) ? -1 : 0;
+    return fab_check(h) || adam_meet_check(h) || bf16_chain_check(h) ? -1 : 0;
 }
 
 int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm) {
@@ -2573,7 +2632,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    if (fab_check(h) || adam_meet_check(h)) return -1;
+    if (fab_check(h) || adam_meet_check(h) || bf16_chain_check(h)) return -1;
     return peer_check(h);
 }
 
@@ -2626,7 +2685,7 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
       h->adam_meet = !(e && e[0] == '1');
       if (h->adam_meet && (dev_alloc(h, &h->adam_meet_words, ADAM_MEET_MAX_GRID + 32) || dev_alloc(h, &h->adam_meet_parts, ADAM_MEET_MAX_GRID))) return -1;
       HIP_OK(h, hipStreamSynchronize(h->stream)); }
-    if (h->fuse_ab && world > 1) {
+    if (world > 1) {
         // Do two ranks share a device (N processes on one GPU: the tests' dry runs)?  Then kernels whose workgroups wait for each other while
         // holding a CU each (train8_dw2_fused_kernel's grid-wide meeting) could starve one another: every rank publishes its device's PCI
         // location in its slot of a table, one all-reduce, and the handles of a job with a shared device fall back to the two-launch form.
@@ -2646,6 +2705,7 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
             for (int i = 0; i < world; ++i) for (int j = i + 1; j < world; ++j) if (tab[(size_t)i] == tab[(size_t)j]) shared = true;
         }
         if (dt) (void)hipFree(dt);
+        h->dev_shared = shared;
         if (shared) h->fuse_ab = false;
     }
     // Collectives inside the update's hipGraph: with a communicator the eager sequence is 5-6 launches and up to three

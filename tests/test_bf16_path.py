@@ -128,3 +128,32 @@ def test_bf16_full_size_config4_properties():
     g.set_flat(theta0); g.set_flat(m0, 1); g.set_flat(v0, 2); g.set_beta_powers(pw0)
     rows2, _ = g.update(LR, CR, epochs, nmb, None, seed=77)
     np.testing.assert_array_equal(rows2, rows); np.testing.assert_array_equal(g.get_flat(0), th1)
+
+
+@pytest.mark.parametrize("hidden,O,A,n", [((1024, 1024, 1024), 256, 64, 4096), ((512, 512), 64, 18, 2048), ((1024, 1024, 1024), 256, 64, 1024)])
+def test_chained_layers_launch_is_bitwise_the_launch_per_layer(hidden, O, A, n, monkeypatch):
+    """gemm_chain_bf16_kernel (ppo_bf16.hpp): the hidden layers of the forward pass, and of the backward pass, as ONE launch each -- a workgroup waits for the
+    tiles_j workgroups of its row group only, which share one XCD's L2 (checked in the kernel against the hardware's XCC id).  Same tiles, same main loop,
+    same epilogues: losses, gradient, norm, weights and both moments of three train steps must be the same BITS as with PPO_HIP_NO_BF16_CHAIN=1 (a launch per
+    layer), at configs[4]'s own 4096-row minibatch (16 row tiles x 8 column tiles x 2 towers = one workgroup per CU), at a [512,512] net with 2048 rows
+    (128 workgroups), and at 1024 rows (4 row tiles per tower: fewer row groups than XCDs -- the chain does not apply and the run must simply agree)."""
+    outs = []
+    for no_chain in ("0", "1"):
+        monkeypatch.setenv("PPO_HIP_NO_BF16_CHAIN", no_chain)
+        orc, g = pair_bf16(hidden, O, A)
+        acc = []
+        for it in range(3):
+            mb = H.synth_minibatch(orc, n, seed=11 + it)
+            args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+            acc.append(np.asarray(g.train_step(LR, CR, *args)).copy())
+            gr, nrm = g.last_grad()
+            acc += [gr.copy(), np.float32(nrm)]
+        acc += [g.get_flat(0), g.get_flat(1), g.get_flat(2)]
+        obs = np.random.RandomState(2).uniform(-1, 1, (n, O)).astype(np.float32)
+        acc += list(g.step(obs, np.zeros((n, A), np.float32)))
+        g.close()
+        outs.append(acc)
+    monkeypatch.delenv("PPO_HIP_NO_BF16_CHAIN", raising=False)
+    assert np.isfinite(outs[0][-4]).all() and np.abs(outs[0][1]).max() > 0
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
