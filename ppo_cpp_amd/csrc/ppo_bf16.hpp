@@ -160,7 +160,9 @@ __device__ __forceinline__ void gb_stage_image(const bf16_t* __restrict__ H, int
 // t+2 into the buffer stage t-1 used -> read fragments of stage t, 32 MFMAs per wave.  A __syncthreads() would drain the
 // LDS-DMA queue (it waits vmcnt(0)), so the barrier is the raw instruction and the wait is counted.
 // The k loop is bound by the bytes a CU can pull from L2 into LDS (measured: 48 KB per stage in ~1975 cycles = 25 B/clk per CU,
-// against 1024 cycles of matrix instructions per SIMD), not by the matrix pipe.
+// against 1024 cycles of matrix instructions per SIMD), not by the matrix pipe.  (Round 5: a software-pipelined form -- fragment reads of the next
+// k-step in flight under the matrix instructions of the current one, the stage's barrier in the middle of its matrix work -- was correct and
+// bought 1 %: 23.6 vs 24.6 us per K = 1024 launch on boxes 3 % apart; 254 VGPRs, spills in the chained kernel.  Not kept: profiles/r05_e_*.)
 template <int WM, bool IMG, bool BT = false>
 __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restrict__ A, int lda, int i0, const bf16_t* __restrict__ B, int ldb, int j0,
                                             int kbeg, int K, char* lds, const bf16_t* __restrict__ H = nullptr, int ldh = 0, unsigned long long* gst = nullptr) {
