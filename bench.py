@@ -270,12 +270,13 @@ def cpu_baseline(cfg, name="cfg3", budget_s=20.0):
 
 def count_gpus_from_sysfs():
     """GPU nodes of /sys/class/kfd/kfd/topology (a node with simd_count > 0 is a GPU; CPUs have 0), cut by ROCR_VISIBLE_DEVICES /
-    HIP_VISIBLE_DEVICES when they are plain index lists; None when the topology cannot be read"""
+    HIP_VISIBLE_DEVICES when they are plain index lists.  No topology directory = no amdgpu compute driver on this machine = 0 devices; None only when the
+    files exist and cannot be read"""
     import glob
     n = 0
     files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
     if not files:
-        return None
+        return 0
     try:
         for f in files:
             for line in open(f):
@@ -304,7 +305,7 @@ def self_launch(n):
     if not os.environ.get("PPO_RCCL_LIBRARY"):
         # RCCL takes ONE rank per device.  (PPO_RCCL_LIBRARY = a stand-in such as tests/fake_rccl lets N ranks share a device: a dry
         # run of the flow, not a measurement.)  The devices are counted from the kernel driver's topology files -- no HIP / torch call, so this
-        # parent really never touches the GPU; when the files are not there the ranks report a shortage themselves.
+        # parent really never touches the GPU.
         ndev = count_gpus_from_sysfs()
         if ndev is not None and ndev < n:
             print(json.dumps({"error": "bench.py --gpus %d: this node exposes %d HIP device(s); RCCL needs one device per rank" % (n, ndev)}), flush=True)
