@@ -18,7 +18,7 @@
  *   - a non-finite gradient norm poisons the weights with NaN exactly like G:24493-24543; not an error
  *   - there is NO CPU fallback: every call fails loudly when no gfx950 device is usable
  *   - PPO_F32 arithmetic: exact-fp32 matrix instructions (a k-ordered fmaf chain), correctly rounded square root / division in
- *     the clip + Adam step.  ONE stated deviation: a handle of the reference's own [64,64] shape (up to 32 observations and 32 actions: 18 / 18) applies Adam
+ *     the clip + Adam step.  ONE stated deviation: a handle of the reference's own [64,64] shape (up to 64 observations and 32 actions: 18 / 18 and the 36 / 18 of observe_velocities) applies Adam
  *     inside the next train kernel's prologue during ppo_update and uses the hardware's 1-ulp reciprocal and square root for the
  *     quotient m * alpha / (sqrt(v) + eps) in ALL its Adam steps (so that both forms agree bit for bit): a 3-ulp error in an update
  *     term that is ~1e-3 of the weight.  PPO_HIP_NO_LAZY_ADAM=1 switches that form, and the deviation, off.
@@ -197,7 +197,10 @@ int ppo_dist_graph_collectives(const ppo_handle* h);
  *     the next ppo_update / ppo_rollout_finish / ppo_collect_synthetic returns an error instead of hanging the device.
  *     The call ends with a collective over the communicator, so no rank returns before every rank has finished its probe.
  *   ppo_dist_peer_active: 1 when the peer path is in use.   ppo_dist_peer_enable: switch between the two paths after a
- *     successful attach (collectively, at the same point on every rank). */
+ *     successful attach (collectively, at the same point on every rank).
+ *   With the peer path on, a [256,256] handle pushes its gradient tiles from inside the weight-gradient kernel and adds the ranks up inside the Adam launch
+ *     (no push / sum launches; PPO_HIP_NO_PEER_TILES=1 restores them).  Kernels whose workgroups wait for each other while holding a CU (the bf16 path's
+ *     chained layers) are switched off when two ranks of the job share a device: ppo_dist_init compares the ranks' PCI ids over the communicator. */
 int ppo_dist_peer_export(ppo_handle* h, char handle[64]);
 int ppo_dist_peer_attach(ppo_handle* h, const char* handles);
 int ppo_dist_peer_active(const ppo_handle* h);
