@@ -118,8 +118,11 @@ __device__ __forceinline__ void dw2_strip_mma(const float (&u)[2][NU], const flo
 // system-scope release, and arrives on the local counter; the last of the 64 finishers raises this rank's flag at every peer.  No push launch; the
 // sum over the ranks happens inside adam_kernel<.., 2>.  (Round 2 pushed from every workgroup that wrote gradient elements -- 590 of them, each with
 // its own fence -- and lost; here at most 64 workgroups fence.)
-template <int KP0, int AP, bool PEER = false>
-__device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int b, const PeerDev* pp = nullptr) {
+// FUSED (second phase of train8_dw2_fused_kernel): the workgroup entered after the 32 workgroups of ITS (tower, row split) had finished the first phase; the
+// slot jobs read rows of EVERY split of either tower, so their loads wait -- behind the chunk loop, when it costs nothing -- until all FAB words show `epoch`.
+struct Dw2Meet { const unsigned* words; unsigned epoch; unsigned* err; int n; };
+template <int KP0, int AP, bool PEER = false, bool FUSED = false>
+__device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int b, const PeerDev* pp = nullptr, const Dw2Meet* mt = nullptr) {
     typedef Dw2L<KP0, AP> LD;
     DW2_STAMP(15); DW2_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
@@ -253,12 +256,13 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
     if (nch > 0) read_frags(fa, 0);
     // ---- slot jobs: 32 lanes per element, loads issued now, finished after the matrix work ------------------------------------
     float sj[DW2_SLOTK];
-    {
+    auto load_slots = [&]() __attribute__((always_inline)) {
         const int ln = tid & 31;
         const float* p = (jraw.x ? a.slots[1] : a.slots[0]) + jraw.y;
 #pragma unroll
         for (int k = 0; k < DW2_SLOTK; ++k) { const int rb = ln + 32 * k; sj[k] = (has_job && rb < a.n_rowblocks) ? p[(size_t)rb * a.slot_w] : 0.f; }
-    }
+    };
+    if constexpr (!FUSED) load_slots();
     DW2_STAMP(2);
     // One iteration = the matrix instructions of chunk i from registers; chunk i+3 is requested into the buffer of chunk i (this wave
     // read its fragments of it in the last iteration), the fragments of chunk i+1 are read (its pieces have landed: the wait at the
@@ -289,6 +293,21 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
         if (i + 1 < nch) iteration(i + 1, fb, fa);
     }
     DW2_STAMP(3);
+    if constexpr (FUSED) {
+        // every workgroup of the launch has finished its first phase by now (this phase's chunk loop is longer than the towers' skew): check it, then the slots
+        if (tid < 256) {
+            unsigned polls = 0;
+            for (;;) {
+                bool ok = true;
+                for (int i = tid; i < mt->n; i += 256) ok = ok && (int)(__hip_atomic_load(mt->words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mt->epoch) >= 0;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > (1u << 20)) { if ((tid & 63) == 0) __hip_atomic_store(mt->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        load_slots();
+    }
     // ---- park: main partials [4 K quarters][64][32], strip partials [8 waves][16 uwk]; slot jobs finish here too --------------------
     __syncthreads();                                          // the partials overlay the chunk ring: every wave is done with it (and its requests have landed)
     float* park = lds;

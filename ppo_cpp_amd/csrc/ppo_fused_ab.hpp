@@ -12,6 +12,9 @@
 // than the writer finds no copy of the line in its own L2 (the launch started with an invalidate and phase A reads no workspace) and takes it
 // from the memory side.  Placement only decides the hit rate.
 //
+// Measured (profiles/r05_a_*): +0.4 us per train step against the two launches (+0.9 with a grid-wide meeting) -- inside one group the slowest first-phase
+// workgroup is ~7 k cycles behind the median, and a workgroup waits for it just as the kernel boundary would.  Opt-in (PPO_HIP_FUSE_AB=1), not the default.
+//
 // The meeting: 256 workgroups of 512 threads, one per CU (both bodies need > 80 KB of LDS), all resident -- the host launches this form only when
 // the grid fits the device.  No read-modify-write on a shared word (256 same-address agent-scope atomics serialise at ~100 cycles each: the first
 // version of this kernel, one arrival counter, spent a median 26 k cycles per workgroup in the meeting -- tools/stamps_fused.py): every workgroup
@@ -45,16 +48,20 @@ __global__ __launch_bounds__(FAB_THREADS) void train8_dw2_fused_kernel(NetDev ne
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's write-through stores are complete at the memory side
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(meet + lid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < FAB_GRID) {                                    // waves 0..3 watch the table, 64 words each
+    // ... of the workgroup's OWN group: the 32 workgroups lid' = (lid & 7) + 8 q wrote the rows (tower lid & 1, row split (lid >> 1) & 3) this workgroup's tile
+    // reads (TrainArgs::xcd_map 1) -- by construction of the two index maps, whatever XCD they ran on.  The slot jobs need every workgroup: dw2_body waits for
+    // those behind its chunk loop.  (A first version met grid-wide here: the value tower's workgroups, 6 k cycles early, waited for the policy tower's.)
+    if (threadIdx.x < 32) {
         unsigned polls = 0;
         for (;;) {
-            const unsigned w = __hip_atomic_load(meet + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all((int)(w - epoch) >= 0)) break;                 // (wave-uniform exit: every word of this wave's 64 has arrived)
+            const unsigned w = __hip_atomic_load(meet + (lid & 7u) + 8u * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(w - epoch) >= 0 || threadIdx.x >= 32)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++polls > (1u << 20)) { if ((threadIdx.x & 63) == 0) __hip_atomic_store(meet + FAB_GRID, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++polls > (1u << 20)) { if (threadIdx.x == 0) __hip_atomic_store(meet + FAB_GRID, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
     }
     __syncthreads();
     // phase B: weight gradients + assembly, tile / split from the linear index as in the standalone launch
-    dw2_body<KP0, AP>(da, lds, (int)lid);
+    const Dw2Meet mt{meet, epoch, meet + FAB_GRID, FAB_GRID};
+    dw2_body<KP0, AP, false, true>(da, lds, (int)lid, nullptr, &mt);
 }

@@ -1379,7 +1379,7 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
       if ((h->t8 || h->dw2) && !(set_lds_pair<32, 32>() && set_lds_pair<64, 32>() && set_lds_pair<32, 64>() && set_lds_pair<64, 64>())) {
           fail(h, "hipFuncSetAttribute failed for train8_kernel / weight_grad_assemble_kernel"); return bail(0); } }
     { const char* e = getenv("PPO_HIP_FUSE_AB");
-      // OPT-IN (measured slower than the two launches, profiles/r05_a_*: 40.7 vs 39.85 us per train step).  The fused form's grid-wide meeting
+      // OPT-IN (measured slower than the two launches, profiles/r05_a_*: 40.3 vs 39.85 us per train step with the group-local meeting, 40.7 grid-wide).  The fused form's grid-wide meeting
       // needs all DW2_GRID workgroups resident at once: one per CU (each takes > 80 KB of LDS)
       h->fuse_ab = (e && e[0] == '1') && h->t8 && h->dw2 && prop.multiProcessorCount >= DW2_GRID;
       if (h->fuse_ab && dev_alloc(h, &h->fab_meet, FAB_GRID + 32)) return bail(0); }
