@@ -17,7 +17,8 @@ def main():
     E, T, nmb, epochs = (int(d[k]) for k in ("E", "T", "nmb", "epochs"))
     El = E // world
     sl = slice(rank * El, (rank + 1) * El)
-    g = ppo_cpp_amd.PPOHip(18, 18, hidden, device=0, compute_dtype=1 if os.environ.get("PPO_TEST_BF16") == "1" else 0)
+    O = int(d["O"]) if "O" in d.files else 18                      # (observation width: 64 / 256 exercise the column-group statistics under data parallelism)
+    g = ppo_cpp_amd.PPOHip(O, 18, hidden, device=0, compute_dtype=1 if os.environ.get("PPO_TEST_BF16") == "1" else 0)
     g.set_flat(d["theta"])
     g.dist_init(world, rank, d["uid"].tobytes())
     if os.environ.get("PPO_TEST_PEER") == "1":

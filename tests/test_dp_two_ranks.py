@@ -228,3 +228,40 @@ def test_statistics_exchange_inside_the_statistics_kernels_is_bitwise_the_all_re
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     close(res[0][0]["obs_mean"], nz.obs_rms.mean, rtol=1e-5, atol=1e-6)
     assert float(res[0][0]["obs_count"]) == nz.obs_rms.count
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("peer", [False, True])
+@pytest.mark.parametrize("world,O,E,T", [(2, 64, 512, 3), (4, 128, 1024, 2)])
+def test_wide_observation_statistics_under_data_parallelism(tmp_path, world, O, E, T, peer):
+    """Observations a multiple of 64 wide with >= 256 environments per rank: norm_batch_kernel's column-group job (obs_cgroup_job) PUBLISHES each rank's batch moments
+    from its group finishers instead of merging them (table all-reduce, or the peer slots written by the job's last group), norm_finalize_kernel combines the ranks.  The
+    rollout shards and the running statistics against the single-process oracle over the union; statistics bit-identical on every rank."""
+    tmp = str(tmp_path)
+    fake = build_fake_rccl(tmp)
+    hidden, nmb, epochs = (256, 256), 4, 1
+    orc = o.Oracle(O, 18, list(hidden)); orc.init_orthogonal(15)
+    rng = np.random.RandomState(53)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    nz = o.Normalizer(E, O)
+    ro, _, _ = o.collect(orc, nz, 1234, T, noise, GAMMA, LAM)
+    El = E // world; Bl = El * T
+    perms = np.stack([np.stack([rng.permutation(Bl).astype(np.int32) for _ in range(epochs)]) for _ in range(world)])
+    uid = np.zeros(128, np.uint8)
+    name = ("/ppo_dp_wide_%d_%d" % (os.getpid(), rng.randint(1 << 30))).encode()
+    uid[:len(name)] = np.frombuffer(name, np.uint8)
+    fin = os.path.join(tmp, "in.npz")
+    np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=orc.theta, uid=uid, gamma=GAMMA, lam=LAM, seed=1234, O=O,
+             noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
+    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="1" if peer else "0")
+    outs = run_workers(tmp, world, fin, env)
+    for r, out in enumerate(outs):
+        sl = slice(r * El, (r + 1) * El)
+        for f in ("obs", "actions", "values", "neglogp", "rewards", "returns"):
+            close(out["ro_" + f], ro[f][:, sl], rtol=2e-4, atol=2e-5, msg="rank %d %s" % (r, f))
+        close(out["obs_mean"], nz.obs_rms.mean, rtol=1e-5, atol=1e-6); close(out["obs_var"], nz.obs_rms.var, rtol=1e-5)
+        assert float(out["obs_count"]) == nz.obs_rms.count and float(out["ret_count"]) == nz.ret_rms.count
+    for k in ("obs_mean", "obs_var", "ret_mean", "ret_var"):
+        for out in outs[1:]:
+            np.testing.assert_array_equal(outs[0][k], out[k])
+
