@@ -57,7 +57,7 @@ def _fake_rccl(tmp):
     (2, (64, 64), 8, 32, 4, 2, 18, "rccl"), (2, (64, 64), 8, 32, 4, 2, 18, "peer"), (2, (256, 256), 8, 16, 4, 2, 18, "rccl"),
     (8, (64, 64), 16, 32, 4, 2, 18, "rccl"), (8, (256, 256), 16, 16, 4, 2, 18, "peer"),
     # the hexapod's other shape (36 observations, env/hexapod_closed_loop_env.hpp:20) through the same path
-    (2, (64, 64), 8, 32, 4, 2, 36, "rccl")])
+    (2, (64, 64), 8, 32, 4, 2, 36, "rccl"), (2, (256, 256), 8, 16, 4, 2, 36, "peer")])
 def test_cpp_driver_ranks_match_the_oracle_over_the_union(tmp_path, world, hidden, E, T, nmb, epochs, O, collective):
     """`ppo_cpp_hip --ranks W` on SeededEnvMock x E (E / W per rank) for two updates with EXPLICIT exploration noise and epoch permutations,
     against oracle.collect + oracle.update over the union of the ranks' environments: every update's five mean losses, the final weights and
