@@ -47,11 +47,11 @@ const char* kProfNames[PK_COUNT] = {"policy_step", "train_fwd_bwd", "weight_grad
 
 // which kernel VARIANT a call took (ppo_kernel_counts): the fast paths are chosen by shape, and a test must be able to say which one ran
 enum KernelVariant { KV_TRAIN8 = 0, KV_TRAIN_FB, KV_DW2, KV_DW, KV_GRAD_REDUCE, KV_NARROW_TRAIN_STATIC, KV_NARROW_TRAIN, KV_NARROW_STEP_STATIC, KV_NARROW_STEP,
-                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_FUSED_AB, KV_COUNT };
+                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_FUSED_AB, KV_DW2_ADAM, KV_COUNT };
 const char* kVariantNames[KV_COUNT] = {"train8_kernel", "train_fwd_bwd_kernel", "weight_grad_assemble_kernel", "weight_grad_kernel", "grad_reduce_kernel",
                                        "narrow_train_kernel<static>", "narrow_train_kernel<runtime>", "narrow_step_kernel<static>", "narrow_step_kernel<runtime>",
                                        "policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_rollout_coop_kernel", "narrow_collect_kernel",
-                                       "bf16_train_sequence", "bf16_step_sequence", "train8_dw2_fused_kernel"};
+                                       "bf16_train_sequence", "bf16_step_sequence", "train8_dw2_fused_kernel", "weight_grad_assemble_adam"};
 
 // RCCL entry points resolved at run time (the single-GPU path must not depend on librccl being loadable)
 struct Rccl {
@@ -107,6 +107,9 @@ struct ppo_handle {
     // data-parallel adam_kernel<.., MEET>: the meeting's epoch words (+ error word) and the workgroups' partial sums of squares; PPO_HIP_NO_ADAM_MEET=1:
     // the round-4 sequence (all-reduce + grad_sumsq_kernel / push + sum kernels, then the plain adam_kernel)
     unsigned* adam_meet_words = nullptr; float* adam_meet_parts = nullptr; bool adam_meet = false;
+    // clip + Adam inside weight_grad_assemble_adam_kernel (single GPU, [256,256] pair; ppo_dw2.hpp): PPO_HIP_ADAM_IN_B=1 on a whole device; measured, breaks
+    // even with the adam_kernel launch, so not the default
+    bool dw2_adam = false; unsigned long long* dw2_meet = nullptr;     // [DW2_TILES + DW2_GRID] {epoch, partial} words, [DW2_ENT_ERR] raised when a wait timed out
     unsigned* fab_meet = nullptr;     // the meeting's table: [FAB_GRID] per-workgroup epoch words, [FAB_GRID] raised when a wait timed out
     unsigned* dw2_counters = nullptr; float* dw2_parts = nullptr; SlotJob* dw2_jobs = nullptr; int dw2_n_jobs = 0, dw2_jpw = 0;
     // staging for host-pointer calls
@@ -978,6 +981,21 @@ int fab_check(ppo_handle* h) {
     return 0;
 }
 
+// after a stream synchronisation: did weight_grad_assemble_adam_kernel's meeting time out?
+int dw2_adam_check(ppo_handle* h) {
+    if (!h->dw2_meet || !h->dw2_adam) return 0;
+    unsigned long long e = 0;
+    HIP_OK(h, hipMemcpy(&e, h->dw2_meet + DW2_ENT_ERR, sizeof e, hipMemcpyDeviceToHost));
+    if (e) {
+        (void)hipMemset(h->dw2_meet, 0, (DW2_ENT_ERR + 8) * sizeof e);
+        h->dw2_adam = false;
+        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        return fail(h, "weight_grad_assemble_adam_kernel: its 256 workgroups were not resident together within ~0.5 s (is another process using this GPU?); this "
+                       "step's results are invalid.  The handle now launches adam_kernel separately (the default without PPO_HIP_ADAM_IN_B=1)");
+    }
+    return 0;
+}
+
 // after a stream synchronisation: did adam_kernel<.., MEET>'s grid-wide meeting time out?
 int adam_meet_check(ppo_handle* h) {
     if (!h->adam_meet_words || !h->comm) return 0;
@@ -1055,6 +1073,11 @@ void launch_dw2(ppo_handle* h, const Dw2Args& da) {
     hipLaunchKernelGGL((weight_grad_assemble_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da);
 }
 template <int KP0, int AP>
+void launch_dw2_adam(ppo_handle* h, const Dw2Args& da, const Dw2Adam& ad) {
+    const size_t lds = sizeof(float) * Dw2L<KP0, AP>::LDS_FLOATS;
+    hipLaunchKernelGGL((weight_grad_assemble_adam_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da, ad);
+}
+template <int KP0, int AP>
 void launch_dw2_peer(ppo_handle* h, const Dw2Args& da) {
     const size_t lds = sizeof(float) * Dw2L<KP0, AP>::LDS_FLOATS;
     hipLaunchKernelGGL((weight_grad_assemble_peer_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da, h->peer.dev);
@@ -1067,6 +1090,7 @@ void launch_fused_ab(ppo_handle* h, const TrainArgs& ta, const Dw2Args& da, int 
 template <int KP0, int AP>
 bool set_lds_pair() {
     return hipFuncSetAttribute((const void*)weight_grad_assemble_peer_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess &&
+           hipFuncSetAttribute((const void*)weight_grad_assemble_adam_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess &&
            hipFuncSetAttribute((const void*)train8_dw2_fused_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * FabL<KP0, AP>::FLOATS) == hipSuccess &&
            hipFuncSetAttribute((const void*)train8_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T8L<KP0, AP>::TOTAL) == hipSuccess &&
            hipFuncSetAttribute((const void*)weight_grad_assemble_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess;
@@ -1215,6 +1239,22 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
             HIP_OK(h, hipGetLastError());
         }
         return enqueue_adam(h, loss_row, 0, nullptr, 2);
+    }
+    if (use_dw2 && !h->comm && h->dw2_adam && !h->adam_fast) {
+        const char* e1 = getenv("PPO_HIP_ADAM_IN_B"); const char* e2 = getenv("PPO_HIP_ADAM_NO_TILES");     // (read per call: tests compare the forms in one process; a graph keeps what it captured)
+        if (e1 && e1[0] == '1' && !(e2 && e2[0] == '1')) {
+            // ... and clip + Adam in the same launch: its 256 workgroups meet once the partial sums of squares are out (ppo_dw2.hpp, Dw2Adam)
+            ProfScope ps(h, PK_DW);
+            ++h->kv[KV_DW2_ADAM];
+            Dw2Adam ad{h->theta, h->adam_m, h->adam_v, h->thetaT, h->par, h->hyper, h->beta_pow, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm,
+                       loss_row, h->norm_out, h->dw2_meet, {n.wT_off[0][1], n.wT_off[1][1]}, n.wmuT_off};
+            if (n.Kp0 == 32 && n.Ap == 32) launch_dw2_adam<32, 32>(h, da, ad);
+            else if (n.Kp0 == 64 && n.Ap == 32) launch_dw2_adam<64, 32>(h, da, ad);
+            else if (n.Kp0 == 32 && n.Ap == 64) launch_dw2_adam<32, 64>(h, da, ad);
+            else launch_dw2_adam<64, 64>(h, da, ad);
+            HIP_OK(h, hipGetLastError());
+            return 0;
+        }
     }
     if (use_dw2) {
         // weight gradients + slab / slot sums + partial sums of squares in ONE launch (ppo_dw2.hpp): no grad_reduce_kernel
@@ -1392,13 +1432,13 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
             const int tower = nm[0] == 'v' ? 1 : 0;
             int l = -1;
             if (nm.find("_fc") != std::string::npos) l = atoi(nm.c_str() + 5);
-            int so = -1, cnt = 0;
-            if (l >= 0 && nm.substr(nm.size() - 2) == "/b") { so = nn.slot_db[l]; cnt = nn.Hp[l]; }
-            else if (nm == "vf/w") { so = nn.slot_head; cnt = nn.Hp[nn.L - 1]; }
-            else if (nm == "vf/b") { so = nn.slot_aux; cnt = 1; }
-            else if (nm == "pi/b") { so = nn.slot_head; cnt = nn.Ap; }
-            else if (nm == "pi/logstd") { so = nn.slot_aux; cnt = nn.Ap; }
-            for (int e2 = 0; e2 < cnt; ++e2) jobs.push_back(SlotJob{tower, so + e2, t.off_pad + e2, 1});
+            int so = -1, cnt = 0, po = 0;                 // po: the tensor's place in the small-parameter mirror (upload_grad_src's p_off)
+            if (l >= 0 && nm.substr(nm.size() - 2) == "/b") { so = nn.slot_db[l]; cnt = nn.Hp[l]; po = tower * nn.par_total + nn.par_b[l]; }
+            else if (nm == "vf/w") { so = nn.slot_head; cnt = nn.Hp[nn.L - 1]; po = nn.par_total + nn.par_wv; }
+            else if (nm == "vf/b") { so = nn.slot_aux; cnt = 1; po = nn.par_total + nn.par_bv; }
+            else if (nm == "pi/b") { so = nn.slot_head; cnt = nn.Ap; po = nn.par_bmu; }
+            else if (nm == "pi/logstd") { so = nn.slot_aux; cnt = nn.Ap; po = nn.par_ls; }
+            for (int e2 = 0; e2 < cnt; ++e2) jobs.push_back(SlotJob{tower, so + e2, t.off_pad + e2, 1 + po + e2});
         }
         for (int q = 0; q < 5; ++q) jobs.push_back(SlotJob{q == 1 ? 1 : 0, nn.slot_loss + (q <= 1 ? 0 : q - 1), h->P_pad + q, 0});   // {pg, vf, ent, kl, cf} sums
         h->dw2_n_jobs = (int)jobs.size();
@@ -1408,6 +1448,9 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
             if (dev_alloc(h, &h->dw2_jobs, jobs.size()) || dev_alloc(h, &h->dw2_counters, (size_t)DW2_TILES) || dev_alloc(h, &h->dw2_parts, (size_t)DW2_TILES + DW2_GRID)) return bail(0);
             HIP_OK(h, hipMemcpyAsync(h->dw2_jobs, jobs.data(), jobs.size() * sizeof(SlotJob), hipMemcpyHostToDevice, h->stream));
             HIP_OK(h, hipStreamSynchronize(h->stream));
+            // clip + Adam in the same launch: its grid-wide meeting needs all DW2_GRID workgroups resident at once -- one per CU of a whole device
+            h->dw2_adam = h->t8 && prop.multiProcessorCount >= DW2_GRID;
+            if (h->dw2_adam && dev_alloc(h, &h->dw2_meet, DW2_ENT_ERR + 8)) return bail(0);
         }
     }
     if (h->bf.on && bf16_create(h)) return bail(0);
@@ -1459,6 +1502,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->dw2_jobs) (void)hipFree(h->dw2_jobs);
     if (h->dw2_counters) (void)hipFree(h->dw2_counters);
     if (h->fab_meet) (void)hipFree(h->fab_meet);
+    if (h->dw2_meet) (void)hipFree(h->dw2_meet);
     for (int d = 0; d < 2; ++d) if (h->bf.chain_words[d]) (void)hipFree(h->bf.chain_words[d]);
     if (h->adam_meet_words) (void)hipFree(h->adam_meet_words);
     if (h->adam_meet_parts) (void)hipFree(h->adam_meet_parts);
@@ -1665,7 +1709,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
     HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    return fab_check(h) || adam_meet_check(h) || bf16_chain_check(h) ? -1 : 0;
+    return fab_check(h) || dw2_adam_check(h) || adam_meet_check(h) || bf16_chain_check(h) ? -1 : 0;
 }
 
 int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm) {
@@ -2632,7 +2676,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    if (fab_check(h) || adam_meet_check(h) || bf16_chain_check(h)) return -1;
+    if (fab_check(h) || dw2_adam_check(h) || adam_meet_check(h) || bf16_chain_check(h)) return -1;
     return peer_check(h);
 }
 

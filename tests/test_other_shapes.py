@@ -208,6 +208,37 @@ def test_fused_train_and_weight_gradient_launch_is_bitwise_the_two_launches(monk
             np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("O,A", [(18, 18), (36, 18), (18, 40), (36, 40)])
+def test_clip_and_adam_inside_the_weight_gradient_launch_are_bitwise_the_adam_launch(monkeypatch, O, A):
+    """Single GPU, [256,256]: weight_grad_assemble_adam_kernel (ppo_dw2.hpp, Dw2Adam) applies clip + Adam from the registers of the workgroups that
+    assembled the gradient, around a meeting of the tiles' 64 finishers (PPO_HIP_ADAM_IN_B=1; measured, breaks even, not the default).  Same arithmetic in
+    the same order: losses, gradient, its norm, weights and both Adam slots of four train steps (each one reads the weights, the transposed copies and the
+    small-parameter mirror the previous one wrote) must be the same BITS, at a full and a partial minibatch, with a clipped (max_grad_norm 0.5 bites on
+    these inputs) gradient.  (Replayed graphs of whole updates against eager launches: tests/test_race_guards.py, test_hip_parity.py -- they run this form.)"""
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PPO_HIP_ADAM_IN_B", mode)
+        for n in (2048, 1000):
+            orc, g = pair((256, 256), O=O, A=A, seed=9)
+            k0 = g.kernel_counts()
+            acc = []
+            for it in range(4):
+                mb = H.synth_minibatch(orc, n, seed=90 + it)
+                args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+                acc.append(np.asarray(g.train_step(LR, CR, *args)).copy())
+                gr, norm = g.last_grad()[:2]
+                acc.append(np.asarray(gr).copy()); acc.append(np.float32(norm))
+            acc += [g.get_flat(0), g.get_flat(1), g.get_flat(2)]
+            ran = delta(g.kernel_counts(), k0)
+            assert ran == ({"train8_kernel": 4, "weight_grad_assemble_adam": 4} if mode == "1" else {"train8_kernel": 4, "weight_grad_assemble_kernel": 4}), ran
+            outs[(mode, n)] = acc
+            g.close()
+    for n in (2048, 1000):
+        assert np.abs(outs[("0", n)][-3] - orc.theta).max() > 0
+        for a, b in zip(outs[("0", n)], outs[("1", n)]):
+            np.testing.assert_array_equal(a, b)
+
+
 
 @pytest.mark.parametrize("O,E", [(256, 4096), (256, 8192), (256, 150000), (64, 300), (192, 5000), (100, 5000)])
 def test_running_statistics_of_wide_observations(O, E):

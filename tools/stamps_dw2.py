@@ -25,3 +25,12 @@ tot = st[:, 7] - st[:, 0]
 print("   whole workgroup: median %d max %d cycles ; last arrivers (phase 6 > 500 cycles): %d" % (np.median(tot), tot.max(), ((st[:, 7] - st[:, 6]) > 500).sum()))
 rt = st[:, 15]
 print("   entry skew (s_memrealtime, 10 ns ticks): %d" % (rt.max() - rt.min()))
+if st[:, 8].any():            # clip + Adam inside the launch (Dw2Adam): stamps 8 (tile work done), 9 (meeting over), 10 (norm known), 7 (applied)
+    fin = (st[:, 8] - st[:, 6]) > 500
+    for nm, a, b in (("tile finisher's work (finishers)", 6, 8), ("drain + word + meeting", 8, 9), ("partials -> norm", 9, 10), ("apply + stores issued", 10, 7)):
+        d = st[:, b] - st[:, a]
+        d = d[fin]                # (only the finishers go on past stamp 8)
+        print("   %-34s median %7.0f  p90 %7.0f  max %7.0f  min %7.0f" % (nm, np.median(d), np.percentile(d, 90), d.max(), d.min()))
+    k = np.array([0 if (b >> 3) < 16 else (1 if (b & 1) == 0 else 2) for b in range(256)])
+    d = (st[:, 7] - st[:, 10])
+    print("   apply by strip kind (first layer / head / none): " + " / ".join("%d" % np.median(d[fin & (k == q)]) for q in range(3)))
