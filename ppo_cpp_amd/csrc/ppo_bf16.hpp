@@ -832,6 +832,64 @@ __global__ __launch_bounds__(256) void bf16_cast_kernel(const float* __restrict_
 // elements per lane (16-byte slab loads); the chunk's sum of squares is a wave reduction.  Same sources as grad_reduce_kernel
 // (kind 0 slabs, kind 1 per-block slots, kind 3 per-row-tile bias sums), same fixed summation orders. ---------------------
 #define BGR_WAVES 16                // chunks (waves) per workgroup of bf16_grad_reduce_kernel: one sum-of-squares partial per workgroup
+// the loss tail {pg, vf, ent, kl, cf, rows} (chunk n_blocks): lanes take the slot rows round robin, then meet in a fixed-shape tree; lane 0 keeps the sums
+__device__ __forceinline__ void bgr_tail(const ReduceArgs& a, int lane, float (&tl)[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int tower = (k == 1) ? 1 : 0, off = a.slot_loss + (k <= 1 ? 0 : k - 1);
+        float s = 0.f;
+        for (int b = lane; b < a.n_rowblocks; b += 64) s += a.slots[tower][(size_t)b * a.slot_w + off];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) a.grad[(size_t)a.n_blocks * 256 + k] = s;
+        tl[k] = s;
+    }
+    if (lane == 5) a.grad[(size_t)a.n_blocks * 256 + 5] = a.n_local;
+    if (lane == 6) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }
+}
+// one 256-element chunk: this lane's four consecutive elements
+__device__ __forceinline__ void bgr_chunk(const ReduceArgs& a, int chunk, int lane, float (&g)[4]) {
+    const GradSrc s = a.src[chunk];
+    const size_t idx = (size_t)chunk * 256 + 4 * lane;
+    g[0] = g[1] = g[2] = g[3] = 0.f;
+    if (s.kind == 0) {
+        // the lane's 4 elements lie in one tile of the weight-gradient GEMM: as many partial sums as workgroups touched that tile
+        const int e = (int)(idx - (size_t)s.base), row = e / s.pcol, col = e - row * s.pcol;
+        const int tile = s.tile0 + (row / a.sk_bm) * (s.pcol / GB_N) + col / GB_N;
+        const int cnt = (tile * a.sk_nst + a.sk_nst - 1) / a.sk_per - (tile * a.sk_nst) / a.sk_per + 1;
+        for (int k = 0; k < cnt; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)k * a.slab_stride + idx);
+            g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
+        }
+    } else if (s.kind == 1 || s.kind == 3) {
+        // rows of a small table, 16 bytes per lane and row, all loads independent (offsets are multiples of 4 floats on this path).
+        // A vector of <= 64 (<= 128) elements occupies 16 (32) lanes: the other lanes take every 4th (2nd) row, and the partial sums
+        // meet as (S0 + S1) + (S2 + S3) -- a quarter of the dependent-free but latency-bound loads per lane (the head bias / logstd
+        // rows, one per 32 minibatch rows, were this launch's critical path)
+        const int split = s.count <= 64 ? 4 : (s.count <= 128 ? 2 : 1);
+        const int el = lane & (64 / split - 1), sub = lane / (64 / split);
+        const int e0 = (int)((size_t)chunk * 256 - (size_t)s.base) + 4 * el;
+        const float* p = (s.kind == 1 ? a.slots[s.tower] : a.direct) + s.slot_off + e0;
+        const int rows = s.kind == 1 ? a.n_rowblocks : a.n_direct;
+        const size_t stride = s.kind == 1 ? (size_t)a.slot_w : (size_t)a.direct_stride;
+        if (e0 < s.count) {
+#pragma unroll 8
+            for (int b = sub; b < rows; b += split) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * stride);
+                g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (e0 + k >= s.count) g[k] = 0.f;
+        }
+        if (split > 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (split == 4) g[k] += __shfl_xor(g[k], 16);
+                g[k] += __shfl_xor(g[k], 32);
+                if (sub != 0) g[k] = 0.f;               // (these lanes' own positions are padding)
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_grad_reduce_kernel(ReduceArgs a) {
     __shared__ float wq[BGR_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -839,60 +897,11 @@ __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_grad_reduce_kernel(Reduce
     // the END of the parameter vector and must not be the launch's tail
     const int chunk = a.n_blocks - (int)(blockIdx.x * BGR_WAVES + wave);
     float q = 0.f;
-    if (chunk == a.n_blocks) {                              // loss tail: {pg, vf, ent, kl, cf, rows}
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {                       // lanes take the slot rows round robin, then meet in a fixed-shape tree
-            const int tower = (k == 1) ? 1 : 0, off = a.slot_loss + (k <= 1 ? 0 : k - 1);
-            float s = 0.f;
-            for (int b = lane; b < a.n_rowblocks; b += 64) s += a.slots[tower][(size_t)b * a.slot_w + off];
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) a.grad[(size_t)a.n_blocks * 256 + k] = s;
-        }
-        if (lane == 5) a.grad[(size_t)a.n_blocks * 256 + 5] = a.n_local;
-        if (lane == 6) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }
-    } else if (chunk >= 0) {
-        const GradSrc s = a.src[chunk];
-        const size_t idx = (size_t)chunk * 256 + 4 * lane;
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        if (s.kind == 0) {
-            // the lane's 4 elements lie in one tile of the weight-gradient GEMM: as many partial sums as workgroups touched that tile
-            const int e = (int)(idx - (size_t)s.base), row = e / s.pcol, col = e - row * s.pcol;
-            const int tile = s.tile0 + (row / a.sk_bm) * (s.pcol / GB_N) + col / GB_N;
-            const int cnt = (tile * a.sk_nst + a.sk_nst - 1) / a.sk_per - (tile * a.sk_nst) / a.sk_per + 1;
-            for (int k = 0; k < cnt; ++k) {
-                const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)k * a.slab_stride + idx);
-                g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
-            }
-        } else if (s.kind == 1 || s.kind == 3) {
-            // rows of a small table, 16 bytes per lane and row, all loads independent (offsets are multiples of 4 floats on this path).
-            // A vector of <= 64 (<= 128) elements occupies 16 (32) lanes: the other lanes take every 4th (2nd) row, and the partial sums
-            // meet as (S0 + S1) + (S2 + S3) -- a quarter of the dependent-free but latency-bound loads per lane (the head bias / logstd
-            // rows, one per 32 minibatch rows, were this launch's critical path)
-            const int split = s.count <= 64 ? 4 : (s.count <= 128 ? 2 : 1);
-            const int el = lane & (64 / split - 1), sub = lane / (64 / split);
-            const int e0 = (int)((size_t)chunk * 256 - (size_t)s.base) + 4 * el;
-            const float* p = (s.kind == 1 ? a.slots[s.tower] : a.direct) + s.slot_off + e0;
-            const int rows = s.kind == 1 ? a.n_rowblocks : a.n_direct;
-            const size_t stride = s.kind == 1 ? (size_t)a.slot_w : (size_t)a.direct_stride;
-            if (e0 < s.count) {
-#pragma unroll 8
-                for (int b = sub; b < rows; b += split) {
-                    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * stride);
-                    g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (e0 + k >= s.count) g[k] = 0.f;
-            }
-            if (split > 1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (split == 4) g[k] += __shfl_xor(g[k], 16);
-                    g[k] += __shfl_xor(g[k], 32);
-                    if (sub != 0) g[k] = 0.f;               // (these lanes' own positions are padding)
-                }
-            }
-        }
-        *reinterpret_cast<float4*>(a.grad + idx) = make_float4(g[0], g[1], g[2], g[3]);
+    if (chunk == a.n_blocks) { float tl[5]; bgr_tail(a, lane, tl); }
+    else if (chunk >= 0) {
+        float g[4];
+        bgr_chunk(a, chunk, lane, g);
+        *reinterpret_cast<float4*>(a.grad + (size_t)chunk * 256 + 4 * lane) = make_float4(g[0], g[1], g[2], g[3]);
         q = (g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]);
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     }
@@ -903,5 +912,123 @@ __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_grad_reduce_kernel(Reduce
 #pragma unroll
         for (int w = BGR_WAVES - 1; w >= 0; --w) t += wq[w];
         a.sumsq[blockIdx.x] = t;
+    }
+}
+
+// ---- gradient assembly + clip + Adam in ONE launch (single GPU): bf16_grad_reduce_kernel's chunks and adam_kernel's elements are the same 256-element
+// chunks, so a persistent launch -- BRA_GRID workgroups of 16 waves, one per CU, each wave up to NR chunks -- keeps the assembled gradient (and the Adam
+// slots and weights it requested meanwhile) in REGISTERS across the one thing in between, the global norm.  Workgroup b plays the workgroups
+// j = r BRA_GRID + b, r = 0 .. NR - 1, of the bf16_grad_reduce_kernel launch it replaces: partial j is formed exactly as there, and the sum over r is
+// exactly what adam_kernel's thread b adds up from the partials (it strides them by 256), so the table the workgroups meet on has ONE {epoch, sum} word
+// per workgroup and the norm, the clip factor and every element come out with the bits of the two launches (tests/test_bf16_path.py).  What goes away:
+// adam_kernel's read of the gradient (4 bytes per parameter), a launch boundary, and the wait for the Adam slots (they arrive while the slabs are
+// summed).  The gradient is still written (ppo_get_last_grad).  Bounded wait; PPO_HIP_NO_REDUCE_ADAM=1 keeps the two launches.
+#define BRA_GRID 256
+struct ReduceAdamArgs {
+    ReduceArgs r;
+    float* theta; float* m; float* v; bf16_t* theta_bf;
+    const float* hyper; float beta1, beta2, eps, max_norm;
+    float* loss_row; float* norm_out;
+    unsigned long long* ent;     // [BRA_GRID] {epoch << 32 | sum of this workgroup's partials}, [BRA_GRID] raised when a wait timed out
+    int n_old;                   // workgroups of the bf16_grad_reduce_kernel launch this one replaces
+};
+template <int NR>
+__global__ __launch_bounds__(64 * BGR_WAVES) void bf16_reduce_adam_kernel(ReduceAdamArgs a) {
+    __shared__ float wq[NR][BGR_WAVES];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = (int)blockIdx.x;
+    // this launch's epoch, the powers and the learning rate NOW: workgroup 0 advances the powers after the meeting (atomic loads in front of the barriers)
+    const unsigned epoch = (unsigned)(__hip_atomic_load(a.ent + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + 1u;
+    const float b1p = __hip_atomic_load(a.r.beta_pow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float b2p = __hip_atomic_load(a.r.beta_pow + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float lr = __hip_atomic_load(a.hyper, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr bool PREF = NR <= 5;        // Adam slots + weights requested beside the slabs and held across the meeting (more rounds than that do not fit the registers)
+    float G[NR][4]; float4 M[PREF ? NR : 1], V[PREF ? NR : 1], T[PREF ? NR : 1];
+    float tl[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = r * BRA_GRID + b;
+        const int chunk = a.r.n_blocks - (j * BGR_WAVES + wave);
+        float q = 0.f;
+        G[r][0] = G[r][1] = G[r][2] = G[r][3] = 0.f;
+        if constexpr (PREF) M[r] = V[r] = T[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < a.n_old) {
+            if (chunk == a.r.n_blocks) bgr_tail(a.r, lane, tl);
+            else if (chunk >= 0) {
+                const size_t idx = (size_t)chunk * 256 + 4 * lane;
+                if constexpr (PREF) { M[r] = *reinterpret_cast<const float4*>(a.m + idx); V[r] = *reinterpret_cast<const float4*>(a.v + idx); T[r] = *reinterpret_cast<const float4*>(a.theta + idx); }
+                bgr_chunk(a.r, chunk, lane, G[r]);
+                *reinterpret_cast<float4*>(a.r.grad + idx) = make_float4(G[r][0], G[r][1], G[r][2], G[r][3]);
+                q = (G[r][0] * G[r][0] + G[r][1] * G[r][1]) + (G[r][2] * G[r][2] + G[r][3] * G[r][3]);
+                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            }
+        }
+        if (lane == 0) wq[r][wave] = q;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float S = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (r * BRA_GRID + b < a.n_old) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = BGR_WAVES - 1; w >= 0; --w) t += wq[r][w];       // the old workgroup's chunks in index order
+                a.r.sumsq[r * BRA_GRID + b] = t;
+                S += t;                                                       // adam_kernel's thread b: partials b, b + 256, ... in this order
+            }
+        __hip_atomic_store(a.ent + b, ((unsigned long long)epoch << 32) | __float_as_uint(S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the meeting: thread t < 256 watches word t; when all show this launch's epoch the values read ARE adam_kernel's per-thread sums ---------------
+    float s = 0.f;
+    unsigned polls = 0;
+    for (;;) {
+        bool ok = true;
+        if (tid < BRA_GRID) {
+            const unsigned long long e = __hip_atomic_load(a.ent + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (int)((unsigned)(e >> 32) - epoch) >= 0; s = __uint_as_float((unsigned)e);
+        }
+        if (__syncthreads_and(ok ? 1 : 0)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++polls > (1u << 20)) { if (tid == 0) __hip_atomic_store(a.ent + BRA_GRID, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (tid < 256 && lane == 0) red[wave] = s;
+    __syncthreads();
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    float scale = a.max_norm * tf_min(1.0f / norm, 1.0f / a.max_norm);          // G:24289-24472
+    if (!isfinite(norm)) scale = __builtin_nanf("");                            // G:24493-24543
+    const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    const float omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = r * BRA_GRID + b;
+        const int chunk = a.r.n_blocks - (j * BGR_WAVES + wave);
+        if (j < a.n_old && chunk >= 0 && chunk < a.r.n_blocks) {
+            const size_t idx = (size_t)chunk * 256 + 4 * lane;
+            float4 m4, v4, t4;
+            if constexpr (PREF) { m4 = M[r]; v4 = V[r]; t4 = T[r]; }
+            else { m4 = *reinterpret_cast<const float4*>(a.m + idx); v4 = *reinterpret_cast<const float4*>(a.v + idx); t4 = *reinterpret_cast<const float4*>(a.theta + idx); }
+            const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
+            float mo[4], vo[4], to[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) adam_element<false>(G[r][k] * scale, mv[k], vv[k], tv[k], omb1, omb2, alpha, a.eps, mo[k], vo[k], to[k]);
+            *reinterpret_cast<float4*>(a.m + idx) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+            *reinterpret_cast<float4*>(a.v + idx) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+            *reinterpret_cast<float4*>(a.theta + idx) = make_float4(to[0], to[1], to[2], to[3]);
+            bf16x4 o4; o4[0] = (bf16_t)to[0]; o4[1] = (bf16_t)to[1]; o4[2] = (bf16_t)to[2]; o4[3] = (bf16_t)to[3];
+            *reinterpret_cast<bf16x4*>(a.theta_bf + idx) = o4;
+        }
+    }
+    if (b == 0 && wave == 0) {                                                  // (the wave that summed the loss tail: chunk n_blocks = old workgroup 0, wave 0)
+        if (lane == 0) {
+            a.r.beta_pow[2] = b1p * a.beta1;                                    // G:31217-31342 (after the applies)
+            a.r.beta_pow[3] = b2p * a.beta2;
+            if (a.norm_out) *a.norm_out = norm;
+            if (a.loss_row) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { float r = tl[k] / a.r.n_local; if (k == 1 || k == 3) r = 0.5f * r; a.loss_row[k] = r; }      // vf_loss, approxkl carry the 0.5
+            }
+        }
     }
 }

@@ -47,11 +47,11 @@ const char* kProfNames[PK_COUNT] = {"policy_step", "train_fwd_bwd", "weight_grad
 
 // which kernel VARIANT a call took (ppo_kernel_counts): the fast paths are chosen by shape, and a test must be able to say which one ran
 enum KernelVariant { KV_TRAIN8 = 0, KV_TRAIN_FB, KV_DW2, KV_DW, KV_GRAD_REDUCE, KV_NARROW_TRAIN_STATIC, KV_NARROW_TRAIN, KV_NARROW_STEP_STATIC, KV_NARROW_STEP,
-                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_FUSED_AB, KV_DW2_ADAM, KV_COUNT };
+                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_FUSED_AB, KV_DW2_ADAM, KV_BF16_REDUCE_ADAM, KV_COUNT };
 const char* kVariantNames[KV_COUNT] = {"train8_kernel", "train_fwd_bwd_kernel", "weight_grad_assemble_kernel", "weight_grad_kernel", "grad_reduce_kernel",
                                        "narrow_train_kernel<static>", "narrow_train_kernel<runtime>", "narrow_step_kernel<static>", "narrow_step_kernel<runtime>",
                                        "policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_rollout_coop_kernel", "narrow_collect_kernel",
-                                       "bf16_train_sequence", "bf16_step_sequence", "train8_dw2_fused_kernel", "weight_grad_assemble_adam"};
+                                       "bf16_train_sequence", "bf16_step_sequence", "train8_dw2_fused_kernel", "weight_grad_assemble_adam", "bf16_reduce_adam_kernel"};
 
 // RCCL entry points resolved at run time (the single-GPU path must not depend on librccl being loadable)
 struct Rccl {
@@ -182,6 +182,8 @@ struct ppo_handle {
         int tile0[2][PPO_MAX_LAYERS + 1]{};             // first weight-gradient tile of every matrix ([L] = the head), in the order of the tile table
         // the hidden layers of a pass as ONE launch (gemm_chain_bf16_kernel): its word tables (forward, backward); PPO_HIP_NO_BF16_CHAIN=1: a launch per layer
         bool chain = false; unsigned* chain_words[2]{}; int n_cu = 0;
+        // gradient assembly + clip + Adam in one persistent launch (bf16_reduce_adam_kernel; single GPU): its meeting's table [BRA_GRID] + error word
+        bool fuse_ra = false; unsigned long long* ra_ent = nullptr;
     } bf;
     bool dev_shared = false;          // data parallel: another rank of the job runs on this device (kernels whose workgroups wait for each other are not used then)
     // narrow-network path (every hidden width <= 64; kernels in ppo_narrow.hpp)
@@ -648,6 +650,9 @@ int bf16_create(ppo_handle* h) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) b.n_cu = prop.multiProcessorCount;
       for (int d = 0; d < 2 && b.chain; ++d) if (dev_alloc(h, &b.chain_words[d], GB_CHAIN_WORDS + 32)) return -1; }
+    // the persistent assembly + Adam launch needs BRA_GRID workgroups of 1024 threads resident at once: one per CU of a whole device
+    b.fuse_ra = b.n_cu >= BRA_GRID && (h->n_blocks + 1 + BGR_WAVES - 1) / BGR_WAVES <= 8 * BRA_GRID;
+    if (b.fuse_ra && dev_alloc(h, &b.ra_ent, BRA_GRID + 8)) return -1;
     return 0;
 }
 
@@ -669,6 +674,17 @@ bool bf16_chain(ppo_handle* h, const GemmArgs* links, int n, int I, int J, int w
 // after a stream synchronisation: did a chained launch time out or find a row group spread over two XCDs?
 int bf16_chain_check(ppo_handle* h) {
     ppo_handle::Bf16& b = h->bf;
+    if (b.on && b.fuse_ra && b.ra_ent) {
+        unsigned long long e = 0;
+        HIP_OK(h, hipMemcpy(&e, b.ra_ent + BRA_GRID, sizeof e, hipMemcpyDeviceToHost));
+        if (e) {
+            (void)hipMemset(b.ra_ent, 0, (BRA_GRID + 8) * sizeof e);
+            b.fuse_ra = false;
+            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            return fail(h, "bf16_reduce_adam_kernel: its 256 workgroups were not resident together within ~1 s (is another process using this GPU?); this step's results "
+                           "are invalid.  The handle now launches bf16_grad_reduce_kernel and adam_kernel (PPO_HIP_NO_REDUCE_ADAM=1 selects them from the start)");
+        }
+    }
     if (!b.on || !b.chain) return 0;
     for (int d = 0; d < 2; ++d) {
         unsigned e = 0;
@@ -1167,7 +1183,24 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
             ra.slots[0] = h->slots[0]; ra.slots[1] = h->slots[1]; ra.n_rowblocks = Rp / BL_ROWS; ra.slot_w = n.slot_w; ra.slot_loss = n.slot_loss;
             ra.grad = h->grad; ra.sumsq = h->sumsq; ra.n_local = (float)ta.n; ra.beta_pow = h->beta_pow; ra.direct = h->bf.dbias;
             ra.n_direct = Rp / (Rp % 256 == 0 ? 256 : 128); ra.direct_stride = h->bf.n_dbias;
-            hipLaunchKernelGGL(bf16_grad_reduce_kernel, dim3((h->n_blocks + 1 + BGR_WAVES - 1) / BGR_WAVES), dim3(64 * BGR_WAVES), 0, h->stream, ra);
+            const int n_old = (h->n_blocks + 1 + BGR_WAVES - 1) / BGR_WAVES;
+            const char* e1 = getenv("PPO_HIP_NO_REDUCE_ADAM");                  // (read per call: a test compares the forms in one process; a graph keeps what it captured)
+            if (!h->comm && h->bf.fuse_ra && !h->adam_fast && !(e1 && e1[0] == '1')) {
+                // ... and clip + Adam in the same persistent launch (ppo_bf16.hpp, bf16_reduce_adam_kernel)
+                ReduceAdamArgs fa{ra, h->theta, h->adam_m, h->adam_v, h->bf.theta_bf, h->hyper, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm,
+                                  loss_row, h->norm_out, h->bf.ra_ent, n_old};
+                const int rounds = (n_old + BRA_GRID - 1) / BRA_GRID;
+                const dim3 g(BRA_GRID), blk(64 * BGR_WAVES);
+                ++h->kv[KV_BF16_REDUCE_ADAM];
+                if (rounds <= 1) hipLaunchKernelGGL(bf16_reduce_adam_kernel<1>, g, blk, 0, h->stream, fa);
+                else if (rounds <= 2) hipLaunchKernelGGL(bf16_reduce_adam_kernel<2>, g, blk, 0, h->stream, fa);
+                else if (rounds <= 3) hipLaunchKernelGGL(bf16_reduce_adam_kernel<3>, g, blk, 0, h->stream, fa);
+                else if (rounds <= 5) hipLaunchKernelGGL(bf16_reduce_adam_kernel<5>, g, blk, 0, h->stream, fa);
+                else hipLaunchKernelGGL(bf16_reduce_adam_kernel<8>, g, blk, 0, h->stream, fa);
+                HIP_OK(h, hipGetLastError());
+                return 0;
+            }
+            hipLaunchKernelGGL(bf16_grad_reduce_kernel, dim3(n_old), dim3(64 * BGR_WAVES), 0, h->stream, ra);
             HIP_OK(h, hipGetLastError());
         }
         if (h->comm) return enqueue_grad_allreduce(h) ? -1 : enqueue_adam(h, loss_row);      // (the exchange recomputes the per-chunk sums of squares)
@@ -1504,6 +1537,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->fab_meet) (void)hipFree(h->fab_meet);
     if (h->dw2_meet) (void)hipFree(h->dw2_meet);
     for (int d = 0; d < 2; ++d) if (h->bf.chain_words[d]) (void)hipFree(h->bf.chain_words[d]);
+    if (h->bf.ra_ent) (void)hipFree(h->bf.ra_ent);
     if (h->adam_meet_words) (void)hipFree(h->adam_meet_words);
     if (h->adam_meet_parts) (void)hipFree(h->adam_meet_parts);
     if (h->dw2_parts) (void)hipFree(h->dw2_parts);

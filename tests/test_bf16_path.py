@@ -157,3 +157,34 @@ def test_chained_layers_launch_is_bitwise_the_launch_per_layer(hidden, O, A, n, 
     assert np.isfinite(outs[0][-4]).all() and np.abs(outs[0][1]).max() > 0
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("hidden,O,A,n", [((1024, 1024, 1024), 256, 64, 4096), ((512, 512), 64, 18, 2048), ((1024, 1024, 1024, 1024), 256, 64, 1000), ((64, 64), 18, 18, 512)])
+def test_assembly_clip_and_adam_in_one_launch_are_bitwise_the_two_launches(hidden, O, A, n, monkeypatch):
+    """bf16_reduce_adam_kernel (ppo_bf16.hpp): the gradient's assembly from the split-K slabs / slots / bias sums and clip + Adam as ONE persistent launch
+    whose 256 workgroups meet once for the global norm, the assembled gradient held in registers meanwhile.  Same chunk arithmetic, same partials, same
+    order of the norm's sum: losses, gradient, norm, weights, both moments and the bf16 operand copy (read by the next step's forward pass) of four train
+    steps -- the clip bites on these inputs -- must be the same BITS as with PPO_HIP_NO_REDUCE_ADAM=1 (bf16_grad_reduce_kernel + adam_kernel), at
+    configs[4]'s net (5 rounds of chunks per wave), a [512,512] net (1 round), a four-layer net (7 rounds: the form that requests the Adam slots after the
+    meeting) and a net far smaller than the launch (most workgroups hold nothing)."""
+    outs = []
+    for two in ("0", "1"):
+        monkeypatch.setenv("PPO_HIP_NO_REDUCE_ADAM", two)
+        orc, g = pair_bf16(hidden, O, A)
+        k0 = g.kernel_counts()
+        acc = []
+        for it in range(4):
+            mb = H.synth_minibatch(orc, n, seed=11 + it)
+            args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+            acc.append(np.asarray(g.train_step(LR, CR, *args)).copy())
+            gr, nrm = g.last_grad()
+            acc += [gr.copy(), np.float32(nrm)]
+        acc += [g.get_flat(0), g.get_flat(1), g.get_flat(2), np.asarray(g.beta_powers())]
+        k1 = g.kernel_counts()
+        assert k1["bf16_reduce_adam_kernel"] - k0["bf16_reduce_adam_kernel"] == (4 if two == "0" else 0)
+        g.close()
+        outs.append(acc)
+    monkeypatch.delenv("PPO_HIP_NO_REDUCE_ADAM", raising=False)
+    assert np.isfinite(outs[0][-4]).all() and np.abs(outs[0][1]).max() > 0
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)

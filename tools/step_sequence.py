@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Per-launch durations of ONE train step from a rocprofv3 --kernel-trace CSV: finds the last adam_kernel-to-adam_kernel span and prints every launch
+"""Per-launch durations of ONE train step from a rocprofv3 --kernel-trace CSV: finds the last span between two launches that end a train step (adam_kernel, or bf16_reduce_adam_kernel on the bf16 path) and prints every launch
 in it in order (kernels that appear several times per step -- the bf16 path's GEMMs -- are told apart by their position).  Median over the last N steps.
 usage: python tools/step_sequence.py <kernel_trace.csv> [steps]"""
 import csv, statistics, sys
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-ends = [i for i, r in enumerate(rows) if r[2].startswith("adam_kernel")]
+ends = [i for i, r in enumerate(rows) if r[2].startswith("adam_kernel") or r[2].startswith("bf16_reduce_adam_kernel")]
 steps = [rows[a + 1:b + 1] for a, b in zip(ends[:-1], ends[1:])]
 steps = [s for s in steps if s and len(s) == len(steps[-1]) and [k[2] for k in s] == [k[2] for k in steps[-1]]][-n_steps:]
 print("%d identical steps of %d launches" % (len(steps), len(steps[-1])))
