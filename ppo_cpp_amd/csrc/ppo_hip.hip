@@ -47,11 +47,11 @@ const char* kProfNames[PK_COUNT] = {"policy_step", "train_fwd_bwd", "weight_grad
 
 // which kernel VARIANT a call took (ppo_kernel_counts): the fast paths are chosen by shape, and a test must be able to say which one ran
 enum KernelVariant { KV_TRAIN8 = 0, KV_TRAIN_FB, KV_DW2, KV_DW, KV_GRAD_REDUCE, KV_NARROW_TRAIN_STATIC, KV_NARROW_TRAIN, KV_NARROW_STEP_STATIC, KV_NARROW_STEP,
-                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_FUSED_AB, KV_DW2_ADAM, KV_BF16_REDUCE_ADAM, KV_COUNT };
+                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_FUSED_AB, KV_DW2_ADAM, KV_BF16_REDUCE_ADAM, KV_NARROW_EPOCH, KV_COUNT };
 const char* kVariantNames[KV_COUNT] = {"train8_kernel", "train_fwd_bwd_kernel", "weight_grad_assemble_kernel", "weight_grad_kernel", "grad_reduce_kernel",
                                        "narrow_train_kernel<static>", "narrow_train_kernel<runtime>", "narrow_step_kernel<static>", "narrow_step_kernel<runtime>",
                                        "policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_rollout_coop_kernel", "narrow_collect_kernel",
-                                       "bf16_train_sequence", "bf16_step_sequence", "train8_dw2_fused_kernel", "weight_grad_assemble_adam", "bf16_reduce_adam_kernel"};
+                                       "bf16_train_sequence", "bf16_step_sequence", "train8_dw2_fused_kernel", "weight_grad_assemble_adam", "bf16_reduce_adam_kernel", "narrow_epoch_kernel"};
 
 // RCCL entry points resolved at run time (the single-GPU path must not depend on librccl being loadable)
 struct Rccl {
@@ -195,6 +195,10 @@ struct ppo_handle {
     // deferred Adam inside ppo_update (reference shape): second parameter / moment set and the step whose clip + Adam is pending
     float *nw_theta1 = nullptr, *nw_m1 = nullptr, *nw_v1 = nullptr;
     bool nw_lazy = false;             // the path is available (static shape, PPO_HIP_NO_LAZY_ADAM unset)
+    // all minibatches of an epoch in one resident launch (narrow_epoch_kernel; minibatches of <= 32 NW_EPOCH_MAX_G rows on the deferred-Adam shapes, single GPU)
+    bool nw_epoch = false; unsigned* nw_epoch_words = nullptr;
+    bool nw_epoch_xl = false;         // ... its XCD-local form (workgroups 0, 8, 16, ... of the launch; ordinary stores / loads through one L2; a partial buffer per step)
+    float* nw_epoch_partials = nullptr; size_t nw_epoch_cap = 0;
     bool adam_fast = false;           // adam_kernel uses the 1-ulp quotient of the deferred form (nw_lazy, or PPO_HIP_ADAM_FAST=1 for the bitwise test)
     int nw_cur = 0;                   // parameter set holding the current weights (0 outside ppo_update)
     bool nw_pending = false; float* nw_pending_loss = nullptr; int nw_pending_parts = 0;
@@ -549,7 +553,7 @@ int ensure_train_ws(ppo_handle* h, int rows) {
         if (groups <= h->nw_groups_cap) return 0;
         if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
         HIP_OK(h, hipStreamSynchronize(h->stream));
-        if (dev_alloc(h, &h->nw_partials, (size_t)2 * groups * h->nw_stride)) return -1;     // zero-filled: padding elements stay zero
+        if (dev_alloc(h, &h->nw_partials, (size_t)4 * groups * h->nw_stride)) return -1;     // zero-filled: padding elements stay zero ([2 towers][groups]; twice: narrow_epoch_kernel alternates two sets)
         h->nw_groups_cap = groups;
         h->ws_rows = std::max(h->ws_rows, groups * NW_ROWS);
         return 0;
@@ -993,6 +997,28 @@ int fab_check(ppo_handle* h) {
         if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
         return fail(h, "train8_dw2_fused_kernel: its 256 workgroups were not resident together within 0.5 s (is another process using this GPU?); this "
                        "step's results are invalid.  The handle now runs the two-launch form (the default without PPO_HIP_FUSE_AB=1)");
+    }
+    return 0;
+}
+
+// after a stream synchronisation: did a meeting of narrow_epoch_kernel time out?
+int nw_epoch_check(ppo_handle* h) {
+    if (!h->nw_epoch || !h->nw_epoch_words) return 0;
+    unsigned e = 0;
+    HIP_OK(h, hipMemcpy(&e, h->nw_epoch_words + NW_EPOCH_WORDS - 1, sizeof e, hipMemcpyDeviceToHost));
+    if (e == 2) {
+        (void)hipMemset(h->nw_epoch_words, 0, NW_EPOCH_WORDS * sizeof e);
+        h->nw_epoch_xl = false;
+        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        return fail(h, "narrow_epoch_kernel: its workgroups were not on one XCD (the launch's workgroup dealing is not round-robin over the XCDs here); this update's results are "
+                       "invalid.  The handle now exchanges the partial gradients write-through (PPO_HIP_NO_NARROW_EPOCH_XL=1 selects that from the start)");
+    }
+    if (e) {
+        (void)hipMemset(h->nw_epoch_words, 0, NW_EPOCH_WORDS * sizeof e);
+        h->nw_epoch = false;
+        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        return fail(h, "narrow_epoch_kernel: its workgroups were not resident together (is another process using this GPU?); this update's results are invalid.  "
+                       "The handle now launches every train step (PPO_HIP_NO_NARROW_EPOCH=1 selects that from the start)");
     }
     return 0;
 }
@@ -1496,6 +1522,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         X(0, 0, 0, 0); X(32, 64, 32, 2); X(64, 64, 32, 2);
 #undef X
         big_lds((const void*)narrow_train_kernel<32, 64, 32, 2, true>); big_lds((const void*)narrow_train_kernel<64, 64, 32, 2, true>);
+        big_lds((const void*)narrow_epoch_kernel<32, false>); big_lds((const void*)narrow_epoch_kernel<64, false>);
+        big_lds((const void*)narrow_epoch_kernel<32, true>); big_lds((const void*)narrow_epoch_kernel<64, true>);
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         { const char* e1 = getenv("PPO_HIP_NO_HOST_FUSED"); const char* e2 = getenv("PPO_HIP_NO_HOST_RESIDENT");
           h->opt_no_host_fused = e1 && e1[0] == '1'; h->opt_no_host_resident = e2 && e2[0] == '1'; }
@@ -1505,6 +1533,10 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
             if (dev_alloc(h, &h->nw_theta1, P) || dev_alloc(h, &h->nw_m1, P) || dev_alloc(h, &h->nw_v1, P)) return bail(0);
             h->nw_lazy = true;
             h->adam_fast = true;
+            const char* ne = getenv("PPO_HIP_NO_NARROW_EPOCH");
+            h->nw_epoch = !(ne && ne[0] == '1') && prop.multiProcessorCount >= 2 * 2 * NW_EPOCH_MAX_G;
+            if (h->nw_epoch && dev_alloc(h, &h->nw_epoch_words, NW_EPOCH_WORDS)) return bail(0);
+            { const char* nx = getenv("PPO_HIP_NO_NARROW_EPOCH_XL"); h->nw_epoch_xl = h->nw_epoch && !(nx && nx[0] == '1') && prop.multiProcessorCount >= 64; }
         }
         if (dev_alloc(h, &h->nw_img, (size_t)2 * h->nw.w_total)) return bail(0);
     }
@@ -1527,6 +1559,8 @@ void ppo_destroy(ppo_handle* h) {
     if (h->peer.local) (void)hipFree(h->peer.local);
     for (float* p : {h->nw_theta1, h->nw_m1, h->nw_v1}) if (p) (void)hipFree(p);
     if (h->nw_partials) (void)hipFree(h->nw_partials);
+    if (h->nw_epoch_words) (void)hipFree(h->nw_epoch_words);
+    if (h->nw_epoch_partials) (void)hipFree(h->nw_epoch_partials);
     if (h->nw_img) (void)hipFree(h->nw_img);
     if (h->nw_alt) (void)hipFree(h->nw_alt);
     if (h->nw_coop) (void)hipFree(h->nw_coop);
@@ -2583,6 +2617,31 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
                 }
             }
         }
+        const int egroups = (M + NW_ROWS - 1) / NW_ROWS;
+        const char* ne = getenv("PPO_HIP_NO_NARROW_EPOCH");     // (read when the update is captured: the test compares both forms)
+        if (h->narrow && h->nw_lazy && h->nw_epoch && !h->comm && egroups <= NW_EPOCH_MAX_G && egroups <= h->nw_groups_cap && !(ne && ne[0] == '1')) {
+            // every minibatch of the epoch in ONE resident launch (ppo_narrow.hpp, narrow_epoch_kernel)
+            ProfScope ps(h, PK_TRAIN_FB);
+            const NetDev& n = h->net;
+            const bool xl = h->nw_epoch_xl && h->nw_epoch_partials && (size_t)nmb * 2 * egroups * h->nw_stride <= h->nw_epoch_cap;
+            NwEpochArgs ea{h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp, M, nmb, 1.0f / (float)M, h->nw_img, xl ? h->nw_epoch_partials : h->nw_partials, h->nw_stride,
+                           h->theta, h->adam_m, h->adam_v, h->grad, h->hyper, h->beta_pow, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm,
+                           h->d_loss_rows + (size_t)ep * nmb * 5, h->norm_out, h->nw_epoch_words, h->P_pad / 64, nullptr};
+#ifdef PPO_STAMPS
+            if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+            ea.stamps = g_stamps;
+#endif
+            const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
+            ++h->kv[KV_NARROW_EPOCH];
+            if (xl) {
+                if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_kernel<32, true>), dim3(16 * egroups), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
+                else hipLaunchKernelGGL((narrow_epoch_kernel<64, true>), dim3(16 * egroups), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
+            }
+            else if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_kernel<32, false>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
+            else hipLaunchKernelGGL((narrow_epoch_kernel<64, false>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
+            HIP_OK(h, hipGetLastError());
+            continue;
+        }
         for (int k = 0; k < nmb; ++k) {
             TrainArgs ta{};
             const size_t r0 = (size_t)k * M;
@@ -2631,6 +2690,16 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
         if (h->bf.on) {
             if (dev_alloc(h, &h->bf.xe, (size_t)cr * h->net.Kp0)) return -1;
             h->bf.xe_rows = cr;
+        }
+    }
+    if (h->narrow && h->nw_epoch && h->nw_epoch_xl && !h->comm && (M + NW_ROWS - 1) / NW_ROWS <= NW_EPOCH_MAX_G) {
+        // the XCD-local epoch kernel's partial gradient vectors: one set per minibatch of an epoch (zero-filled: padding elements are never written and must read 0)
+        const size_t need = (size_t)nmb * 2 * ((M + NW_ROWS - 1) / NW_ROWS) * h->nw_stride;
+        if (need > h->nw_epoch_cap) {
+            HIP_OK(h, hipStreamSynchronize(h->stream));
+            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            if (dev_alloc(h, &h->nw_epoch_partials, need)) return -1;
+            h->nw_epoch_cap = need;
         }
     }
     if (set_hyper(h, lr, cliprange)) return -1;
@@ -2710,7 +2779,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    if (fab_check(h) || dw2_adam_check(h) || adam_meet_check(h) || bf16_chain_check(h)) return -1;
+    if (fab_check(h) || dw2_adam_check(h) || adam_meet_check(h) || bf16_chain_check(h) || nw_epoch_check(h)) return -1;
     return peer_check(h);
 }
 

@@ -76,8 +76,9 @@ struct NwShape {
 // read issued first, four interleaved accumulator chains (the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 is
 // hidden and the result is ((c0 + c1) + (c2 + c3)): fp32 reassociation of the k-ordered sum, nothing else).
 template <int CK, class Ep>
-__device__ __forceinline__ void nw_dense(const float* Xs, int ldx, int K, const float* Ws, int ldw, int Np, Ep&& ep) {
-    const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;
+__device__ __forceinline__ void nw_dense(const float* Xs, int ldx, int K, const float* Ws, int ldw, int Np, Ep&& ep, const int tidx = (int)threadIdx.x) {
+    // (tidx: the thread index; narrow_epoch_kernel passes a per-iteration opaque copy so that the address arithmetic is not hoisted out of its minibatch loop)
+    const int lane = tidx & 63, w = uni((tidx >> 6) & 3);            // (wave-uniform: said explicitly, an opaque tidx hides it)
     const int g = lane >> 4, c = lane & 15;
     for (int n0 = 16 * w; n0 < Np; n0 += 64) {
         const float* xp = Xs + c * ldx + g;
@@ -114,8 +115,8 @@ __device__ __forceinline__ void nw_dense(const float* Xs, int ldx, int K, const 
 template <class S>
 __device__ __forceinline__ void nw_stage(const NetDev& net, const NwLayout& lay, const float* __restrict__ img, int n_img, float* lds,
                                          const float* __restrict__ obs, int row0, int nrows, ObsNorm nz, float* __restrict__ obs_out, int tower,
-                                         const float* __restrict__ actions, const float* __restrict__ v0, const float* __restrict__ v1, int mode) {
-    const int tid = threadIdx.x;
+                                         const float* __restrict__ actions, const float* __restrict__ v0, const float* __restrict__ v1, int mode, const int tidx = (int)threadIdx.x) {
+    const int tid = tidx;
     constexpr int WV = 16 / NW_PIPES;                       // float4 loads per thread: 64 KB in flight covers the image
     float4 wv[WV];
     const int n4 = n_img / 4;
@@ -270,10 +271,13 @@ __device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArg
 }
 
 // `red`: 4 floats of LDS scratch.  Ends with the image complete in LDS (caller synchronises).
-template <int NP>
+// RESIDENT (narrow_epoch_kernel): the moments and the weights stay in R from step to step (R.m / R.v / R.t receive the results), the pieces go back to
+// memory only when `write_back` says so (the epoch's last step), and the caller keeps the powers, the loss row and the norm.
+template <int NP, bool RESIDENT = false>
 __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout& lay, const NwLazyArgs& z, int tower, int grp, int n_groups,
-                                              NwLazyRegs<NP>& R, float* lds, float* red, unsigned long long* st = nullptr) {
-    const int tid = threadIdx.x;
+                                              NwLazyRegs<NP>& R, float* lds, float* red, unsigned long long* st = nullptr, bool write_back = true, float* norm_ret = nullptr,
+                                              const int tidx = (int)threadIdx.x) {
+    const int tid = tidx;
 #ifdef PPO_STAMPS
 #define LSTAMP(i) do { if (st && tid == 0) st[i] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -335,13 +339,15 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
             *reinterpret_cast<float4*>(par + po) = t4;                          // (par_bv: 4 floats reserved; the 3 behind b_v are padding zeros)
             mine = grp == 0;
         }
-        if (mine) {
+        if constexpr (RESIDENT) { R.t[k] = t4; R.m[k] = make_float4(mo[0], mo[1], mo[2], mo[3]); R.v[k] = make_float4(vo[0], vo[1], vo[2], vo[3]); }
+        if (mine && write_back) {
             *reinterpret_cast<float4*>(z.th_out + pc.off) = t4;
             *reinterpret_cast<float4*>(z.m_out + pc.off) = make_float4(mo[0], mo[1], mo[2], mo[3]);
             *reinterpret_cast<float4*>(z.v_out + pc.off) = make_float4(vo[0], vo[1], vo[2], vo[3]);
         }
     }
     LSTAMP(21);
+    if constexpr (RESIDENT) { if (norm_ret) *norm_ret = norm; return; }
     if (tower == 0 && grp == 0) {                                               // adam_kernel's block 0
         if (tid == 0) {
             z.beta_pow[2] = b1p * z.beta1;                                      // G:31217-31342
@@ -361,35 +367,15 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
 // ------------------------------------------------------------------------------------------------------------------------
 // Train step, first launch: forward + loss + backward + weight gradients of 32 rows of ONE tower (blockIdx.y).
 // ------------------------------------------------------------------------------------------------------------------------
-template <int KP0, int HP, int AP, int LL, bool LAZY = false>
-__global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, NwLayout lay, NwTrainArgs a, NwLazyArgs z) {
+// The train step of one workgroup behind its prologue (weight image and this workgroup's rows in LDS): forward, loss, backward, weight gradients ->
+// one partial gradient vector.  Called by narrow_train_kernel and, once per minibatch, by narrow_epoch_kernel.
+template <int KP0, int HP, int AP, int LL, bool WT = true>
+__device__ __forceinline__ void nw_train_body(const NetDev& net, const NwLayout& lay, const NwTrainArgs& a, float* lds, const int tower, const int grp,
+                                              const int tidx = (int)threadIdx.x) {
     typedef NwShape<KP0, HP, AP, LL> S;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwTrainArgs) + sizeof(NwLazyArgs)>();
-    const int tower = blockIdx.y, grp = blockIdx.x;
-    const int tid = threadIdx.x, pipe = tid >> 8, ptid = tid & 255;
+    const int tid = tidx, pipe = uni(tid >> 8), ptid = tid & 255;
     const int row0 = grp * NW_ROWS;
     const int L = S::L(net), Kp0 = S::Kp0(net), Ap = S::Ap(net);
-    NSTAMP(0);
-    if constexpr (LAZY) {
-        static_assert((KP0 == 32 || KP0 == 64) && HP == 64 && AP == 32 && LL == 2, "deferred Adam: the reference's shapes only (18 or 36 observations)");
-        float* lazy_red = lds + lay.w_total + lay.misc;      // 4 floats of pipe 0's loss scratch (no static LDS: the launch may ask for all 160 KB)
-        NwLazyRegs<NwLazyN<KP0>::N> R;
-        nw_lazy_issue(net, z, a.hyper, tower, R);
-        NSTAMP(12);
-        nw_stage<S>(net, lay, nullptr, 0, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
-                    a.actions, tower == 0 ? a.advs : a.returns, tower == 0 ? a.old_neglogp : a.old_values, tower == 0 ? 1 : 2);
-        NSTAMP(13);
-        nw_lazy_apply(net, lay, z, tower, grp, (int)gridDim.x, R, lds, lazy_red
-#ifdef PPO_STAMPS
-                      , a.stamps ? a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr
-#endif
-                      );
-        NSTAMP(14);
-    } else {
-        nw_stage<S>(net, lay, a.img + (size_t)tower * lay.w_total, lay.w_total, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
-                    a.actions, tower == 0 ? a.advs : a.returns, tower == 0 ? a.old_neglogp : a.old_values, tower == 0 ? 1 : 2);
-    }
     __syncthreads();
     NSTAMP(1);
     float* P = lds + lay.w_total + pipe * lay.pipe_total;            // this pipe's tiles
@@ -403,8 +389,8 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ys[(4 * g + r) * ldy + col] = fast_tanh(acc[r] + b);
         };
-        if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep);
-        else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep);
+        if (l == 0) nw_dense<KP0>(P + lay.x[0], lay.ldx[0], Kp0, lds + lay.wf[0], lay.wf_ld[0], S::Hp(net, 0), ep, tid);
+        else nw_dense<HP>(P + lay.x[l], lay.ldx[l], S::Hp(net, l - 1), lds + lay.wf[l], lay.wf_ld[l], S::Hp(net, l), ep, tid);
         __syncthreads();
         NSTAMP(2 + l);
     }
@@ -423,7 +409,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
             const float b = par[net.par_bmu + col];
 #pragma unroll
             for (int q = 0; q < 4; ++q) mus[(4 * g + q) * ldm + col] = acc[q] + b;
-        });
+        }, tid);
         __syncthreads();
         NSTAMP(6);
         // every lane keeps its (at most four: A <= 64) elements' z and sigma from the first pass: the second pass used to recompute both
@@ -487,7 +473,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
         nw_dense<AP>(dmu_t, ldm, Ap, lds + lay.wht, lay.wht_ld, HpL, [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const float h = hL[(4 * g + q) * ldh + col]; dYtop[(4 * g + q) * ldt + col] = acc[q] * (1.0f - h * h); }
-        });
+        }, tid);
     } else {
         // ---- value head + clipped value loss (G:10213-10837) and its gradient (G:14975-19571) ------------------------
         const float* wv = par + net.par_wv;
@@ -527,7 +513,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
                      [&](const f32x4& acc, int g, int col) __attribute__((always_inline)) {
 #pragma unroll
                          for (int q = 0; q < 4; ++q) { const float h = hl[(4 * g + q) * ldhl + col]; dn[(4 * g + q) * ldn + col] = acc[q] * (1.0f - h * h); }
-                     });
+                     }, tid);
         __syncthreads();
     }
     NSTAMP(9);
@@ -536,9 +522,10 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
     // partial-vector stores are agent-scope WRITE-THROUGH: the next kernel reads them on other XCDs, and as ordinary stores they
     // sit dirty in this XCD's L2 until the end-of-kernel write-back (26 KB per workgroup, 16 workgroups per XCD): 20.5 -> 19.5 us
     // per train step at M = 2048
-    auto pst = [](float* p, float v) __attribute__((always_inline)) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // (WT = false, narrow_epoch_kernel's XCD-local form: the readers share this XCD's L2 -- ordinary stores)
+    auto pst = [](float* p, float v) __attribute__((always_inline)) { if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
     const float* PB = lds + lay.w_total;                              // pipe q's tiles at PB + q * pipe_total
-    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int lane = tid & 63, wave = uni(tid >> 6), g = lane >> 4, c = lane & 15;
     constexpr int NWV = NW_THREADS / 64;
     // dW = X^T dY: tile (i0, j0), reduction over the NW_ROWS rows: k-step s covers rows 4s .. 4s+3 (pipe = s >> 2).  A wave
     // walks tiles t = wave, wave + 8, ... of the concatenated tile list of all matrices (balanced: 32 tiles at [64,64]).
@@ -599,6 +586,36 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
     NSTAMP(11);
 }
 
+template <int KP0, int HP, int AP, int LL, bool LAZY = false>
+__global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, NwLayout lay, NwTrainArgs a, NwLazyArgs z) {
+    typedef NwShape<KP0, HP, AP, LL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwTrainArgs) + sizeof(NwLazyArgs)>();
+    const int tower = blockIdx.y, grp = blockIdx.x;
+    const int row0 = grp * NW_ROWS;
+    NSTAMP(0);
+    if constexpr (LAZY) {
+        static_assert((KP0 == 32 || KP0 == 64) && HP == 64 && AP == 32 && LL == 2, "deferred Adam: the reference's shapes only (18 or 36 observations)");
+        float* lazy_red = lds + lay.w_total + lay.misc;      // 4 floats of pipe 0's loss scratch (no static LDS: the launch may ask for all 160 KB)
+        NwLazyRegs<NwLazyN<KP0>::N> R;
+        nw_lazy_issue(net, z, a.hyper, tower, R);
+        NSTAMP(12);
+        nw_stage<S>(net, lay, nullptr, 0, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
+                    a.actions, tower == 0 ? a.advs : a.returns, tower == 0 ? a.old_neglogp : a.old_values, tower == 0 ? 1 : 2);
+        NSTAMP(13);
+        nw_lazy_apply(net, lay, z, tower, grp, (int)gridDim.x, R, lds, lazy_red
+#ifdef PPO_STAMPS
+                      , a.stamps ? a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr
+#endif
+                      );
+        NSTAMP(14);
+    } else {
+        nw_stage<S>(net, lay, a.img + (size_t)tower * lay.w_total, lay.w_total, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
+                    a.actions, tower == 0 ? a.advs : a.returns, tower == 0 ? a.old_neglogp : a.old_values, tower == 0 ? 1 : 2);
+    }
+    nw_train_body<KP0, HP, AP, LL>(net, lay, a, lds, tower, grp);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // Gradient assembly for the narrow path: 64 consecutive elements per block, 4 threads per element (each adds a quarter of
 // the row groups in index order, the four meet in a fixed order).  Emits the sum of squares per 64-element chunk for the
@@ -652,6 +669,242 @@ __global__ __launch_bounds__(256) void narrow_reduce_kernel(NwReduceArgs a) {
     if ((tid & 63) == 0) red[tid >> 6] = q;
     __syncthreads();
     if (tid == 0) a.sumsq[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// ALL minibatches of an epoch in ONE launch, for minibatches of <= 64 rows on the deferred-Adam shapes (the reference's own command line: 1 environment x
+// 2048 steps, 32 minibatches of 64 rows, ppo2.cpp:114-128): 2 G workgroups (G = row groups of 32, 2 towers) stay resident, keep their tower's weight image in
+// LDS and its Adam moments and weights in registers, and per minibatch run nw_train_body, publish their partial gradient vector (write-through, two buffers
+// by step parity), MEET (one word per workgroup), add the partial vectors up themselves in narrow_reduce_kernel's order -- both towers': the global norm needs
+// every chunk's sum of squares, and reading the other tower's 2 x 26 KB is cheaper than a second meeting -- and apply clip + Adam with nw_lazy_apply's code to
+// the LDS image.  Same arithmetic in the same order as narrow_train_kernel<.., LAZY> + narrow_reduce_kernel per step: bit-identical
+// (tests/test_other_shapes.py), without 2 launches and 2 dependent prologues per step.  (Round 3's resident form put a whole tower on ONE CU and was issue-
+// bound, profiles/r03_d_*; this one keeps the launch form's 2 CUs per tower.)  At exit the owners write weights, moments and the packed image back.
+// ------------------------------------------------------------------------------------------------------------------------
+#define NW_EPOCH_MAX_G 2
+#define NW_EPOCH_WORDS 16                // meeting table: [2 G] step counters ... [NW_EPOCH_WORDS - 1] raised when a wait timed out
+struct NwEpochArgs {
+    const float* obs; const float* actions; const float* advs; const float* returns; const float* old_values; const float* old_neglogp;   // minibatch k = rows [k M, (k + 1) M)
+    int M, nmb; float inv_n;
+    float* img;                          // [2][w_total]: read at entry, written back at exit
+    float* partials; int part_stride;    // [nmb steps (XL) | 2 step parities][2 towers][G][part_stride]
+    float* theta; float* m; float* v;    // in place
+    float* grad;                         // the LAST step's assembled gradient + tail (ppo_get_last_grad)
+    const float* hyper; float* beta_pow; float beta1, beta2, eps, max_norm;
+    float* loss_rows;                    // [nmb][5]
+    float* norm_out;
+    unsigned* words;
+    int n_chunks;                        // 64-element chunks of the padded parameter vector
+    unsigned long long* stamps;          // diagnostic builds only
+};
+
+// XL (the default): the 2 G workgroups are the launch's workgroups 0, 8, 16, ... -- dealt to ONE XCD (workgroup b runs on XCD b % 8; the others leave at once) --
+// so a partial vector written with ordinary stores (complete in that XCD's L2 once acknowledged: s_waitcnt vmcnt(0)) is what the other workgroups read through the
+// same L2 with ordinary loads, at L2 latency and bandwidth instead of a write-through trip to the memory side (4.4 k -> ~1.6 k cycles for the 104 KB a workgroup
+// reads per step).  Every step has its own partial buffers: no address is read twice in a launch, so no CU's L1 holds a stale line.  The placement is CHECKED (every
+// word carries its writer's hardware XCC id, as in gemm_chain_bf16_kernel); a mismatch raises error word 2 and the handle goes back to the write-through form.
+template <int KP0, bool XL>
+__global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, NwLayout lay, NwEpochArgs e) {
+    constexpr int HP = 64, AP = 32, LL = 2, NP = NwLazyN<KP0>::N;
+    typedef NwShape<KP0, HP, AP, LL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (XL && (blockIdx.x & 7u) != 0) return;
+    const int G = XL ? (int)(gridDim.x >> 4) : (int)gridDim.x, nwg = 2 * G;
+    const int wid = XL ? (int)(blockIdx.x >> 3) : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int tower = wid / G, grp = wid - tower * G;
+    const int tid0 = threadIdx.x;
+    const int row0 = grp * NW_ROWS;
+    unsigned xcc = 0;
+    if constexpr (XL) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 15u; }
+    const unsigned e0 = __hip_atomic_load(e.words + wid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 4;      // (only this workgroup writes its word: (steps so far << 4) | XCC id)
+    NwLazyRegs<NP> R;
+    R.b1p = e.beta_pow[2]; R.b2p = e.beta_pow[3]; R.lr = e.hyper[0];           // `next` = the powers the first step applies (the launch form copies them to `cur` first)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int off = nw_lazy_piece(net, tower, k, tid0).off;
+        R.g[k] = R.m[k] = R.v[k] = R.t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (off >= 0) { R.m[k] = *reinterpret_cast<const float4*>(e.m + off); R.v[k] = *reinterpret_cast<const float4*>(e.v + off); R.t[k] = *reinterpret_cast<const float4*>(e.theta + off); }
+    }
+    const float* v0 = tower == 0 ? e.advs : e.returns; const float* v1 = tower == 0 ? e.old_neglogp : e.old_values;
+    nw_stage<S>(net, lay, e.img + (size_t)tower * lay.w_total, lay.w_total, lds, e.obs, row0, e.M, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
+                e.actions, v0, v1, tower == 0 ? 1 : 2);
+    float* parts = lds + lay.w_total + lay.dy[0];            // [512] chunk sums of squares: over pipe 0's dY tile, dead between a step's last product and the next step
+    float* red = lds + lay.w_total + lay.misc;               // 4 floats of pipe 0's loss scratch (not touched by the row staging)
+    NwTrainArgs ta{};
+    ta.hyper = e.hyper; ta.n = e.M; ta.inv_n = e.inv_n; ta.n_groups = G; ta.part_stride = e.part_stride; ta.stamps = e.stamps;
+    NwLazyArgs z{};
+    z.n_parts = e.n_chunks; z.parts = parts; z.th_out = e.theta; z.m_out = e.m; z.v_out = e.v; z.beta1 = e.beta1; z.beta2 = e.beta2; z.eps = e.eps; z.max_norm = e.max_norm;
+    float norm = 0.f;
+#ifdef PPO_STAMPS
+#define ESTAMP(i) do { if (e.stamps && threadIdx.x == 0 && k == e.nmb - 2) e.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ESTAMP(i) do { } while (0)
+#endif
+    for (int k = 0; k < e.nmb; ++k) {
+        // an OPAQUE copy of the thread index per iteration: with the plain one the compiler hoists every thread-dependent LDS address of the step out of this
+        // loop (hundreds of live registers: 256 VGPRs + 190 spilled, measured)
+        int tid = tid0, lane = tid0 & 63;
+        asm volatile("" : "+v"(tid), "+v"(lane));
+        __syncthreads();                                      // image (first step: the copy; later: Adam's writes) and this minibatch's rows are in LDS
+        const bool last = k == e.nmb - 1;
+        // the NEXT minibatch's rows are requested now and wait in registers under this step (nw_stage's loads, element for element; 2.5 k cycles of exposed
+        // latency when requested after the step)
+        constexpr int OVN = NW_ROWS * KP0 / NW_THREADS, AVN = NW_ROWS * AP / NW_THREADS;
+        float nxo[OVN], nxa[AVN], nx0 = 0.f, nx1 = 0.f;
+        {
+            const size_t ro = (size_t)(k + 1) * e.M;
+#pragma unroll
+            for (int q = 0; q < OVN; ++q) {
+                const int i = tid + NW_THREADS * q, r = i / KP0, j = i - r * KP0, row = row0 + r;
+                nxo[q] = (!last && row < e.M && j < net.O) ? e.obs[(ro + row) * net.O + j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < AVN; ++q) {
+                const int i = tid + NW_THREADS * q, r = i / AP, j = i - r * AP, row = row0 + r;
+                nxa[q] = (!last && tower == 0 && row < e.M && j < net.A) ? e.actions[(ro + row) * net.A + j] : 0.f;
+            }
+            if (!last && tid < NW_ROWS && row0 + tid < e.M) { nx0 = v0[ro + row0 + tid]; nx1 = v1[ro + row0 + tid]; }
+        }
+        float* pb = e.partials + (size_t)(XL ? k : (k & 1)) * nwg * e.part_stride;
+        ta.partials = pb;
+        ta.stamps = (k == e.nmb - 2) ? e.stamps : nullptr;
+        ESTAMP(0);
+        nw_train_body<KP0, HP, AP, LL, !XL>(net, lay, ta, lds, tower, grp, tid);
+        // ---- arrival: the partial vector was stored write-through; every wave drains, one word says "step k of this workgroup is out" ---------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ESTAMP(16);
+        const unsigned target = e0 + (unsigned)k + 1u;
+        if (tid == 0) __hip_atomic_store(e.words + wid, (target << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        parts[tid] = 0.f;                                     // (NW_THREADS = 512 entries; chunks without a piece -- alignment gaps -- stay zero)
+        if (tid < 64) {
+            unsigned polls = 0;
+            for (;;) {
+                const unsigned w = lane < nwg ? __hip_atomic_load(e.words + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((target << 4) | xcc);
+                if (__all((int)((w >> 4) - target) >= 0)) {
+                    if (XL && (w & 15u) != xcc) __hip_atomic_store(e.words + NW_EPOCH_WORDS - 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > (1u << 22)) { if (lane == 0) __hip_atomic_store(e.words + NW_EPOCH_WORDS - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        ESTAMP(17);
+        // ---- assembly: (p0 + p1) + (0 + 0) per element as narrow_reduce_kernel adds two row groups; per 64-element chunk the sum of squares in ITS tree --------
+        // (16 consecutive threads hold a chunk's 16 pieces: levels 1-2 across pieces c ^ 2, c ^ 1 = elements e ^ 8, e ^ 4; levels 3-4 inside the piece; then the
+        // kernel's four waves as piece groups: (r0 + r1) + (r2 + r3))
+        // every load first -- both towers' pieces of the partial vectors (write-through loads: ~2 k cycles to the memory side and back) and, behind them, the
+        // NEXT minibatch's rows (nw_stage: its wait covers them all) -- then the arithmetic
+        f32x4 p0[2][NP], p1[2][NP];
+        int offs[2][NP];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int t2 = side == 0 ? tower : 1 - tower;
+#pragma unroll
+            for (int kk = 0; kk < NP; ++kk) {
+                offs[side][kk] = nw_lazy_piece(net, t2, kk, tid).off;
+                const float* src = pb + (size_t)t2 * G * e.part_stride + (offs[side][kk] >= 0 ? offs[side][kk] : 0);
+                if constexpr (XL) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + (G > 1 ? e.part_stride : 0));
+                    p0[side][kk] = (f32x4){x0.x, x0.y, x0.z, x0.w}; p1[side][kk] = (f32x4){x1.x, x1.y, x1.z, x1.w};
+                } else {
+                    p0[side][kk] = nb_ld4_sc1(src);
+                    p1[side][kk] = nb_ld4_sc1(src + (G > 1 ? e.part_stride : 0));
+                }
+            }
+        }
+        if (!last) {                                          // the next minibatch's rows: registers -> the tiles nw_stage fills (the step's last reads of them are done)
+#pragma unroll
+            for (int q = 0; q < OVN; ++q) {
+                const int i = tid + NW_THREADS * q, r = i / KP0, j = i - r * KP0;
+                lds[lay.w_total + (r >> 4) * lay.pipe_total + lay.x[0] + (r & 15) * lay.ldx[0] + j] = nxo[q];
+            }
+            if (tower == 0) {
+#pragma unroll
+                for (int q = 0; q < AVN; ++q) {
+                    const int i = tid + NW_THREADS * q, r = i / AP, j = i - r * AP;
+                    lds[lay.w_total + (r >> 4) * lay.pipe_total + lay.acts + (r & 15) * AP + j] = nxa[q];
+                }
+            }
+            if (tid < NW_ROWS) {
+                float* rv = lds + lay.w_total + (tid >> 4) * lay.pipe_total + lay.rowv;
+                rv[2 * (tid & 15)] = nx0; rv[2 * (tid & 15) + 1] = nx1;
+            }
+        }
+        if constexpr (!XL)
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {   // (the loads are inline asm: the compiler does not count them)
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0;
+            if constexpr (NP == 5) { nb_wait8(p0[side][0], p0[side][1], p0[side][2], p0[side][3], p0[side][4], d0, d1, d2); nb_wait8(p1[side][0], p1[side][1], p1[side][2], p1[side][3], p1[side][4], d0, d1, d2); }
+            else { nb_wait8(p0[side][0], p0[side][1], p0[side][2], p0[side][3], p0[side][4], p0[side][5], d0, d1); nb_wait8(p1[side][0], p1[side][1], p1[side][2], p1[side][3], p1[side][4], p1[side][5], d0, d1); }
+        }
+        ESTAMP(23);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int t2 = side == 0 ? tower : 1 - tower;
+#pragma unroll
+            for (int kk = 0; kk < NP; ++kk) {
+                const bool has = offs[side][kk] >= 0;
+                float g4[4], q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float a0 = has ? p0[side][kk][i] : 0.f, a1 = (has && G > 1) ? p1[side][kk][i] : 0.f;
+                    g4[i] = (a0 + a1) + (0.f + 0.f);
+                    q[i] = g4[i] * g4[i];
+                    q[i] += dpp_move<0x4E>(q[i]);            // lane ^ 2 (quad_perm [2,3,0,1]): one VALU instruction each (a __shfl_xor is a trip through the LDS crossbar:
+                    q[i] += dpp_move<0xB1>(q[i]);            // lane ^ 1 (quad_perm [1,0,3,2])   100 of them per step and wave made this phase 8 k cycles)
+                }
+                if (side == 0) R.g[kk] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+                const float r = (q[0] + q[2]) + (q[1] + q[3]);
+                const float t = r + dpp_move<0x141>(r);      // r is uniform over 4 lanes: row_half_mirror (lane i <-> 7 - i) reaches the other group of 4
+                const float t8 = dpp_move<0x140>(t);         // t is uniform over 8 lanes: row_mirror (i <-> 15 - i) reaches the other half
+                const bool half_chunk = kk == 4 && t2 == 0 && tid >= 32 && tid < 48;          // b_mu | logstd: 8 pieces each, neighbours in the lanes but not in memory
+                const float u = t + (half_chunk ? 0.f : t8);
+                if (has && ((tid & 15) == 0 || (half_chunk && tid == 40))) parts[offs[side][kk] >> 6] = u;
+            }
+        }
+        // the loss sums {pg, vf, ent, kl, cf} of the minibatch: narrow_reduce_kernel's 32-lane tree over the row groups = (p0 + p2) + (p1 + p3)
+        float tail = 0.f;
+        if (wid == 0 && tid < 5) {
+            const int tw = tid == 1 ? 1 : 0, off = net.n_theta + (tid <= 1 ? 0 : tid - 1);
+            const float* src = pb + (size_t)tw * G * e.part_stride + off;
+            float a0, a1 = 0.f;
+            if constexpr (XL) { a0 = src[0]; if (G > 1) a1 = src[e.part_stride]; }               // (XL: the producers' ordinary stores may still be dirty in the shared L2)
+            else { a0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (G > 1) a1 = __hip_atomic_load(src + e.part_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            tail = (a0 + 0.f) + (a1 + 0.f);
+        }
+        __syncthreads();                                      // parts complete
+        ESTAMP(18);
+        R.part = (tid < 256 && tid < e.n_chunks) ? parts[tid] : 0.f;
+        nw_lazy_apply<NP, true>(net, lay, z, tower, grp, G, R, lds, red, nullptr, last, &norm, tid);
+        ESTAMP(19);
+        if (wid == 0 && tid < 5) {
+            float r = tail / (float)e.M;
+            if (tid == 1 || tid == 3) r = 0.5f * r;           // vf_loss, approxkl carry the 0.5
+            e.loss_rows[(size_t)k * 5 + tid] = r;
+            if (last) e.grad[net.n_theta + tid] = tail;
+        }
+        if (last && grp == 0) {                               // the assembled gradient of the last step (what the launch form leaves in `grad`)
+#pragma unroll
+            for (int kk = 0; kk < NP; ++kk) { const int off = nw_lazy_piece(net, tower, kk, tid).off; if (off >= 0) *reinterpret_cast<float4*>(e.grad + off) = R.g[kk]; }
+        }
+        if (!last) { R.b1p = R.b1p * e.beta1; R.b2p = R.b2p * e.beta2; }                         // G:31217-31342: the next step's powers
+        ESTAMP(22);
+    }
+    __syncthreads();
+    const int tid = tid0;
+    // ---- exit: the packed image of this tower (its LDS copy IS the layout), the powers, the norm --------------------------------------------------------
+    if (grp == 0) {
+        float* img = e.img + (size_t)tower * lay.w_total;
+        for (int i = tid; i < lay.w_total / 4; i += NW_THREADS) reinterpret_cast<float4*>(img)[i] = reinterpret_cast<const float4*>(lds)[i];
+    }
+    if (wid == 0 && tid == 0) {
+        e.beta_pow[0] = R.b1p; e.beta_pow[1] = R.b2p;                                              // cur = what the last step applied
+        e.beta_pow[2] = R.b1p * e.beta1; e.beta_pow[3] = R.b2p * e.beta2;
+        if (e.norm_out) *e.norm_out = norm;
+        e.grad[net.n_theta + 5] = (float)e.M;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

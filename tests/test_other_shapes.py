@@ -208,6 +208,47 @@ def test_fused_train_and_weight_gradient_launch_is_bitwise_the_two_launches(monk
             np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("O,E,T,nmb,explicit", [(18, 1, 2048, 32, False), (36, 1, 2048, 32, True), (18, 4, 120, 10, True), (18, 1, 512, 32, False), (36, 2, 24, 1, False)])
+def test_resident_epoch_kernel_is_bitwise_the_launch_per_train_step(O, E, T, nmb, explicit, monkeypatch):
+    """narrow_epoch_kernel (ppo_narrow.hpp): on the reference's own shape -- [64,64], minibatches of <= 64 rows (ppo2.cpp:114-128: 1 environment x 2048 steps, 32
+    minibatches) -- ALL minibatches of an epoch run in one launch whose 2 - 4 workgroups keep the weight image in LDS, the Adam moments in registers and meet once per
+    minibatch over their partial gradient vectors -- through one XCD's L2 (the default) or write-through (PPO_HIP_NO_NARROW_EPOCH_XL=1).  Same arithmetic in the
+    same order as narrow_train_kernel<.., LAZY> + narrow_reduce_kernel per step (PPO_HIP_NO_NARROW_EPOCH=1): the loss rows of every train step, the last step's gradient and norm, weights, both moments, the beta powers and the next rollout's
+    actions / values (the packed image the act kernels read is written back at the kernel's exit) must be the same BITS after two three-epoch updates -- 64-row
+    minibatches (two row groups per tower), 48 rows (a ragged second group), 16 rows (one group), one minibatch per epoch; 18 and 36 observations."""
+    rng = np.random.RandomState(5)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    perms = [np.stack([rng.permutation(E * T).astype(np.int32) for _ in range(3)]) if explicit else None for _ in range(2)]
+    obs2 = rng.uniform(-1, 1, (E, O)).astype(np.float32); nz2 = rng.normal(size=(E, 18)).astype(np.float32)
+    outs = []
+    for mode in ("one XCD", "write-through", "launches"):
+        monkeypatch.setenv("PPO_HIP_NO_NARROW_EPOCH", "1" if mode == "launches" else "0")
+        monkeypatch.setenv("PPO_HIP_NO_NARROW_EPOCH_XL", "1" if mode == "write-through" else "0")
+        g = hip((64, 64), O=O); g.init_orthogonal(2)
+        g.norm_init(E); g.rollout_alloc(E, T)
+        g.collect_synthetic(55, GAMMA, LAM, noise)
+        k0 = g.kernel_counts()
+        acc = []
+        for u in range(2):
+            rows, mean = g.update(LR, CR, 3, nmb, perms[u], seed=9 + u)
+            gr, nrm = g.last_grad()
+            acc += [rows.copy(), mean.copy(), gr.copy(), np.float32(nrm), g.get_flat(0), g.get_flat(1), g.get_flat(2), np.asarray(g.beta_powers()).copy()]
+            acc += [np.asarray(x).copy() for x in g.step(obs2, nz2)]
+        ran = delta(g.kernel_counts(), k0)
+        if mode != "launches":
+            assert ran.get("narrow_epoch_kernel", 0) >= 3 and "narrow_train_kernel<static>" not in ran, ran    # (one per epoch; a captured graph counts once per capture)
+        else:
+            assert "narrow_epoch_kernel" not in ran and ran.get("narrow_train_kernel<static>", 0) > 0, ran
+        outs.append(acc)
+        g.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    outs = [outs[0], outs[2]]
+    assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][2]).max() > 0
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("O,A", [(18, 18), (36, 18), (18, 40), (36, 40)])
 def test_clip_and_adam_inside_the_weight_gradient_launch_are_bitwise_the_adam_launch(monkeypatch, O, A):
     """Single GPU, [256,256]: weight_grad_assemble_adam_kernel (ppo_dw2.hpp, Dw2Adam) applies clip + Adam from the registers of the workgroups that
