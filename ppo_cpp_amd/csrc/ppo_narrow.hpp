@@ -735,6 +735,12 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
     NwLazyArgs z{};
     z.n_parts = e.n_chunks; z.parts = parts; z.th_out = e.theta; z.m_out = e.m; z.v_out = e.v; z.beta1 = e.beta1; z.beta2 = e.beta2; z.eps = e.eps; z.max_norm = e.max_norm;
     float norm = 0.f;
+    // the pieces' offsets of both towers, once (inside the loop the thread index is opaque and they would be recomputed every step)
+    int offs[2][NP];
+#pragma unroll
+    for (int side = 0; side < 2; ++side)
+#pragma unroll
+        for (int kk = 0; kk < NP; ++kk) offs[side][kk] = nw_lazy_piece(net, side == 0 ? tower : 1 - tower, kk, tid0).off;
 #ifdef PPO_STAMPS
 #define ESTAMP(i) do { if (e.stamps && threadIdx.x == 0 && k == e.nmb - 2) e.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -797,13 +803,11 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
         // every load first -- both towers' pieces of the partial vectors (write-through loads: ~2 k cycles to the memory side and back) and, behind them, the
         // NEXT minibatch's rows (nw_stage: its wait covers them all) -- then the arithmetic
         f32x4 p0[2][NP], p1[2][NP];
-        int offs[2][NP];
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const int t2 = side == 0 ? tower : 1 - tower;
 #pragma unroll
             for (int kk = 0; kk < NP; ++kk) {
-                offs[side][kk] = nw_lazy_piece(net, t2, kk, tid).off;
                 const float* src = pb + (size_t)t2 * G * e.part_stride + (offs[side][kk] >= 0 ? offs[side][kk] : 0);
                 if constexpr (XL) {
                     const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + (G > 1 ? e.part_stride : 0));
