@@ -16,7 +16,7 @@ def run(E, T, nmb, eager):
         means.append(g.update(3.93141e-4, 0.161023, 4, nmb, None, seed=1000 + i, want_rows=False)[1].copy())
     th = g.get_flat(0); st = g.norm_stats(0); g.close()
     return th, np.array(means), st
-for E, T, nmb in ((1024, 64, 32), (1, 512, 8), (48, 32, 4)):
+for E, T, nmb in ((1024, 64, 32), (1, 512, 8), (48, 32, 4), (1, 2048, 32)):      # (the last two-but-one and the last: minibatches of 64 rows = narrow_epoch_kernel; the last is the reference's own command line)
     t0 = time.time(); a = run(E, T, nmb, False); b = run(E, T, nmb, True)
     ok = np.isfinite(a[0]).all() and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2][0], b[2][0]) and a[2][2] == b[2][2]
     print("E %4d T %3d: %d iterations graph vs eager bitwise equal: %s (%.1f s)" % (E, T, N, ok, time.time() - t0), flush=True)
