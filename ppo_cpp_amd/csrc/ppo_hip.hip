@@ -199,6 +199,7 @@ struct ppo_handle {
     bool nw_epoch = false; unsigned* nw_epoch_words = nullptr;
     bool nw_epoch_xl = false;         // ... its XCD-local form (workgroups 0, 8, 16, ... of the launch; ordinary stores / loads through one L2; a partial buffer per step)
     float* nw_epoch_partials = nullptr; size_t nw_epoch_cap = 0;
+    bool nw_epoch_dist = false; unsigned* nw_epochd_words = nullptr; int n_cu = 0;      // ... and its form for larger minibatches (narrow_epoch_dist_kernel: one workgroup per row group and tower)
     bool adam_fast = false;           // adam_kernel uses the 1-ulp quotient of the deferred form (nw_lazy, or PPO_HIP_ADAM_FAST=1 for the bitwise test)
     int nw_cur = 0;                   // parameter set holding the current weights (0 outside ppo_update)
     bool nw_pending = false; float* nw_pending_loss = nullptr; int nw_pending_parts = 0;
@@ -1005,6 +1006,16 @@ int fab_check(ppo_handle* h) {
 int nw_epoch_check(ppo_handle* h) {
     if (!h->nw_epoch || !h->nw_epoch_words) return 0;
     unsigned e = 0;
+    if (h->nw_epoch_dist && h->nw_epochd_words) {
+        HIP_OK(h, hipMemcpy(&e, h->nw_epochd_words + NW_EPOCHD_MAX_WG, sizeof e, hipMemcpyDeviceToHost));
+        if (e) {
+            (void)hipMemset(h->nw_epochd_words, 0, (NW_EPOCHD_MAX_WG + 64 + 5 * 128) * sizeof e);
+            h->nw_epoch_dist = false;
+            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            return fail(h, "narrow_epoch_dist_kernel: its workgroups were not resident together (is another process using this GPU?); this update's results are invalid.  "
+                           "The handle now launches every train step (the default without PPO_HIP_NARROW_EPOCH_DIST=1)");
+        }
+    }
     HIP_OK(h, hipMemcpy(&e, h->nw_epoch_words + NW_EPOCH_WORDS - 1, sizeof e, hipMemcpyDeviceToHost));
     if (e == 2) {
         (void)hipMemset(h->nw_epoch_words, 0, NW_EPOCH_WORDS * sizeof e);
@@ -1524,6 +1535,7 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         big_lds((const void*)narrow_train_kernel<32, 64, 32, 2, true>); big_lds((const void*)narrow_train_kernel<64, 64, 32, 2, true>);
         big_lds((const void*)narrow_epoch_kernel<32, false>); big_lds((const void*)narrow_epoch_kernel<64, false>);
         big_lds((const void*)narrow_epoch_kernel<32, true>); big_lds((const void*)narrow_epoch_kernel<64, true>);
+        big_lds((const void*)narrow_epoch_dist_kernel<32>); big_lds((const void*)narrow_epoch_dist_kernel<64>);
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         { const char* e1 = getenv("PPO_HIP_NO_HOST_FUSED"); const char* e2 = getenv("PPO_HIP_NO_HOST_RESIDENT");
           h->opt_no_host_fused = e1 && e1[0] == '1'; h->opt_no_host_resident = e2 && e2[0] == '1'; }
@@ -1537,6 +1549,9 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
             h->nw_epoch = !(ne && ne[0] == '1') && prop.multiProcessorCount >= 2 * 2 * NW_EPOCH_MAX_G;
             if (h->nw_epoch && dev_alloc(h, &h->nw_epoch_words, NW_EPOCH_WORDS)) return bail(0);
             { const char* nx = getenv("PPO_HIP_NO_NARROW_EPOCH_XL"); h->nw_epoch_xl = h->nw_epoch && !(nx && nx[0] == '1') && prop.multiProcessorCount >= 64; }
+            { const char* nd = getenv("PPO_HIP_NARROW_EPOCH_DIST"); h->n_cu = prop.multiProcessorCount;       // OPT-IN: measured slower than the launches (profiles/r05_i_*)
+              h->nw_epoch_dist = h->nw_epoch && nd && nd[0] == '1' && h->P_pad / 64 <= NW_THREADS;
+              if (h->nw_epoch_dist && dev_alloc(h, &h->nw_epochd_words, NW_EPOCHD_MAX_WG + 64 + 5 * 128)) return bail(0); }
         }
         if (dev_alloc(h, &h->nw_img, (size_t)2 * h->nw.w_total)) return bail(0);
     }
@@ -1561,6 +1576,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->nw_partials) (void)hipFree(h->nw_partials);
     if (h->nw_epoch_words) (void)hipFree(h->nw_epoch_words);
     if (h->nw_epoch_partials) (void)hipFree(h->nw_epoch_partials);
+    if (h->nw_epochd_words) (void)hipFree(h->nw_epochd_words);
     if (h->nw_img) (void)hipFree(h->nw_img);
     if (h->nw_alt) (void)hipFree(h->nw_alt);
     if (h->nw_coop) (void)hipFree(h->nw_coop);
@@ -2639,6 +2655,26 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             }
             else if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_kernel<32, false>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
             else hipLaunchKernelGGL((narrow_epoch_kernel<64, false>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
+            HIP_OK(h, hipGetLastError());
+            continue;
+        }
+        if (h->narrow && h->nw_lazy && h->nw_epoch && h->nw_epoch_dist && !h->comm && egroups > NW_EPOCH_MAX_G && egroups <= h->nw_groups_cap &&
+            2 * egroups <= std::min(NW_EPOCHD_MAX_WG, h->n_cu) && !(ne && ne[0] == '1')) {
+            // larger minibatches: the resident epoch with a distributed assembly (ppo_narrow.hpp, narrow_epoch_dist_kernel; one workgroup per row group and tower, all resident)
+            ProfScope ps(h, PK_TRAIN_FB);
+            const NetDev& n = h->net;
+            NwEpochDistArgs da{NwEpochArgs{h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp, M, nmb, 1.0f / (float)M, h->nw_img, h->nw_partials, h->nw_stride,
+                                           h->theta, h->adam_m, h->adam_v, h->grad, h->hyper, h->beta_pow, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm,
+                                           h->d_loss_rows + (size_t)ep * nmb * 5, h->norm_out, h->nw_epochd_words, h->P_pad / 64, nullptr},
+                               h->grad_src, h->sumsq, reinterpret_cast<float*>(h->nw_epochd_words + NW_EPOCHD_MAX_WG + 64)};
+#ifdef PPO_STAMPS
+            if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
+            da.e.stamps = g_stamps;
+#endif
+            const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
+            ++h->kv[KV_NARROW_EPOCH];
+            if (n.Kp0 == 32) hipLaunchKernelGGL(narrow_epoch_dist_kernel<32>, dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
+            else hipLaunchKernelGGL(narrow_epoch_dist_kernel<64>, dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
             HIP_OK(h, hipGetLastError());
             continue;
         }

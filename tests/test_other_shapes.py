@@ -249,6 +249,44 @@ def test_resident_epoch_kernel_is_bitwise_the_launch_per_train_step(O, E, T, nmb
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("O,E,T,nmb,explicit", [(18, 64, 16, 4, False), (36, 48, 12, 4, True), (18, 1024, 64, 32, False), (18, 20, 33, 5, True), (36, 1024, 16, 8, False)])
+def test_resident_epoch_kernel_with_distributed_assembly_is_bitwise_the_launch_per_train_step(O, E, T, nmb, explicit, monkeypatch):
+    """narrow_epoch_dist_kernel (ppo_narrow.hpp): the resident epoch for minibatches of more than 64 rows -- one workgroup per 32-row group and tower (BASELINE
+    configs[3]: 2048 rows = 128 workgroups), the gradient's assembly dealt over the workgroups in narrow_reduce_kernel's order, two meetings per minibatch (opt-in,
+    PPO_HIP_NARROW_EPOCH_DIST=1: correct but slower than the launches there).  Against the
+    launch per train step (PPO_HIP_NO_NARROW_EPOCH=1): loss rows, the last gradient and its norm, weights, moments, powers and the act model after two three-epoch
+    updates must be the same BITS -- 256-row minibatches (8 groups), 144 rows (a ragged 5th group), configs[3]'s own shape, 132 rows (odd group counts: the four
+    quarter sums of an element cover 2 + 2 + 1 + 0 groups), 2048 rows behind 36 observations (320 chunks: three per workgroup pair)."""
+    rng = np.random.RandomState(6)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    perms = [np.stack([rng.permutation(E * T).astype(np.int32) for _ in range(3)]) if explicit else None for _ in range(2)]
+    obs2 = rng.uniform(-1, 1, (E, O)).astype(np.float32); nz2 = rng.normal(size=(E, 18)).astype(np.float32)
+    outs = []
+    for mode in ("resident", "launches"):
+        monkeypatch.setenv("PPO_HIP_NO_NARROW_EPOCH", "1" if mode == "launches" else "0")
+        monkeypatch.setenv("PPO_HIP_NARROW_EPOCH_DIST", "1")          # (opt-in: measured slower than the launches at configs[3], profiles/r05_i_*)
+        g = hip((64, 64), O=O); g.init_orthogonal(2)
+        g.norm_init(E); g.rollout_alloc(E, T)
+        g.collect_synthetic(55, GAMMA, LAM, noise)
+        k0 = g.kernel_counts()
+        acc = []
+        for u in range(2):
+            rows, mean = g.update(LR, CR, 3, nmb, perms[u], seed=9 + u)
+            gr, nrm = g.last_grad()
+            acc += [rows.copy(), mean.copy(), gr.copy(), np.float32(nrm), g.get_flat(0), g.get_flat(1), g.get_flat(2), np.asarray(g.beta_powers()).copy()]
+            acc += [np.asarray(x).copy() for x in g.step(obs2, nz2)]
+        ran = delta(g.kernel_counts(), k0)
+        if mode == "resident":
+            assert ran.get("narrow_epoch_kernel", 0) >= 3 and "narrow_train_kernel<static>" not in ran, ran
+        else:
+            assert "narrow_epoch_kernel" not in ran and ran.get("narrow_train_kernel<static>", 0) > 0, ran
+        outs.append(acc)
+        g.close()
+    assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][2]).max() > 0
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("O,A", [(18, 18), (36, 18), (18, 40), (36, 40)])
 def test_clip_and_adam_inside_the_weight_gradient_launch_are_bitwise_the_adam_launch(monkeypatch, O, A):
     """Single GPU, [256,256]: weight_grad_assemble_adam_kernel (ppo_dw2.hpp, Dw2Adam) applies clip + Adam from the registers of the workgroups that
