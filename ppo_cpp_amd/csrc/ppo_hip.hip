@@ -2133,10 +2133,14 @@ static void launch_rollout_kernel(ppo_handle* h, const NwRolloutArgs& q, size_t 
     // ONE environment on the device env, reference shape: the whole rollout in one wave, weights in registers (ppo_rollout1.hpp)
     const char* e1 = getenv("PPO_HIP_NO_ROLLOUT1");               // (read per call: the tests compare both forms in one process)
     const bool no_r1 = e1 && e1[0] == '1';
-    if (h->nw_static && q.E == 1 && !q.host_mode && !no_r1) {      // (any observation width up to 64, any action width up to 32)
+    if (h->nw_static && q.E == 1 && !no_r1) {                      // (any observation width up to 64, any action width up to 32)
         ++h->kv[KV_ROLLOUT1];
-        if (n.Kp0 == 32) hipLaunchKernelGGL(narrow_rollout1_kernel<32>, dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
-        else hipLaunchKernelGGL(narrow_rollout1_kernel<64>, dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
+        if (q.host_mode) {                                          // the same three waves resident behind a host Env (round 5)
+            if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_rollout1_kernel<32, true>), dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
+            else hipLaunchKernelGGL((narrow_rollout1_kernel<64, true>), dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
+        }
+        else if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_rollout1_kernel<32, false>), dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
+        else hipLaunchKernelGGL((narrow_rollout1_kernel<64, false>), dim3(1), dim3(192), 0, h->stream, n, h->nw, q);
         return;
     }
     ++h->kv[KV_ROLLOUT_PERSISTENT];

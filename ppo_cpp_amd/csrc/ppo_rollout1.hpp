@@ -27,10 +27,16 @@
         ACC[(k_ >> 2) & 3] = fmaf(xk_, WREG[k_], ACC[(k_ >> 2) & 3]);                                   \
     }
 
+// HOST (round 5; the reference's real setting: ONE environment stepped on the host, ppo2.cpp:215-217): the same three waves stay resident across the env
+// steps of a host-Env rollout and speak narrow_rollout_kernel's protocol (NwRolloutArgs: host_act / ctl[PCTL_D2H], host_in / ctl[PCTL_H2D], bounded waits,
+// ctl[PCTL_EXIT] = 1 + booked transitions, relaunch at t0 with a pending transition).  The env wave cannot run ahead any more -- the transition depends on the
+// action -- so a step is: main wave forward + sample (~1 us) -> action into pinned memory -> host Env::step -> env wave reads the transition, books it (statistics,
+// reward) and hands the next normalised observation over.  narrow_rollout_kernel spent 10.5 k cycles of LDS tiles and barriers on that one live row.
 // KP0 = observation tile (32 or 64 columns); the dense widths O <= KP0 and A <= 32 are uniform run-time values
-template <int KP0>
+template <int KP0, bool HOST = false>
 __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayout lay, NwRolloutArgs q) {
     __shared__ float s_hand[2][96];                          // [parity of t]: 0..A-1 noise of step t, 32..32+O-1 the normalised observation of step t
+    __shared__ int s_stop;                                   // HOST: the env wave gave up waiting for the host (or was asked to stop): everybody leaves at the next barrier
     warm_kernargs<sizeof(NetDev) + sizeof(NwLayout) + sizeof(NwRolloutArgs)>();
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const int O = __builtin_amdgcn_readfirstlane(net.O), A = __builtin_amdgcn_readfirstlane(net.A);
@@ -44,6 +50,7 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
         produce(q.t0);
         for (int t = q.t0; t < q.T; ++t) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // what was produced for step t is visible to the main wave
+            if (HOST && *(volatile int*)&s_stop) break;
             if (t + 1 < q.T) produce(t + 1);
         }
         return;
@@ -75,6 +82,14 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
                 s_hand[t & 1][32 + lane] = x;
             }
         };
+        // HOST: the transition the host posted into the pinned block [O obs | reward | done] (system-scope loads: never served by a cache)
+        auto read_host = [&](float& rew_out) __attribute__((always_inline)) {
+            raw = lj ? __hip_atomic_load(q.host_in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+            rew_out = __hip_atomic_load(q.host_in + O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            done = __hip_atomic_load(q.host_in + O + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        };
+        int booked = q.t0;                                   // HOST: transitions whose bookkeeping is done (the exit report)
+        if constexpr (!HOST) {
         publish(q.t0);
         for (int t = q.t0; t < q.T; ++t) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // block t is complete; the main wave is done with block t + 1's buffer
@@ -119,12 +134,67 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
             }
             if (t + 1 < q.T) publish(t + 1);
         }
+        } else {
+        // ---- HOST: the same statements, the transition from the host instead of the counter hash; t = t0 - 1 books a transition posted before this launch ----
+        bool stopped = false;
+        if (lane == 0) s_stop = 0;
+        for (int t = q.pending ? q.t0 - 1 : q.t0; t < q.T; ++t) {
+            float rew;
+            if (t < q.t0) read_host(rew);
+            else {
+                if (t == q.t0 && !q.pending) publish(q.t0);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block t is complete; the main wave is done with block t + 1's buffer
+                if (stopped) break;
+                int ok = 1;                                  // the host's transition after action t: bounded wait on its sequence word
+                if (lane == 0) {
+                    unsigned n = 0;
+                    while (peer_ld_sys(q.ctl + PCTL_H2D) < (unsigned)(t + 1)) {
+                        if (++n > q.poll_cap || peer_ld_sys(q.ctl + PCTL_STOP)) { ok = 0; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                ok = __builtin_amdgcn_readfirstlane(ok);
+                if (!ok) { if (lane == 0) s_stop = 1; stopped = true; continue; }       // (one more barrier: the other waves see the flag there)
+                read_host(rew);
+            }
+            // ---- EnvNormalize::step bookkeeping for a batch of ONE row ----------------------------------------------------------------------------
+            if (q.norm_obs) {
+                float sum = 0.f; sum += raw;
+                const float bmean = sum / 1.0f;                                        // colwise().mean()
+                float m2 = 0.f; { const float d = raw - bmean; m2 += d * d; }
+                float m1, v1;
+                merge(mean, var, obs_cnt, bmean, m2, 1.0f, m1, v1);
+                mean = m1; var = v1; istd = 1.0f / sqrtf(v1 + q.eps);
+                obs_cnt = (double)1.0f + obs_cnt;                                      // :103
+            }
+            {
+                ret = ret * q.gamma + rew;                                             // env_normalize.hpp:66
+                float sum = 0.f; sum += ret;
+                float m1 = ret_mean, v1 = ret_var;
+                if (q.norm_rew) {                                                      // :75-77 (training)
+                    const float bmean = sum / 1.0f;
+                    float m2 = 0.f; { const float d = ret - bmean; m2 += d * d; }
+                    merge(ret_mean, ret_var, ret_cnt, bmean, m2, 1.0f, m1, v1);
+                    ret_cnt = (double)1.0f + ret_cnt;
+                }
+                ret_mean = m1; ret_var = v1;
+                const float inv = 1.0f / sqrtf(v1 + q.eps);                            // :79
+                float y = rew;
+                if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
+                if (lane == 0) q.ro_rew[t] = y;
+                ret = ret * (1.0f - done);                                             // :88-91
+            }
+            booked = t + 1;
+            if (t + 1 < q.T) publish(t + 1);
+        }
+        }
         // ---- exit: the state goes home ---------------------------------------------------------------------------------------------------------
         if (lj) { q.st.raw_obs[lane] = raw; q.st.obs_mean[lane] = mean; q.st.obs_var[lane] = var; }
         if (lane == 0) {
             q.st.done[0] = done; q.st.ret[0] = ret;
             *q.st.obs_count = obs_cnt; *q.st.ret_mean = ret_mean; *q.st.ret_var = ret_var; *q.st.ret_count = ret_cnt;
         }
+        if (HOST && lane == 0) peer_st_sys(q.ctl + PCTL_EXIT, 1u + (unsigned)booked);      // (the state is read by the NEXT launch: the kernel boundary orders it)
         return;
     }
     // ---- main wave: this lane's weight columns and biases ------------------------------------------------------------------------------------
@@ -143,6 +213,7 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
     const float bmu = lane < 32 ? par[net.par_bmu + lane] : 0.f, lsj = lane < 32 ? par[net.par_ls + lane] : 0.f;
     for (int t = q.t0; t < q.T; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // the other waves' block of step t is complete (and they may overwrite the other one)
+        if (HOST && *(volatile int*)&s_stop) break;
         const float* hb = s_hand[t & 1];
         float eps = 0.f, x = 0.f;
         if (la) eps = q.noise ? q.noise[(size_t)t * A + lane] : hb[lane];
@@ -158,6 +229,13 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
         const float act = mu + sigma * eps;
         const float z = (act - mu) / sigma;
         if (la) q.ro_act[(size_t)t * A + lane] = act;
+        if constexpr (HOST) {
+            // the action goes out FIRST (system-scope write-through stores into pinned host memory, drained, then the sequence word): the host steps its Env
+            // while this wave finishes the row
+            if (la) __hip_atomic_store(q.host_act + lane, act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) peer_st_sys(q.ctl + PCTL_D2H, (unsigned)(t + 1));
+        }
         // the per-step kernels add elements j and j + 16 on lane j of a 16-lane group, then group16_sum: same order here
         float zz = la ? z * z : 0.f, sl = la ? logstd : 0.f;
         const float zz_hi = __shfl_down(zz, 16), sl_hi = __shfl_down(sl, 16);

@@ -335,14 +335,17 @@ def test_host_env_small_batches_three_forms_agree(hidden, E, T, monkeypatch):
     rollout from one launch, talking to the host through sequence words in pinned memory, (b) one fused launch per env step,
     (c) the general path (copy, statistics kernel, both towers, copy back).  (a) and (b) run the same statements: every rollout
     field and the statistics must be bit-identical, over two rollouts (state carried over); (c) agrees to rounding.  A host that
-    pauses longer than the kernel is willing to poll makes it park itself and be relaunched mid-rollout: same bits."""
+    pauses longer than the kernel is willing to poll makes it park itself and be relaunched mid-rollout: same bits.  With ONE environment on the
+    reference's shape the resident kernel is narrow_rollout1_kernel<.., HOST> -- three waves, the policy's weights in registers (round 5) --;
+    PPO_HIP_NO_ROLLOUT1=1 ("resident_tiles") keeps the 32-row resident workgroup there: same bits again."""
     import time
     rng = np.random.RandomState(7)
     trans = [(rng.uniform(-1, 1, (E, 18)).astype(np.float32), rng.uniform(-1, 1, E).astype(np.float32), (rng.uniform(size=E) < 0.1).astype(np.float32))
              for _ in range(2 * T + 1)]
     outs = {}
-    for form in ("resident", "resident_parking", "fused", "general"):
+    for form in ("resident", "resident_parking", "resident_tiles", "fused", "general"):
         monkeypatch.setenv("PPO_HIP_NO_HOST_RESIDENT", "0" if form.startswith("resident") else "1")
+        monkeypatch.setenv("PPO_HIP_NO_ROLLOUT1", "1" if form == "resident_tiles" else "0")
         monkeypatch.setenv("PPO_HIP_NO_HOST_FUSED", "1" if form == "general" else "0")
         monkeypatch.setenv("PPO_HIP_HOST_POLLS", "300" if form == "resident_parking" else "150000")
         orc, g = pair(hidden)
@@ -363,10 +366,16 @@ def test_host_env_small_batches_three_forms_agree(hidden, E, T, monkeypatch):
                 m, v, c = g.norm_stats(which)
                 got["%s_mean%d" % (nm, it)], got["%s_var%d" % (nm, it)], got["%s_cnt%d" % (nm, it)] = m, v, np.float64(c)
         outs[form] = got
+        kc = g.kernel_counts()
+        if form.startswith("resident"):
+            one_wave = hidden == (64, 64) and E == 1 and form != "resident_tiles"
+            assert (kc["narrow_rollout1_kernel"] > 0) == one_wave and (kc["narrow_rollout_kernel"] > 0) == (not one_wave), (form, kc)
         g.close()
+    monkeypatch.delenv("PPO_HIP_NO_ROLLOUT1", raising=False)
     assert np.abs(outs["fused"]["actions1"]).max() > 0
     for key in outs["fused"]:
         np.testing.assert_array_equal(outs["resident"][key], outs["fused"][key], err_msg="resident vs fused: " + key)
+        np.testing.assert_array_equal(outs["resident_tiles"][key], outs["fused"][key], err_msg="resident (32-row workgroup) vs fused: " + key)
         np.testing.assert_array_equal(outs["resident_parking"][key], outs["fused"][key], err_msg="parking vs fused: " + key)
         close(outs["general"][key], outs["fused"][key], rtol=2e-4, atol=2e-5, msg="general vs fused: " + key)
 
