@@ -2735,7 +2735,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     if (h->narrow && h->nw_epoch && h->nw_epoch_xl && !h->comm && (M + NW_ROWS - 1) / NW_ROWS <= NW_EPOCH_MAX_G) {
         // the XCD-local epoch kernel's partial gradient vectors: one set per minibatch of an epoch (zero-filled: padding elements are never written and must read 0)
         const size_t need = (size_t)nmb * 2 * ((M + NW_ROWS - 1) / NW_ROWS) * h->nw_stride;
-        if (need > h->nw_epoch_cap) {
+        if (need > h->nw_epoch_cap && need <= ((size_t)256 << 20) / sizeof(float)) {      // (thousands of tiny minibatches: the write-through form's two sets instead)
             HIP_OK(h, hipStreamSynchronize(h->stream));
             if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
             if (dev_alloc(h, &h->nw_epoch_partials, need)) return -1;
