@@ -13,6 +13,8 @@
 #include "ppo_rollout1.hpp"
 
 #include <dlfcn.h>
+#include <immintrin.h>     // _mm_sfence (host side of the VRAM inbox)
+#include <sys/mman.h>      // msync: is a device allocation mapped into this process?
 
 #include <algorithm>
 #include <cmath>
@@ -146,6 +148,9 @@ struct ppo_handle {
     int norm_obs_flag = 1, norm_rew_flag = 1;   // EnvNormalize's norm_obs / norm_reward (env_normalize.hpp:75,95)
     float* env_in = nullptr;          // [E*O | E | E] raw obs | raw reward | dones of the current env step, one block: one H2D per env step
     float* pin_in = nullptr;          // pinned host mirror of env_in (hipHostMalloc, owned by the handle)
+    // ONE environment behind a host Env, resident three-wave kernel: the transition ALSO goes straight into device memory through the BAR (posted writes) with its own
+    // sequence word, so the kernel polls and reads local memory instead of host memory over PCIe (large-BAR devices; PPO_HIP_NO_VRAM_INBOX=1 keeps the pinned block only)
+    float* vram_in = nullptr; unsigned* vram_h2d = nullptr;
     float* pin_out = nullptr;         // pinned host landing buffer for the actions of one env step [E*A]
     size_t pin_in_n = 0, pin_out_n = 0;
     // fused host-Env step for <= 32 environments (narrow_host_step_kernel): the kernel reads pin_in / writes pin_out itself
@@ -1606,6 +1611,7 @@ void ppo_destroy(ppo_handle* h) {
         for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) for (bf16_t* p : {b.hb[t][l], b.dy[t][l]}) if (p) (void)hipFree(p);
     }
     if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->vram_in) (void)hipFree(h->vram_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_flag) (void)hipHostFree(h->pin_flag);
     if (h->pin_wgflag) (void)hipHostFree(h->pin_wgflag);
@@ -1881,6 +1887,24 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
     }
     h->host_pending = false;
     h->pin_in_n = in_n; h->pin_out_n = (size_t)n_envs * h->net.A;
+    {
+        if (h->vram_in) { (void)hipFree(h->vram_in); h->vram_in = nullptr; h->vram_h2d = nullptr; }
+        int large_bar = 0;
+        const char* nv = getenv("PPO_HIP_NO_VRAM_INBOX");
+        if (n_envs == 1 && h->narrow && h->nw_static && !(nv && nv[0] == '1') &&
+            hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
+            const size_t words = ru((int)in_n, 32) + 64;
+            float* box = nullptr;
+            if (hipMalloc((void**)&box, words * sizeof(float)) == hipSuccess) {
+                (void)hipMemset(box, 0, words * sizeof(float));
+                (void)hipDeviceSynchronize();
+                // is the allocation mapped into this process (the host will store into it)?  msync on an unmapped page fails with ENOMEM
+                const uintptr_t pg = (uintptr_t)box & ~(uintptr_t)4095;
+                if (msync((void*)pg, 4096, MS_ASYNC) == 0) { h->vram_in = box; h->vram_h2d = reinterpret_cast<unsigned*>(box + ru((int)in_n, 32) + 32); }
+                else (void)hipFree(box);
+            }
+        }
+    }
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -2150,6 +2174,14 @@ static void launch_rollout_kernel(ppo_handle* h, const NwRolloutArgs& q, size_t 
 #undef X
 }
 
+// the VRAM inbox's sequence word, stored by the host through the BAR (write-combined: fenced on both sides)
+static void vram_word(ppo_handle* h, unsigned v) {
+    if (!h->vram_h2d) return;
+    _mm_sfence();
+    *reinterpret_cast<volatile unsigned*>(h->vram_h2d) = v;
+    _mm_sfence();
+}
+
 // ---- resident host-Env rollout kernel (see NwRolloutArgs) -----------------------------------------------------------------------
 // control words live at pin_flag + 64 (the first line is the per-launch completion word of narrow_host_step_kernel)
 static unsigned* hp_ctl(ppo_handle* h) { return h->pin_flag + 64; }
@@ -2164,6 +2196,8 @@ static int hp_launch(ppo_handle* h, int t0, uint32_t rng_step_t0) {
     q.gamma = h->nz_gamma; q.clip_rew = h->nz_clip_rew; q.clip_obs = h->nz_clip_obs; q.eps = h->nz_eps; q.norm_obs = h->norm_obs_flag; q.norm_rew = h->norm_rew_flag;
     q.host_mode = 1; q.t0 = t0; q.pending = h->host_pending ? 1 : 0;
     q.host_in = h->pin_in_dev; q.host_act = h->pin_out_dev; q.ctl = h->pin_flag_dev + 64;
+    { const char* e1 = getenv("PPO_HIP_NO_ROLLOUT1");
+      if (h->vram_in && h->E == 1 && h->nw_static && !(e1 && e1[0] == '1')) { q.host_in = h->vram_in; q.h2d = h->vram_h2d; } }     // (narrow_rollout1_kernel<.., HOST>: system-scope loads only)
     const char* pc = getenv("PPO_HIP_HOST_POLLS");
     q.poll_cap = pc ? (unsigned)atol(pc) : 150000u;                 // ~2 us per poll over PCIe: a fraction of a second, then the kernel parks itself
     __atomic_store_n(hp_ctl(h) + PCTL_EXIT, 0u, __ATOMIC_RELEASE);
@@ -2217,7 +2251,7 @@ int ppo_rollout_reset(ppo_handle* h, const float* raw_obs) {
     if (host_quiesce(h)) return -1;                             // (a transition observed before the reset is still booked, as on the general path)
     if (h->pin_in_busy) HIP_OK(h, hipStreamSynchronize(h->stream));
     h->pin_in_busy = false; h->host_pending = false; h->hp_posted = 0;
-    if (h->pin_flag) { __atomic_store_n(hp_ctl(h) + PCTL_H2D, 0u, __ATOMIC_RELEASE); __atomic_store_n(hp_ctl(h) + PCTL_D2H, 0u, __ATOMIC_RELEASE); }
+    if (h->pin_flag) { __atomic_store_n(hp_ctl(h) + PCTL_H2D, 0u, __ATOMIC_RELEASE); __atomic_store_n(hp_ctl(h) + PCTL_D2H, 0u, __ATOMIC_RELEASE); vram_word(h, 0u); }
     memcpy(h->pin_in, raw_obs, on * sizeof(float));
     HIP_OK(h, hipMemcpyAsync(h->raw_obs, h->pin_in, on * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemsetAsync(h->nz_ret, 0, (size_t)h->E * sizeof(float), h->stream));          // env_normalize.hpp:114
@@ -2249,6 +2283,7 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
                 HIP_OK(h, hipStreamSynchronize(h->stream));
                 __atomic_store_n(ctl + PCTL_H2D, 0u, __ATOMIC_RELEASE);
                 __atomic_store_n(ctl + PCTL_D2H, 0u, __ATOMIC_RELEASE);
+                vram_word(h, 0u);
             }
             h->hp_posted = 0;
         }
@@ -2351,6 +2386,7 @@ int ppo_rollout_observe(ppo_handle* h, int32_t t, const float* raw_obs, const fl
     memcpy(h->pin_in + on + E, dones, E * sizeof(float));
     if (host_small(h) && h->host_proto) {                       // the (next or resident) launch reads the block in place
         h->host_pending = true; h->host_pending_t = t; h->hp_posted = t + 1;
+        if (h->vram_in) { memcpy(h->vram_in, h->pin_in, (on + 2 * E) * sizeof(float)); vram_word(h, (unsigned)(t + 1)); }      // (posted writes; the data first)
         __atomic_store_n(hp_ctl(h) + PCTL_H2D, (unsigned)(t + 1), __ATOMIC_RELEASE);
         return 0;
     }
@@ -2369,7 +2405,7 @@ int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
             // stopped early it is asked to leave
             if (hp_retire(h, h->hp_posted < h->T)) return -1;
         }
-        if (h->pin_flag) { __atomic_store_n(hp_ctl(h) + PCTL_H2D, 0u, __ATOMIC_RELEASE); __atomic_store_n(hp_ctl(h) + PCTL_D2H, 0u, __ATOMIC_RELEASE); }
+        if (h->pin_flag) { __atomic_store_n(hp_ctl(h) + PCTL_H2D, 0u, __ATOMIC_RELEASE); __atomic_store_n(hp_ctl(h) + PCTL_D2H, 0u, __ATOMIC_RELEASE); vram_word(h, 0u); }
         if (host_flush_pending(h)) return -1;                                              // the last transition's bookkeeping
         StepArgs va{};                                                                     // values of all T x E normalised rows, batched
         va.obs = h->ro_obs; va.value = h->ro_val; va.n = h->E * h->T; va.nz = no_norm();

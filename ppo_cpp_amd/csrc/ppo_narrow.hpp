@@ -1372,6 +1372,8 @@ struct NwRolloutArgs {
     // (t0, pending = a posted transition is still unbooked).  step0 is then the counter-RNG step of row t0 minus t0.
     int host_mode, t0, pending;
     const float* host_in; float* host_act; unsigned* ctl; unsigned poll_cap;
+    const unsigned* h2d;         // narrow_rollout1_kernel<.., HOST> only: the host's sequence word in DEVICE memory (the host stores the transition and this word through the
+                                 // BAR: posted writes, and the kernel polls its own memory -- two PCIe read round trips per env step less); null: ctl[PCTL_H2D] in pinned host memory
 };
 #define PCTL_H2D 0
 #define PCTL_D2H 16

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
                 int ok = 1;                                  // the host's transition after action t: bounded wait on its sequence word
                 if (lane == 0) {
                     unsigned n = 0;
-                    while (peer_ld_sys(q.ctl + PCTL_H2D) < (unsigned)(t + 1)) {
+                    const unsigned* hw = q.h2d ? q.h2d : q.ctl + PCTL_H2D;
+                    while (peer_ld_sys(hw) < (unsigned)(t + 1)) {
                         if (++n > q.poll_cap || peer_ld_sys(q.ctl + PCTL_STOP)) { ok = 0; break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
