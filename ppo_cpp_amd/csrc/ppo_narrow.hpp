@@ -688,7 +688,8 @@ __global__ __launch_bounds__(256) void narrow_reduce_kernel(NwReduceArgs a) {
 // bound, profiles/r03_d_*; this one keeps the launch form's 2 CUs per tower.)  At exit the owners write weights, moments and the packed image back.
 // ------------------------------------------------------------------------------------------------------------------------
 #define NW_EPOCH_MAX_G 2
-#define NW_EPOCH_WORDS 16                // meeting table: [2 G] step counters ... [NW_EPOCH_WORDS - 1] raised when a wait timed out
+#define NW_EPOCH_WORDS 16                // meeting table: [2 G] step counters ... [NW_EPOCH_BASE] steps completed by earlier launches, [NW_EPOCH_WORDS - 1] raised when a wait timed out
+#define NW_EPOCH_BASE 8                  // (ONE base for all workgroups: a word of its own per workgroup breaks when the number of row groups changes between launches)
 struct NwEpochArgs {
     const float* obs; const float* actions; const float* advs; const float* returns; const float* old_values; const float* old_neglogp;   // minibatch k = rows [k M, (k + 1) M)
     int M, nmb; float inv_n;
@@ -722,7 +723,9 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
     const int row0 = grp * NW_ROWS;
     unsigned xcc = 0;
     if constexpr (XL) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 15u; }
-    const unsigned e0 = __hip_atomic_load(e.words + wid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 4;      // (only this workgroup writes its word: (steps so far << 4) | XCC id)
+    // steps completed by earlier launches: written by workgroup 0 at its exit only (behind the last meeting, so every workgroup of THIS launch has read it by then); a
+    // workgroup's word holds (absolute step count << 4) | XCC id, compared modulo 2^28
+    const unsigned e0 = __hip_atomic_load(e.words + NW_EPOCH_BASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x0FFFFFFFu;
     NwLazyRegs<NP> R;
     R.b1p = e.beta_pow[2]; R.b2p = e.beta_pow[3]; R.lr = e.hyper[0];           // `next` = the powers the first step applies (the launch form copies them to `cur` first)
 #pragma unroll
@@ -786,14 +789,14 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         ESTAMP(16);
-        const unsigned target = e0 + (unsigned)k + 1u;
+        const unsigned target = (e0 + (unsigned)k + 1u) & 0x0FFFFFFFu;
         if (tid == 0) __hip_atomic_store(e.words + wid, (target << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         parts[tid] = 0.f;                                     // (NW_THREADS = 512 entries; chunks without a piece -- alignment gaps -- stay zero)
         if (tid < 64) {
             unsigned polls = 0;
             for (;;) {
                 const unsigned w = lane < nwg ? __hip_atomic_load(e.words + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((target << 4) | xcc);
-                if (__all((int)((w >> 4) - target) >= 0)) {
+                if (__all((((w >> 4) - target) & 0x0FFFFFFFu) < 0x08000000u)) {
                     if (XL && (w & 15u) != xcc) __hip_atomic_store(e.words + NW_EPOCH_WORDS - 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -910,6 +913,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
         for (int i = tid; i < lay.w_total / 4; i += NW_THREADS) reinterpret_cast<float4*>(img)[i] = reinterpret_cast<const float4*>(lds)[i];
     }
     if (wid == 0 && tid == 0) {
+        __hip_atomic_store(e.words + NW_EPOCH_BASE, (e0 + (unsigned)e.nmb) & 0x0FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         e.beta_pow[0] = R.b1p; e.beta_pow[1] = R.b2p;                                              // cur = what the last step applied
         e.beta_pow[2] = R.b1p * e.beta1; e.beta_pow[3] = R.b2p * e.beta2;
         if (e.norm_out) *e.norm_out = norm;
@@ -947,7 +951,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev ne
     const int G = (int)gridDim.x, nwg = 2 * G, tower = blockIdx.y, grp = blockIdx.x, wid = tower * G + grp;
     const int tid0 = threadIdx.x;
     const int row0 = grp * NW_ROWS;
-    const unsigned e0 = __hip_atomic_load(e.words + wid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (only this workgroup writes its word)
+    const unsigned e0 = __hip_atomic_load(e.words + NW_EPOCHD_MAX_WG + 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // meetings completed by earlier launches (see narrow_epoch_kernel)
     NwLazyRegs<NP> R;
     R.b1p = e.beta_pow[2]; R.b2p = e.beta_pow[3]; R.lr = e.hyper[0];
     int offs[NP];
@@ -1133,6 +1137,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev ne
         for (int i = tid; i < lay.w_total / 4; i += NW_THREADS) reinterpret_cast<float4*>(img)[i] = reinterpret_cast<const float4*>(lds)[i];
     }
     if (wid == 0 && tid == 0) {
+        __hip_atomic_store(e.words + NW_EPOCHD_MAX_WG + 48, e0 + 2u * (unsigned)e.nmb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         e.beta_pow[0] = R.b1p; e.beta_pow[1] = R.b2p;
         e.beta_pow[2] = R.b1p * e.beta1; e.beta_pow[3] = R.b2p * e.beta2;
         if (e.norm_out) *e.norm_out = norm;

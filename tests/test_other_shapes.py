@@ -208,7 +208,8 @@ def test_fused_train_and_weight_gradient_launch_is_bitwise_the_two_launches(monk
             np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("O,E,T,nmb,explicit", [(18, 1, 2048, 32, False), (36, 1, 2048, 32, True), (18, 4, 120, 10, True), (18, 1, 512, 32, False), (36, 2, 24, 1, False)])
+@pytest.mark.parametrize("O,E,T,nmb,explicit", [(18, 1, 2048, 32, False), (36, 1, 2048, 32, True), (18, 4, 120, 10, True), (18, 1, 512, 32, False), (36, 2, 24, 1, False),
+                                                (18, 1, 7, 7, True), (18, 3, 11, 1, False)])      # one-row minibatches; 33 rows in one minibatch (a second group of ONE row)
 def test_resident_epoch_kernel_is_bitwise_the_launch_per_train_step(O, E, T, nmb, explicit, monkeypatch):
     """narrow_epoch_kernel (ppo_narrow.hpp): on the reference's own shape -- [64,64], minibatches of <= 64 rows (ppo2.cpp:114-128: 1 environment x 2048 steps, 32
     minibatches) -- ALL minibatches of an epoch run in one launch whose 2 - 4 workgroups keep the weight image in LDS, the Adam moments in registers and meet once per
@@ -245,6 +246,29 @@ def test_resident_epoch_kernel_is_bitwise_the_launch_per_train_step(O, E, T, nmb
         np.testing.assert_array_equal(a, b)
     outs = [outs[0], outs[2]]
     assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][2]).max() > 0
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_resident_epoch_kernel_follows_a_changing_minibatch_count(monkeypatch):
+    """One handle, three updates with 8, then 32, then 4 minibatches (the XCD-local form's per-step partial buffers grow with the count; the captured graph is rebuilt):
+    bit-identical to the launch per train step."""
+    E, T = 2, 128
+    noise = np.random.RandomState(8).normal(size=(T, E, 18)).astype(np.float32)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PPO_HIP_NO_NARROW_EPOCH", mode)
+        g = hip((64, 64)); g.init_orthogonal(4)
+        g.norm_init(E); g.rollout_alloc(E, T)
+        g.collect_synthetic(77, GAMMA, LAM, noise)
+        acc = []
+        for u, nmb in enumerate((8, 32, 4)):
+            rows, mean = g.update(LR, CR, 2, nmb, None, seed=20 + u)
+            acc += [rows.copy(), mean.copy(), g.get_flat(0), g.get_flat(1)]
+        kc = g.kernel_counts()
+        assert (kc["narrow_epoch_kernel"] > 0) == (mode == "0")
+        outs.append(acc)
+        g.close()
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
 
