@@ -403,10 +403,14 @@ __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_nt_bf16_kernel(GemmArgs a
 struct ChainArgs {
     int n;                                    // links: link l + 1 reads link l's C as its A
     int tiles_i, tiles_j;                     // of every link (same output shape)
-    unsigned* words;                          // [GB_CHAIN_MAX][2 * tiles_i groups][16]: (epoch << 4) | xcc per workgroup; then the error word at [GB_CHAIN_WORDS]
+    unsigned* words;                          // [GB_CHAIN_MAX][2 * tiles_i groups][16]: (epoch << 4) | xcc per workgroup.  ONE table per number of row groups (the host keeps
+                                              // GB_CHAIN_SHAPES of them): a workgroup's epoch is its own word + 1, and in a table shared between shapes -- the act path's rows and
+                                              // the minibatch's -- a slot means different (link, group) pairs, so a stale word could satisfy a wait
+    unsigned* err;                            // raised on a time-out (1) or a row group spread over two XCDs (2)
     GemmArgs link[GB_CHAIN_MAX];
 };
 #define GB_CHAIN_WORDS (GB_CHAIN_MAX * 64 * 16)           // up to 64 row groups
+#define GB_CHAIN_SHAPES 8                                 // row-group counts 8, 16, .. 64
 
 template <int EPI>
 __global__ __launch_bounds__(GB_THREADS(4)) void gemm_chain_bf16_kernel(ChainArgs ca) {
@@ -429,9 +433,9 @@ __global__ __launch_bounds__(GB_THREADS(4)) void gemm_chain_bf16_kernel(ChainArg
                 unsigned polls = 0, v;
                 while ((int)(((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) - epoch) < 0) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++polls > (1u << 21)) { __hip_atomic_store(ca.words + GB_CHAIN_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (++polls > (1u << 21)) { __hip_atomic_store(ca.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                 }
-                if ((v & 15u) != xcc) __hip_atomic_store(ca.words + GB_CHAIN_WORDS, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v & 15u) != xcc) __hip_atomic_store(ca.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
         }

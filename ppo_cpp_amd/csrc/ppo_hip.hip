@@ -659,7 +659,7 @@ int bf16_create(ppo_handle* h) {
       b.chain = !(e && e[0] == '1');
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) b.n_cu = prop.multiProcessorCount;
-      for (int d = 0; d < 2 && b.chain; ++d) if (dev_alloc(h, &b.chain_words[d], GB_CHAIN_WORDS + 32)) return -1; }
+      for (int d = 0; d < 2 && b.chain; ++d) if (dev_alloc(h, &b.chain_words[d], (size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS + 32)) return -1; }
     // the persistent assembly + Adam launch needs BRA_GRID workgroups of 1024 threads resident at once: one per CU of a whole device
     b.fuse_ra = b.n_cu >= BRA_GRID && (h->n_blocks + 1 + BGR_WAVES - 1) / BGR_WAVES <= 8 * BRA_GRID;
     if (b.fuse_ra && dev_alloc(h, &b.ra_ent, BRA_GRID + 8)) return -1;
@@ -675,7 +675,9 @@ bool bf16_chain(ppo_handle* h, const GemmArgs* links, int n, int I, int J, int w
     const int tiles_i = I / 256, tiles_j = J / GB_N, G = 2 * tiles_i;
     if (G % 8 != 0 || G > 64 || tiles_j > 16 || G * tiles_j > b.n_cu) return false;
     ChainArgs ca{};
-    ca.n = n; ca.tiles_i = tiles_i; ca.tiles_j = tiles_j; ca.words = b.chain_words[which];
+    ca.n = n; ca.tiles_i = tiles_i; ca.tiles_j = tiles_j;
+    ca.words = b.chain_words[which] + (size_t)(G / 8 - 1) * GB_CHAIN_WORDS;      // a table per number of row groups (ChainArgs::words)
+    ca.err = b.chain_words[which] + (size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS;
     for (int l = 0; l < n; ++l) { ca.link[l] = links[l]; ca.link[l].ksplit = 1; ca.link[l].tiles_i = tiles_i; ca.link[l].tiles_ij = tiles_i * tiles_j; }
     hipLaunchKernelGGL((gemm_chain_bf16_kernel<EPI>), dim3(G * tiles_j), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, ca);
     return hipGetLastError() == hipSuccess;
@@ -699,9 +701,9 @@ int bf16_chain_check(ppo_handle* h) {
     for (int d = 0; d < 2; ++d) {
         unsigned e = 0;
         if (!b.chain_words[d]) continue;
-        HIP_OK(h, hipMemcpy(&e, b.chain_words[d] + GB_CHAIN_WORDS, sizeof e, hipMemcpyDeviceToHost));
+        HIP_OK(h, hipMemcpy(&e, b.chain_words[d] + (size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS, sizeof e, hipMemcpyDeviceToHost));
         if (e) {
-            for (int k = 0; k < 2; ++k) (void)hipMemset(b.chain_words[k], 0, (GB_CHAIN_WORDS + 32) * sizeof e);
+            for (int k = 0; k < 2; ++k) (void)hipMemset(b.chain_words[k], 0, ((size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS + 32) * sizeof e);
             b.chain = false;
             if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
             return fail(h, "gemm_chain_bf16_kernel: %s; this call's results are invalid.  The handle now launches layer by layer (PPO_HIP_NO_BF16_CHAIN=1 selects "

@@ -188,3 +188,26 @@ def test_assembly_clip_and_adam_in_one_launch_are_bitwise_the_two_launches(hidde
     assert np.isfinite(outs[0][-4]).all() and np.abs(outs[0][1]).max() > 0
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_chained_launches_of_two_row_counts_on_one_handle(monkeypatch):
+    """One handle alternating between 4096-row and 2048-row train steps (32 and 16 row groups per chained launch -- as the act path's row count and the minibatch's
+    do in a rollout + update): every shape has its own table of workgroup words (a shared table means a slot is different (link, row group) pairs under different
+    shapes, and a stale word could then satisfy a wait).  Same BITS as a launch per layer (PPO_HIP_NO_BF16_CHAIN=1) after an irregular sequence of both."""
+    seq = [4096] * 6 + [2048] + [4096] * 3 + [2048] * 2 + [4096] * 2 + [2048] + [4096]
+    outs = []
+    for no_chain in ("0", "1"):
+        monkeypatch.setenv("PPO_HIP_NO_BF16_CHAIN", no_chain)
+        orc, g = pair_bf16((1024, 1024, 1024), 256, 64)
+        mbs = {n: H.synth_minibatch(orc, n, seed=5 + n) for n in (4096, 2048)}
+        acc = []
+        for n in seq:
+            mb = mbs[n]
+            acc.append(np.asarray(g.train_step(LR, CR, mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])).copy())
+        acc += [g.get_flat(0), g.get_flat(1), g.get_flat(2)]
+        g.close()
+        outs.append(acc)
+    monkeypatch.delenv("PPO_HIP_NO_BF16_CHAIN", raising=False)
+    assert np.isfinite(outs[0][-3]).all()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
