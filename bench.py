@@ -581,20 +581,32 @@ def main():
         # same run, so that both single-GPU configurations of the baseline are on record; `value` stays configs[2]
         g.close()
         c2 = CONFIGS["cfg2"]
-        g2 = ppo_cpp_amd.PPOHip(c2["obs"], c2["act"], c2["hidden"], device=device)
-        g2.init_orthogonal(0); g2.norm_init(c2["n_envs"], GAMMA); g2.rollout_alloc(c2["n_envs"], c2["n_steps"])
-        def step2(i, first=False):
-            g2.collect_synthetic(1234, GAMMA, LAM, None, env0=0, step0=i * c2["n_steps"], first=first)
-            g2.update(LR, CR, c2["noptepochs"], c2["nminibatches"], None, seed=2000 + i, want_rows=False)
-        step2(0, True); g2.sync()
-        t0 = time.perf_counter()
-        for i in range(3):
-            step2(1 + i)
-        g2.sync()
-        dt2 = (time.perf_counter() - t0) / 3
-        out["also"] = {"BASELINE configs[1] (cfg2)": {"workload": c2["desc"], "value": c2["n_envs"] * c2["n_steps"] / dt2, "unit": "env-steps/s",
-                                                      "ms_per_step": 1e3 * dt2, "steps": 3, "warmup": 1}}
-        g2.close()
+        out["also"] = {}
+        g2 = None
+        for attempt in range(2):                             # extra leg: never fatal for the contract line.  (A kernel whose workgroups meet inside a launch reports a
+            try:                                             # failed placement / residency check ONCE and the handle falls back to the launch per step: second attempt.)
+                if g2 is None:
+                    g2 = ppo_cpp_amd.PPOHip(c2["obs"], c2["act"], c2["hidden"], device=device)
+                    g2.init_orthogonal(0); g2.norm_init(c2["n_envs"], GAMMA); g2.rollout_alloc(c2["n_envs"], c2["n_steps"])
+                def step2(i, first=False):
+                    g2.collect_synthetic(1234, GAMMA, LAM, None, env0=0, step0=i * c2["n_steps"], first=first)
+                    g2.update(LR, CR, c2["noptepochs"], c2["nminibatches"], None, seed=2000 + i, want_rows=False)
+                step2(0, True); g2.sync()
+                t0 = time.perf_counter()
+                for i in range(3):
+                    step2(1 + i)
+                g2.sync()
+                dt2 = (time.perf_counter() - t0) / 3
+                out["also"]["BASELINE configs[1] (cfg2)"] = {"workload": c2["desc"], "value": c2["n_envs"] * c2["n_steps"] / dt2, "unit": "env-steps/s",
+                                                             "ms_per_step": 1e3 * dt2, "steps": 3, "warmup": 1}
+                break
+            except Exception as e:
+                out["also"]["BASELINE configs[1] (cfg2)"] = {"error": repr(e)}
+        if g2 is not None:
+            try:
+                g2.close()
+            except Exception:
+                pass
         g = None
         try:
             # ... and the same configuration as the reference actually runs it: the ONE environment stepped on the HOST (Env::step
