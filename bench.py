@@ -30,7 +30,7 @@ CONFIGS = {
     "cfg3o36": dict(n_envs=4096, n_steps=16, hidden=[256, 256], obs=36, act=18, nminibatches=32, noptepochs=10,
                     desc="configs[2]'s workload with the reference's 36-observation hexapod shape: 4096 envs x 16 steps, MLP [256,256], 32 minibatches x 10 epochs"),
     "cfg2": dict(n_envs=1, n_steps=2048, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
-                 desc="1 env x 2048 steps, MLP [64,64] (launch-latency bound)"),
+                 desc="1 env x 2048 steps, MLP [64,64] (the reference's own command line; one resident launch per epoch)"),
     "cfg4": dict(n_envs=1024, n_steps=64, hidden=[64, 64], obs=18, act=18, nminibatches=32, noptepochs=10,
                  desc="1024 envs x 64 steps, MLP [64,64]"),
     # configs[1] / configs[3] with the hexapod's 36-observation shape (observe_velocities, env/hexapod_closed_loop_env.hpp:20,61-72)
