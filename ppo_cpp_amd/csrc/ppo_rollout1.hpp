@@ -135,8 +135,31 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
             if (t + 1 < q.T) publish(t + 1);
         }
         } else {
-        // ---- HOST: the same statements, the transition from the host instead of the counter hash; t = t0 - 1 books a transition posted before this launch ----
-        bool stopped = false;
+        // ---- HOST: the same statements, the transition from the host instead of the counter hash; t = t0 - 1 books a transition posted before this launch.
+        // The main wave waits for the next NORMALISED OBSERVATION only: the observation statistics are merged and the row handed over first, the reward side of the
+        // transition (return statistics: three dependent divisions and a square root) is booked behind the barrier, while the main wave runs the policy ----
+        bool stopped = false, owe = false;
+        float owe_rew = 0.f, owe_done = 0.f; int owe_t = 0;
+        auto book_reward = [&]() __attribute__((always_inline)) {
+            if (!owe) return;
+            owe = false;
+            const float rew = owe_rew;
+            ret = ret * q.gamma + rew;                                             // env_normalize.hpp:66
+            float sum = 0.f; sum += ret;
+            float m1 = ret_mean, v1 = ret_var;
+            if (q.norm_rew) {                                                      // :75-77 (training)
+                const float bmean = sum / 1.0f;
+                float m2 = 0.f; { const float d = ret - bmean; m2 += d * d; }
+                merge(ret_mean, ret_var, ret_cnt, bmean, m2, 1.0f, m1, v1);
+                ret_cnt = (double)1.0f + ret_cnt;
+            }
+            ret_mean = m1; ret_var = v1;
+            const float inv = 1.0f / sqrtf(v1 + q.eps);                            // :79
+            float y = rew;
+            if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
+            if (lane == 0) q.ro_rew[owe_t] = y;
+            ret = ret * (1.0f - owe_done);                                         // :88-91
+        };
         if (lane == 0) s_stop = 0;
         for (int t = q.pending ? q.t0 - 1 : q.t0; t < q.T; ++t) {
             float rew;
@@ -144,6 +167,7 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
             else {
                 if (t == q.t0 && !q.pending) publish(q.t0);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block t is complete; the main wave is done with block t + 1's buffer
+                book_reward();                               // (of transition t - 1: the main wave is busy with step t)
                 if (stopped) break;
                 int ok = 1;                                  // the host's transition after action t: bounded wait on its sequence word
                 if (lane == 0) {
@@ -151,14 +175,14 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
                     const unsigned* hw = q.h2d ? q.h2d : q.ctl + PCTL_H2D;
                     while (peer_ld_sys(hw) < (unsigned)(t + 1)) {
                         if (++n > q.poll_cap || peer_ld_sys(q.ctl + PCTL_STOP)) { ok = 0; break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                     }
                 }
                 ok = __builtin_amdgcn_readfirstlane(ok);
                 if (!ok) { if (lane == 0) s_stop = 1; stopped = true; continue; }       // (one more barrier: the other waves see the flag there)
                 read_host(rew);
             }
-            // ---- EnvNormalize::step bookkeeping for a batch of ONE row ----------------------------------------------------------------------------
+            // ---- EnvNormalize::step bookkeeping for a batch of ONE row: the observation side now ... ------------------------------------------------
             if (q.norm_obs) {
                 float sum = 0.f; sum += raw;
                 const float bmean = sum / 1.0f;                                        // colwise().mean()
@@ -168,26 +192,11 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
                 mean = m1; var = v1; istd = 1.0f / sqrtf(v1 + q.eps);
                 obs_cnt = (double)1.0f + obs_cnt;                                      // :103
             }
-            {
-                ret = ret * q.gamma + rew;                                             // env_normalize.hpp:66
-                float sum = 0.f; sum += ret;
-                float m1 = ret_mean, v1 = ret_var;
-                if (q.norm_rew) {                                                      // :75-77 (training)
-                    const float bmean = sum / 1.0f;
-                    float m2 = 0.f; { const float d = ret - bmean; m2 += d * d; }
-                    merge(ret_mean, ret_var, ret_cnt, bmean, m2, 1.0f, m1, v1);
-                    ret_cnt = (double)1.0f + ret_cnt;
-                }
-                ret_mean = m1; ret_var = v1;
-                const float inv = 1.0f / sqrtf(v1 + q.eps);                            // :79
-                float y = rew;
-                if (q.norm_rew) { y = y * inv; y = tf_min(tf_max(y, -q.clip_rew), q.clip_rew); }
-                if (lane == 0) q.ro_rew[t] = y;
-                ret = ret * (1.0f - done);                                             // :88-91
-            }
+            owe = true; owe_rew = rew; owe_done = done; owe_t = t;                     // ... the reward side behind the next barrier (or at the exit)
             booked = t + 1;
             if (t + 1 < q.T) publish(t + 1);
         }
+        book_reward();
         }
         // ---- exit: the state goes home ---------------------------------------------------------------------------------------------------------
         if (lj) { q.st.raw_obs[lane] = raw; q.st.obs_mean[lane] = mean; q.st.obs_var[lane] = var; }
@@ -229,7 +238,6 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
         const float sigma = expf(logstd);
         const float act = mu + sigma * eps;
         const float z = (act - mu) / sigma;
-        if (la) q.ro_act[(size_t)t * A + lane] = act;
         if constexpr (HOST) {
             // the action goes out FIRST (system-scope write-through stores into pinned host memory, drained, then the sequence word): the host steps its Env
             // while this wave finishes the row
@@ -237,6 +245,7 @@ __global__ __launch_bounds__(192) void narrow_rollout1_kernel(NetDev net, NwLayo
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) peer_st_sys(q.ctl + PCTL_D2H, (unsigned)(t + 1));
         }
+        if (la) q.ro_act[(size_t)t * A + lane] = act;
         // the per-step kernels add elements j and j + 16 on lane j of a 16-lane group, then group16_sum: same order here
         float zz = la ? z * z : 0.f, sl = la ? logstd : 0.f;
         const float zz_hi = __shfl_down(zz, 16), sl_hi = __shfl_down(sl, 16);
