@@ -19,7 +19,7 @@
  *   - there is NO CPU fallback: every call fails loudly when no gfx950 device is usable
  *   - PPO_F32 arithmetic: exact-fp32 matrix instructions (a k-ordered fmaf chain), correctly rounded square root / division in
  *     the clip + Adam step.  ONE stated deviation: a handle of the reference's own [64,64] shape (up to 64 observations and 32 actions: 18 / 18 and the 36 / 18 of observe_velocities) applies Adam
- *     inside the next train kernel's prologue during ppo_update and uses the hardware's 1-ulp reciprocal and square root for the
+ *     inside the next train kernel's prologue (or, with minibatches of <= 64 rows, inside the resident epoch kernel) during ppo_update and uses the hardware's 1-ulp reciprocal and square root for the
  *     quotient m * alpha / (sqrt(v) + eps) in ALL its Adam steps (so that both forms agree bit for bit): a 3-ulp error in an update
  *     term that is ~1e-3 of the weight.  PPO_HIP_NO_LAZY_ADAM=1 switches that form, and the deviation, off.
  */
@@ -167,7 +167,8 @@ int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count
  * perms [noptepochs, B] int32: perms[ep][i] = destination row of flattened source row i in epoch ep
  * (out.row(perm[i]) = in.row(i), ppo2.hpp:291-296), or NULL = fresh on-device pseudo-random permutation per
  * epoch keyed by (seed, epoch).  loss_rows [noptepochs*nminibatches, 5] (may be NULL); mean_losses = their
- * column means (ppo2.hpp:335).  One HIP launch sequence per minibatch, replayed from a hipGraph. */
+ * column means (ppo2.hpp:335).  One HIP launch sequence per minibatch, replayed from a hipGraph (the reference's own shape -- [64,64], minibatches of <= 64 rows --
+ * runs all minibatches of an epoch inside ONE resident launch; same results bit for bit, PPO_HIP_NO_NARROW_EPOCH=1 keeps the launches). */
 int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t noptepochs, int32_t nminibatches,
                const int32_t* perms, uint64_t seed, float* loss_rows, float mean_losses[5]);
 
@@ -221,7 +222,7 @@ int ppo_prof_read(ppo_handle* h, int max, char names[][32], double* total_ms, in
 int ppo_sync(ppo_handle* h);
 /* which kernel VARIANT the calls so far took: the library picks its kernels from the shape, and a caller or a
  * test can ask which ones were ENQUEUED since ppo_create (a hipGraph capture counts once, its replays do not).  names: e.g.
- * "train8_kernel", "weight_grad_assemble_kernel", "narrow_train_kernel<static>", "narrow_rollout1_kernel"; returns the count of entries */
+ * "train8_kernel", "weight_grad_assemble_kernel", "narrow_train_kernel<static>", "narrow_epoch_kernel", "narrow_rollout1_kernel"; returns the count of entries */
 int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueued);
 
 #ifdef __cplusplus
