@@ -122,12 +122,13 @@ __device__ __forceinline__ void dw2_strip_mma(const float (&u)[2][NU], const flo
 // slot jobs read rows of EVERY split of either tower, so their loads wait -- behind the chunk loop, when it costs nothing -- until all FAB words show `epoch`.
 struct Dw2Meet { const unsigned* words; unsigned epoch; unsigned* err; int n; };
 // ADAM (single GPU, the launch every workgroup of which is resident at once: one per CU): clip + Adam ride in THIS launch.  A tile's finisher holds the
-// assembled gradient tile (and strip) in registers and a slot job's lanes hold its element; the only thing missing is the global norm -- a sum over all
-// DW2_TILES + DW2_GRID partials.  So every partial is published as ONE 8-byte word {epoch, partial} (a write-through store, no read-modify-write: the
-// epoch says "written in this launch", the table needs no reset), 256 threads of every workgroup watch the 320 words, and when the last one shows this
-// launch's epoch the values they just read ARE the partials -- no second round trip.  Everybody adds them up in adam_kernel's order and applies TF's
-// ApplyAdam to what it holds: weights, transposed copies (the W1 tile leaves through LDS as 256-byte rows), the small-parameter mirror.  Same arithmetic,
-// same order, same bits as the adam_kernel launch it replaces (tests/test_other_shapes.py).
+// assembled gradient tile (and strip) in registers; the only thing missing is the global norm -- a sum over all DW2_TILES + DW2_GRID partials.  So every
+// partial is published as ONE 8-byte word {epoch, partial} (a write-through store, no read-modify-write: the epoch says "written in this launch", the table
+// needs no reset); the 64 FINISHERS go on (the other 192 workgroups leave after their arrival: they would only add pollers to the table's lines), each also
+// takes the slot-job elements of its tile's four workgroups, 256 of its threads watch the 320 words, and when the last one shows this launch's epoch the values
+// they just read ARE the partials -- no second round trip.  They add them up in adam_kernel's order and apply TF's ApplyAdam to what they hold: weights,
+// transposed copies (the W1 tile leaves through LDS as 256-byte rows), the small-parameter mirror.  Same arithmetic, same order, same bits as the adam_kernel
+// launch it replaces (tests/test_other_shapes.py).
 // OPT-IN (PPO_HIP_ADAM_IN_B=1), because it only breaks even: 39.6 us per train step at BASELINE configs[2] against 39.35 - 39.5 with the launch
 // (profiles/r05_g_adam_in_weight_grad_launch.txt).  Behind the last tile arrival the chain is finisher 3.2 k cycles -> meeting >= 3.3 k (the last word's
 // store, then a poll that sees it: two trips to the memory side) -> norm 0.7 k -> apply 2.6 - 3.2 k, and the apply is instruction-issue bound: TF's Adam
