@@ -375,3 +375,22 @@ def test_running_statistics_of_wide_observations(O, E):
     if E <= 8192:
         b = run()
         np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("O", [18, 256, 100])
+def test_running_statistics_with_a_changing_row_count_on_one_handle(O):
+    """ONE handle re-initialised (ppo_norm_init) for 5000, 300, 150 000, 64, 4097, 1, 9000 and 5000 environments in turn, three batches each: the statistics kernel's
+    chunking, its arrival counters and (256 columns) its column-group dealing all depend on the row count, and whatever a launch of one shape leaves behind in the
+    handle's scratch must not disturb the next shape.  Every normalised batch and the statistics against a fresh oracle normaliser
+    (RunningStatistics::update, common/running_statistics.hpp:26-104); the count exact."""
+    g = hip((256, 256), O, 18)
+    rng = np.random.RandomState(11)
+    for it, n in enumerate((5000, 300, 150000, 64, 4097, 1, 9000, 5000)):
+        g.norm_init(n)
+        nz = o.Normalizer(n, O)
+        for b in range(3):
+            raw = rng.normal(loc=-0.3, scale=1.5, size=(n, O)).astype(np.float32)
+            close(g.norm_obs(raw, True), nz.obs(raw), rtol=3e-5, atol=3e-6, msg="shape %d (%d rows), batch %d" % (it, n, b))
+        m, v, c = g.norm_stats(0)
+        close(m, nz.obs_rms.mean, rtol=1e-5, atol=1e-6); close(v, nz.obs_rms.var, rtol=2e-5); assert c == nz.obs_rms.count
+    g.close()
