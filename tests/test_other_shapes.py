@@ -394,3 +394,26 @@ def test_running_statistics_with_a_changing_row_count_on_one_handle(O):
         m, v, c = g.norm_stats(0)
         close(m, nz.obs_rms.mean, rtol=1e-5, atol=1e-6); close(v, nz.obs_rms.var, rtol=2e-5); assert c == nz.obs_rms.count
     g.close()
+
+
+@pytest.mark.parametrize("hidden,O", [((256, 256), 18), ((256, 256), 36), ((64, 64), 18), ((512, 256, 256), 18)])
+def test_train_steps_of_changing_row_counts_on_one_handle(hidden, O):
+    """ONE handle, train steps of 2048, 1000, 64, 4096, 17, 2048 and 333 rows in turn ([256,256]: the tile / row-split counters and per-row-block slots of the fast pair;
+    [64,64]: 1 to 128 row groups of partial vectors; the general family): every step's losses, gradient and norm and the weights against the oracle stepping through the
+    same sequence -- whatever a launch of one row count leaves in the handle's workspaces (arrival counters, slots, partial vectors beyond the live rows) must not reach
+    the next one."""
+    orc, g = pair(hidden, O=O, seed=5)
+    for it, n in enumerate((2048, 1000, 64, 4096, 17, 2048, 333)):
+        mb = H.synth_minibatch(orc, n, seed=70 + it)
+        args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+        ref_losses, ref_grad = orc.loss_grad(*args, CR)
+        _, ref_norm = orc.clip(ref_grad)
+        losses = g.train_step(LR, CR, *args)
+        orc.train_step(LR, CR, *args)
+        grad, norm = g.last_grad()
+        close(losses[:4], ref_losses[:4], rtol=1e-4, atol=1e-6, msg="losses, step %d (%d rows)" % (it, n))
+        gs = float(np.abs(ref_grad).max())
+        close(grad, ref_grad, rtol=2e-4, atol=2e-6 * gs, msg="gradient, step %d (%d rows)" % (it, n))
+        assert norm == pytest.approx(ref_norm, rel=1e-4)
+        close(g.get_flat(0), orc.theta, rtol=1e-4, atol=3e-6, msg="weights, step %d" % it)
+    g.close()
