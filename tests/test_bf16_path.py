@@ -211,3 +211,28 @@ def test_chained_launches_of_two_row_counts_on_one_handle(monkeypatch):
     assert np.isfinite(outs[0][-3]).all()
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_bf16_train_steps_of_changing_row_counts_on_one_handle():
+    """ONE bf16 handle, train steps of 4096, 1000, 2048, 300, 4096 and 130 rows in turn (256- and 128-row tiles, chained and per-layer launches, a different
+    work-balanced split of the weight-gradient GEMM every time, the persistent assembly + Adam launch behind each): losses, gradient direction and norm of every step
+    against the fp32 oracle at the bf16 tolerances.  The oracle takes the SAME weights before every step (the bf16 path's fp32 master weights are copied over), so a
+    step is compared on its own: anything stale from the previous shape would show as a wrong gradient, not as drift."""
+    orc, g = pair_bf16((1024, 1024, 1024), 256, 64)
+    for it, n in enumerate((4096, 1000, 2048, 300, 4096, 130)):
+        orc.theta[:] = g.get_flat(0)
+        mb = H.synth_minibatch(orc, n, seed=40 + it)
+        args = (mb["obs"], mb["actions"], mb["advs"], mb["returns"], mb["old_neglogp"], mb["old_values"])
+        ref_losses, ref_grad = orc.loss_grad(*args, CR)
+        _, ref_norm = orc.clip(ref_grad.copy())
+        losses = g.train_step(LR, CR, *args)
+        grad, norm = g.last_grad()
+        assert losses[1] == pytest.approx(ref_losses[1], rel=3e-2), ("vf_loss", it, n)
+        assert losses[2] == pytest.approx(ref_losses[2], rel=1e-5), ("entropy", it, n)
+        assert norm == pytest.approx(ref_norm, rel=3e-2), ("norm", it, n)
+        for name, off, shape in orc.tensors:
+            cnt = int(np.prod(shape))
+            gt, rt = grad[off:off + cnt], ref_grad[off:off + cnt]
+            if np.linalg.norm(rt) > 1e-3 * ref_norm:
+                assert cosine(gt, rt) > 0.995, (name, it, n, cosine(gt, rt))
+    g.close()
