@@ -417,3 +417,32 @@ def test_train_steps_of_changing_row_counts_on_one_handle(hidden, O):
         assert norm == pytest.approx(ref_norm, rel=1e-4)
         close(g.get_flat(0), orc.theta, rtol=1e-4, atol=3e-6, msg="weights, step %d" % it)
     g.close()
+
+
+@pytest.mark.parametrize("hidden", [(64, 64), (256, 256)])
+def test_one_handle_through_several_rollout_shapes_equals_fresh_handles(hidden):
+    """ONE handle taken through five (environments, steps, minibatches) shapes in turn -- ppo_norm_init + ppo_rollout_alloc again, a collect and two updates each
+    ([64,64]: the per-step kernels, the one-wave rollout + the resident epoch kernel, the cooperative rollout, ...; [256,256]: the fast pair at several minibatch sizes)
+    -- against a FRESH handle per shape started from the same weights, Adam slots and powers: rollout, loss rows and weights must be the same BITS.  Buffers are
+    re-allocated, captured graphs rebuilt and meeting tables carried over between the shapes; nothing of one shape may leak into the next."""
+    shapes = ((64, 16, 4), (1, 512, 8), (1024, 64, 32), (1, 2048, 32), (48, 32, 4)) if hidden == (64, 64) else ((64, 16, 4), (512, 16, 8), (4096, 4, 8), (100, 10, 5))
+    g = hip(hidden); g.init_orthogonal(7)
+    for E, T, nmb in shapes:
+        state = (g.get_flat(0), g.get_flat(1), g.get_flat(2), np.asarray(g.beta_powers()).copy())
+        outs = []
+        for fresh in (False, True):
+            h = hip(hidden) if fresh else g
+            if fresh:
+                h.set_flat(state[0]); h.set_flat(state[1], 1); h.set_flat(state[2], 2); h.set_beta_powers(state[3])
+            h.norm_init(E); h.rollout_alloc(E, T)
+            h.collect_synthetic(31, GAMMA, LAM, None)
+            acc = [h.rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns")]
+            for u in range(2):
+                rows, mean = h.update(LR, CR, 2, nmb, None, seed=3 + u)
+                acc += [rows.copy(), h.get_flat(0), h.get_flat(1)]
+            outs.append(acc)
+            if fresh:
+                h.close()
+        for a, b in zip(*outs):
+            np.testing.assert_array_equal(a, b, err_msg="shape %s" % ((E, T, nmb),))
+    g.close()
