@@ -21,7 +21,8 @@
  *     the clip + Adam step.  ONE stated deviation: a handle of the reference's own [64,64] shape (up to 64 observations and 32 actions: 18 / 18 and the 36 / 18 of observe_velocities) applies Adam
  *     inside the next train kernel's prologue (or, with minibatches of <= 64 rows, inside the resident epoch kernel) during ppo_update and uses the hardware's 1-ulp reciprocal and square root for the
  *     quotient m * alpha / (sqrt(v) + eps) in ALL its Adam steps (so that both forms agree bit for bit): a 3-ulp error in an update
- *     term that is ~1e-3 of the weight.  PPO_HIP_NO_LAZY_ADAM=1 switches that form, and the deviation, off.
+ *     term that is ~1e-3 of the weight.  PPO_HIP_ADAM_EXACT=1 keeps those fast forms and computes the quotient with the correctly rounded square root and division
+ *     (no deviation; 5 - 7 % of that shape's train step); PPO_HIP_NO_LAZY_ADAM=1 switches the forms themselves, and the deviation, off.
  */
 #ifndef PPO_HIP_H
 #define PPO_HIP_H

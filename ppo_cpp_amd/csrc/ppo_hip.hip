@@ -206,6 +206,7 @@ struct ppo_handle {
     float* nw_epoch_partials = nullptr; size_t nw_epoch_cap = 0;
     bool nw_epoch_dist = false; unsigned* nw_epochd_words = nullptr; int n_cu = 0;      // ... and its form for larger minibatches (narrow_epoch_dist_kernel: one workgroup per row group and tower)
     bool adam_fast = false;           // adam_kernel uses the 1-ulp quotient of the deferred form (nw_lazy, or PPO_HIP_ADAM_FAST=1 for the bitwise test)
+    bool adam_exact = false;          // PPO_HIP_ADAM_EXACT=1: the deferred / resident forms with the correctly rounded quotient (no deviation from the reference's arithmetic)
     int nw_cur = 0;                   // parameter set holding the current weights (0 outside ppo_update)
     bool nw_pending = false; float* nw_pending_loss = nullptr; int nw_pending_parts = 0;
     float* nw_coop = nullptr; int nw_coop_G = 0;      // cooperative persistent rollout: [2][G][NW_COOP_PW] chunk moments, then {arrive, err}
@@ -1190,7 +1191,11 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
                 const int ci = h->nw_cur, co = ci ^ 1;
                 z = NwLazyArgs{h->grad, h->sumsq, h->nw_pending_parts, set[ci][0], set[ci][1], set[ci][2], set[co][0], set[co][1], set[co][2], h->beta_pow,
                                h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, h->nw_pending_loss, h->norm_out};
-                if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
+                if (h->adam_exact) {
+                    if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2, true, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
+                    else hipLaunchKernelGGL((narrow_train_kernel<64, 64, 32, 2, true, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
+                }
+                else if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_train_kernel<32, 64, 32, 2, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
                 else hipLaunchKernelGGL((narrow_train_kernel<64, 64, 32, 2, true>), dim3(groups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, na, z);
                 h->nw_cur = co; h->nw_pending = false;
             }
@@ -1540,9 +1545,13 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         X(0, 0, 0, 0); X(32, 64, 32, 2); X(64, 64, 32, 2);
 #undef X
         big_lds((const void*)narrow_train_kernel<32, 64, 32, 2, true>); big_lds((const void*)narrow_train_kernel<64, 64, 32, 2, true>);
+        big_lds((const void*)narrow_train_kernel<32, 64, 32, 2, true, true>); big_lds((const void*)narrow_train_kernel<64, 64, 32, 2, true, true>);
         big_lds((const void*)narrow_epoch_kernel<32, false>); big_lds((const void*)narrow_epoch_kernel<64, false>);
         big_lds((const void*)narrow_epoch_kernel<32, true>); big_lds((const void*)narrow_epoch_kernel<64, true>);
+        big_lds((const void*)narrow_epoch_kernel<32, false, true>); big_lds((const void*)narrow_epoch_kernel<64, false, true>);
+        big_lds((const void*)narrow_epoch_kernel<32, true, true>); big_lds((const void*)narrow_epoch_kernel<64, true, true>);
         big_lds((const void*)narrow_epoch_dist_kernel<32>); big_lds((const void*)narrow_epoch_dist_kernel<64>);
+        big_lds((const void*)narrow_epoch_dist_kernel<32, true>); big_lds((const void*)narrow_epoch_dist_kernel<64, true>);
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         { const char* e1 = getenv("PPO_HIP_NO_HOST_FUSED"); const char* e2 = getenv("PPO_HIP_NO_HOST_RESIDENT");
           h->opt_no_host_fused = e1 && e1[0] == '1'; h->opt_no_host_resident = e2 && e2[0] == '1'; }
@@ -1551,7 +1560,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
             // second parameter / moment set of the deferred Adam (zero-filled: the padding elements are never written and must read 0)
             if (dev_alloc(h, &h->nw_theta1, P) || dev_alloc(h, &h->nw_m1, P) || dev_alloc(h, &h->nw_v1, P)) return bail(0);
             h->nw_lazy = true;
-            h->adam_fast = true;
+            { const char* ex = getenv("PPO_HIP_ADAM_EXACT"); h->adam_exact = ex && ex[0] == '1'; }      // keep the deferred / resident forms, drop their 1-ulp quotient (~6 - 9 % of the train step)
+            h->adam_fast = !h->adam_exact;
             const char* ne = getenv("PPO_HIP_NO_NARROW_EPOCH");
             h->nw_epoch = !(ne && ne[0] == '1') && prop.multiProcessorCount >= 2 * 2 * NW_EPOCH_MAX_G;
             if (h->nw_epoch && dev_alloc(h, &h->nw_epoch_words, NW_EPOCH_WORDS)) return bail(0);
@@ -2691,12 +2701,16 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
 #endif
             const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
             ++h->kv[KV_NARROW_EPOCH];
+#define EPOCH_LAUNCH(K, X, EX, GRID) hipLaunchKernelGGL((narrow_epoch_kernel<K, X, EX>), GRID, dim3(NW_THREADS), lds, h->stream, n, h->nw, ea)
+            const dim3 gx(16 * egroups), gw(egroups, 2);
             if (xl) {
-                if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_kernel<32, true>), dim3(16 * egroups), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
-                else hipLaunchKernelGGL((narrow_epoch_kernel<64, true>), dim3(16 * egroups), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
+                if (h->adam_exact) { if (n.Kp0 == 32) EPOCH_LAUNCH(32, true, true, gx); else EPOCH_LAUNCH(64, true, true, gx); }
+                else if (n.Kp0 == 32) EPOCH_LAUNCH(32, true, false, gx); else EPOCH_LAUNCH(64, true, false, gx);
+            } else {
+                if (h->adam_exact) { if (n.Kp0 == 32) EPOCH_LAUNCH(32, false, true, gw); else EPOCH_LAUNCH(64, false, true, gw); }
+                else if (n.Kp0 == 32) EPOCH_LAUNCH(32, false, false, gw); else EPOCH_LAUNCH(64, false, false, gw);
             }
-            else if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_kernel<32, false>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
-            else hipLaunchKernelGGL((narrow_epoch_kernel<64, false>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, ea);
+#undef EPOCH_LAUNCH
             HIP_OK(h, hipGetLastError());
             continue;
         }
@@ -2715,8 +2729,12 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
 #endif
             const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
             ++h->kv[KV_NARROW_EPOCH];
-            if (n.Kp0 == 32) hipLaunchKernelGGL(narrow_epoch_dist_kernel<32>, dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
-            else hipLaunchKernelGGL(narrow_epoch_dist_kernel<64>, dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
+            if (h->adam_exact) {
+                if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_dist_kernel<32, true>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
+                else hipLaunchKernelGGL((narrow_epoch_dist_kernel<64, true>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
+            }
+            else if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_dist_kernel<32>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
+            else hipLaunchKernelGGL((narrow_epoch_dist_kernel<64>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
             HIP_OK(h, hipGetLastError());
             continue;
         }

@@ -274,7 +274,9 @@ __device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArg
 // `red`: 4 floats of LDS scratch.  Ends with the image complete in LDS (caller synchronises).
 // RESIDENT (narrow_epoch_kernel): the moments and the weights stay in R from step to step (R.m / R.v / R.t receive the results), the pieces go back to
 // memory only when `write_back` says so (the epoch's last step), and the caller keeps the powers, the loss row and the norm.
-template <int NP, bool RESIDENT = false>
+// EXACT (PPO_HIP_ADAM_EXACT=1): correctly rounded square root and division instead of the 1-ulp instructions -- a template parameter, not a run-time flag: with both
+// sequences in one kernel the default form lost 6 % (measured).
+template <int NP, bool RESIDENT = false, bool EXACT = false>
 __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout& lay, const NwLazyArgs& z, int tower, int grp, int n_groups,
                                               NwLazyRegs<NP>& R, float* lds, float* red, unsigned long long* st = nullptr, bool write_back = true, float* norm_ret = nullptr,
                                               const int tidx = (int)threadIdx.x) {
@@ -317,7 +319,7 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
         const float vv[4] = {R.v[k].x, R.v[k].y, R.v[k].z, R.v[k].w}, tv[4] = {R.t[k].x, R.t[k].y, R.t[k].z, R.t[k].w};
         float mo[4], vo[4], to[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) adam_element<true>(gv[i] * scale, mv[i], vv[i], tv[i], 1.0f - z.beta1, 1.0f - z.beta2, alpha, z.eps, mo[i], vo[i], to[i]);
+        for (int i = 0; i < 4; ++i) adam_element<!EXACT>(gv[i] * scale, mv[i], vv[i], tv[i], 1.0f - z.beta1, 1.0f - z.beta2, alpha, z.eps, mo[i], vo[i], to[i]);
         const float4 t4 = make_float4(to[0], to[1], to[2], to[3]);
         bool mine;                                                              // who writes this piece back
         if (k < 2) {                                                            // W1 [64][64]: forward + transposed copies
@@ -592,7 +594,7 @@ __device__ __forceinline__ void nw_train_body(const NetDev& net, const NwLayout&
     NSTAMP(11);
 }
 
-template <int KP0, int HP, int AP, int LL, bool LAZY = false>
+template <int KP0, int HP, int AP, int LL, bool LAZY = false, bool EXACT = false>
 __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, NwLayout lay, NwTrainArgs a, NwLazyArgs z) {
     typedef NwShape<KP0, HP, AP, LL> S;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_train_kernel(NetDev net, Nw
         nw_stage<S>(net, lay, nullptr, 0, lds, a.obs, row0, a.n, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
                     a.actions, tower == 0 ? a.advs : a.returns, tower == 0 ? a.old_neglogp : a.old_values, tower == 0 ? 1 : 2);
         NSTAMP(13);
-        nw_lazy_apply(net, lay, z, tower, grp, (int)gridDim.x, R, lds, lazy_red
+        nw_lazy_apply<NwLazyN<KP0>::N, false, EXACT>(net, lay, z, tower, grp, (int)gridDim.x, R, lds, lazy_red
 #ifdef PPO_STAMPS
                       , a.stamps ? a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr
 #endif
@@ -710,7 +712,7 @@ struct NwEpochArgs {
 // same L2 with ordinary loads, at L2 latency and bandwidth instead of a write-through trip to the memory side (4.4 k -> ~1.6 k cycles for the 104 KB a workgroup
 // reads per step).  Every step has its own partial buffers: no address is read twice in a launch, so no CU's L1 holds a stale line.  The placement is CHECKED (every
 // word carries its writer's hardware XCC id, as in gemm_chain_bf16_kernel); a mismatch raises error word 2 and the handle goes back to the write-through form.
-template <int KP0, bool XL>
+template <int KP0, bool XL, bool EXACT = false>
 __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, NwLayout lay, NwEpochArgs e) {
     constexpr int HP = 64, AP = 32, LL = 2, NP = NwLazyN<KP0>::N;
     typedef NwShape<KP0, HP, AP, LL> S;
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
         __syncthreads();                                      // parts complete
         ESTAMP(18);
         R.part = (tid < 256 && tid < e.n_chunks) ? parts[tid] : 0.f;
-        nw_lazy_apply<NP, true>(net, lay, z, tower, grp, G, R, lds, red, nullptr, last, &norm, tid);
+        nw_lazy_apply<NP, true, EXACT>(net, lay, z, tower, grp, G, R, lds, red, nullptr, last, &norm, tid);
         ESTAMP(19);
         if (wid == 0 && tid < 5) {
             float r = tail / (float)e.M;
@@ -942,7 +944,7 @@ struct NwEpochDistArgs {
     float* loss_compact;         // [5][128]: every row group's loss sums, compact (the partial vectors hold them 64 KB apart)
 };
 
-template <int KP0>
+template <int KP0, bool EXACT = false>
 __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev net, NwLayout lay, NwEpochDistArgs d) {
     constexpr int HP = 64, AP = 32, LL = 2, NP = NwLazyN<KP0>::N;
     typedef NwShape<KP0, HP, AP, LL> S;
@@ -1125,7 +1127,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev ne
         __syncthreads();
         R.part = (tid < 256 && tid < e.n_chunks) ? parts[tid] : 0.f;
         ESTAMP(24);
-        nw_lazy_apply<NP, true>(net, lay, z, tower, grp, G, R, lds, red, nullptr, last, &norm, tid);
+        nw_lazy_apply<NP, true, EXACT>(net, lay, z, tower, grp, G, R, lds, red, nullptr, last, &norm, tid);
         ESTAMP(19);
         if (wid == 0 && tid < 5) e.loss_rows[(size_t)k * 5 + tid] = tailv / (float)e.M * ((tid == 1 || tid == 3) ? 0.5f : 1.0f);       // (vf_loss, approxkl carry the 0.5)
         if (!last) { R.b1p = R.b1p * e.beta1; R.b2p = R.b2p * e.beta2; }

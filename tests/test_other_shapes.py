@@ -446,3 +446,33 @@ def test_one_handle_through_several_rollout_shapes_equals_fresh_handles(hidden):
         for a, b in zip(*outs):
             np.testing.assert_array_equal(a, b, err_msg="shape %s" % ((E, T, nmb),))
     g.close()
+
+
+@pytest.mark.parametrize("O,E,T,nmb,epochs", [(18, 16, 16, 4, 3), (36, 1, 256, 8, 2), (18, 64, 64, 32, 1), (36, 3, 100, 4, 2)])
+def test_exact_adam_in_the_deferred_and_resident_forms(O, E, T, nmb, epochs, monkeypatch):
+    """PPO_HIP_ADAM_EXACT=1: the reference's [64,64] shapes keep their fast forms (Adam deferred into the next train launch; the resident epoch kernel for minibatches of
+    <= 64 rows) but compute the quotient m alpha / (sqrt(v) + eps) with the correctly rounded square root and division -- NO deviation from the reference's arithmetic.
+    Must be the same BITS as an adam_kernel launch per step with the exact arithmetic (PPO_HIP_NO_LAZY_ADAM=1), and must differ from the default's 1-ulp quotient."""
+    rng = np.random.RandomState(12)
+    noise = rng.normal(size=(T, E, 18)).astype(np.float32)
+    outs = {}
+    for mode in ("exact fast forms", "exact launches", "default"):
+        monkeypatch.setenv("PPO_HIP_ADAM_EXACT", "1" if mode == "exact fast forms" else "0")
+        monkeypatch.setenv("PPO_HIP_NO_LAZY_ADAM", "1" if mode == "exact launches" else "0")
+        monkeypatch.delenv("PPO_HIP_ADAM_FAST", raising=False)
+        g = hip((64, 64), O=O); g.init_orthogonal(2)
+        g.norm_init(E); g.rollout_alloc(E, T)
+        g.collect_synthetic(55, GAMMA, LAM, noise)
+        acc = []
+        for u in range(2):
+            rows, mean = g.update(LR, CR, epochs, nmb, None, seed=9 + u)
+            acc += [rows.copy(), g.get_flat(0), g.get_flat(1), g.get_flat(2)]
+        kc = g.kernel_counts()
+        if mode == "exact fast forms":
+            assert kc["narrow_epoch_kernel"] + kc["narrow_train_kernel<static>"] > 0 and (kc["narrow_epoch_kernel"] > 0) == (E * T // nmb <= 64), kc
+        outs[mode] = acc
+        g.close()
+    for a, b in zip(outs["exact fast forms"], outs["exact launches"]):
+        np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(outs["exact fast forms"][-3], outs["default"][-3])          # (the weights: the 1-ulp quotient moves some last bits)
+    np.testing.assert_allclose(outs["exact fast forms"][-3], outs["default"][-3], rtol=1e-4, atol=1e-6)
