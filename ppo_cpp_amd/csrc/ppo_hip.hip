@@ -2670,10 +2670,18 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             GatherArgs ga{h->d_gidx, h->d_advstats, B, M, h->net.O, h->net.A, h->ro_obs, h->ro_act, h->ro_ret, h->ro_val, h->ro_nlp,
                           h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};
             if (h->global_shuffle && h->comm && h->world > 1) { ga.obs = h->gs_obs; ga.act = h->gs_act; ga.ret = h->gs_ret; ga.val = h->gs_val; ga.nlp = h->gs_nlp; }
-            hipLaunchKernelGGL(epoch_gather_kernel, dim3((B + 15) / 16), dim3(256), 0, h->stream, ga);
+            const char* ng = getenv("PPO_HIP_NO_GATHER4");         // (read when the update is captured: the test compares both forms)
+            const bool wide4 = h->net.O % 4 == 0 && h->net.A % 4 == 0 && !(ng && ng[0] == '1');
+            // bf16 path: the epoch's observations become bf16 once; a minibatch is then a row slice.  With 16-byte rows the gather writes them itself
+            const bool fuse_stage = wide4 && h->bf.on && M % GB_PAD == 0 && h->bf.xe_rows >= B && h->net.Kp0 % 4 == 0 && !(h->global_shuffle && h->comm && h->world > 1);
+            if (wide4) {
+                Gather4Args g4{ga, fuse_stage ? h->bf.xe : nullptr, h->net.Kp0};
+                hipLaunchKernelGGL(epoch_gather4_kernel, dim3((B + 15) / 16), dim3(256), 0, h->stream, g4);
+            }
+            else hipLaunchKernelGGL(epoch_gather_kernel, dim3((B + 15) / 16), dim3(256), 0, h->stream, ga);
             HIP_OK(h, hipGetLastError());
-            if (h->bf.on) {
-                // bf16 path: the epoch's observations become bf16 once; a minibatch is then a row slice
+            if (h->bf.on && fuse_stage) h->bf.epoch_staged = true;
+            else if (h->bf.on) {
                 ppo_handle::Bf16& bb = h->bf;
                 bb.epoch_staged = M % GB_PAD == 0 && bb.xe_rows >= B;
                 if (bb.epoch_staged) {

@@ -2010,6 +2010,39 @@ __global__ __launch_bounds__(256) void epoch_gather_kernel(GatherArgs a) {
     }
 }
 
+// The same gather for observation / action widths that are multiples of 4 (configs[4]: 256 / 64), 16 bytes per access (a wave instruction of the element-wise form
+// touches 64 x 4 bytes of 1 - 2 rows; this one 64 x 16), and -- bf16 path -- the observations written ONCE, as the bf16 operand rows the GEMMs read (X [B][Kp0]; the
+// padding columns of a row are never written and stay zero): the fp32 copy of the epoch and the staging launch behind it (read it again, write bf16) go away.
+// 16 rows per workgroup as above; same values, same statistics.
+struct Gather4Args { GatherArgs g; __bf16* xe; int Kp0; };
+__global__ __launch_bounds__(256) void epoch_gather4_kernel(Gather4Args q) {
+    const GatherArgs& a = q.g;
+    __shared__ int src[16];
+    const int pos0 = blockIdx.x * 16, tid = threadIdx.x;
+    if (tid < 16 && pos0 + tid < a.B) src[tid] = a.gidx[pos0 + tid];
+    __syncthreads();
+    const int QO = a.O >> 2, QW = (a.O + a.A) >> 2;
+    typedef __bf16 bf16q_t __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < 16 * QW; i += 256) {
+        const int r = i / QW, jq = i - r * QW;
+        if (pos0 + r >= a.B) continue;
+        if (jq < QO) {
+            const float4 v = *reinterpret_cast<const float4*>(a.obs + (size_t)src[r] * a.O + 4 * jq);
+            if (q.xe) { bf16q_t o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w; *reinterpret_cast<bf16q_t*>(q.xe + (size_t)(pos0 + r) * q.Kp0 + 4 * jq) = o; }
+            else *reinterpret_cast<float4*>(a.mb_obs + (size_t)(pos0 + r) * a.O + 4 * jq) = v;
+        } else {
+            const int ja = 4 * (jq - QO);
+            *reinterpret_cast<float4*>(a.mb_act + (size_t)(pos0 + r) * a.A + ja) = *reinterpret_cast<const float4*>(a.act + (size_t)src[r] * a.A + ja);
+        }
+    }
+    if (tid < 16 && pos0 + tid < a.B) {
+        const int p = pos0 + tid, s = src[tid], k = p / a.M;
+        const float R = a.ret[s], V = a.val[s];
+        a.mb_ret[p] = R; a.mb_val[p] = V; a.mb_nlp[p] = a.nlp[s];
+        a.mb_adv[p] = ((R - V) - a.stats[2 * k]) / a.stats[2 * k + 1];          // ppo2.hpp:401-406
+    }
+}
+
 // epoch_prepare_kernel (single rank, local shuffle) AND epoch_gather_kernel in one launch: EPG_SPLIT workgroups per minibatch each derive the
 // minibatch's index map and advantage statistics (the same statements in the same order: every one of them holds the same bits; the redundant
 // work is a few thousand integer hashes) and then copy their 1 / EPG_SPLIT share of its rows.  One launch and one dependent round trip through
