@@ -476,3 +476,39 @@ def test_exact_adam_in_the_deferred_and_resident_forms(O, E, T, nmb, epochs, mon
         np.testing.assert_array_equal(a, b)
     assert not np.array_equal(outs["exact fast forms"][-3], outs["default"][-3])          # (the weights: the 1-ulp quotient moves some last bits)
     np.testing.assert_allclose(outs["exact fast forms"][-3], outs["default"][-3], rtol=1e-4, atol=1e-6)
+
+
+def test_two_handles_interleaved_equal_the_same_handles_run_alone():
+    """Two handles in one process, their calls interleaved (A collect, B collect, A update, B update, ...): the reference's shape with the resident epoch kernel and a
+    [256,256] handle.  Each must produce exactly what it produces alone -- every meeting table, counter and workspace belongs to its handle."""
+    def make(hidden, E, T, seed):
+        g = hip(hidden); g.init_orthogonal(seed); g.norm_init(E); g.rollout_alloc(E, T)
+        return g
+    specs = (((64, 64), 1, 512, 8, 1), ((256, 256), 64, 16, 4, 2), ((64, 64), 2, 128, 4, 3))
+    def run(order):
+        hs = [make(hd, E, T, sd) for hd, E, T, nmb, sd in specs]
+        out = [[] for _ in specs]
+        for it in range(3):
+            for i in order:
+                hs[i].collect_synthetic(40 + i, GAMMA, LAM, None, step0=it * specs[i][2], first=(it == 0))
+            for i in order:
+                rows, mean = hs[i].update(LR, CR, 2, specs[i][3], None, seed=it)
+                out[i] += [rows.copy(), hs[i].get_flat(0)]
+        for h in hs:
+            h.close()
+        return out
+    together = run((0, 1, 2))
+    alone = [None] * len(specs)
+    for i in range(len(specs)):
+        hd, E, T, nmb, sd = specs[i]
+        g = make(hd, E, T, sd)
+        acc = []
+        for it in range(3):
+            g.collect_synthetic(40 + i, GAMMA, LAM, None, step0=it * T, first=(it == 0))
+            rows, mean = g.update(LR, CR, 2, nmb, None, seed=it)
+            acc += [rows.copy(), g.get_flat(0)]
+        g.close()
+        alone[i] = acc
+    for i in range(len(specs)):
+        for a, b in zip(together[i], alone[i]):
+            np.testing.assert_array_equal(a, b, err_msg="handle %d" % i)
