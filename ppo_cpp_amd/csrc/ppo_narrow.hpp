@@ -753,9 +753,9 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
 #pragma unroll
         for (int kk = 0; kk < NP; ++kk) offs[side][kk] = nw_lazy_piece(net, side == 0 ? tower : 1 - tower, kk, tid0).off;
 #ifdef PPO_STAMPS
-#define ESTAMP(i) do { if (e.stamps && threadIdx.x == 0 && k == e.nmb - 2) e.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define EPSTAMP(i) do { if (e.stamps && threadIdx.x == 0 && k == e.nmb - 2) e.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
-#define ESTAMP(i) do { } while (0)
+#define EPSTAMP(i) do { } while (0)
 #endif
     for (int k = 0; k < e.nmb; ++k) {
         // an OPAQUE copy of the thread index per iteration: with the plain one the compiler hoists every thread-dependent LDS address of the step out of this
@@ -785,12 +785,12 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
         float* pb = e.partials + (size_t)(XL ? k : (k & 1)) * nwg * e.part_stride;
         ta.partials = pb;
         ta.stamps = (k == e.nmb - 2) ? e.stamps : nullptr;
-        ESTAMP(0);
+        EPSTAMP(0);
         nw_train_body<KP0, HP, AP, LL, !XL>(net, lay, ta, lds, tower, grp, tid);
         // ---- arrival: the partial vector was stored write-through; every wave drains, one word says "step k of this workgroup is out" ---------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        ESTAMP(16);
+        EPSTAMP(16);
         const unsigned target = (e0 + (unsigned)k + 1u) & 0x0FFFFFFFu;
         if (tid == 0) __hip_atomic_store(e.words + wid, (target << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         parts[tid] = 0.f;                                     // (NW_THREADS = 512 entries; chunks without a piece -- alignment gaps -- stay zero)
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
             }
         }
         __syncthreads();
-        ESTAMP(17);
+        EPSTAMP(17);
         // ---- assembly: (p0 + p1) + (0 + 0) per element as narrow_reduce_kernel adds two row groups; per 64-element chunk the sum of squares in ITS tree --------
         // (16 consecutive threads hold a chunk's 16 pieces: levels 1-2 across pieces c ^ 2, c ^ 1 = elements e ^ 8, e ^ 4; levels 3-4 inside the piece; then the
         // kernel's four waves as piece groups: (r0 + r1) + (r2 + r3))
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
             if constexpr (NP == 5) { nb_wait8(p0[side][0], p0[side][1], p0[side][2], p0[side][3], p0[side][4], d0, d1, d2); nb_wait8(p1[side][0], p1[side][1], p1[side][2], p1[side][3], p1[side][4], d0, d1, d2); }
             else { nb_wait8(p0[side][0], p0[side][1], p0[side][2], p0[side][3], p0[side][4], p0[side][5], d0, d1); nb_wait8(p1[side][0], p1[side][1], p1[side][2], p1[side][3], p1[side][4], p1[side][5], d0, d1); }
         }
-        ESTAMP(23);
+        EPSTAMP(23);
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const int t2 = side == 0 ? tower : 1 - tower;
@@ -890,10 +890,10 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
             tail = (a0 + 0.f) + (a1 + 0.f);
         }
         __syncthreads();                                      // parts complete
-        ESTAMP(18);
+        EPSTAMP(18);
         R.part = (tid < 256 && tid < e.n_chunks) ? parts[tid] : 0.f;
         nw_lazy_apply<NP, true, EXACT>(net, lay, z, tower, grp, G, R, lds, red, nullptr, last, &norm, tid);
-        ESTAMP(19);
+        EPSTAMP(19);
         if (wid == 0 && tid < 5) {
             float r = tail / (float)e.M;
             if (tid == 1 || tid == 3) r = 0.5f * r;           // vf_loss, approxkl carry the 0.5
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
             for (int kk = 0; kk < NP; ++kk) { const int off = nw_lazy_piece(net, tower, kk, tid).off; if (off >= 0) *reinterpret_cast<float4*>(e.grad + off) = R.g[kk]; }
         }
         if (!last) { R.b1p = R.b1p * e.beta1; R.b2p = R.b2p * e.beta2; }                         // G:31217-31342: the next step's powers
-        ESTAMP(22);
+        EPSTAMP(22);
     }
     __syncthreads();
     const int tid = tid0;
@@ -1029,11 +1029,11 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev ne
             if (!last && tid < NW_ROWS && row0 + tid < e.M) { nx0 = v0[ro + row0 + tid]; nx1 = v1[ro + row0 + tid]; }
         }
         ta.stamps = (k == e.nmb - 2) ? e.stamps : nullptr;
-        ESTAMP(0);
+        EPSTAMP(0);
         nw_train_body<KP0, HP, AP, LL, true>(net, lay, ta, lds, tower, grp, tid);
-        ESTAMP(16);
+        EPSTAMP(16);
         meet(e0 + 2u * (unsigned)k + 1u, tid, lane);
-        ESTAMP(17);          // ---- every partial vector of the step is out ----------------------------------------------------
+        EPSTAMP(17);          // ---- every partial vector of the step is out ----------------------------------------------------
         if (!last) {                                          // the next minibatch's rows: registers -> the tiles nw_stage fills
 #pragma unroll
             for (int q = 0; q < OVN; ++q) {
@@ -1108,10 +1108,10 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev ne
             for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
             if (ln == 0) __hip_atomic_store(e.grad + net.n_theta + wid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        ESTAMP(23);
+        EPSTAMP(23);
         meet(e0 + 2u * (unsigned)k + 2u, tid, lane);
         float tailv = 0.f;
-        ESTAMP(18);          // ---- the reduced gradient and every chunk's sum of squares are out --------------------------------
+        EPSTAMP(18);          // ---- the reduced gradient and every chunk's sum of squares are out --------------------------------
         {
             f32x4 g4[NP];
 #pragma unroll
@@ -1126,9 +1126,9 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev ne
         }
         __syncthreads();
         R.part = (tid < 256 && tid < e.n_chunks) ? parts[tid] : 0.f;
-        ESTAMP(24);
+        EPSTAMP(24);
         nw_lazy_apply<NP, true, EXACT>(net, lay, z, tower, grp, G, R, lds, red, nullptr, last, &norm, tid);
-        ESTAMP(19);
+        EPSTAMP(19);
         if (wid == 0 && tid < 5) e.loss_rows[(size_t)k * 5 + tid] = tailv / (float)e.M * ((tid == 1 || tid == 3) ? 0.5f : 1.0f);       // (vf_loss, approxkl carry the 0.5)
         if (!last) { R.b1p = R.b1p * e.beta1; R.b2p = R.b2p * e.beta2; }
     }
