@@ -39,7 +39,11 @@ def host(E, T, resident):
 for E, T in ((1, 64), (20, 32), (64, 16)):
     t0 = time.time(); a = host(E, T, True); b = host(E, T, False)
     ok = np.isfinite(a[0]).all() and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2][0], b[2][0])
-    print("host Env E %3d T %3d: %d rollouts + updates, resident vs %s: bitwise equal: %s (%.1f s)" % (E, T, N // 4, "fused launches" if E <= 32 else "general path (rounding only)", ok, time.time() - t0), flush=True)
-    if E <= 32: assert ok
-    else: np.testing.assert_allclose(a[1][:8], b[1][:8], rtol=5e-3, atol=5e-3)      # (rounding only, and only the first rollouts: the env reacts to the actions, so two
-                                                                                   #  runs that differ in the last bit drift apart over hundreds of updates)
+    if E <= 32:
+        print("host Env E %3d T %3d: %d rollouts + updates, resident vs fused launches: bitwise equal: %s (%.1f s)" % (E, T, N // 4, ok, time.time() - t0), flush=True)
+        assert ok
+    else:
+        # resident workgroup against the GENERAL path: different kernels, agreement to rounding only -- and only over the first rollouts: the env reacts to the actions, so two
+        # runs that differ in the last bit drift apart over hundreds of updates
+        np.testing.assert_allclose(a[1][:8], b[1][:8], rtol=5e-3, atol=5e-3)
+        print("host Env E %3d T %3d: %d rollouts + updates, resident vs general path: first 8 rollouts agree to rounding (5e-3): True (%.1f s)" % (E, T, N // 4, time.time() - t0), flush=True)
