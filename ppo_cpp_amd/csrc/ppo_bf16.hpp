@@ -843,7 +843,7 @@ __device__ __forceinline__ void bgr_tail(const ReduceArgs& a, int lane, float (&
         const int tower = (k == 1) ? 1 : 0, off = a.slot_loss + (k <= 1 ? 0 : k - 1);
         float s = 0.f;
         for (int b = lane; b < a.n_rowblocks; b += 64) s += a.slots[tower][(size_t)b * a.slot_w + off];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = wave_sum_lane0(s);
         if (lane == 0) a.grad[(size_t)a.n_blocks * 256 + k] = s;
         tl[k] = s;
     }
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_grad_reduce_kernel(Reduce
         bgr_chunk(a, chunk, lane, g);
         *reinterpret_cast<float4*>(a.grad + (size_t)chunk * 256 + 4 * lane) = make_float4(g[0], g[1], g[2], g[3]);
         q = (g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]);
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        q = wave_sum_lane0(q);
     }
     if (lane == 0) wq[wave] = q;
     __syncthreads();
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_reduce_adam_kernel(Reduce
                 bgr_chunk(a.r, chunk, lane, G[r]);
                 *reinterpret_cast<float4*>(a.r.grad + idx) = make_float4(G[r][0], G[r][1], G[r][2], G[r][3]);
                 q = (G[r][0] * G[r][0] + G[r][1] * G[r][1]) + (G[r][2] * G[r][2] + G[r][3] * G[r][3]);
-                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                q = wave_sum_lane0(q);
             }
         }
         if (lane == 0) wq[r][wave] = q;
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_reduce_adam_kernel(Reduce
         __builtin_amdgcn_s_sleep(2);
         if (++polls > (1u << 20)) { if (tid == 0) __hip_atomic_store(a.ent + BRA_GRID, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum_lane0(s);
     if (tid < 256 && lane == 0) red[wave] = s;
     __syncthreads();
     const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));

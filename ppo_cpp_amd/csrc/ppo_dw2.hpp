@@ -368,7 +368,7 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
     }
     {
         float s = ((sj[0] + sj[1]) + (sj[2] + sj[3])) + ((sj[4] + sj[5]) + (sj[6] + sj[7]));
-        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);                                       // within the 32 lanes of the job
+        s = half_sum_lane0(s);                                       // within the 32 lanes of the job
         if ((tid & 31) == 0) {
             if (has_job) st_wt<PEER || ADAM>(a.grad + jraw.z, s);  // (PEER: the tile's finisher reads it back with a write-through load and pushes it; ADAM: the loss sums, after the meeting)
             red2[tid >> 5] = (has_job && jraw.w) ? s * s : 0.f;
@@ -450,7 +450,7 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
             *reinterpret_cast<float4*>(a.grad + soff) = make_float4(u4[0], u4[1], u4[2], u4[3]);
             sq += (u4[0] * u4[0] + u4[1] * u4[1]) + (u4[2] * u4[2] + u4[3] * u4[3]);
         }
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        sq = wave_sum_lane0(sq);
         float* red = lds + DW2_NBUF * LD::BUF + 16;
         if (lane == 0) red[wave] = sq;
         __syncthreads();
@@ -542,7 +542,7 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
         DW2_STAMP(9);
         // ---- the global norm: adam_kernel's tree (wave butterfly; the four waves pairwise) -------------------------------------------------------------
         float* red = lds + DW2_NBUF * LD::BUF + 16;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = wave_sum_lane0(s);
         if (tid < 256 && lane == 0) red[wave] = s;
         __syncthreads();
         const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));

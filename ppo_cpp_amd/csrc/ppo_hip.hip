@@ -147,6 +147,7 @@ struct ppo_handle {
     uint32_t rng_seed = 0x5EEDu;      // ppo_seed
     int norm_obs_flag = 1, norm_rew_flag = 1;   // EnvNormalize's norm_obs / norm_reward (env_normalize.hpp:75,95)
     float* env_in = nullptr;          // [E*O | E | E] raw obs | raw reward | dones of the current env step, one block: one H2D per env step
+    float* hyper_host = nullptr;      // pinned {lr, cliprange}: the source of set_hyper's asynchronous copy
     float* pin_in = nullptr;          // pinned host mirror of env_in (hipHostMalloc, owned by the handle)
     // ONE environment behind a host Env, resident three-wave kernel: the transition ALSO goes straight into device memory through the BAR (posted writes) with its own
     // sequence word, so the kernel polls and reads local memory instead of host memory over PCIe (large-BAR devices; PPO_HIP_NO_VRAM_INBOX=1 keeps the pinned block only)
@@ -1388,8 +1389,13 @@ int flush_pending_adam(ppo_handle* h) {
 }
 
 int set_hyper(ppo_handle* h, float lr, float cr) {
-    const float hv[2] = {lr, cr};
-    HIP_OK(h, hipMemcpyAsync(h->hyper, hv, sizeof hv, hipMemcpyHostToDevice, h->stream));
+    // The source of an ASYNCHRONOUS copy must outlive this function: the runtime may read it when the copy executes, not when it is enqueued.  (Rounds 1 - 5 passed a
+    // stack array here; at the end of a long process the second update of a handle then trained with whatever lay on the stack -- found by
+    // tests/test_other_shapes.py::test_two_handles_interleaved_equal_the_same_handles_run_alone, which only failed behind the rest of the suite.)  The two floats
+    // live in pinned memory owned by the handle; every API call that sets them synchronises the stream before it returns, so they are never rewritten under a copy.
+    if (!h->hyper_host) HIP_OK(h, hipHostMalloc((void**)&h->hyper_host, 64, hipHostMallocDefault));
+    h->hyper_host[0] = lr; h->hyper_host[1] = cr;
+    HIP_OK(h, hipMemcpyAsync(h->hyper, h->hyper_host, 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
@@ -1623,6 +1629,7 @@ void ppo_destroy(ppo_handle* h) {
         for (int t = 0; t < 2; ++t) for (int l = 0; l < PPO_MAX_LAYERS; ++l) for (bf16_t* p : {b.hb[t][l], b.dy[t][l]}) if (p) (void)hipFree(p);
     }
     if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->hyper_host) (void)hipHostFree(h->hyper_host);
     if (h->vram_in) (void)hipFree(h->vram_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_flag) (void)hipHostFree(h->pin_flag);

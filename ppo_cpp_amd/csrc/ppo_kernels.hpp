@@ -162,6 +162,19 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// The 64-lane (32-lane) xor butterfly `for (o = 32 (16); o > 0; o >>= 1) v += __shfl_xor(v, o)` where only LANE 0 of the wave (lanes 0 and 32) uses the result: the
+// levels 8, 4, 2, 1 as DPP row operations instead of trips through the LDS crossbar (~100 cycles of latency each, on the critical path of a kernel's tail).  Lane 0
+// receives the same partners' partial sums in the same order -- row_shl:4 hands lane i the value of lane i + 4, which is the xor partner for the lanes below 4 of every
+// 8 and garbage elsewhere, and everything lane 0 depends on afterwards comes from such lanes -- so it holds the same BITS (tools/ubench/lane0_sum.hip); other lanes do not.
+__device__ __forceinline__ float half_sum_lane0(float v) {
+    v += __shfl_xor(v, 16);
+    v += dpp_move<0x128>(v);     // row_ror:8  (lane i <-> i ^ 8, exact in every lane)
+    v += dpp_move<0x104>(v);     // row_shl:4  (lane i <- lane i + 4)
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    return v;
+}
+__device__ __forceinline__ float wave_sum_lane0(float v) { v += __shfl_xor(v, 32); return half_sum_lane0(v); }
 __device__ __forceinline__ float group16_sum(float v) {
     v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
     v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
@@ -1489,7 +1502,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
             const int off = a.slot_loss + (q <= 1 ? 0 : q - 1);
             float s = 0.f;
             for (int b = ln; b < a.n_rowblocks; b += 32) s += a.slots[tower][(size_t)b * a.slot_w + off];
-            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            s = half_sum_lane0(s);
             if (ln == 0) a.grad[(size_t)a.n_blocks * 256 + q] = s;
         }
         if (tid == 160) a.grad[(size_t)a.n_blocks * 256 + 5] = a.n_local;
@@ -1525,7 +1538,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(ReduceArgs a) {
     }
     st_wt<PPO_WT_C1>(a.grad + idx, gsum);
     float q = gsum * gsum;
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    q = wave_sum_lane0(q);
     if ((tid & 63) == 0) red[tid >> 6] = q;
     __syncthreads();
     if (tid == 0) st_wt<PPO_WT_C1>(a.sumsq + blk, (red[0] + red[1]) + (red[2] + red[3]));
@@ -1556,7 +1569,7 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* grad, floa
     const int tid = threadIdx.x;
     const float gv = grad[(size_t)blockIdx.x * 256 + tid];
     float q = gv * gv;
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    q = wave_sum_lane0(q);
     if ((tid & 63) == 0) red[tid >> 6] = q;
     __syncthreads();
     if (tid == 0) sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -1608,7 +1621,7 @@ __global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* sumsq, int
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int i = base + tid + 256 * k; if (i < n) s += sumsq[i]; }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum_lane0(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     if (tid == 0) parts[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -1729,7 +1742,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     if constexpr (MEET > 0) {
         // this workgroup's partial: the squares of its 1024 elements in a fixed tree, published behind a write-through store; then the meeting
         float q = (g4.x * g4.x + g4.y * g4.y) + (g4.z * g4.z + g4.w * g4.w);
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        q = wave_sum_lane0(q);
         if ((tid & 63) == 0) red[tid >> 6] = q;
         __syncthreads();
         if (tid == 0) {
@@ -1761,7 +1774,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         for (int i = tid; i < a.n_parts; i += 256) s += a.norm_parts[i];
     }
     ASTAMP(2);
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum_lane0(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     ASTAMP(3);
@@ -1901,7 +1914,7 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_kernel(EpochArgs a) 
             if (li >= 0 && li < a.M) a.gidx[k * a.M + li] = s;
             sum += a.returns[s] - a.values[s];
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = wave_sum_lane0(sum);
         if ((tid & 63) == 0) red[tid >> 6] = sum;
         __syncthreads();
         if (tid == 0) { float tot = 0.f; for (int w = 0; w < EP_THREADS / 64; ++w) tot += red[w]; s_mean = tot / (float)Mg; }
@@ -1913,7 +1926,7 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_kernel(EpochArgs a) 
             const float d = (a.returns[s] - a.values[s]) - mean;
             sq += d * d;
         }
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        sq = wave_sum_lane0(sq);
         __syncthreads();
         if ((tid & 63) == 0) red[tid >> 6] = sq;
         __syncthreads();
@@ -1940,7 +1953,7 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_kernel(EpochArgs a) 
             a.gidx[pos] = s;
             sum += a.returns[s] - a.values[s];
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = wave_sum_lane0(sum);
         if ((tid & 63) == 0) red[tid >> 6] = sum;
         __syncthreads();
         if (tid == 0) {
@@ -1962,7 +1975,7 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_kernel(EpochArgs a) 
         const float d = (a.returns[s] - a.values[s]) - mean;
         sq += d * d;
     }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = wave_sum_lane0(sq);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
@@ -2094,7 +2107,7 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_gather_kernel(EpochA
         }
     }
     ESTAMP(1);
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum_lane0(sum);
     if ((tid & 63) == 0) red[tid >> 6] = sum;
     __syncthreads();
     if (tid == 0) {
@@ -2111,7 +2124,7 @@ __global__ __launch_bounds__(EP_THREADS) void epoch_prepare_gather_kernel(EpochA
         if (tid + EP_THREADS * u < a.M) { const float d = adv[u] - mean; sq += d * d; }
     }
     ESTAMP(3);
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = wave_sum_lane0(sq);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
@@ -2163,7 +2176,7 @@ __global__ __launch_bounds__(1024) void adv_normalize_kernel(const float* return
     const int tid = threadIdx.x;
     float sum = 0.f;
     for (int i = tid; i < n; i += 1024) sum += returns[i] - values[i];
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum_lane0(sum);
     if ((tid & 63) == 0) red[tid >> 6] = sum;
     __syncthreads();
     if (tid == 0) { float s = 0.f; for (int w = 0; w < 16; ++w) s += red[w]; s_val = s / (float)n; }
@@ -2171,7 +2184,7 @@ __global__ __launch_bounds__(1024) void adv_normalize_kernel(const float* return
     const float mean = s_val;
     float sq = 0.f;
     for (int i = tid; i < n; i += 1024) { const float d = (returns[i] - values[i]) - mean; sq += d * d; }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = wave_sum_lane0(sq);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();

@@ -289,7 +289,7 @@ __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout&
     const float b1p = R.b1p, b2p = R.b2p, lr = R.lr;
     float s = 0.f + R.part;
     if (tid < 256) for (int i = tid + 256; i < z.n_parts; i += 256) s += z.parts[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum_lane0(s);
     if (tid < 256 && (tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void narrow_reduce_kernel(NwReduceArgs a) {
             const int off = a.n_theta + (q <= 1 ? 0 : q - 1);
             float s = 0.f;
             for (int gidx = ln; gidx < a.n_groups; gidx += 32) s += a.partials[((size_t)tower * a.n_groups + gidx) * a.part_stride + off];
-            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            s = half_sum_lane0(s);
             if (ln == 0) a.grad[a.n_theta + q] = s;
         }
         if (tid == 160) a.grad[a.n_theta + 5] = a.n_local;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void narrow_reduce_kernel(NwReduceArgs a) {
     sum += __shfl_xor(sum, 2);
     if (sub == 0) a.grad[idx] = sum;
     float q = (sub == 0) ? sum * sum : 0.f;
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    q = wave_sum_lane0(q);
     if ((tid & 63) == 0) red[tid >> 6] = q;
     __syncthreads();
     if (tid == 0) a.sumsq[blk] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev ne
                 sum += dpp_move<0x4E>(sum);
                 if (have && sub == 0) __hip_atomic_store(e.grad + idx, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 float q = (sub == 0) ? sum * sum : 0.f;
-                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                q = wave_sum_lane0(q);
                 if ((t & 63) == 0) red2[4 * half + (t >> 6)] = q;
                 __syncthreads();
                 if (t == 0 && have) __hip_atomic_store(d.sumsq + c, (red2[4 * half] + red2[4 * half + 1]) + (red2[4 * half + 2] + red2[4 * half + 3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev ne
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < NW_EPOCHD_MAX_WG / 2 / 32; ++j) if (ln < 32 && ln + 32 * j < G) s += tlv[j];
-            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            s = half_sum_lane0(s);
             if (ln == 0) __hip_atomic_store(e.grad + net.n_theta + wid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         EPSTAMP(23);
