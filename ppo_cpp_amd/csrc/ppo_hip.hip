@@ -141,6 +141,7 @@ struct ppo_handle {
     uint32_t* d_keys = nullptr; float* d_loss_rows = nullptr; float* d_loss_mean = nullptr;
     int upd_cap_rows = 0, upd_cap_steps = 0;
     hipGraphExec_t upd_graph = nullptr;
+    hipGraph_t upd_graph_tmpl = nullptr;      // the captured graph the executable one was instantiated from: kept until the executable one goes (drop_graph)
     int g_epochs = 0, g_nmb = 0, g_E = 0, g_T = 0, g_explicit = -1, g_world = 0;
     bool use_graph = true;
     uint32_t rng_calls = 0;
@@ -266,6 +267,15 @@ int fail(ppo_handle* h, const char* fmt, ...) {
     do {                                                                                             \
         if (hipSetDevice((h)->device) != hipSuccess) return fail(h, "hipSetDevice(%d) failed", (h)->device); \
     } while (0)
+
+// The update's executable graph AND the captured graph it came from go together.  (Rounds 1 - 5 destroyed the captured graph right after hipGraphInstantiate; that is
+// allowed, but the one unexplained observation of round 5 -- DESIGN.md section 9: a replay whose later train steps went wrong after OTHER handles had captured their
+// graphs in between, only late in a long process -- is what a runtime that keeps pointers into the captured graph's node parameters would produce once the heap reuses
+// them, and keeping a few hundred KB alive per handle costs nothing.)
+static void drop_graph(ppo_handle* h) {
+    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    if (h->upd_graph_tmpl) { (void)hipGraphDestroy(h->upd_graph_tmpl); h->upd_graph_tmpl = nullptr; }
+}
 
 template <typename T>
 int dev_alloc(ppo_handle* h, T** p, size_t n) {
@@ -559,7 +569,7 @@ int ensure_train_ws(ppo_handle* h, int rows) {
     if (h->narrow) {
         const int groups = (rows + NW_ROWS - 1) / NW_ROWS;
         if (groups <= h->nw_groups_cap) return 0;
-        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        drop_graph(h);
         HIP_OK(h, hipStreamSynchronize(h->stream));
         if (dev_alloc(h, &h->nw_partials, (size_t)4 * groups * h->nw_stride)) return -1;     // zero-filled: padding elements stay zero ([2 towers][groups]; twice: narrow_epoch_kernel alternates two sets)
         h->nw_groups_cap = groups;
@@ -568,7 +578,7 @@ int ensure_train_ws(ppo_handle* h, int rows) {
     }
     rows = ru(rows, h->dw2 ? DW2_CH : 16);                 // (weight_grad_assemble_kernel walks whole 64-row chunks: the train kernel's grid is padded to them)
     if (rows <= h->ws_rows) return 0;
-    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    drop_graph(h);
     HIP_OK(h, hipStreamSynchronize(h->stream));
     const NetDev& n = h->net;
     if (dev_alloc(h, &h->x0g, (size_t)rows * n.Kp0)) return -1;
@@ -694,7 +704,7 @@ int bf16_chain_check(ppo_handle* h) {
         if (e) {
             (void)hipMemset(b.ra_ent, 0, (BRA_GRID + 8) * sizeof e);
             b.fuse_ra = false;
-            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            drop_graph(h);
             return fail(h, "bf16_reduce_adam_kernel: its 256 workgroups were not resident together within ~1 s (is another process using this GPU?); this step's results "
                            "are invalid.  The handle now launches bf16_grad_reduce_kernel and adam_kernel (PPO_HIP_NO_REDUCE_ADAM=1 selects them from the start)");
         }
@@ -707,7 +717,7 @@ int bf16_chain_check(ppo_handle* h) {
         if (e) {
             for (int k = 0; k < 2; ++k) (void)hipMemset(b.chain_words[k], 0, ((size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS + 32) * sizeof e);
             b.chain = false;
-            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            drop_graph(h);
             return fail(h, "gemm_chain_bf16_kernel: %s; this call's results are invalid.  The handle now launches layer by layer (PPO_HIP_NO_BF16_CHAIN=1 selects "
                            "that from the start)", e == 2 ? "a row group's workgroups were not on one XCD (the launch's workgroup dealing is not round-robin over the XCDs here)"
                                                           : "its workgroups were not resident together within ~1 s (is another process using this GPU?)");
@@ -720,7 +730,7 @@ int bf16_ensure_ws(ppo_handle* h, int rows) {
     ppo_handle::Bf16& b = h->bf;
     const int R = ru(rows, GB_PAD);
     if (R <= b.Rcap) return 0;
-    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    drop_graph(h);
     HIP_OK(h, hipStreamSynchronize(h->stream));
     const NetDev& n = h->net;
     if (dev_alloc(h, &b.x0, (size_t)R * n.Kp0)) return -1;
@@ -1004,7 +1014,7 @@ int fab_check(ppo_handle* h) {
     if (e) {
         (void)hipMemset(h->fab_meet, 0, (FAB_GRID + 32) * sizeof e);
         h->fuse_ab = false;
-        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        drop_graph(h);
         return fail(h, "train8_dw2_fused_kernel: its 256 workgroups were not resident together within 0.5 s (is another process using this GPU?); this "
                        "step's results are invalid.  The handle now runs the two-launch form (the default without PPO_HIP_FUSE_AB=1)");
     }
@@ -1020,7 +1030,7 @@ int nw_epoch_check(ppo_handle* h) {
         if (e) {
             (void)hipMemset(h->nw_epochd_words, 0, (NW_EPOCHD_MAX_WG + 64 + 5 * 128) * sizeof e);
             h->nw_epoch_dist = false;
-            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            drop_graph(h);
             return fail(h, "narrow_epoch_dist_kernel: its workgroups were not resident together (is another process using this GPU?); this update's results are invalid.  "
                            "The handle now launches every train step (the default without PPO_HIP_NARROW_EPOCH_DIST=1)");
         }
@@ -1029,14 +1039,14 @@ int nw_epoch_check(ppo_handle* h) {
     if (e == 2) {
         (void)hipMemset(h->nw_epoch_words, 0, NW_EPOCH_WORDS * sizeof e);
         h->nw_epoch_xl = false;
-        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        drop_graph(h);
         return fail(h, "narrow_epoch_kernel: its workgroups were not on one XCD (the launch's workgroup dealing is not round-robin over the XCDs here); this update's results are "
                        "invalid.  The handle now exchanges the partial gradients write-through (PPO_HIP_NO_NARROW_EPOCH_XL=1 selects that from the start)");
     }
     if (e) {
         (void)hipMemset(h->nw_epoch_words, 0, NW_EPOCH_WORDS * sizeof e);
         h->nw_epoch = false;
-        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        drop_graph(h);
         return fail(h, "narrow_epoch_kernel: its workgroups were not resident together (is another process using this GPU?); this update's results are invalid.  "
                        "The handle now launches every train step (PPO_HIP_NO_NARROW_EPOCH=1 selects that from the start)");
     }
@@ -1051,7 +1061,7 @@ int dw2_adam_check(ppo_handle* h) {
     if (e) {
         (void)hipMemset(h->dw2_meet, 0, (DW2_ENT_ERR + 8) * sizeof e);
         h->dw2_adam = false;
-        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        drop_graph(h);
         return fail(h, "weight_grad_assemble_adam_kernel: its 256 workgroups were not resident together within ~0.5 s (is another process using this GPU?); this "
                        "step's results are invalid.  The handle now launches adam_kernel separately (the default without PPO_HIP_ADAM_IN_B=1)");
     }
@@ -1066,7 +1076,7 @@ int adam_meet_check(ppo_handle* h) {
     if (e) {
         (void)hipMemset(h->adam_meet_words, 0, (ADAM_MEET_MAX_GRID + 32) * sizeof e);
         h->adam_meet = false;
-        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        drop_graph(h);
         return fail(h, "adam_kernel: the workgroups of its data-parallel form were not resident together within ~0.5 s; this step's results are invalid.  "
                        "The handle now uses the launches that need no meeting (PPO_HIP_NO_ADAM_MEET=1 selects them from the start)");
     }
@@ -1590,7 +1600,7 @@ void ppo_destroy(ppo_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->hp_active && h->pin_flag) __atomic_store_n(h->pin_flag + 64 + PCTL_STOP, 1u, __ATOMIC_RELEASE);    // a resident rollout kernel: ask it to leave
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->upd_graph) (void)hipGraphExecDestroy(h->upd_graph);
+    drop_graph(h);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
     for (void* m : h->peer.mapped) if (m) (void)hipIpcCloseMemHandle(m);
     if (h->peer.region) (void)hipFree(h->peer.region);
@@ -2083,7 +2093,7 @@ int ppo_rollout_alloc(ppo_handle* h, int32_t E, int32_t T) {
     if (h->nz_envs != E) return fail(h, "ppo_rollout_alloc: n_envs %d != normaliser's %d", E, h->nz_envs);
     if (host_quiesce(h)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    drop_graph(h);
     const NetDev& n = h->net;
     const size_t B = (size_t)E * T;
     if (dev_alloc(h, &h->ro_obs, B * n.O) || dev_alloc(h, &h->ro_act, B * n.A) || dev_alloc(h, &h->ro_val, B) || dev_alloc(h, &h->ro_nlp, B) ||
@@ -2781,14 +2791,14 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     const int Bp = gs ? B * h->world : B;                      // rows one permutation covers
     if (gs && Bp > h->gs_rows) {
         HIP_OK(h, hipStreamSynchronize(h->stream));
-        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        drop_graph(h);
         if (dev_alloc(h, &h->gs_obs, (size_t)Bp * h->net.O) || dev_alloc(h, &h->gs_act, (size_t)Bp * h->net.A) || dev_alloc(h, &h->gs_ret, Bp) ||
             dev_alloc(h, &h->gs_val, Bp) || dev_alloc(h, &h->gs_nlp, Bp)) return -1;
         h->gs_rows = Bp;
     }
     if (Bp > h->upd_cap_rows || steps > h->upd_cap_steps || !h->d_keys) {
         HIP_OK(h, hipStreamSynchronize(h->stream));
-        if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+        drop_graph(h);
         const int cr = std::max(Bp, h->upd_cap_rows), cs = std::max(steps, h->upd_cap_steps);
         if (dev_alloc(h, &h->mb_obs, (size_t)cr * h->net.O) || dev_alloc(h, &h->mb_act, (size_t)cr * h->net.A) || dev_alloc(h, &h->mb_adv, cr) ||
             dev_alloc(h, &h->mb_ret, cr) || dev_alloc(h, &h->mb_val, cr) || dev_alloc(h, &h->mb_nlp, cr)) return -1;
@@ -2808,7 +2818,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
         const size_t need = (size_t)nmb * 2 * ((M + NW_ROWS - 1) / NW_ROWS) * h->nw_stride;
         if (need > h->nw_epoch_cap && need <= ((size_t)256 << 20) / sizeof(float)) {      // (thousands of tiny minibatches: the write-through form's two sets instead)
             HIP_OK(h, hipStreamSynchronize(h->stream));
-            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            drop_graph(h);
             if (dev_alloc(h, &h->nw_epoch_partials, need)) return -1;
             h->nw_epoch_cap = need;
         }
@@ -2830,7 +2840,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
         // [epochs, Bp] ints, allocated only when explicit permutations are used (on-device shuffles need none)
         if (!h->d_perms || epochs > h->upd_cap_epochs) {
             HIP_OK(h, hipStreamSynchronize(h->stream));
-            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            drop_graph(h);
             if (dev_alloc(h, &h->d_perms, (size_t)epochs * h->upd_cap_rows)) return -1;
             h->upd_cap_epochs = epochs;
         }
@@ -2862,7 +2872,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
         const bool same = h->upd_graph && h->g_epochs == epochs && h->g_nmb == nmb && h->g_E == h->E && h->g_T == h->T &&
                           h->g_explicit == (int)explicit_perms && h->g_world == (gs ? -h->world : h->world);
         if (!same) {
-            if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+            drop_graph(h);
             HIP_OK(h, hipStreamSynchronize(h->stream));
             hipGraph_t graph = nullptr;
             // a runtime that cannot capture or instantiate this sequence is not fatal: the same launches run eagerly
@@ -2872,7 +2882,8 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
                 const int rc = enqueue_update(h, epochs, nmb, explicit_perms);
                 const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
                 ok = rc == 0 && ce == hipSuccess && graph != nullptr && hipGraphInstantiate(&h->upd_graph, graph, nullptr, nullptr, 0) == hipSuccess;
-                if (graph) (void)hipGraphDestroy(graph);
+                if (ok) h->upd_graph_tmpl = graph;            // (kept alive beside the executable graph: drop_graph)
+                else if (graph) (void)hipGraphDestroy(graph);
             }
             if (!ok) {
                 (void)hipGetLastError();
@@ -2938,7 +2949,7 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
     const int rc = init(&h->comm, world, u, rank);
     if (rc) return fail(h, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
     h->world = world; h->rank = rank;
-    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    drop_graph(h);
     { const char* e = getenv("PPO_HIP_NO_ADAM_MEET");
       h->adam_meet = !(e && e[0] == '1');
       if (h->adam_meet && (dev_alloc(h, &h->adam_meet_words, ADAM_MEET_MAX_GRID + 32) || dev_alloc(h, &h->adam_meet_parts, ADAM_MEET_MAX_GRID))) return -1;
@@ -3104,7 +3115,7 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
     ppo_handle::Peer& P = h->peer;
     if (!h->comm || !P.region) return fail(h, "ppo_dist_peer_attach: call ppo_dist_init and ppo_dist_peer_export first");
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    drop_graph(h);
     P.on = false;
     bool mapped = true;
     for (int r = 0; r < h->world; ++r) {
@@ -3179,7 +3190,7 @@ int ppo_dist_global_shuffle(ppo_handle* h, int on) {
     if (on && !h->comm) return fail(h, "ppo_dist_global_shuffle: call ppo_dist_init first (no communicator)");
     if (on && h->world > 1 && !h->rccl.AllGather) return fail(h, "ppo_dist_global_shuffle: the collective library has no ncclAllGather");
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    drop_graph(h);
     h->global_shuffle = on != 0;
     return 0;
 }
@@ -3188,7 +3199,7 @@ int ppo_dist_peer_enable(ppo_handle* h, int on) {
     ENTER(h);
     if (on && !h->peer.usable) return fail(h, "ppo_dist_peer_enable: not attached, or the probe failed");
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
+    drop_graph(h);
     h->peer.on = on != 0;
     return 0;
 }
