@@ -268,10 +268,9 @@ int fail(ppo_handle* h, const char* fmt, ...) {
         if (hipSetDevice((h)->device) != hipSuccess) return fail(h, "hipSetDevice(%d) failed", (h)->device); \
     } while (0)
 
-// The update's executable graph AND the captured graph it came from go together.  (Rounds 1 - 5 destroyed the captured graph right after hipGraphInstantiate; that is
-// allowed, but the one unexplained observation of round 5 -- DESIGN.md section 9: a replay whose later train steps went wrong after OTHER handles had captured their
-// graphs in between, only late in a long process -- is what a runtime that keeps pointers into the captured graph's node parameters would produce once the heap reuses
-// them, and keeping a few hundred KB alive per handle costs nothing.)
+// The update's executable graph AND the captured graph it came from go together.  (Rounds 1 - 5 destroyed the captured graph right after hipGraphInstantiate, which
+// is allowed; it is kept now because a runtime that held pointers into the captured graph's node parameters was one suspect for the open observation of DESIGN.md
+// section 9.  It was NOT the cause -- the observation is unchanged with the graph kept -- but a few hundred KB per handle cost nothing and rule that class out.)
 static void drop_graph(ppo_handle* h) {
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
     if (h->upd_graph_tmpl) { (void)hipGraphDestroy(h->upd_graph_tmpl); h->upd_graph_tmpl = nullptr; }
