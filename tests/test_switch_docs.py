@@ -1,0 +1,31 @@
+"""Documentation against code: every run-time switch the documents name exists in the sources, and every switch the sources read is named in INTEGRATION.md / README.md /
+DESIGN.md / include/ppo_hip.h (test-only hooks excepted).  CPU only."""
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TEST_ONLY = {"PPO_CTL_SELFTEST_DIE", "PPO_TEST_ITERS"}
+
+
+def _read(paths):
+    out = ""
+    for p in paths:
+        with open(p, errors="replace") as f:
+            out += f.read()
+    return out
+
+
+def test_documented_switches_exist_and_read_switches_are_documented():
+    docs = _read(os.path.join(ROOT, f) for f in ("INTEGRATION.md", "README.md", "DESIGN.md", os.path.join("include", "ppo_hip.h")))
+    documented = set(re.findall(r"PPO_(?:HIP|RCCL|CTL|VECENV)_[A-Z0-9_]+", docs))
+    product = _read(glob.glob(os.path.join(ROOT, "ppo_cpp_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "ppo_cpp_amd", "*.py")) +
+                    glob.glob(os.path.join(ROOT, "ppo_cpp_amd", "host", "*.cpp")) + glob.glob(os.path.join(ROOT, "ppo_cpp_amd", "host", "*", "*.hpp")))
+    everything = product + _read(glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "*.sh")) + glob.glob(os.path.join(ROOT, "tests", "*.py")) +
+                                 [os.path.join(ROOT, "bench.py")])
+    missing = sorted(d for d in documented if d not in everything)
+    assert not missing, "documented but not in any source: %s" % missing
+    read = set(re.findall(r'getenv\("(PPO_[A-Z0-9_]+)"\)', product))
+    undocumented = sorted(r for r in read if r not in documented and r not in TEST_ONLY)
+    assert not undocumented, "read by the library / host layer but not documented: %s" % undocumented
+    assert len(read) >= 30                      # (the pattern still finds them)
