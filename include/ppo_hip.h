@@ -226,6 +226,13 @@ int ppo_sync(ppo_handle* h);
  * "train8_kernel", "weight_grad_assemble_kernel", "narrow_train_kernel<static>", "narrow_epoch_kernel", "narrow_rollout1_kernel"; returns the count of entries */
 int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueued);
 
+/* ---- debug: a raw device buffer by name, padding included (the getters above copy the dense part of every tensor) ----------------
+ * "theta" "adam_m" "adam_v" (padded), "thetaT" / "par" (the transposed and small-parameter mirrors the train kernels read), "grad" (+ its tail), "sumsq", "beta_pow", "hyper",
+ * "norm_out", "dw2_parts", the last train step's workspaces ("x0g" "dmug" "h_pi_0" ... "slots_pi" "slabs"), the gathered epoch ("mb_obs" ... "gidx" "advstats" "keys"), the
+ * narrow path's packed image and second weight set ("nw_img" "nw_theta1" ...), the normaliser's state.  *count = the buffer's length in 4-byte words (0: not used by this shape);
+ * at most max_count words are copied.  Two runs that must agree bit for bit are compared buffer by buffer with it (tests/test_other_shapes.py).  No reference counterpart. */
+int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_count, int64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -323,5 +323,14 @@ class PPOHip:
         n = self.lib.ppo_kernel_counts(self.h, 32, names, cnt)
         return {names[i].value.decode(): cnt[i] for i in range(n)}
 
+    def debug_buffer(self, name):
+        """a raw device buffer by name, padding included, as uint32 words (include/ppo_hip.h, ppo_debug_buffer); empty when this shape does not use it"""
+        cnt = C.c_int64(0)
+        self._ck(self.lib.ppo_debug_buffer(self.h, name.encode(), None, C.c_int64(0), C.byref(cnt)))
+        out = np.empty(cnt.value, np.uint32)
+        if cnt.value:
+            self._ck(self.lib.ppo_debug_buffer(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(cnt.value), C.byref(cnt)))
+        return out
+
     def sync(self):
         self._ck(self.lib.ppo_sync(self.h))

@@ -3231,6 +3231,43 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
     return n;
 }
 
+// Raw device buffers by name, PADDING INCLUDED (ppo_get_flat and ppo_get_last_grad copy the dense part of every tensor only): the transposed mirrors, the small-parameter
+// mirrors, the assembled gradient with its tail, the workspaces of the last train step, the gathered epoch.  For bitwise comparisons of two runs (tests/test_other_shapes.py,
+// the interleaved-handles test's report); not part of the reference's interface.  *count = the buffer's length in 4-byte words; at most max_count are copied.
+int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_count, int64_t* count) {
+    ENTER_Q(h);
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    const NetDev& n = h->net;
+    const size_t P = (size_t)h->P_pad, R = (size_t)h->ws_rows, U = (size_t)h->upd_cap_rows;
+    struct Ent { const char* name; const void* p; size_t words; };
+    const Ent tab[] = {
+        {"theta", h->theta, P}, {"adam_m", h->adam_m, P}, {"adam_v", h->adam_v, P}, {"thetaT", h->thetaT, (size_t)h->PT}, {"par", h->par, (size_t)2 * n.par_total},
+        {"grad", h->grad, P + 256}, {"sumsq", h->sumsq, (size_t)4 * h->n_blocks}, {"beta_pow", h->beta_pow, 4}, {"hyper", h->hyper, 2}, {"norm_out", h->norm_out, 1},
+        {"dw2_parts", h->dw2_parts, (size_t)DW2_TILES + DW2_GRID}, {"dw2_counters", h->dw2_counters, (size_t)DW2_TILES},
+        {"x0g", h->narrow || h->bf.on ? nullptr : h->x0g, R * n.Kp0}, {"dmug", h->narrow || h->bf.on ? nullptr : h->dmug, R * n.Ap},
+        {"h_pi_0", h->narrow || h->bf.on ? nullptr : h->hg[0][0], R * n.Hp[0]}, {"h_vf_0", h->narrow || h->bf.on ? nullptr : h->hg[1][0], R * n.Hp[0]},
+        {"dy_pi_0", h->narrow || h->bf.on ? nullptr : h->dyg[0][0], R * n.Hp[0]}, {"dy_vf_0", h->narrow || h->bf.on ? nullptr : h->dyg[1][0], R * n.Hp[0]},
+        {"h_pi_1", h->narrow || h->bf.on || n.L < 2 ? nullptr : h->hg[0][1], R * n.Hp[n.L > 1 ? 1 : 0]}, {"dy_pi_1", h->narrow || h->bf.on || n.L < 2 ? nullptr : h->dyg[0][1], R * n.Hp[n.L > 1 ? 1 : 0]},
+        {"dy_vf_1", h->narrow || h->bf.on || n.L < 2 ? nullptr : h->dyg[1][1], R * n.Hp[n.L > 1 ? 1 : 0]},
+        {"slots_pi", h->narrow || h->bf.on ? nullptr : h->slots[0], (R / 16) * n.slot_w}, {"slots_vf", h->narrow || h->bf.on ? nullptr : h->slots[1], (R / 16) * n.slot_w},
+        {"slabs", h->narrow ? nullptr : h->slabs, (size_t)h->max_split * P},
+        {"mb_obs", h->mb_obs, U * n.O}, {"mb_act", h->mb_act, U * n.A}, {"mb_adv", h->mb_adv, U}, {"mb_ret", h->mb_ret, U}, {"mb_val", h->mb_val, U}, {"mb_nlp", h->mb_nlp, U},
+        {"gidx", h->d_gidx, U}, {"advstats", h->d_advstats, (size_t)2 * h->upd_cap_steps}, {"keys", h->d_keys, (size_t)2 * h->upd_cap_steps}, {"loss_rows", h->d_loss_rows, (size_t)5 * h->upd_cap_steps},
+        {"nw_img", h->nw_img, h->narrow ? (size_t)2 * h->nw.w_total : 0}, {"nw_partials", h->nw_partials, (size_t)4 * h->nw_groups_cap * h->nw_stride},
+        {"nw_theta1", h->nw_theta1, P}, {"nw_m1", h->nw_m1, P}, {"nw_v1", h->nw_v1, P}, {"nw_epoch_words", h->nw_epoch_words, NW_EPOCH_WORDS},
+        {"obs_mean", h->obs_rms.mean, (size_t)n.O}, {"obs_var", h->obs_rms.var, (size_t)n.O}, {"nz_ret", h->nz_ret, (size_t)h->nz_envs}, {"cur_done", h->cur_done, (size_t)h->nz_envs},
+    };
+    for (const Ent& e : tab) {
+        if (strcmp(e.name, name)) continue;
+        if (!e.p || !e.words) { *count = 0; return 0; }        // this handle's shape does not use the buffer
+        *count = (int64_t)e.words;
+        const size_t c = std::min<size_t>(e.words, (size_t)std::max<int64_t>(max_count, 0));
+        if (c) HIP_OK(h, hipMemcpy(dst, e.p, c * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    return fail(h, "ppo_debug_buffer: no buffer named '%s'", name);
+}
+
 #ifdef PPO_STAMPS
 int ppo_debug_read_stamps(ppo_handle* h, unsigned long long* dst, int n) {
     HIP_OK(h, hipStreamSynchronize(h->stream));

@@ -478,44 +478,141 @@ def test_exact_adam_in_the_deferred_and_resident_forms(O, E, T, nmb, epochs, mon
     np.testing.assert_allclose(outs["exact fast forms"][-3], outs["default"][-3], rtol=1e-4, atol=1e-6)
 
 
+# raw device buffers (padding included) compared by the interleaved-handles test's report: persistent state first, then what the last train step / epoch left behind
+_IL_STATE = ("theta", "adam_m", "adam_v", "thetaT", "par", "beta_pow", "hyper", "nw_img", "nw_theta1", "nw_m1", "nw_v1", "obs_mean", "obs_var", "nz_ret", "cur_done")
+_IL_WORK = ("keys", "gidx", "advstats", "mb_obs", "mb_act", "mb_adv", "mb_ret", "mb_val", "mb_nlp", "x0g", "h_pi_0", "h_vf_0", "h_pi_1", "dmug", "dy_pi_1", "dy_vf_1", "dy_pi_0", "dy_vf_0",
+            "slots_pi", "slots_vf", "slabs", "dw2_parts", "nw_partials", "grad", "sumsq", "norm_out", "loss_rows")
+_IL_SPECS = (((64, 64), 1, 512, 8, 1), ((256, 256), 64, 16, 4, 2), ((64, 64), 2, 128, 4, 3))
+_IL_NAMES = ("obs", "actions", "values", "neglogp", "rewards", "returns", "loss rows", "weights", "adam m", "adam v", "beta powers")
+
+
+@pytest.mark.parametrize("member", [0, 1, 2])
+def test_debug_buffer_reads_every_named_buffer(member):
+    """ppo_debug_buffer (include/ppo_hip.h): every name the interleaved-handles report compares can be read after a collect and an update on each of its three shapes, and the
+    buffers whose content is known from the public getters hold it: the padded weights are the dense weights plus zeros, `hyper` the learning rate and clip range of the last update,
+    `beta_pow` the powers, `loss_rows` the rows the update returned.  An unknown name is an error."""
+    from ppo_cpp_amd.capi import PPOHipError
+    hd, E, T, nmb, sd = _IL_SPECS[member]
+    g = hip(hd); g.init_orthogonal(sd); g.norm_init(E); g.rollout_alloc(E, T)
+    g.collect_synthetic(40, GAMMA, LAM, None, step0=0, first=True)
+    rows, mean = g.update(LR, CR, 2, nmb, None, seed=0)
+    got = {k: g.debug_buffer(k) for k in _IL_STATE + _IL_WORK}
+    for k in ("theta", "adam_m", "adam_v", "thetaT", "par", "grad", "beta_pow", "hyper", "keys", "gidx", "mb_obs", "loss_rows", "obs_mean", "cur_done"):
+        assert got[k].size > 0, k
+    narrow = hd == (64, 64)
+    for k in ("x0g", "dmug", "slabs", "dw2_parts", "slots_pi"):
+        assert (got[k].size == 0) == narrow, k
+    for k in ("nw_img", "nw_partials"):
+        assert (got[k].size > 0) == narrow, k
+    for which, k in enumerate(("theta", "adam_m", "adam_v")):
+        dense, padded = g.get_flat(which), got[k].view(np.float32)
+        assert padded.size > dense.size and np.isfinite(padded).all()
+        np.testing.assert_array_equal(np.sort(padded[padded != 0]), np.sort(dense[dense != 0]), err_msg=k + ": the padding is not zero")
+    np.testing.assert_array_equal(got["hyper"].view(np.float32), np.float32([LR, CR]))
+    np.testing.assert_array_equal(got["beta_pow"].view(np.float32)[2:4], np.asarray(g.beta_powers(), np.float32))
+    np.testing.assert_array_equal(got["loss_rows"].view(np.float32)[:rows.size], rows.ravel())
+    assert sorted(got["gidx"][:E * T].tolist()) == list(range(E * T))                  # the last epoch's row map is a permutation of the rollout's rows
+    with pytest.raises(PPOHipError, match="no buffer named"):
+        g.debug_buffer("no_such_buffer")
+    g.close()
+
+
+def _il_run(members, iterations=3):
+    """the handles `members` of _IL_SPECS in one process, calls interleaved (every member collects, then every member updates); per member: the public outputs in _IL_NAMES order per
+    iteration, and {stage: {buffer: words}} of the raw device buffers"""
+    hs = {}
+    for i in members:
+        hd, E, T, nmb, sd = _IL_SPECS[i]
+        g = hip(hd); g.init_orthogonal(sd); g.norm_init(E); g.rollout_alloc(E, T)
+        hs[i] = g
+    out = {i: [] for i in members}
+    dbg = {i: {} for i in members}
+    for it in range(iterations):
+        for i in members:
+            hs[i].collect_synthetic(40 + i, GAMMA, LAM, None, step0=it * _IL_SPECS[i][2], first=(it == 0))
+            out[i] += [hs[i].rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns")]
+            dbg[i]["iteration %d, after the collect" % it] = {k: hs[i].debug_buffer(k) for k in _IL_STATE}
+        for i in members:
+            rows, mean = hs[i].update(LR, CR, 2, _IL_SPECS[i][3], None, seed=it)
+            out[i] += [rows.copy(), hs[i].get_flat(0), hs[i].get_flat(1), hs[i].get_flat(2), np.asarray(hs[i].beta_powers()).copy()]
+            dbg[i]["iteration %d, after the update" % it] = {k: hs[i].debug_buffer(k) for k in _IL_STATE + _IL_WORK}
+    for g in hs.values():
+        g.close()
+    return out, dbg
+
+
+def _il_first_difference(a, b):
+    """(index of the first differing public output, its name) of two members' outputs, or None"""
+    for j, (x, y) in enumerate(zip(a, b)):
+        if not np.array_equal(x, y):
+            return j, "iteration %d: %s" % (j // len(_IL_NAMES), _IL_NAMES[j % len(_IL_NAMES)])
+    return None
+
+
+def _il_report(together, alone, monkeypatch):
+    """Everything that tells the causes apart, as text: which raw buffer differs FIRST (stage by stage, persistent state before workspaces), and the same scenario under other
+    conditions (again; other neighbours; other order; eager launches; elementwise Adam) -- each compared with the members run alone."""
+    lines = []
+    for i in sorted(together[0]):
+        d = _il_first_difference(together[0][i], alone[0][i])
+        lines.append("handle %d %s: public outputs %s" % (i, _IL_SPECS[i][:4], "equal" if d is None else "differ first at " + d[1]))
+        for stage in together[1][i]:
+            for k, x in together[1][i][stage].items():
+                y = alone[1][i][stage][k]
+                if x.shape != y.shape:
+                    lines.append("  %s: %s has %d words together, %d alone" % (stage, k, x.size, y.size))
+                elif not np.array_equal(x, y):
+                    bad = np.flatnonzero(x != y)
+                    lines.append("  %s: %s differs in %d of %d words, first at %d (together %r, alone %r), last at %d" % (
+                        stage, k, bad.size, x.size, bad[0], x.view(np.float32)[bad[0]], y.view(np.float32)[bad[0]], bad[-1]))
+    def variant(title, members, env=()):
+        for k, v in env:
+            monkeypatch.setenv(k, v)
+        try:
+            got = _il_run(members)[0]
+            ref = alone[0] if not env else {i: _il_run((i,))[0][i] for i in members}       # (a switch changes the arithmetic's form: compare with the members alone under the same switch)
+        finally:
+            for k, v in env:
+                monkeypatch.delenv(k, raising=False)
+        res = []
+        for i in members:
+            d = _il_first_difference(got[i], ref[i])
+            res.append("handle %d %s" % (i, "equal" if d is None else "differs (" + d[1] + ")"))
+        lines.append("%s: %s" % (title, "; ".join(res)))
+    variant("the same three again, against alone", (0, 1, 2))
+    variant("order 1, 0, 2", (1, 0, 2))
+    variant("order 2, 1, 0", (2, 1, 0))
+    variant("handles 0 and 1 only", (0, 1))
+    variant("handles 1 and 2 only", (1, 2))
+    variant("eager launches (PPO_HIP_NO_GRAPH=1)", (0, 1, 2), (("PPO_HIP_NO_GRAPH", "1"),))
+    variant("elementwise Adam (PPO_HIP_ADAM_NO_TILES=1)", (0, 1, 2), (("PPO_HIP_ADAM_NO_TILES", "1"),))
+    variant("launch per minibatch for the narrow handles (PPO_HIP_NO_NARROW_EPOCH=1)", (0, 1, 2), (("PPO_HIP_NO_NARROW_EPOCH", "1"),))
+    again = {i: _il_run((i,))[0][i] for i in (0, 1, 2)}
+    lines.append("alone again, against alone: " + "; ".join("handle %d %s" % (i, "equal" if _il_first_difference(again[i], alone[0][i]) is None else "differs") for i in (0, 1, 2)))
+    return "\n".join(lines)
+
+
 @pytest.mark.xfail(strict=False, reason="OPEN at the end of round 5: alone, in its file and behind every subset of the suite tried this passes (and a 300-trial stress of the same "
                    "scenario has no mismatch), but at the end of the whole -m gpu run the [256,256] handle's SECOND update gives other loss rows from its second train step on "
                    "when the two [64,64] handles run in between -- with the rollout, the weights, both Adam slots and the powers equal going in, deterministically.  Not understood "
-                   "(DESIGN.md section 9); the three handles' own determinism tests are green in the same run")
-def test_two_handles_interleaved_equal_the_same_handles_run_alone():
-    """Two handles in one process, their calls interleaved (A collect, B collect, A update, B update, ...): the reference's shape with the resident epoch kernel and a
-    [256,256] handle.  Each must produce exactly what it produces alone -- every meeting table, counter and workspace belongs to its handle."""
-    def make(hidden, E, T, seed):
-        g = hip(hidden); g.init_orthogonal(seed); g.norm_init(E); g.rollout_alloc(E, T)
-        return g
-    specs = (((64, 64), 1, 512, 8, 1), ((256, 256), 64, 16, 4, 2), ((64, 64), 2, 128, 4, 3))
-    def run(order):
-        hs = [make(hd, E, T, sd) for hd, E, T, nmb, sd in specs]
-        out = [[] for _ in specs]
-        for it in range(3):
-            for i in order:
-                hs[i].collect_synthetic(40 + i, GAMMA, LAM, None, step0=it * specs[i][2], first=(it == 0))
-                out[i] += [hs[i].rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns")]
-            for i in order:
-                rows, mean = hs[i].update(LR, CR, 2, specs[i][3], None, seed=it)
-                out[i] += [rows.copy(), hs[i].get_flat(0), hs[i].get_flat(1), hs[i].get_flat(2), np.asarray(hs[i].beta_powers()).copy()]
-        for h in hs:
-            h.close()
-        return out
-    together = run((0, 1, 2))
-    alone = [None] * len(specs)
-    for i in range(len(specs)):
-        hd, E, T, nmb, sd = specs[i]
-        g = make(hd, E, T, sd)
-        acc = []
-        for it in range(3):
-            g.collect_synthetic(40 + i, GAMMA, LAM, None, step0=it * T, first=(it == 0))
-            acc += [g.rollout_get(f) for f in ("obs", "actions", "values", "neglogp", "rewards", "returns")]
-            rows, mean = g.update(LR, CR, 2, nmb, None, seed=it)
-            acc += [rows.copy(), g.get_flat(0), g.get_flat(1), g.get_flat(2), np.asarray(g.beta_powers()).copy()]
-        g.close()
-        alone[i] = acc
-    names = ("obs", "actions", "values", "neglogp", "rewards", "returns", "loss rows", "weights", "adam m", "adam v", "beta powers")
-    for i in range(len(specs)):
-        for j, (a, b) in enumerate(zip(together[i], alone[i])):
-            np.testing.assert_array_equal(a, b, err_msg="handle %d, iteration %d: %s" % (i, j // len(names), names[j % len(names)]))
+                   "(DESIGN.md section 9); the three handles' own determinism tests are green in the same run.  On a mismatch the test writes gpurun_out/interleaved_report.txt")
+def test_two_handles_interleaved_equal_the_same_handles_run_alone(monkeypatch):
+    """Three handles in one process, their calls interleaved (A collect, B collect, C collect, A update, B update, ...): the reference's shape with the resident epoch kernel, a
+    [256,256] handle and a second narrow shape.  Each must produce exactly what it produces alone -- every meeting table, counter and workspace belongs to its handle.  The public
+    outputs are what is asserted; on a mismatch the raw device buffers (padding, mirrors, workspaces: ppo_debug_buffer) of the two runs are compared stage by stage and the scenario
+    is repeated under other conditions, and the findings go to gpurun_out/interleaved_report.txt and into the assertion's message."""
+    import os
+    together = _il_run((0, 1, 2))
+    alone_runs = {i: _il_run((i,)) for i in (0, 1, 2)}
+    alone = ({i: alone_runs[i][0][i] for i in alone_runs}, {i: alone_runs[i][1][i] for i in alone_runs})
+    if all(_il_first_difference(together[0][i], alone[0][i]) is None for i in (0, 1, 2)):
+        return
+    report = _il_report(together, alone, monkeypatch)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "interleaved_report.txt"), "w") as f:
+            f.write(report + "\n")
+    except OSError:
+        pass
+    raise AssertionError("interleaved handles differ from the same handles run alone:\n" + report)
