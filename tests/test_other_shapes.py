@@ -582,6 +582,22 @@ def _il_report(plain_together, plain_alone, monkeypatch):
                     bad = np.flatnonzero(x != y)
                     lines.append("  %s: %s differs in %d of %d words, first at %d (together %r, alone %r), last at %d" % (
                         stage, k, bad.size, x.size, bad[0], x.view(np.float32)[bad[0]], y.view(np.float32)[bad[0]], bad[-1]))
+    # the [256,256] handle's last train step of every update: the assembled gradient must be the four row-split slabs added in split order (weight_grad_assemble_kernel's finisher;
+    # a finisher that met a slab of the PREVIOUS step would break this)
+    for run, src in (("together", together), ("alone", alone)):
+        for stage, bufs in src[1][1].items():
+            if "update" not in stage or not bufs["slabs"].size:
+                continue
+            P = bufs["theta"].size
+            sl = bufs["slabs"].view(np.float32).reshape(-1, P)[:4]
+            acc = sl[0].copy()
+            for k in range(1, 4):
+                acc = acc + sl[k]
+            covered = (sl != 0).any(axis=0)
+            g = bufs["grad"].view(np.float32)[:P]
+            bad = np.flatnonzero(covered & (acc.view(np.uint32) != g.view(np.uint32)))
+            lines.append("%s, %s: gradient == sum of the slabs on %d of %d covered words%s" % (stage, run, int(covered.sum()) - bad.size, int(covered.sum()),
+                                                                                            "" if not bad.size else " (first mismatch at %d: %r against %r)" % (bad[0], acc[bad[0]], g[bad[0]])))
     def variant(title, members, env=()):
         for k, v in env:
             monkeypatch.setenv(k, v)
