@@ -499,11 +499,6 @@ def test_debug_buffer_reads_every_named_buffer(member):
     got = {k: g.debug_buffer(k) for k in _IL_STATE + _IL_WORK}
     for k in ("theta", "adam_m", "adam_v", "thetaT", "par", "grad", "beta_pow", "hyper", "keys", "gidx", "mb_obs", "loss_rows", "obs_mean", "cur_done"):
         assert got[k].size > 0, k
-    narrow = hd == (64, 64)
-    for k in ("x0g", "dmug", "slabs", "dw2_parts", "slots_pi"):
-        assert (got[k].size == 0) == narrow, k
-    for k in ("nw_img", "nw_partials"):
-        assert (got[k].size > 0) == narrow, k
     for which, k in enumerate(("theta", "adam_m", "adam_v")):
         dense, padded = g.get_flat(which), got[k].view(np.float32)
         assert padded.size > dense.size
@@ -567,6 +562,22 @@ def _il_report(plain_together, plain_alone, monkeypatch, emit):
     for i in sorted(plain_together):
         d = _il_first_difference(plain_together[i], plain_alone[i])
         emit("asserted run, handle %d %s: public outputs %s" % (i, _IL_SPECS[i][:4], "equal" if d is None else "differ first at " + d[1]))
+        if d is None:
+            continue
+        # EVERY public output that differs (are the weights behind the differing loss rows different too, or only what the host was handed?) ...
+        for j, (x, y) in enumerate(zip(plain_together[i], plain_alone[i])):
+            if not np.array_equal(x, y):
+                bad = np.flatnonzero(np.asarray(x).ravel() != np.asarray(y).ravel())
+                emit("  iteration %d: %s differs in %d of %d elements (first at %d: %r together, %r alone)" % (
+                    j // len(_IL_NAMES), _IL_NAMES[j % len(_IL_NAMES)], bad.size, np.asarray(x).size, bad[0], np.asarray(x).ravel()[bad[0]], np.asarray(y).ravel()[bad[0]]))
+        # ... and whether a differing loss row is the row the PREVIOUS update left at that place (a copy that ran before the update had finished would hand that over)
+        for run, src in (("together", plain_together[i]), ("alone", plain_alone[i])):
+            for it in range(1, len(src) // len(_IL_NAMES)):
+                rows, prev, other = src[6 + 11 * it], src[6 + 11 * (it - 1)], (plain_alone if run == "together" else plain_together)[i][6 + 11 * it]
+                stale = [k for k in range(rows.shape[0]) if np.array_equal(rows[k], prev[k])]
+                off = [k for k in range(rows.shape[0]) if not np.array_equal(rows[k], other[k])]
+                if off:
+                    emit("  iteration %d, %s: loss rows %s differ from the other run's; rows equal to the previous update's at the same place: %s" % (it, run, off, stale))
 
     def variant(title, members, env=()):
         def run():
@@ -648,8 +659,17 @@ def _il_report(plain_together, plain_alone, monkeypatch, emit):
                 covered = (sl != 0).any(axis=0)
                 g = bufs["grad"].view(np.float32)[:P]
                 bad = np.flatnonzero(covered & (acc.view(np.uint32) != g.view(np.uint32)))
-                emit("%s, %s: gradient == sum of the slabs on %d of %d covered words%s" % (stage, run, int(covered.sum()) - bad.size, int(covered.sum()),
-                                                                                         "" if not bad.size else " (first mismatch at %d: %r against %r)" % (bad[0], acc[bad[0]], g[bad[0]])))
+                # (should a slab ever keep a region in another order than the gradient -- DESIGN.md section 9 proposes that for the first-layer strips -- those words differ in
+                # place and agree as a multiset: told apart here)
+                # (in place the permuted words meet zeros of the padding rows and the slot jobs' elements: every non-zero sum must be SOMEWHERE among the gradient's differing words)
+                from collections import Counter
+                off = np.flatnonzero(acc.view(np.uint32) != g.view(np.uint32))
+                have = Counter(g[off][g[off] != 0].view(np.uint32).tolist())
+                need = Counter(acc[off][acc[off] != 0].view(np.uint32).tolist())
+                same_values = bool(bad.size) and all(have[k] >= c for k, c in need.items())
+                emit("%s, %s: gradient == sum of the slabs in place on %d of %d covered words%s" % (
+                    stage, run, int(covered.sum()) - bad.size, int(covered.sum()),
+                    "" if not bad.size else "; the other %d (words %d .. %d) hold %s" % (bad.size, bad[0], bad[-1], "the same values in another order" if same_values else "OTHER values")))
     section(slabs)
 
 
