@@ -61,6 +61,9 @@ struct Dw2Args {
     const float* slots[2]; int n_rowblocks, slot_w;
     float n_local; float* beta_pow; int tail_off;
     unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS): [grid][16]
+    // two OPT-IN forms of the slab hand-off, for telling a suspected hand-off fault from anything else; 0 = the measured default:
+    int own_lines;               // PPO_HIP_DW2_OWN_LINES=1: a slab keeps every first-layer strip contiguous, so that no 128-byte line of a slab belongs to two tiles
+    int model_fences;            // PPO_HIP_DW2_FENCES=1: agent-scope RELEASE on the arrival and ACQUIRE in the last arriver (the language model's form; ~2x the launch's time)
 };
 
 // write-through (sc1) 16-byte load for bytes another workgroup stored write-through in this launch.  Inline asm: the compiler
@@ -390,9 +393,15 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
     unsigned soff = 0;
     if (kind == 0) soff = (unsigned)(a.w0_off[tower] + (tid >> 2) * 256 + 16 * sidx + 4 * (tid & 3));                 // W0 [KP0][256]
     else if (kind == 1) soff = (unsigned)(a.wmu_off + (16 * sidx + (4 * tid) / AP) * AP + (4 * tid) % AP);            // W_mu [256][AP]
+    // ... and inside a SLAB.  The main tile's row segments (32 floats) and the head's strip rows (AP floats) are whole 128-byte lines of their own; a first-layer strip is 16 columns of
+    // a 256-float row -- half a line, the other half the neighbour tile's.  In the parameter vector that is harmless (plain stores, merged by byte mask at the kernel's end); in a slab it
+    // means the finisher of one tile pulls lines into its XCD's L2 whose other half a split of the neighbour may not have written yet (sc1 loads bypass the L1, not the L2).  Never seen
+    // to matter (it would have to show in most launches); own_lines keeps the strips contiguous in the slab ([16 strips][KP0][16]) -- only the finisher reads a slab, and it writes the
+    // natural layout -- so that the question can be asked of the hardware.
+    const unsigned sslab = (a.own_lines && kind == 0) ? (unsigned)(a.w0_off[tower] + sidx * sn + 4 * tid) : soff;
     float* slab = a.slabs + (size_t)split * a.slab_stride;
     st_wt4<true>(slab + moff, m4);
-    if (strip_thread) st_wt4<true>(slab + soff, sv);
+    if (strip_thread) st_wt4<true>(slab + sslab, sv);
     if (tid == 0) {
         float q = 0.f;
         for (int j = 0; j < 16; ++j) q += red2[j];
@@ -419,7 +428,8 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
 #if DW2_MODEL_FENCES
         const unsigned old = __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
-        const unsigned old = __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = a.model_fences ? __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+                                            : __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
         flag[0] = (old == DW2_SPLITS - 1) ? 1 : 0;
     }
@@ -431,13 +441,15 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
     if (fin) {
 #if DW2_MODEL_FENCES
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+        if (a.model_fences) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
         // last arriver: the four slabs in split order (its own included: same bits whoever is last), all loads first
         f32x4 p[DW2_SPLITS], q[DW2_SPLITS];
 #pragma unroll
         for (int s = 0; s < DW2_SPLITS; ++s) {
             p[s] = dw2_ld_sc1(a.slabs + (size_t)s * a.slab_stride + moff);
-            q[s] = dw2_ld_sc1(a.slabs + (size_t)s * a.slab_stride + (strip_thread ? soff : moff));
+            q[s] = dw2_ld_sc1(a.slabs + (size_t)s * a.slab_stride + (strip_thread ? sslab : moff));
         }
         dw2_wait4(p[0], p[1], p[2], p[3]);
         dw2_wait4(q[0], q[1], q[2], q[3]);

@@ -1282,6 +1282,8 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
         da.stamps = g_stamps + 4096 * 16;
 #endif
         da.n_rowblocks = n_rb; da.slot_w = n.slot_w; da.n_local = (float)ta.n; da.beta_pow = h->beta_pow; da.tail_off = h->P_pad;
+        { const char* e1 = getenv("PPO_HIP_DW2_OWN_LINES"); const char* e2 = getenv("PPO_HIP_DW2_FENCES");       // (read per call: a test compares the forms in one process; a graph keeps what it captured)
+          da.own_lines = (e1 && e1[0] == '1') ? 1 : 0; da.model_fences = (e2 && e2[0] == '1') ? 1 : 0; }
     }
     // one launch for both kernels when every workgroup of both phases is resident at once (<= 2048 rows: 2 n_rb <= 256 = one workgroup per CU)
     if (use_dw2 && h->t8 && h->fuse_ab && 2 * n_rb <= DW2_GRID && n_rb % 4 == 0) {

@@ -603,6 +603,11 @@ def _il_report(plain_together, plain_alone, monkeypatch, emit):
     variant("eager launches (PPO_HIP_NO_GRAPH=1)", (0, 1, 2), (("PPO_HIP_NO_GRAPH", "1"),))
     variant("elementwise Adam (PPO_HIP_ADAM_NO_TILES=1)", (0, 1, 2), (("PPO_HIP_ADAM_NO_TILES", "1"),))
     variant("launch per minibatch for the narrow handles (PPO_HIP_NO_NARROW_EPOCH=1)", (0, 1, 2), (("PPO_HIP_NO_NARROW_EPOCH", "1"),))
+    # the [256,256] handle's slab hand-off in its two other forms (ppo_dw2.hpp, Dw2Args::model_fences / own_lines): equal HERE and not above = the default hand-off is at fault
+    variant("slab hand-off with release / acquire fences (PPO_HIP_DW2_FENCES=1)", (0, 1, 2), (("PPO_HIP_DW2_FENCES", "1"),))
+    variant("first-layer strips on lines of their own inside a slab (PPO_HIP_DW2_OWN_LINES=1)", (0, 1, 2), (("PPO_HIP_DW2_OWN_LINES", "1"),))
+    variant("the round-2 weight-gradient + assembly kernels (PPO_HIP_NO_DW2=1)", (0, 1, 2), (("PPO_HIP_NO_DW2", "1"),))
+    variant("the round-2 train kernel (PPO_HIP_NO_T8=1)", (0, 1, 2), (("PPO_HIP_NO_T8", "1"),))
 
     def alone_again():
         again = {i: _il_run((i,))[0][i] for i in (0, 1, 2)}
