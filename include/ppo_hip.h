@@ -230,7 +230,8 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
  * "theta" "adam_m" "adam_v" (padded), "thetaT" / "par" (the transposed and small-parameter mirrors the train kernels read), "grad" (+ its tail), "sumsq", "beta_pow", "hyper",
  * "norm_out", "dw2_parts", the last train step's workspaces ("x0g" "dmug" "h_pi_0" ... "slots_pi" "slabs"), the gathered epoch ("mb_obs" ... "gidx" "advstats" "keys"), the
  * narrow path's packed image and second weight set ("nw_img" "nw_theta1" ...), the normaliser's state.  *count = the buffer's length in 4-byte words (0: not used by this shape);
- * at most max_count words are copied.  Two runs that must agree bit for bit are compared buffer by buffer with it (tests/test_other_shapes.py).  No reference counterpart. */
+ * at most max_count words are copied.  Two runs that must agree bit for bit are compared buffer by buffer with it (tests/test_other_shapes.py).  No reference counterpart.
+ * "snap:<name>": the same buffer as it was right behind train step n of the last ppo_update, for a handle created under PPO_HIP_DEBUG_SNAPSHOT=n (launch-per-step paths). */
 int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_count, int64_t* count);
 
 #ifdef __cplusplus

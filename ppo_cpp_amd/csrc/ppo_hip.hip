@@ -91,6 +91,12 @@ struct ppo_handle {
     int n_tiled = 0; AdamArgs::Tiled tiled[ADAM_MAX_TILED]{};   // matrices whose transposed copy adam_kernel writes tile by tile
     // train workspaces (sized for ws_rows minibatch rows)
     int ws_rows = 0;
+    // diagnostic (PPO_HIP_DEBUG_SNAPSHOT=<train step of an update>, read at ppo_create): ppo_update copies every buffer ppo_debug_buffer knows into an arena right behind that train
+    // step's launches (device-to-device copies in the stream / nodes of the update's graph), readable as "snap:<name>".  -1 = off: nothing is enqueued, nothing allocated.
+    int snap_step = -1;
+    float* snap_arena = nullptr; size_t snap_words = 0;
+    struct SnapEnt { std::string name; size_t off, words; };
+    std::vector<SnapEnt> snap_index;
     float* x0g = nullptr;
     float* hg[2][PPO_MAX_LAYERS]{};
     float* dyg[2][PPO_MAX_LAYERS]{};
@@ -1484,6 +1490,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { fail(h, "hipStreamCreate failed"); return bail(0); }
     const char* ng = getenv("PPO_HIP_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
+    { const char* sn = getenv("PPO_HIP_DEBUG_SNAPSHOT");     // diagnostic: copy every buffer behind train step <n> of each update (ppo_debug_buffer "snap:<name>")
+      if (sn && sn[0] >= '0' && sn[0] <= '9') h->snap_step = atoi(sn); }
     if (cfg->compute_dtype != PPO_F32 && cfg->compute_dtype != PPO_BF16) { fail(h, "ppo_create: compute_dtype must be PPO_F32 or PPO_BF16"); return bail(0); }
     h->bf.on = cfg->compute_dtype == PPO_BF16;
     if (build_layout(h)) return bail(0);
@@ -1607,6 +1615,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->peer.region) (void)hipFree(h->peer.region);
     if (h->peer.local) (void)hipFree(h->peer.local);
     for (float* p : {h->nw_theta1, h->nw_m1, h->nw_v1}) if (p) (void)hipFree(p);
+    if (h->snap_arena) (void)hipFree(h->snap_arena);
     if (h->nw_partials) (void)hipFree(h->nw_partials);
     if (h->nw_epoch_words) (void)hipFree(h->nw_epoch_words);
     if (h->nw_epoch_partials) (void)hipFree(h->nw_epoch_partials);
@@ -2623,6 +2632,58 @@ int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count
 }
 
 // ---- update -----------------------------------------------------------------------------------------------------------
+// every device buffer of a handle by name (ppo_debug_buffer; the diagnostic snapshot): pointer (null = this shape does not use it) and length in 4-byte words
+struct DbgEnt { const char* name; const void* p; size_t words; };
+static std::vector<DbgEnt> debug_table(ppo_handle* h) {
+    const NetDev& n = h->net;
+    const size_t P = (size_t)h->P_pad, R = (size_t)h->ws_rows, U = (size_t)h->upd_cap_rows;
+    const bool ws = !(h->narrow || h->bf.on);                 // the fp32 wide path's train workspaces
+    return {
+        {"theta", h->theta, P}, {"adam_m", h->adam_m, P}, {"adam_v", h->adam_v, P}, {"thetaT", h->thetaT, (size_t)h->PT}, {"par", h->par, (size_t)2 * n.par_total},
+        {"grad", h->grad, P + 256}, {"sumsq", h->sumsq, (size_t)4 * h->n_blocks}, {"beta_pow", h->beta_pow, 4}, {"hyper", h->hyper, 2}, {"norm_out", h->norm_out, 1},
+        {"dw2_parts", h->dw2_parts, (size_t)DW2_TILES + DW2_GRID}, {"dw2_counters", h->dw2_counters, (size_t)DW2_TILES},
+        {"x0g", ws ? h->x0g : nullptr, R * n.Kp0}, {"dmug", ws ? h->dmug : nullptr, R * n.Ap},
+        {"h_pi_0", ws ? h->hg[0][0] : nullptr, R * n.Hp[0]}, {"h_vf_0", ws ? h->hg[1][0] : nullptr, R * n.Hp[0]},
+        {"dy_pi_0", ws ? h->dyg[0][0] : nullptr, R * n.Hp[0]}, {"dy_vf_0", ws ? h->dyg[1][0] : nullptr, R * n.Hp[0]},
+        {"h_pi_1", ws && n.L > 1 ? h->hg[0][1] : nullptr, R * n.Hp[n.L > 1 ? 1 : 0]}, {"dy_pi_1", ws && n.L > 1 ? h->dyg[0][1] : nullptr, R * n.Hp[n.L > 1 ? 1 : 0]},
+        {"dy_vf_1", ws && n.L > 1 ? h->dyg[1][1] : nullptr, R * n.Hp[n.L > 1 ? 1 : 0]},
+        {"slots_pi", ws ? h->slots[0] : nullptr, (R / 16) * n.slot_w}, {"slots_vf", ws ? h->slots[1] : nullptr, (R / 16) * n.slot_w},
+        {"slabs", h->narrow ? nullptr : h->slabs, (size_t)h->max_split * P},
+        {"mb_obs", h->mb_obs, U * n.O}, {"mb_act", h->mb_act, U * n.A}, {"mb_adv", h->mb_adv, U}, {"mb_ret", h->mb_ret, U}, {"mb_val", h->mb_val, U}, {"mb_nlp", h->mb_nlp, U},
+        {"gidx", h->d_gidx, U}, {"advstats", h->d_advstats, (size_t)2 * h->upd_cap_steps}, {"keys", h->d_keys, (size_t)2 * h->upd_cap_steps}, {"loss_rows", h->d_loss_rows, (size_t)5 * h->upd_cap_steps},
+        {"nw_img", h->nw_img, h->narrow ? (size_t)2 * h->nw.w_total : 0}, {"nw_partials", h->nw_partials, (size_t)4 * h->nw_groups_cap * h->nw_stride},
+        {"nw_theta1", h->nw_theta1, P}, {"nw_m1", h->nw_m1, P}, {"nw_v1", h->nw_v1, P}, {"nw_epoch_words", h->nw_epoch_words, NW_EPOCH_WORDS},
+        {"obs_mean", h->obs_rms.mean, (size_t)n.O}, {"obs_var", h->obs_rms.var, (size_t)n.O}, {"nz_ret", h->nz_ret, (size_t)h->nz_envs}, {"cur_done", h->cur_done, (size_t)h->nz_envs},
+    };
+}
+
+// diagnostic snapshot (ppo_handle::snap_step): the arena is laid out -- and (re)allocated, which drops the update's graph -- outside any capture, from ppo_update
+static int snapshot_prepare(ppo_handle* h) {
+    std::vector<ppo_handle::SnapEnt> idx;
+    size_t total = 0;
+    for (const DbgEnt& e : debug_table(h)) {
+        if (!e.p || !e.words) continue;
+        idx.push_back({e.name, total, e.words});
+        total += (e.words + 63) / 64 * 64;
+    }
+    bool same = h->snap_arena && total == h->snap_words && idx.size() == h->snap_index.size();
+    for (size_t i = 0; same && i < idx.size(); ++i) same = idx[i].name == h->snap_index[i].name && idx[i].off == h->snap_index[i].off && idx[i].words == h->snap_index[i].words;
+    if (same) return 0;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    if (dev_alloc(h, &h->snap_arena, total)) return -1;
+    h->snap_words = total; h->snap_index = std::move(idx);
+    return 0;
+}
+static int enqueue_snapshot(ppo_handle* h) {
+    const std::vector<DbgEnt> tab = debug_table(h);
+    for (const ppo_handle::SnapEnt& s : h->snap_index)
+        for (const DbgEnt& e : tab)
+            if (s.name == e.name && e.p && e.words == s.words)
+                HIP_OK(h, hipMemcpyAsync(h->snap_arena + s.off, e.p, s.words * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
 static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perms) {
     const int B = h->E * h->T, M = B / nmb;
     // the per-tile arrival counters of weight_grad_assemble_kernel are reset by their last arriver; an update that was cut short
@@ -2771,6 +2832,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             ta.old_neglogp = h->mb_nlp + r0; ta.advs = h->mb_adv + r0; ta.adv_stats = nullptr; ta.n = M;
             ta.inv_n = 1.0f / (float)((int64_t)M * h->world);
             if (enqueue_train(h, ta, h->d_loss_rows + (size_t)(ep * nmb + k) * 5, /*defer*/ true)) return -1;
+            if (h->snap_step == ep * nmb + k && h->snap_arena && enqueue_snapshot(h)) return -1;       // (diagnostic, off by default)
         }
     }
     if (flush_pending_adam(h)) return -1;
@@ -2824,6 +2886,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
             h->nw_epoch_cap = need;
         }
     }
+    if (h->snap_step >= 0 && snapshot_prepare(h)) return -1;
     if (set_hyper(h, lr, cliprange)) return -1;
     const bool explicit_perms = perms != nullptr;
     if (explicit_perms) {
@@ -3239,35 +3302,20 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
 int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_count, int64_t* count) {
     ENTER_Q(h);
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    const NetDev& n = h->net;
-    const size_t P = (size_t)h->P_pad, R = (size_t)h->ws_rows, U = (size_t)h->upd_cap_rows;
-    struct Ent { const char* name; const void* p; size_t words; };
-    const Ent tab[] = {
-        {"theta", h->theta, P}, {"adam_m", h->adam_m, P}, {"adam_v", h->adam_v, P}, {"thetaT", h->thetaT, (size_t)h->PT}, {"par", h->par, (size_t)2 * n.par_total},
-        {"grad", h->grad, P + 256}, {"sumsq", h->sumsq, (size_t)4 * h->n_blocks}, {"beta_pow", h->beta_pow, 4}, {"hyper", h->hyper, 2}, {"norm_out", h->norm_out, 1},
-        {"dw2_parts", h->dw2_parts, (size_t)DW2_TILES + DW2_GRID}, {"dw2_counters", h->dw2_counters, (size_t)DW2_TILES},
-        {"x0g", h->narrow || h->bf.on ? nullptr : h->x0g, R * n.Kp0}, {"dmug", h->narrow || h->bf.on ? nullptr : h->dmug, R * n.Ap},
-        {"h_pi_0", h->narrow || h->bf.on ? nullptr : h->hg[0][0], R * n.Hp[0]}, {"h_vf_0", h->narrow || h->bf.on ? nullptr : h->hg[1][0], R * n.Hp[0]},
-        {"dy_pi_0", h->narrow || h->bf.on ? nullptr : h->dyg[0][0], R * n.Hp[0]}, {"dy_vf_0", h->narrow || h->bf.on ? nullptr : h->dyg[1][0], R * n.Hp[0]},
-        {"h_pi_1", h->narrow || h->bf.on || n.L < 2 ? nullptr : h->hg[0][1], R * n.Hp[n.L > 1 ? 1 : 0]}, {"dy_pi_1", h->narrow || h->bf.on || n.L < 2 ? nullptr : h->dyg[0][1], R * n.Hp[n.L > 1 ? 1 : 0]},
-        {"dy_vf_1", h->narrow || h->bf.on || n.L < 2 ? nullptr : h->dyg[1][1], R * n.Hp[n.L > 1 ? 1 : 0]},
-        {"slots_pi", h->narrow || h->bf.on ? nullptr : h->slots[0], (R / 16) * n.slot_w}, {"slots_vf", h->narrow || h->bf.on ? nullptr : h->slots[1], (R / 16) * n.slot_w},
-        {"slabs", h->narrow ? nullptr : h->slabs, (size_t)h->max_split * P},
-        {"mb_obs", h->mb_obs, U * n.O}, {"mb_act", h->mb_act, U * n.A}, {"mb_adv", h->mb_adv, U}, {"mb_ret", h->mb_ret, U}, {"mb_val", h->mb_val, U}, {"mb_nlp", h->mb_nlp, U},
-        {"gidx", h->d_gidx, U}, {"advstats", h->d_advstats, (size_t)2 * h->upd_cap_steps}, {"keys", h->d_keys, (size_t)2 * h->upd_cap_steps}, {"loss_rows", h->d_loss_rows, (size_t)5 * h->upd_cap_steps},
-        {"nw_img", h->nw_img, h->narrow ? (size_t)2 * h->nw.w_total : 0}, {"nw_partials", h->nw_partials, (size_t)4 * h->nw_groups_cap * h->nw_stride},
-        {"nw_theta1", h->nw_theta1, P}, {"nw_m1", h->nw_m1, P}, {"nw_v1", h->nw_v1, P}, {"nw_epoch_words", h->nw_epoch_words, NW_EPOCH_WORDS},
-        {"obs_mean", h->obs_rms.mean, (size_t)n.O}, {"obs_var", h->obs_rms.var, (size_t)n.O}, {"nz_ret", h->nz_ret, (size_t)h->nz_envs}, {"cur_done", h->cur_done, (size_t)h->nz_envs},
-    };
-    for (const Ent& e : tab) {
-        if (strcmp(e.name, name)) continue;
-        if (!e.p || !e.words) { *count = 0; return 0; }        // this handle's shape does not use the buffer
-        *count = (int64_t)e.words;
-        const size_t c = std::min<size_t>(e.words, (size_t)std::max<int64_t>(max_count, 0));
-        if (c) HIP_OK(h, hipMemcpy(dst, e.p, c * sizeof(float), hipMemcpyDeviceToHost));
-        return 0;
+    const void* p = nullptr; size_t words = 0; bool found = false;
+    if (!strncmp(name, "snap:", 5)) {
+        // the copy PPO_HIP_DEBUG_SNAPSHOT=<step> made right behind that train step of the last ppo_update (0 words: no snapshot, or the buffer is not used by this shape)
+        for (const DbgEnt& e : debug_table(h)) if (!strcmp(e.name, name + 5)) found = true;
+        for (const ppo_handle::SnapEnt& s : h->snap_index) if (s.name == name + 5) { p = h->snap_arena + s.off; words = s.words; }
+    } else {
+        for (const DbgEnt& e : debug_table(h)) if (!strcmp(e.name, name)) { found = true; p = e.p; words = e.words; }
     }
-    return fail(h, "ppo_debug_buffer: no buffer named '%s'", name);
+    if (!found) return fail(h, "ppo_debug_buffer: no buffer named '%s'", name);
+    if (!p || !words) { *count = 0; return 0; }               // this handle's shape does not use the buffer
+    *count = (int64_t)words;
+    const size_t c = std::min<size_t>(words, (size_t)std::max<int64_t>(max_count, 0));
+    if (c) HIP_OK(h, hipMemcpy(dst, p, c * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 #ifdef PPO_STAMPS

@@ -9,7 +9,7 @@ import pytest
 import tests.test_other_shapes as t
 
 
-def _fake_run(members, iterations=3, debug=False):
+def _fake_run(members, iterations=3, debug=False, snap=False):
     together = len(members) > 1
     out = {i: [] for i in members}
     dbg = {i: {} for i in members}
@@ -24,6 +24,11 @@ def _fake_run(members, iterations=3, debug=False):
             if together and i == 1 and it == 1:
                 rows[1:] = np.arange(40, dtype=np.float32).reshape(8, 5)[1:]           # the rows the previous update left behind
             out[i] += [rows, w, w.copy(), w.copy(), np.zeros(2, np.float32)]
+            if snap:
+                sd = {k: np.zeros(8, np.uint32) for k in t._IL_WORK + t._IL_STATE}
+                if together and i == 1 and it == 1:
+                    sd["slabs"][2] = 5                                                    # the first train step's slabs differ: the weight-gradient kernel
+                dbg[i]["iteration %d, behind the first train step of the update" % it] = sd
             if not debug:
                 continue
             d = {k: np.zeros(8, np.uint32) for k in t._IL_STATE + t._IL_WORK}
@@ -63,12 +68,13 @@ def test_report_names_every_finding_and_survives_a_failing_section(monkeypatch, 
     assert "iteration 2, after the update, together: gradient == sum of the slabs in place on 11 of 12 covered words; the other 1 (words 0 .. 0) hold OTHER values" in text
     assert "iteration 2, after the update, alone: gradient == sum of the slabs in place on 12 of 12 covered words" in text
     assert "(this part of the report failed: KeyError: 'par')" in text
+    assert "iteration 1, behind the first train step of the update: slabs differs in 1 of 8 words, first at 2" in text
     written = (tmp_path / "gpurun_out" / "interleaved_report.txt").read_text()
     assert written.strip() == text.split("\n", 1)[1].strip()                            # the file holds the same lines as the assertion's message
 
 
 def test_equal_runs_pass_without_a_report(monkeypatch, tmp_path):
-    monkeypatch.setattr(t, "_il_run", lambda members, iterations=3, debug=False: _fake_run((members[0],), iterations, debug) if len(members) == 1 else
+    monkeypatch.setattr(t, "_il_run", lambda members, iterations=3, debug=False, snap=False: _fake_run((members[0],), iterations, debug) if len(members) == 1 else
                         ({i: _fake_run((i,), iterations, debug)[0][i] for i in members}, {}))
     monkeypatch.setattr(os.path, "abspath", lambda p: str(tmp_path / "tests" / "x.py") if p.endswith("test_other_shapes.py") else p)
     t.test_two_handles_interleaved_equal_the_same_handles_run_alone(monkeypatch)

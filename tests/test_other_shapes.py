@@ -512,7 +512,7 @@ def test_debug_buffer_reads_every_named_buffer(member):
     g.close()
 
 
-def _il_run(members, iterations=3, debug=False):
+def _il_run(members, iterations=3, debug=False, snap=False):
     """the handles `members` of _IL_SPECS in one process, calls interleaved (every member collects, then every member updates); per member: the public outputs in _IL_NAMES order per
     iteration, and (debug) {stage: {buffer: words}} of the raw device buffers -- read with extra synchronous copies between the calls, which is why the asserted run does without them"""
     hs = {}
@@ -531,6 +531,8 @@ def _il_run(members, iterations=3, debug=False):
         for i in members:
             rows, mean = hs[i].update(LR, CR, 2, _IL_SPECS[i][3], None, seed=it)
             out[i] += [rows.copy(), hs[i].get_flat(0), hs[i].get_flat(1), hs[i].get_flat(2), np.asarray(hs[i].beta_powers()).copy()]
+            if snap:                                                                     # (handles created under PPO_HIP_DEBUG_SNAPSHOT=0: as things were behind the update's FIRST train step)
+                dbg[i]["iteration %d, behind the first train step of the update" % it] = {k: hs[i].debug_buffer("snap:" + k) for k in _IL_WORK + _IL_STATE}
             if debug:
                 dbg[i]["iteration %d, after the update" % it] = {k: hs[i].debug_buffer(k) for k in _IL_STATE + _IL_WORK}
     for g in hs.values():
@@ -676,6 +678,30 @@ def _il_report(plain_together, plain_alone, monkeypatch, emit):
                     stage, run, int(covered.sum()) - bad.size, int(covered.sum()),
                     "" if not bad.size else "; the other %d (words %d .. %d) hold %s" % (bad.size, bad[0], bad[-1], "the same values in another order" if same_values else "OTHER values")))
     section(slabs)
+
+    # the same with a snapshot behind the FIRST train step of every update (PPO_HIP_DEBUG_SNAPSHOT=0: device-to-device copies in the update's graph), in the order the data flows: the
+    # epoch's keys and gathered rows, the train kernel's workspaces and slots, the slabs / gradient / partial sums of squares, then what Adam wrote.  The first line names the kernel.
+    def snapshots():
+        monkeypatch.setenv("PPO_HIP_DEBUG_SNAPSHOT", "0")
+        try:
+            tg = _il_run((0, 1, 2), snap=True)
+            al = {i: _il_run((i,), snap=True) for i in (0, 1, 2)}
+        finally:
+            monkeypatch.delenv("PPO_HIP_DEBUG_SNAPSHOT", raising=False)
+        emit("with a snapshot behind the first train step of every update (PPO_HIP_DEBUG_SNAPSHOT=0):")
+        for i in (0, 1, 2):
+            d = _il_first_difference(tg[0][i], al[i][0][i])
+            emit("handle %d %s: public outputs %s" % (i, _IL_SPECS[i][:4], "equal" if d is None else "differ first at " + d[1]))
+            for stage, bufs in tg[1][i].items():
+                for k, x in bufs.items():
+                    y = al[i][1][i][stage][k]
+                    if x.shape != y.shape:
+                        emit("  %s: %s has %d words together, %d alone" % (stage, k, x.size, y.size))
+                    elif not np.array_equal(x, y):
+                        bad = np.flatnonzero(x != y)
+                        emit("  %s: %s differs in %d of %d words, first at %d (together %r, alone %r), last at %d" % (
+                            stage, k, bad.size, x.size, bad[0], x.view(np.float32)[bad[0]], y.view(np.float32)[bad[0]], bad[-1]))
+    section(snapshots)
 
 
 @pytest.mark.xfail(strict=False, reason="OPEN at the end of round 5: alone, in its file and behind every subset of the suite tried this passes (and a 300-trial stress of the same "
