@@ -201,8 +201,10 @@ int ppo_dist_graph_collectives(const ppo_handle* h);
  *   ppo_dist_peer_active: 1 when the peer path is in use.   ppo_dist_peer_enable: switch between the two paths after a
  *     successful attach (collectively, at the same point on every rank).
  *   With the peer path on, a [256,256] handle pushes its gradient tiles from inside the weight-gradient kernel and adds the ranks up inside the Adam launch
- *     (no push / sum launches; PPO_HIP_NO_PEER_TILES=1 restores them).  Kernels whose workgroups wait for each other while holding a CU (the bf16 path's
- *     chained layers) are switched off when two ranks of the job share a device: ppo_dist_init compares the ranks' PCI ids over the communicator. */
+ *     (no push / sum launches; PPO_HIP_NO_PEER_TILES=1 restores them).  Single-rank kernels whose workgroups wait for EACH OTHER while holding a CU (the bf16
+ *     path's chained layers) are switched off when two ranks of the job share a device: ppo_dist_init compares the ranks' PCI ids over the communicator.
+ *     The data-parallel forms that wait on the PEERS' flags (the tile push, adam_kernel's meeting) stay on there -- one device with several ranks is how this path
+ *     is tested -- and every such wait is bounded (PPO_HIP_PEER_TIMEOUT_MS): a rank whose peers cannot become resident beside it reports an error, it does not hang. */
 int ppo_dist_peer_export(ppo_handle* h, char handle[64]);
 int ppo_dist_peer_attach(ppo_handle* h, const char* handles);
 int ppo_dist_peer_active(const ppo_handle* h);
@@ -233,6 +235,9 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
  * at most max_count words are copied.  Two runs that must agree bit for bit are compared buffer by buffer with it (tests/test_other_shapes.py).  No reference counterpart.
  * "snap:<name>": the same buffer as it was right behind train step n of the last ppo_update, for a handle created under PPO_HIP_DEBUG_SNAPSHOT=n (launch-per-step paths). */
 int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_count, int64_t* count);
+/* debug: leave `word` in every LDS word of every CU (a launch of whole-CU workgroups on the handle's stream, synchronised).  A kernel that reads LDS it never wrote sees
+ * what the previous workgroup on its CU left there; with a NaN pattern in place such a read shows in the results (tests/test_race_guards.py).  No reference counterpart. */
+int ppo_debug_poison_lds(ppo_handle* h, uint32_t word);
 
 #ifdef __cplusplus
 }

@@ -332,5 +332,9 @@ class PPOHip:
             self._ck(self.lib.ppo_debug_buffer(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(cnt.value), C.byref(cnt)))
         return out
 
+    def debug_poison_lds(self, word=0x7FC0DEAD):
+        """leave `word` (default: a NaN pattern) in every LDS word of every CU (include/ppo_hip.h, ppo_debug_poison_lds)"""
+        self._ck(self.lib.ppo_debug_poison_lds(self.h, C.c_uint32(word)))
+
     def sync(self):
         self._ck(self.lib.ppo_sync(self.h))

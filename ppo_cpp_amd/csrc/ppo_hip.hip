@@ -13,8 +13,10 @@
 #include "ppo_rollout1.hpp"
 
 #include <dlfcn.h>
-#include <immintrin.h>     // _mm_sfence (host side of the VRAM inbox)
-#include <sys/mman.h>      // msync: is a device allocation mapped into this process?
+#include <atomic>
+#if defined(__x86_64__)
+#include <immintrin.h>     // _mm_sfence (host side of the VRAM inbox: drains the write-combining buffers behind the posted stores)
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -195,10 +197,11 @@ struct ppo_handle {
         int tile0[2][PPO_MAX_LAYERS + 1]{};             // first weight-gradient tile of every matrix ([L] = the head), in the order of the tile table
         // the hidden layers of a pass as ONE launch (gemm_chain_bf16_kernel): its word tables (forward, backward); PPO_HIP_NO_BF16_CHAIN=1: a launch per layer
         bool chain = false; unsigned* chain_words[2]{}; int n_cu = 0;
+        bool chain_used = false; unsigned* chain_err_host = nullptr;     // a chained launch since the last check; pinned landing words of its two error words (act paths)
         // gradient assembly + clip + Adam in one persistent launch (bf16_reduce_adam_kernel; single GPU): its meeting's table [BRA_GRID] + error word
         bool fuse_ra = false; unsigned long long* ra_ent = nullptr;
     } bf;
-    bool dev_shared = false;          // data parallel: another rank of the job runs on this device (kernels whose workgroups wait for each other are not used then)
+    bool dev_shared = false;          // data parallel: another rank of the job runs on this device (single-rank kernels whose workgroups wait for each other -- the bf16 chain, the fused train launch -- are not used then; the peer forms' waits on other ranks are time-bounded instead: include/ppo_hip.h)
     // narrow-network path (every hidden width <= 64; kernels in ppo_narrow.hpp)
     bool narrow = false;
     NwLayout nw{};
@@ -697,6 +700,7 @@ bool bf16_chain(ppo_handle* h, const GemmArgs* links, int n, int I, int J, int w
     ca.err = b.chain_words[which] + (size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS;
     for (int l = 0; l < n; ++l) { ca.link[l] = links[l]; ca.link[l].ksplit = 1; ca.link[l].tiles_i = tiles_i; ca.link[l].tiles_ij = tiles_i * tiles_j; }
     hipLaunchKernelGGL((gemm_chain_bf16_kernel<EPI>), dim3(G * tiles_j), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, ca);
+    b.chain_used = true;
     return hipGetLastError() == hipSuccess;
 }
 
@@ -715,6 +719,7 @@ int bf16_chain_check(ppo_handle* h) {
         }
     }
     if (!b.on || !b.chain) return 0;
+    b.chain_used = false;
     for (int d = 0; d < 2; ++d) {
         unsigned e = 0;
         if (!b.chain_words[d]) continue;
@@ -729,6 +734,27 @@ int bf16_chain_check(ppo_handle* h) {
         }
     }
     return 0;
+}
+
+// The act paths (ppo_step / ppo_value / the rollout calls) chain their layers too: the error words ride out with the call's own results -- two 4-byte copies
+// into pinned memory IN FRONT of the call's stream synchronisation (bf16_chain_err_async), looked at right behind it (bf16_chain_err_test: 1 = this call's
+// results are invalid; the handle launches layer by layer from now on and says so) -- so a failed hand-off is an error of the call that produced the garbage,
+// not of the next update.
+int bf16_chain_err_async(ppo_handle* h) {
+    ppo_handle::Bf16& b = h->bf;
+    if (!b.on || !b.chain || !b.chain_used) return 0;
+    if (!b.chain_err_host) { HIP_OK(h, hipHostMalloc((void**)&b.chain_err_host, 64, hipHostMallocDefault)); b.chain_err_host[0] = b.chain_err_host[1] = 0u; }
+    for (int d = 0; d < 2; ++d)
+        if (b.chain_words[d]) HIP_OK(h, hipMemcpyAsync(b.chain_err_host + d, b.chain_words[d] + (size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+int bf16_chain_err_test(ppo_handle* h) {                        // (after the stream synchronisation that follows bf16_chain_err_async)
+    ppo_handle::Bf16& b = h->bf;
+    if (!b.on || !b.chain || !b.chain_used || !b.chain_err_host) return 0;
+    b.chain_used = false;
+    if (!(b.chain_err_host[0] | b.chain_err_host[1])) return 0;
+    b.chain_err_host[0] = b.chain_err_host[1] = 0u;
+    return bf16_chain_check(h) ? 1 : 0;                         // (reads the words again, resets them, switches the chain off, sets the message)
 }
 
 int bf16_ensure_ws(ppo_handle* h, int rows) {
@@ -1405,6 +1431,31 @@ int flush_pending_adam(ppo_handle* h) {
     return enqueue_adam(h, h->nw_pending_loss, h->nw_pending_parts == h->n_blocks ? 0 : h->nw_pending_parts);
 }
 
+// host stores into device memory through the BAR: order them (and push them out of the write-combining buffers) before the word that publishes them
+static inline void host_store_fence() {
+#if defined(__x86_64__)
+    _mm_sfence();
+#else
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+#endif
+}
+// May the HOST store into [p, p + bytes)?  The range must lie inside ONE mapping of this process with read AND write permission (/proc/self/maps).  (msync() is not
+// a probe for this: it succeeds on the runtime's reserved PROT_NONE aperture as well, and the first host store into such a page is a SIGSEGV.)
+static bool host_can_store(const void* p, size_t bytes) {
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return false;
+    const unsigned long long lo = (unsigned long long)(uintptr_t)p, hi = lo + bytes;
+    char line[512];
+    bool ok = false;
+    while (fgets(line, sizeof line, f)) {
+        unsigned long long a = 0, b = 0; char perm[8] = {0};
+        if (sscanf(line, "%llx-%llx %7s", &a, &b, perm) != 3) continue;
+        if (a <= lo && hi <= b) { ok = perm[0] == 'r' && perm[1] == 'w'; break; }
+    }
+    fclose(f);
+    return ok;
+}
+
 int set_hyper(ppo_handle* h, float lr, float cr) {
     // The source of an ASYNCHRONOUS copy must outlive this function: the runtime may read it when the copy executes, not when it is enqueued.  (Rounds 1 - 5 passed a
     // stack array here; at the end of a long process the second update of a handle then trained with whatever lay on the stack -- found by
@@ -1630,6 +1681,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->fab_meet) (void)hipFree(h->fab_meet);
     if (h->dw2_meet) (void)hipFree(h->dw2_meet);
     for (int d = 0; d < 2; ++d) if (h->bf.chain_words[d]) (void)hipFree(h->bf.chain_words[d]);
+    if (h->bf.chain_err_host) (void)hipHostFree(h->bf.chain_err_host);
     if (h->bf.ra_ent) (void)hipFree(h->bf.ra_ent);
     if (h->adam_meet_words) (void)hipFree(h->adam_meet_words);
     if (h->adam_meet_parts) (void)hipFree(h->adam_meet_parts);
@@ -1801,7 +1853,13 @@ static int step_common(ppo_handle* h, const float* obs, int n, const float* nois
     if (action || det_action) HIP_OK(h, hipMemcpyAsync(action ? action : det_action, h->st_act, (size_t)n * net.A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (value) HIP_OK(h, hipMemcpyAsync(value, h->st_vec[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (neglogp) HIP_OK(h, hipMemcpyAsync(neglogp, h->st_vec[1], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (bf16_chain_err_async(h)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (bf16_chain_err_test(h)) {
+        // a stateless pass: run it again, layer by layer this time (the handle has switched), and keep the finding on stderr
+        fprintf(stderr, "libppo_hip: %s -- the pass was repeated with a launch per layer\n", h->err.c_str());
+        return step_common(h, obs, n, noise, sample, action, det_action, value, neglogp);
+    }
     return 0;
 }
 
@@ -1937,9 +1995,8 @@ int ppo_norm_init(ppo_handle* h, int32_t n_envs, float gamma, float clip_obs, fl
             if (hipMalloc((void**)&box, words * sizeof(float)) == hipSuccess) {
                 (void)hipMemset(box, 0, words * sizeof(float));
                 (void)hipDeviceSynchronize();
-                // is the allocation mapped into this process (the host will store into it)?  msync on an unmapped page fails with ENOMEM
-                const uintptr_t pg = (uintptr_t)box & ~(uintptr_t)4095;
-                if (msync((void*)pg, 4096, MS_ASYNC) == 0) { h->vram_in = box; h->vram_h2d = reinterpret_cast<unsigned*>(box + ru((int)in_n, 32) + 32); }
+                // is the allocation mapped read-write into this process (the host will store into it)?
+                if (host_can_store(box, words * sizeof(float))) { h->vram_in = box; h->vram_h2d = reinterpret_cast<unsigned*>(box + ru((int)in_n, 32) + 32); }
                 else (void)hipFree(box);
             }
         }
@@ -2216,9 +2273,9 @@ static void launch_rollout_kernel(ppo_handle* h, const NwRolloutArgs& q, size_t 
 // the VRAM inbox's sequence word, stored by the host through the BAR (write-combined: fenced on both sides)
 static void vram_word(ppo_handle* h, unsigned v) {
     if (!h->vram_h2d) return;
-    _mm_sfence();
+    host_store_fence();
     *reinterpret_cast<volatile unsigned*>(h->vram_h2d) = v;
-    _mm_sfence();
+    host_store_fence();
 }
 
 // ---- resident host-Env rollout kernel (see NwRolloutArgs) -----------------------------------------------------------------------
@@ -2400,6 +2457,7 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
     // one D2H into the handle's pinned landing buffer and the ONLY stream synchronisation of an env step: the statistics
     // kernel of the previous ppo_rollout_observe, this policy step and the copy drain together
     HIP_OK(h, hipMemcpyAsync(h->pin_out, h->ro_act + (size_t)t * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (bf16_chain_err_async(h)) return -1;
     // busy-wait on the stream: the blocking synchronise parks the thread on an interrupt and wakes it ~100-200 us late,
     // several times the whole GPU-side cost of an env step; this thread has nothing else to do until the actions are here
     {
@@ -2409,6 +2467,7 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
         if (q != hipSuccess) return fail(h, "hipStreamQuery failed: %s", hipGetErrorString(q));
     }
     h->pin_in_busy = false;
+    if (bf16_chain_err_test(h)) return -1;                       // (row t of the rollout is invalid; the message says what happened and what the handle does from now on)
     memcpy(actions_out, h->pin_out, cnt * sizeof(float));
     return 0;
 }
@@ -2450,9 +2509,10 @@ int ppo_rollout_finish(ppo_handle* h, float gamma, float lam) {
         va.obs = h->ro_obs; va.value = h->ro_val; va.n = h->E * h->T; va.nz = no_norm();
         if (launch_step(h, va)) return -1;
     }
-    if (enqueue_finish(h, gamma, lam)) return -1;
+    if (enqueue_finish(h, gamma, lam) || bf16_chain_err_async(h)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
+    if (bf16_chain_err_test(h)) return -1;
     return peer_check(h);
 }
 
@@ -2586,9 +2646,10 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
           HIP_OK(h, hipGetLastError()); }
         if (enqueue_observe(h, t)) return -1;
     }
-    if (enqueue_finish(h, gamma, lam)) return -1;
+    if (enqueue_finish(h, gamma, lam) || bf16_chain_err_async(h)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
+    if (bf16_chain_err_test(h)) return -1;                       // (the rollout is invalid)
     if (coop) {
         unsigned e = 0;
         HIP_OK(h, hipMemcpy(&e, reinterpret_cast<unsigned*>(h->nw_coop + (size_t)2 * coopG * NW_COOP_PW) + 16 * (size_t)coopG, sizeof e, hipMemcpyDeviceToHost));
@@ -2688,7 +2749,8 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
     const int B = h->E * h->T, M = B / nmb;
     // the per-tile arrival counters of weight_grad_assemble_kernel are reset by their last arriver; an update that was cut short
     // (a failed launch) must not leave them half-counted for the next one: zeroed here, a memset node of the replayed graph
-    if (h->dw2) HIP_OK(h, hipMemsetAsync(h->dw2_counters, 0, DW2_TILES * sizeof(unsigned), h->stream));
+    { const char* nm = getenv("PPO_HIP_DW2_NO_MEMSET");           // (diagnostic, read when the update is captured: the counters are zero between launches anyway)
+      if (h->dw2 && !(nm && nm[0] == '1')) HIP_OK(h, hipMemsetAsync(h->dw2_counters, 0, DW2_TILES * sizeof(unsigned), h->stream)); }
     h->nw_pending = false; h->nw_cur = 0;                      // outside an update the weights always live in set 0
     uint32_t bits = 1;
     while ((1u << bits) < (uint32_t)B) ++bits;
@@ -3315,6 +3377,28 @@ int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_co
     *count = (int64_t)words;
     const size_t c = std::min<size_t>(words, (size_t)std::max<int64_t>(max_count, 0));
     if (c) HIP_OK(h, hipMemcpy(dst, p, c * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Fill the LDS of every CU with one word (and leave it there): a kernel whose result depends on LDS it never wrote -- what the previous workgroup on its CU left behind --
+// shows it as soon as that word is a NaN pattern.  Every workgroup takes a CU's whole 160 KB and holds it ~30 us, so the launch's first 256 workgroups land one per CU;
+// two more rounds behind them for CUs the dispatcher served late.  tests/test_race_guards.py (results must not depend on what the LDS held); no reference counterpart.
+__global__ void __launch_bounds__(256) debug_poison_lds_kernel(unsigned word, unsigned* sink) {
+    extern __shared__ unsigned poison_lds[];
+    for (int i = threadIdx.x; i < 160 * 256; i += 256) poison_lds[i] = word;
+    __syncthreads();
+    for (int k = 0; k < 40; ++k) __builtin_amdgcn_s_sleep(127);
+    if (poison_lds[(threadIdx.x * 131) % (160 * 256)] != word) sink[0] = 1u;       // (keeps the stores)
+}
+int ppo_debug_poison_lds(ppo_handle* h, uint32_t word) {
+    ENTER_Q(h);
+    static bool attr_set = false;
+    if (!attr_set) { HIP_OK(h, hipFuncSetAttribute((const void*)debug_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    hipDeviceProp_t prop;
+    HIP_OK(h, hipGetDeviceProperties(&prop, h->device));
+    hipLaunchKernelGGL(debug_poison_lds_kernel, dim3(3 * prop.multiProcessorCount), dim3(256), 160 * 1024, h->stream, word, reinterpret_cast<unsigned*>(h->norm_out));
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

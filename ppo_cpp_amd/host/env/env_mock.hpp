@@ -3,6 +3,9 @@
 //                  are the constant scaling_coeff, done on every 300th call, actions ignored.
 //   SeededEnvMock  same shape, non-degenerate data: obs ~ U(-1,1)^18, reward ~ U(-1,1), done ~ Bernoulli(1/300) from
 //                  the counter hash keyed by (seed, env id, step) that the device-side synthetic env also uses.
+//   TargetEnv      a LEARNABLE task on SeededEnvMock's observation stream: reward = -mean_j (a_j - (W obs)_j)^2 for a fixed hashed
+//                  matrix W, episodes of a fixed length.  The reference's only validation is that it learns (README.md:22-24: the
+//                  hexapod's reward curves); this is the environment behind tests/test_learning.py, small enough for the oracle.
 #pragma once
 #include <cstdint>
 
@@ -88,4 +91,52 @@ private:
     float last_rew_;
     uint64_t key_;                  // splitmix64(seed, env id): the step-independent half of the counter hash
     int kDim, kAct;
+};
+
+class TargetEnv : public Env {
+public:
+    TargetEnv(uint32_t seed, uint32_t env_id, int obs_dim = 18, int act_dim = 18, int episode_len = 100)
+        : step_(0), last_rew_(0.f), key_(ppo_detail::ctr_key(seed, env_id)), kDim(obs_dim), kAct(act_dim), len_(episode_len), w_((size_t)act_dim * obs_dim) {
+        const uint64_t wkey = ppo_detail::splitmix64(((uint64_t)seed << 32) | 0xffffffffull);       // one W per seed, shared by every environment of the job
+        for (int j = 0; j < kAct; ++j)
+            for (int k = 0; k < kDim; ++k) w_[(size_t)j * kDim + k] = 0.5f * ppo_detail::sym_unit((uint32_t)(ppo_detail::splitmix64(wkey ^ (((uint64_t)j << 32) | (uint32_t)k)) >> 32));
+    }
+    std::string get_action_space() override { return Env::SPACE_CONTINOUS; }
+    std::string get_observation_space() override { return Env::SPACE_CONTINOUS; }
+    int get_action_space_size() override { return kAct; }
+    int get_observation_space_size() override { return kDim; }
+    Mat reset() override { step_ = 0; return obs_at(0); }
+    std::vector<Mat> step(const Mat& actions) override {
+        const Mat cur = obs_at(step_);                       // the observation the action answers
+        float acc = 0.f;
+        for (int j = 0; j < kAct; ++j) {
+            float tgt = 0.f;
+            for (int k = 0; k < kDim; ++k) tgt += w_[(size_t)j * kDim + k] * cur(0, k);
+            const float d = actions(0, j) - tgt;
+            acc += d * d;
+        }
+        last_rew_ = -acc / (float)kAct;
+        ++step_;
+        Mat rew(1, 1), done(1, 1);
+        rew(0, 0) = last_rew_;
+        done(0, 0) = (step_ % (uint32_t)len_ == 0u) ? 1.f : 0.f;
+        std::vector<Mat> out;
+        out.reserve(3);
+        out.push_back(obs_at(step_)); out.push_back(std::move(rew)); out.push_back(std::move(done));
+        return out;
+    }
+    Mat get_original_obs() override { return obs_at(step_); }
+    Mat get_original_rew() override { Mat r(1, 1); r(0, 0) = last_rew_; return r; }
+    void serialize(nlohmann::json&) override {}
+    void deserialize(nlohmann::json&) override {}
+    void render() override {}
+    float get_time() override { return 0.f; }
+
+private:
+    Mat obs_at(uint32_t step) const { Mat m(1, kDim); for (int j = 0; j < kDim; ++j) m(0, j) = ppo_detail::sym_unit(ppo_detail::ctr_hash_keyed(key_, step, (uint32_t)j)); return m; }
+    uint32_t step_;
+    float last_rew_;
+    uint64_t key_;
+    int kDim, kAct, len_;
+    std::vector<float> w_;          // [act][obs], row-major
 };

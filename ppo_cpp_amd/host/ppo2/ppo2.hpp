@@ -34,7 +34,7 @@ public:
         n_batch_ = n_envs_ * n_steps_;
     }
 
-    struct UpdateLog { int fps; float losses[5]; double collect_ms, update_ms; };
+    struct UpdateLog { int fps; float losses[5]; double collect_ms, update_ms; float mean_reward; };     // mean_reward: the rollout's un-normalised rewards (the learning curve)
     // Data parallel (no reference counterpart): this PPO2 is rank `rank` of `world` processes, one per GPU, whose handles share a
     // communicator (ppo_dist_init, see dist.hpp).  `env` holds THIS rank's share of the environments; n_batch, total_timesteps, the fps of the
     // CSV line and the checkpoint's n_envs are job-wide quantities.  The replicas stay bit-identical, so rank 0 alone prints and saves
@@ -247,6 +247,7 @@ private:
     void finish_update(UpdateLog& log, clk::time_point t0, clk::time_point t1, clk::time_point t2, const Mat& rew_view, const Mat& done_view) {
         log.collect_ms = ms(t0, t1);
         log.update_ms = ms(t1, t2);
+        { double acc = 0; const long cnt = (long)rew_view.rows() * rew_view.cols(); for (long i = 0; i < cnt; ++i) acc += rew_view.data()[i]; log.mean_reward = (float)(acc / (double)std::max(cnt, 1l)); }
         const double total = std::max(ms(t0, t2), 1e-3);
         // ppo2.hpp:337-341; data parallel: the job's env steps over THIS rank's wall time (the ranks meet in a collective every minibatch,
         // so their update times differ by less than one exchange)

@@ -165,7 +165,7 @@ struct ppo_host_args {
     int n_envs, n_steps, n_hidden, hidden[8];
     int nminibatches, noptepochs, n_updates;
     float lr, cliprange, gamma, lam;
-    int seeded_env;          // 0: EnvMock(i+1) (degenerate constant data, the reference's stub) ; 1: SeededEnvMock
+    int seeded_env;          // 0: EnvMock(i+1) (degenerate constant data, the reference's stub) ; 1: SeededEnvMock ; 2: TargetEnv (learnable: tests/test_learning.py)
     int device;
     int max_workers;
     int reference_loop;      // 1: force the literal reference loop (Runner::run + host shuffle + _train_step)
@@ -192,6 +192,7 @@ struct ppo_host_explicit {
     float* theta_out;            // [P]
     float* obs_mean; float* obs_var; double* obs_count;      // obs_rms [18], [18], [1]
     float* ret_mean; float* ret_var; double* ret_count;      // ret_rms [1], [1], [1]
+    float* reward_curve;         // [n_updates] mean un-normalised reward of every update's rollout
 };
 
 static int run_learn(const ppo_host_args* a, ppo_host_result* out, const ppo_host_explicit* x) {
@@ -208,13 +209,14 @@ static int run_learn(const ppo_host_args* a, ppo_host_result* out, const ppo_hos
         if (x && x->theta_in && ppo_set_flat(h, 0, x->theta_in, ppo_num_params(h)) != 0) throw std::runtime_error(ppo_last_error(h));
         std::vector<std::shared_ptr<Env>> envs;
         for (int i = 0; i < a->n_envs; ++i) {
-            if (a->seeded_env) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i, O, A));
+            if (a->seeded_env == 2) envs.push_back(std::make_shared<TargetEnv>(1234u, (uint32_t)i, O, A));
+            else if (a->seeded_env) envs.push_back(std::make_shared<SeededEnvMock>(1234u, (uint32_t)i, O, A));
             else envs.push_back(std::make_shared<EnvMock>(i + 1));
         }
         std::unique_ptr<Env> inner;
         VecEnv* pool = nullptr;
         if (a->n_envs > 1) inner.reset(pool = new VecEnv(envs, a->max_workers));
-        else inner.reset(a->seeded_env ? static_cast<Env*>(new SeededEnvMock(1234u, 0, O, A)) : static_cast<Env*>(new EnvMock(1)));
+        else inner.reset(a->seeded_env == 2 ? static_cast<Env*>(new TargetEnv(1234u, 0, O, A)) : a->seeded_env ? static_cast<Env*>(new SeededEnvMock(1234u, 0, O, A)) : static_cast<Env*>(new EnvMock(1)));
         {
             EnvNormalize env{std::move(inner), h, /*training=*/true, a->norm_obs != 0, a->norm_reward != 0, 10.f, 10.f, a->gamma};
             PPO2 algorithm{h, env, a->gamma, a->n_steps, cfg.ent_coef, a->lr, 0.5f, 0.5f, a->lam, a->nminibatches, a->noptepochs, a->cliprange};
@@ -264,6 +266,7 @@ static int run_learn(const ppo_host_args* a, ppo_host_result* out, const ppo_hos
             env.deserialize(j);
             if (x) {
                 if (x->losses_out) for (size_t i = 0; i < hist.size(); ++i) std::memcpy(x->losses_out + 5 * i, hist[i].losses, sizeof(float) * 5);
+                if (x->reward_curve) for (size_t i = 0; i < hist.size(); ++i) x->reward_curve[i] = hist[i].mean_reward;
                 if (x->theta_out && ppo_get_flat(h, 0, x->theta_out, ppo_num_params(h)) != 0) throw std::runtime_error(ppo_last_error(h));
                 if (x->obs_mean && ppo_norm_get_stats(h, 0, x->obs_mean, x->obs_var, x->obs_count) != 0) throw std::runtime_error(ppo_last_error(h));
                 if (x->ret_mean && ppo_norm_get_stats(h, 1, x->ret_mean, x->ret_var, x->ret_count) != 0) throw std::runtime_error(ppo_last_error(h));

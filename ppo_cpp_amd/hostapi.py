@@ -59,7 +59,7 @@ def learn(n_envs, n_steps, hidden, n_updates, nminibatches=32, noptepochs=10, lr
 class HostExplicit(C.Structure):
     _fields_ = [("theta_in", C.c_void_p), ("noise", C.c_void_p), ("perms", C.c_void_p), ("losses_out", C.c_void_p), ("theta_out", C.c_void_p),
                 ("obs_mean", C.c_void_p), ("obs_var", C.c_void_p), ("obs_count", C.c_void_p),
-                ("ret_mean", C.c_void_p), ("ret_var", C.c_void_p), ("ret_count", C.c_void_p)]
+                ("ret_mean", C.c_void_p), ("ret_var", C.c_void_p), ("ret_count", C.c_void_p), ("reward_curve", C.c_void_p)]
 
 
 def learn_explicit(n_envs, n_steps, hidden, theta, noise, perms, nminibatches, lr=3.93141e-4, cliprange=0.161023, gamma=0.99, lam=0.95,
@@ -86,8 +86,32 @@ def learn_explicit(n_envs, n_steps, hidden, theta, noise, perms, nminibatches, l
            "ret_mean": np.zeros(1, np.float32), "ret_var": np.zeros(1, np.float32), "ret_count": np.zeros(1, np.float64)}
     x = HostExplicit(theta.ctypes.data, noise.ctypes.data, perms.ctypes.data, out["losses"].ctypes.data, out["theta"].ctypes.data,
                      out["obs_mean"].ctypes.data, out["obs_var"].ctypes.data, out["obs_count"].ctypes.data,
-                     out["ret_mean"].ctypes.data, out["ret_var"].ctypes.data, out["ret_count"].ctypes.data)
+                     out["ret_mean"].ctypes.data, out["ret_var"].ctypes.data, out["ret_count"].ctypes.data, None)
     r = HostResult()
     if lib.ppo_host_learn_explicit(C.byref(a), C.byref(x), C.byref(r)) != 0:
         raise RuntimeError(r.error.decode())
+    return out
+
+
+def learn_curve(n_envs, n_steps, hidden, n_updates, nminibatches, noptepochs, lr, cliprange, gamma=0.99, lam=0.95, seed=0, reference_loop=False, device=-1,
+                obs_dim=18, act_dim=18):
+    """PPO2::learn on TargetEnv x n_envs (a learnable task, host/env/env_mock.hpp) behind VecEnv + EnvNormalize with the library's own exploration noise and shuffles:
+    returns the mean un-normalised reward of every update's rollout [n_updates], the per-update mean losses and the final weights."""
+    import numpy as np
+    lib = load_host_library()
+    a = HostArgs()
+    a.n_envs, a.n_steps, a.n_hidden = n_envs, n_steps, len(hidden)
+    for i, h in enumerate(hidden):
+        a.hidden[i] = h
+    a.nminibatches, a.noptepochs, a.n_updates = nminibatches, noptepochs, n_updates
+    a.lr, a.cliprange, a.gamma, a.lam = lr, cliprange, gamma, lam
+    a.seeded_env, a.device, a.max_workers, a.reference_loop = 2, device, 0, int(reference_loop)
+    a.norm_obs, a.norm_reward, a.seed = 1, 1, seed
+    a.obs_dim, a.act_dim = obs_dim, act_dim
+    out = {"losses": np.zeros((n_updates, 5), np.float32), "reward_curve": np.zeros(n_updates, np.float32)}
+    x = HostExplicit(None, None, None, out["losses"].ctypes.data, None, None, None, None, None, None, None, out["reward_curve"].ctypes.data)
+    r = HostResult()
+    if lib.ppo_host_learn_explicit(C.byref(a), C.byref(x), C.byref(r)) != 0:
+        raise RuntimeError(r.error.decode())
+    out["env_steps_per_s"] = r.env_steps_per_s
     return out

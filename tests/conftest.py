@@ -17,3 +17,23 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line per failed / xfailed test with what its assertion FOUND (the head of the message: the first differing buffer, the first differing output), printed at the very
+    end so that a driver that keeps only the tail of the log still carries the finding (`pytest -q` prints nothing at all for an xfail)."""
+    lines = []
+    for kind in ("failed", "error", "xfailed"):
+        for rep in terminalreporter.stats.get(kind, []):
+            msg = ""
+            crash = getattr(getattr(rep, "longrepr", None), "reprcrash", None)
+            if crash is not None:
+                msg = crash.message
+            elif rep.longrepr is not None:
+                msg = str(rep.longrepr)
+            head = [l.strip() for l in msg.splitlines() if l.strip()][:3]
+            lines.append("%s %s: %s" % (kind.upper(), rep.nodeid, " | ".join(head)[:600] or getattr(rep, "wasxfail", "")))
+    if lines:
+        terminalreporter.write_sep("=", "findings (tests/conftest.py)")
+        for l in lines:
+            terminalreporter.write_line(l)

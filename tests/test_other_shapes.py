@@ -512,7 +512,14 @@ def test_debug_buffer_reads_every_named_buffer(member):
     g.close()
 
 
-def _il_run(members, iterations=3, debug=False, snap=False):
+def _il_perms(i, it, epochs=2):
+    """the explicit permutations of member i's update `it` (the oracle leg of the report: the on-device shuffle needs none)"""
+    hd, E, T, nmb, sd = _IL_SPECS[i]
+    rng = np.random.RandomState(1000 * i + it)
+    return np.stack([rng.permutation(E * T).astype(np.int32) for _ in range(epochs)])
+
+
+def _il_run(members, iterations=3, debug=False, snap=False, perms=False, before_update=None, after_update=None):
     """the handles `members` of _IL_SPECS in one process, calls interleaved (every member collects, then every member updates); per member: the public outputs in _IL_NAMES order per
     iteration, and (debug) {stage: {buffer: words}} of the raw device buffers -- read with extra synchronous copies between the calls, which is why the asserted run does without them"""
     hs = {}
@@ -529,7 +536,11 @@ def _il_run(members, iterations=3, debug=False, snap=False):
             if debug:
                 dbg[i]["iteration %d, after the collect" % it] = {k: hs[i].debug_buffer(k) for k in _IL_STATE}
         for i in members:
-            rows, mean = hs[i].update(LR, CR, 2, _IL_SPECS[i][3], None, seed=it)
+            if before_update:
+                before_update(hs, i, it)
+            rows, mean = hs[i].update(LR, CR, 2, _IL_SPECS[i][3], _il_perms(i, it) if perms else None, seed=it)
+            if after_update:
+                after_update(hs, i, it, dbg)
             out[i] += [rows.copy(), hs[i].get_flat(0), hs[i].get_flat(1), hs[i].get_flat(2), np.asarray(hs[i].beta_powers()).copy()]
             if snap:                                                                     # (handles created under PPO_HIP_DEBUG_SNAPSHOT=0: as things were behind the update's FIRST train step)
                 dbg[i]["iteration %d, behind the first train step of the update" % it] = {k: hs[i].debug_buffer("snap:" + k) for k in _IL_WORK + _IL_STATE}
@@ -546,6 +557,80 @@ def _il_first_difference(a, b):
         if not np.array_equal(x, y):
             return j, "iteration %d: %s" % (j // len(_IL_NAMES), _IL_NAMES[j % len(_IL_NAMES)])
     return None
+
+
+def _il_oracle_leg(out1, it):
+    """the oracle's update `it` of member 1 from the public outputs of a run made with explicit permutations: state = what the run itself reported after update it - 1
+    (both runs agree there), rollout = what it collected; returns (loss rows, weights)"""
+    hd, E, T, nmb, sd = _IL_SPECS[1]
+    n = len(_IL_NAMES)
+    orc = o.Oracle(18, 18, list(hd))
+    prev = out1[n * (it - 1):n * it]
+    orc.theta[:] = prev[7]; orc.m[:] = prev[8]; orc.v[:] = prev[9]; orc.pow[:] = prev[10]
+    cur = out1[n * it:n * (it + 1)]
+    ro = {"obs": cur[0], "actions": cur[1], "values": cur[2], "neglogp": cur[3], "returns": cur[5]}
+    rows, _ = orc.update(ro, _il_perms(1, it), nmb, LR, CR)
+    return rows, orc.theta.copy()
+
+
+def _il_probe(emit, monkeypatch):
+    """round 6: which run is RIGHT (the oracle on the same rollout and permutations), and what the [256,256] handle's update picks up from the process: LDS left behind by
+    other kernels (ppo_debug_poison_lds), the memset node in front of its graph, the arrival counters"""
+    n = len(_IL_NAMES)
+
+    def against_oracle(title, out1):
+        for it in (1, 2):
+            rows, theta = _il_oracle_leg(out1, it)
+            got_rows, got_theta = out1[n * it + 6], out1[n * it + 7]
+            emit("  %s, update %d against the oracle: loss rows max rel %.3g, weights max abs %.3g (rel to max |w| %.3g)" % (
+                title, it, float(np.max(np.abs(got_rows[:, :4] - rows[:, :4]) / (np.abs(rows[:, :4]) + 1e-6))), float(np.max(np.abs(got_theta - theta))),
+                float(np.max(np.abs(got_theta - theta)) / np.max(np.abs(theta)))))
+
+    tg = _il_run((0, 1), perms=True)[0]
+    al = _il_run((1,), perms=True)[0]
+    d = _il_first_difference(tg[1], al[1])
+    emit("explicit permutations, handles 0 and 1: handle 1 %s" % ("equal" if d is None else "differs (" + d[1] + ")"))
+    against_oracle("together", tg[1]); against_oracle("alone", al[1])
+
+    def lds(word):
+        def hook(hs, i, it):
+            if i == 1:
+                hs[1].debug_poison_lds(word)
+        return hook
+    seen = {}
+
+    def counters(hs, i, it, dbg):
+        if i == 1:
+            seen[it] = (hs[1].debug_buffer("dw2_counters").copy(), hs[1].debug_buffer("hyper").copy())
+    for perms in (False, True):
+        emit("%s:" % ("explicit permutations" if perms else "on-device shuffle"))
+        base = _il_run((1,), perms=perms)[0]
+        r = _il_run((0, 1), perms=perms)[0]
+        emit("  together: handle 1 %s against alone" % ("equal" if _il_first_difference(r[1], base[1]) is None else "differs"))
+        for title, members, word in (("alone, LDS full of NaN before every update", (1,), 0x7FC0DEAD), ("alone, LDS zeroed before every update", (1,), 0),
+                                     ("together, LDS full of NaN before every update of handle 1", (0, 1), 0x7FC0DEAD), ("together, LDS zeroed before every update of handle 1", (0, 1), 0)):
+            r = _il_run(members, perms=perms, before_update=lds(word))[0]
+            d = _il_first_difference(r[1], base[1])
+            emit("  %s: handle 1 %s against alone%s" % (title, "equal" if d is None else "differs (" + d[1] + ")", "" if np.isfinite(r[1][-4]).all() else "; NOT FINITE"))
+            if d is not None and perms:
+                against_oracle(title, r[1])
+        # the memset node in front of the update's graph (the counters are zero between launches: without it nothing should change)
+        monkeypatch.setenv("PPO_HIP_DW2_NO_MEMSET", "1")
+        try:
+            r = _il_run((0, 1), perms=perms)[0]
+            a2 = _il_run((1,), perms=perms)[0]
+        finally:
+            monkeypatch.delenv("PPO_HIP_DW2_NO_MEMSET", raising=False)
+        emit("  without the memset node (PPO_HIP_DW2_NO_MEMSET=1): together %s against alone under the same switch; alone %s against alone with the node" % (
+            "equal" if _il_first_difference(r[1], a2[1]) is None else "differs", "equal" if _il_first_difference(a2[1], base[1]) is None else "differs"))
+        # the arrival counters right behind every update of handle 1 (one small read, after the update: it cannot disturb the update it follows)
+        for title, members in (("together", (0, 1)), ("alone", (1,))):
+            seen.clear()
+            r = _il_run(members, perms=perms, after_update=counters)[0]
+            d = _il_first_difference(r[1], base[1])
+            emit("  %s with the counters read behind every update of handle 1: handle 1 %s against alone; non-zero counters per update %s; hyper %s" % (
+                title, "equal" if d is None else "differs (" + d[1] + ")", [int(np.count_nonzero(seen[k][0])) for k in sorted(seen)],
+                [seen[k][1].view(np.float32).tolist() for k in sorted(seen)]))
 
 
 def _il_report(plain_together, plain_alone, monkeypatch, emit):
@@ -580,6 +665,8 @@ def _il_report(plain_together, plain_alone, monkeypatch, emit):
                 off = [k for k in range(rows.shape[0]) if not np.array_equal(rows[k], other[k])]
                 if off:
                     emit("  iteration %d, %s: loss rows %s differ from the other run's; rows equal to the previous update's at the same place: %s" % (it, run, off, stale))
+
+    section(lambda: _il_probe(emit, monkeypatch))
 
     def variant(title, members, env=()):
         def run():
