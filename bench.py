@@ -582,31 +582,44 @@ def main():
         g.close()
         c2 = CONFIGS["cfg2"]
         out["also"] = {}
-        g2 = None
-        for attempt in range(2):                             # extra leg: never fatal for the contract line.  (A kernel whose workgroups meet inside a launch reports a
-            try:                                             # failed placement / residency check ONCE and the handle falls back to the launch per step: second attempt.)
-                if g2 is None:
-                    g2 = ppo_cpp_amd.PPOHip(c2["obs"], c2["act"], c2["hidden"], device=device)
-                    g2.init_orthogonal(0); g2.norm_init(c2["n_envs"], GAMMA); g2.rollout_alloc(c2["n_envs"], c2["n_steps"])
-                def step2(i, first=False):
-                    g2.collect_synthetic(1234, GAMMA, LAM, None, env0=0, step0=i * c2["n_steps"], first=first)
-                    g2.update(LR, CR, c2["noptepochs"], c2["nminibatches"], None, seed=2000 + i, want_rows=False)
-                step2(0, True); g2.sync()
-                t0 = time.perf_counter()
-                for i in range(3):
-                    step2(1 + i)
-                g2.sync()
-                dt2 = (time.perf_counter() - t0) / 3
-                out["also"]["BASELINE configs[1] (cfg2)"] = {"workload": c2["desc"], "value": c2["n_envs"] * c2["n_steps"] / dt2, "unit": "env-steps/s",
-                                                             "ms_per_step": 1e3 * dt2, "steps": 3, "warmup": 1}
-                break
-            except Exception as e:
-                out["also"]["BASELINE configs[1] (cfg2)"] = {"error": repr(e)}
-        if g2 is not None:
+        def cfg2_leg(fast):
+            """configs[1] on the device env; fast = the opt-in 1-ulp Adam quotient (PPO_HIP_ADAM_FAST=1, read at ppo_create), else the default (correctly rounded: no deviation)"""
+            if fast:
+                os.environ["PPO_HIP_ADAM_FAST"] = "1"
+            g2, res = None, None
             try:
-                g2.close()
-            except Exception:
-                pass
+                for attempt in range(2):                         # extra leg: never fatal for the contract line.  (A kernel whose workgroups meet inside a launch reports a
+                    try:                                         # failed placement / residency check ONCE and the handle falls back to the launch per step: second attempt.)
+                        if g2 is None:
+                            g2 = ppo_cpp_amd.PPOHip(c2["obs"], c2["act"], c2["hidden"], device=device)
+                            g2.init_orthogonal(0); g2.norm_init(c2["n_envs"], GAMMA); g2.rollout_alloc(c2["n_envs"], c2["n_steps"])
+                        def step2(i, first=False):
+                            g2.collect_synthetic(1234, GAMMA, LAM, None, env0=0, step0=i * c2["n_steps"], first=first)
+                            g2.update(LR, CR, c2["noptepochs"], c2["nminibatches"], None, seed=2000 + i, want_rows=False)
+                        step2(0, True); g2.sync()
+                        t0 = time.perf_counter()
+                        for i in range(3):
+                            step2(1 + i)
+                        g2.sync()
+                        dt2 = (time.perf_counter() - t0) / 3
+                        res = {"value": c2["n_envs"] * c2["n_steps"] / dt2, "unit": "env-steps/s", "ms_per_step": 1e3 * dt2, "steps": 3, "warmup": 1}
+                        break
+                    except Exception as e:
+                        res = {"error": repr(e)}
+            finally:
+                if fast:
+                    os.environ.pop("PPO_HIP_ADAM_FAST", None)
+                if g2 is not None:
+                    try:
+                        g2.close()
+                    except Exception:
+                        pass
+            return res
+        leg = cfg2_leg(False)
+        leg.update({"workload": c2["desc"], "adam": "correctly rounded quotient (the default since round 6: no deviation from the reference's arithmetic)"})
+        fast = cfg2_leg(True)
+        leg["with PPO_HIP_ADAM_FAST=1 (opt-in 1-ulp quotient)"] = {k: fast[k] for k in fast if k in ("value", "ms_per_step", "error")}
+        out["also"]["BASELINE configs[1] (cfg2)"] = leg
         g = None
         try:
             # ... and the same configuration as the reference actually runs it: the ONE environment stepped on the HOST (Env::step

@@ -18,11 +18,11 @@
  *   - a non-finite gradient norm poisons the weights with NaN exactly like G:24493-24543; not an error
  *   - there is NO CPU fallback: every call fails loudly when no gfx950 device is usable
  *   - PPO_F32 arithmetic: exact-fp32 matrix instructions (a k-ordered fmaf chain), correctly rounded square root / division in
- *     the clip + Adam step.  ONE stated deviation: a handle of the reference's own [64,64] shape (up to 64 observations and 32 actions: 18 / 18 and the 36 / 18 of observe_velocities) applies Adam
- *     inside the next train kernel's prologue (or, with minibatches of <= 64 rows, inside the resident epoch kernel) during ppo_update and uses the hardware's 1-ulp reciprocal and square root for the
- *     quotient m * alpha / (sqrt(v) + eps) in ALL its Adam steps (so that both forms agree bit for bit): a 3-ulp error in an update
- *     term that is ~1e-3 of the weight.  PPO_HIP_ADAM_EXACT=1 keeps those fast forms and computes the quotient with the correctly rounded square root and division
- *     (no deviation; 5 - 7 % of that shape's train step); PPO_HIP_NO_LAZY_ADAM=1 switches the forms themselves, and the deviation, off.
+ *     the clip + Adam step -- in EVERY form of it since round 6, including the reference's own [64,64] shape, whose handle applies Adam inside the next train kernel's
+ *     prologue (or, with minibatches of <= 64 rows, inside the resident epoch kernel) during ppo_update.  No stated deviation is left in the default build.
+ *     PPO_HIP_ADAM_FAST=1 (read at ppo_create) opts a handle into the hardware's 1-ulp reciprocal and square root for the quotient m * alpha / (sqrt(v) + eps) in ALL its
+ *     Adam steps (a 3-ulp error in an update term that is ~1e-3 of the weight; 5 - 9 % of that shape's train step: bench.py reports both);
+ *     PPO_HIP_NO_LAZY_ADAM=1 switches the deferred / resident forms themselves off.
  */
 #ifndef PPO_HIP_H
 #define PPO_HIP_H
@@ -232,12 +232,14 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
  * "theta" "adam_m" "adam_v" (padded), "thetaT" / "par" (the transposed and small-parameter mirrors the train kernels read), "grad" (+ its tail), "sumsq", "beta_pow", "hyper",
  * "norm_out", "dw2_parts", the last train step's workspaces ("x0g" "dmug" "h_pi_0" ... "slots_pi" "slabs"), the gathered epoch ("mb_obs" ... "gidx" "advstats" "keys"), the
  * narrow path's packed image and second weight set ("nw_img" "nw_theta1" ...), the normaliser's state.  *count = the buffer's length in 4-byte words (0: not used by this shape);
- * at most max_count words are copied.  Two runs that must agree bit for bit are compared buffer by buffer with it (tests/test_other_shapes.py).  No reference counterpart.
- * "snap:<name>": the same buffer as it was right behind train step n of the last ppo_update, for a handle created under PPO_HIP_DEBUG_SNAPSHOT=n (launch-per-step paths). */
+ * at most max_count words are copied.  Two runs that must agree bit for bit are compared buffer by buffer with it (tests/test_other_shapes.py).  No reference counterpart. */
 int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_count, int64_t* count);
 /* debug: leave `word` in every LDS word of every CU (a launch of whole-CU workgroups on the handle's stream, synchronised).  A kernel that reads LDS it never wrote sees
  * what the previous workgroup on its CU left there; with a NaN pattern in place such a read shows in the results (tests/test_race_guards.py).  No reference counterpart. */
 int ppo_debug_poison_lds(ppo_handle* h, uint32_t word);
+/* debug: the node types of the hipGraph the last ppo_update captured: counts = {kernel, memset, memcpy, other}; -1 when the handle holds no graph.  The library's rule is
+ * kernel nodes only (a memset node replayed out of order on ROCm 7.0.2: DESIGN.md section 9). */
+int ppo_debug_graph_nodes(ppo_handle* h, int32_t counts[4]);
 
 #ifdef __cplusplus
 }

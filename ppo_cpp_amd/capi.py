@@ -332,6 +332,13 @@ class PPOHip:
             self._ck(self.lib.ppo_debug_buffer(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(cnt.value), C.byref(cnt)))
         return out
 
+    def debug_graph_nodes(self):
+        """{kernel, memset, memcpy, other: count} of the update's captured hipGraph, or None when the handle holds none (include/ppo_hip.h, ppo_debug_graph_nodes)"""
+        c = (C.c_int32 * 4)()
+        if self.lib.ppo_debug_graph_nodes(self.h, c) != 0:
+            return None
+        return dict(zip(("kernel", "memset", "memcpy", "other"), [int(x) for x in c]))
+
     def debug_poison_lds(self, word=0x7FC0DEAD):
         """leave `word` (default: a NaN pattern) in every LDS word of every CU (include/ppo_hip.h, ppo_debug_poison_lds)"""
         self._ck(self.lib.ppo_debug_poison_lds(self.h, C.c_uint32(word)))

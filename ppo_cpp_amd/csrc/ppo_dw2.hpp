@@ -24,9 +24,6 @@
 #define DW2_GRID (DW2_TILES * DW2_SPLITS)
 #define DW2_CH 64                           // minibatch rows per LDS chunk
 #define DW2_NBUF 3
-#ifndef DW2_MODEL_FENCES
-#define DW2_MODEL_FENCES 0                  // see the arrival below
-#endif
 // one chunk in LDS (floats): X [64][64] | Y [64][32] | U [64][UW] | W [64][16], UW = the wider of the observation and the action tile;
 // a ring of three chunks + 64 words of flags / scratch
 template <int KP0, int AP>
@@ -61,9 +58,6 @@ struct Dw2Args {
     const float* slots[2]; int n_rowblocks, slot_w;
     float n_local; float* beta_pow; int tail_off;
     unsigned long long* stamps;  // diagnostic builds only (-DPPO_STAMPS): [grid][16]
-    // two OPT-IN forms of the slab hand-off, for telling a suspected hand-off fault from anything else; 0 = the measured default:
-    int own_lines;               // PPO_HIP_DW2_OWN_LINES=1: a slab keeps every first-layer strip contiguous, so that no 128-byte line of a slab belongs to two tiles
-    int model_fences;            // PPO_HIP_DW2_FENCES=1: agent-scope RELEASE on the arrival and ACQUIRE in the last arriver (the language model's form; ~2x the launch's time)
 };
 
 // write-through (sc1) 16-byte load for bytes another workgroup stored write-through in this launch.  Inline asm: the compiler
@@ -114,54 +108,19 @@ __device__ __forceinline__ void dw2_strip_mma(const float (&u)[2][NU], const flo
                               : __builtin_amdgcn_mfma_f32_16x16x4f32(ww[ks], u[ks][t], sacc[t], 0, 0, 0);
 }
 
-// The kernel's body; b = the workgroup's linear index 0 .. DW2_GRID - 1 (blockIdx.x of the standalone launch; also called as the second phase
-// of train8_dw2_fused_kernel, ppo_fused_ab.hpp).
+// The kernel's body; b = the workgroup's linear index 0 .. DW2_GRID - 1 (blockIdx.x).  (Round 5 also called it as the second phase of a fused train + weight-gradient
+// launch and, in a third form, let the 64 finishers apply clip + Adam behind a grid-wide meeting: both measured slower than the launches they replaced
+// -- profiles/r05_a_*, r05_g_* -- and removed in round 6; branch experiments-r05.)
 // PEER (data parallel over peer-mapped regions, ppo_peer.hpp): the workgroup that finishes a tile LAST holds the assembled tile -- it also stores it,
 // its strip and the 24-odd slot-job results of the tile's four workgroups into slot [rank] of EVERY rank's gather region (16-byte stores), takes ONE
 // system-scope release, and arrives on the local counter; the last of the 64 finishers raises this rank's flag at every peer.  No push launch; the
 // sum over the ranks happens inside adam_kernel<.., 2>.  (Round 2 pushed from every workgroup that wrote gradient elements -- 590 of them, each with
 // its own fence -- and lost; here at most 64 workgroups fence.)
-// FUSED (second phase of train8_dw2_fused_kernel): the workgroup entered after the 32 workgroups of ITS (tower, row split) had finished the first phase; the
-// slot jobs read rows of EVERY split of either tower, so their loads wait -- behind the chunk loop, when it costs nothing -- until all FAB words show `epoch`.
-struct Dw2Meet { const unsigned* words; unsigned epoch; unsigned* err; int n; };
-// ADAM (single GPU, the launch every workgroup of which is resident at once: one per CU): clip + Adam ride in THIS launch.  A tile's finisher holds the
-// assembled gradient tile (and strip) in registers; the only thing missing is the global norm -- a sum over all DW2_TILES + DW2_GRID partials.  So every
-// partial is published as ONE 8-byte word {epoch, partial} (a write-through store, no read-modify-write: the epoch says "written in this launch", the table
-// needs no reset); the 64 FINISHERS go on (the other 192 workgroups leave after their arrival: they would only add pollers to the table's lines), each also
-// takes the slot-job elements of its tile's four workgroups, 256 of its threads watch the 320 words, and when the last one shows this launch's epoch the values
-// they just read ARE the partials -- no second round trip.  They add them up in adam_kernel's order and apply TF's ApplyAdam to what they hold: weights,
-// transposed copies (the W1 tile leaves through LDS as 256-byte rows), the small-parameter mirror.  Same arithmetic, same order, same bits as the adam_kernel
-// launch it replaces (tests/test_other_shapes.py).
-// OPT-IN (PPO_HIP_ADAM_IN_B=1), because it only breaks even: 39.6 us per train step at BASELINE configs[2] against 39.35 - 39.5 with the launch
-// (profiles/r05_g_adam_in_weight_grad_launch.txt).  Behind the last tile arrival the chain is finisher 3.2 k cycles -> meeting >= 3.3 k (the last word's
-// store, then a poll that sees it: two trips to the memory side) -> norm 0.7 k -> apply 2.6 - 3.2 k, and the apply is instruction-issue bound: TF's Adam
-// needs a correctly rounded square root and division per element (~50 instructions), 13 elements per pair of waves sharing a SIMD, on the 64 finishers'
-// CUs only; adam_kernel spreads the same elements over 148 workgroups.  ~10.9 k cycles against ~10.4 k for kernel boundary + adam_kernel.
-#define DW2_ENT_ERR (DW2_TILES + DW2_GRID)
-struct Dw2Adam {
-    float* theta; float* m; float* v; float* thetaT; float* par;
-    const float* hyper;          // {lr, cliprange}
-    float* beta_pow;             // {cur b1, cur b2, next b1, next b2}: this launch applies `next` (what its workgroup 0 copies to `cur`) and advances it
-    float beta1, beta2, eps, max_norm;
-    float* loss_row; float* norm_out;
-    unsigned long long* ent;     // [DW2_TILES + DW2_GRID] {epoch << 32 | partial sum of squares}, indexed like Dw2Args::parts; [DW2_ENT_ERR] raised when a wait timed out
-    int w1T_off[2], wmuT_off;    // transposed copies inside thetaT: W1^T [256][256] per tower, W_mu^T [AP][256]
-};
-template <int KP0, int AP, bool PEER = false, bool FUSED = false, bool ADAM = false>
-__device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int b, const PeerDev* pp = nullptr, const Dw2Meet* mt = nullptr, const Dw2Adam* ad = nullptr) {
+template <int KP0, int AP, bool PEER = false>
+__device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int b, const PeerDev* pp = nullptr) {
     typedef Dw2L<KP0, AP> LD;
-    static_assert(!(ADAM && (PEER || FUSED)), "clip + Adam ride in the single-GPU two-launch form only");
     DW2_STAMP(15); DW2_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-    // ADAM: this workgroup's epoch, the powers and the learning rate are read NOW: workgroup 0 overwrites the powers after the meeting, and every
-    // workgroup has these values in registers before it arrives there (atomic loads in front of the barriers' release fences)
-    unsigned epoch = 0; float b1p = 0.f, b2p = 0.f, lr = 0.f;
-    if constexpr (ADAM) {
-        epoch = (unsigned)(__hip_atomic_load(ad->ent + DW2_TILES + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + 1u;      // (only this workgroup writes that word)
-        b1p = __hip_atomic_load(ad->beta_pow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b2p = __hip_atomic_load(ad->beta_pow + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lr = __hip_atomic_load(ad->hyper, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     const int g = lane >> 4, c = lane & 15;
     // workgroups are dealt round-robin over the 8 XCDs: XCD x takes row split x >> 1 of tower x & 1, so the rows x 2 operands
     // of that split (1 MB at M = 2048) are fetched from the fabric once per XCD and shared by its 32 tiles through the L2, and
@@ -298,7 +257,7 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
 #pragma unroll
         for (int k = 0; k < DW2_SLOTK; ++k) { const int rb = ln + 32 * k; sj[k] = (has_job && rb < a.n_rowblocks) ? p[(size_t)rb * a.slot_w] : 0.f; }
     };
-    if constexpr (!FUSED) load_slots();
+    load_slots();
     DW2_STAMP(2);
     // One iteration = the matrix instructions of chunk i from registers; chunk i+3 is requested into the buffer of chunk i (this wave
     // read its fragments of it in the last iteration), the fragments of chunk i+1 are read (its pieces have landed: the wait at the
@@ -329,21 +288,6 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
         if (i + 1 < nch) iteration(i + 1, fb, fa);
     }
     DW2_STAMP(3);
-    if constexpr (FUSED) {
-        // every workgroup of the launch has finished its first phase by now (this phase's chunk loop is longer than the towers' skew): check it, then the slots
-        if (tid < 256) {
-            unsigned polls = 0;
-            for (;;) {
-                bool ok = true;
-                for (int i = tid; i < mt->n; i += 256) ok = ok && (int)(__hip_atomic_load(mt->words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mt->epoch) >= 0;
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++polls > (1u << 20)) { if ((tid & 63) == 0) __hip_atomic_store(mt->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        __syncthreads();
-        load_slots();
-    }
     // ---- park: main partials [4 K quarters][64][32], strip partials [8 waves][16 uwk]; slot jobs finish here too --------------------
     __syncthreads();                                          // the partials overlay the chunk ring: every wave is done with it (and its requests have landed)
     float* park = lds;
@@ -373,7 +317,7 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
         float s = ((sj[0] + sj[1]) + (sj[2] + sj[3])) + ((sj[4] + sj[5]) + (sj[6] + sj[7]));
         s = half_sum_lane0(s);                                       // within the 32 lanes of the job
         if ((tid & 31) == 0) {
-            if (has_job) st_wt<PEER || ADAM>(a.grad + jraw.z, s);  // (PEER: the tile's finisher reads it back with a write-through load and pushes it; ADAM: the loss sums, after the meeting)
+            if (has_job) st_wt<PEER>(a.grad + jraw.z, s);          // (PEER: the tile's finisher reads it back with a write-through load and pushes it)
             red2[tid >> 5] = (has_job && jraw.w) ? s * s : 0.f;
         }
     }
@@ -393,12 +337,12 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
     unsigned soff = 0;
     if (kind == 0) soff = (unsigned)(a.w0_off[tower] + (tid >> 2) * 256 + 16 * sidx + 4 * (tid & 3));                 // W0 [KP0][256]
     else if (kind == 1) soff = (unsigned)(a.wmu_off + (16 * sidx + (4 * tid) / AP) * AP + (4 * tid) % AP);            // W_mu [256][AP]
-    // ... and inside a SLAB.  The main tile's row segments (32 floats) and the head's strip rows (AP floats) are whole 128-byte lines of their own; a first-layer strip is 16 columns of
-    // a 256-float row -- half a line, the other half the neighbour tile's.  In the parameter vector that is harmless (plain stores, merged by byte mask at the kernel's end); in a slab it
-    // means the finisher of one tile pulls lines into its XCD's L2 whose other half a split of the neighbour may not have written yet (sc1 loads bypass the L1, not the L2).  Never seen
-    // to matter (it would have to show in most launches); own_lines keeps the strips contiguous in the slab ([16 strips][KP0][16]) -- only the finisher reads a slab, and it writes the
-    // natural layout -- so that the question can be asked of the hardware.
-    const unsigned sslab = (a.own_lines && kind == 0) ? (unsigned)(a.w0_off[tower] + sidx * sn + 4 * tid) : soff;
+    // ... and inside a SLAB every 128-byte line belongs to ONE tile: the main tile's row segments (32 floats) and the head's strip rows (AP floats) are whole lines as they
+    // lie; a first-layer strip -- 16 columns of a 256-float row, HALF a line whose other half is the neighbour tile's -- is kept contiguous instead ([16 strips][KP0][16]: only
+    // the finisher reads a slab, and it writes the natural layout into the gradient).  Rounds 3 - 5 stored the strips in place, which broke the hand-off's own rule (the last
+    // arriver must meet no line another workgroup on its XCD touched in this launch: sc1 loads bypass the L1, not the L2); never seen to matter, bit-identical and
+    // equally fast either way (profiles/r06_b_dw2_own_lines_ab.txt), so the layout that keeps the rule true is the only one since round 6.
+    const unsigned sslab = kind == 0 ? (unsigned)(a.w0_off[tower] + sidx * sn + 4 * tid) : soff;
     float* slab = a.slabs + (size_t)split * a.slab_stride;
     st_wt4<true>(slab + moff, m4);
     if (strip_thread) st_wt4<true>(slab + sslab, sv);
@@ -406,9 +350,8 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
         float q = 0.f;
         for (int j = 0; j < 16; ++j) q += red2[j];
         a.parts[DW2_TILES + b] = q;
-        if constexpr (ADAM) __hip_atomic_store(ad->ent + DW2_TILES + b, ((unsigned long long)epoch << 32) | __float_as_uint(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (b == 0 && tid == 64) st_wt<PEER || ADAM>(a.grad + a.tail_off + 5, a.n_local);
+    if (b == 0 && tid == 64) st_wt<PEER>(a.grad + a.tail_off + 5, a.n_local);
     if (b == 0 && tid == 65) { a.beta_pow[0] = a.beta_pow[2]; a.beta_pow[1] = a.beta_pow[3]; }    // cur <- next (adam writes next)
     DW2_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // EVERY storing wave drains its write-through stores ...
@@ -421,29 +364,18 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
         // storing wave has waited `s_waitcnt vmcnt(0)` (its stores are complete at that level), the barrier orders all of them before
         // this thread, and the last arriver reads with `global_load ... sc1` (never served by its own XCD's L2).  The stores and loads
         // are volatile inline asm with memory clobbers, so the compiler cannot move them across the atomic either.  The model's form --
-        // an agent-scope RELEASE on this arrival and an ACQUIRE fence in the last arriver (-DDW2_MODEL_FENCES=1) -- was measured: on
+        // an agent-scope RELEASE on this arrival and an ACQUIRE fence in the last arriver -- was measured in rounds 4 and 6 (same bits): on
         // gfx950 an agent-scope release is a write-back of the XCD's whole L2 and the acquire an invalidate, 256 + 64 of them per launch:
         // 15.6 -> 30.8 us per launch (profiles/r04_a_dw2_model_fences_measured_not_kept.txt).  ppo_peer.hpp pays for fences because its
         // data crosses DEVICES through plain stores; here both sides are sc1 accesses of one device.
-#if DW2_MODEL_FENCES
-        const unsigned old = __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        const unsigned old = a.model_fences ? __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
-                                            : __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+        const unsigned old = __hip_atomic_fetch_add(a.counters + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag[0] = (old == DW2_SPLITS - 1) ? 1 : 0;
     }
     __syncthreads();
     DW2_STAMP(6);
     const bool fin = flag[0] != 0;
     f32x4 t4 = {0.f, 0.f, 0.f, 0.f}, u4 = t4;
-    float4 am = make_float4(0.f, 0.f, 0.f, 0.f), av = am, at = am, sm = am, sv2 = am, st = am;      // ADAM: Adam slots + weights of the tile / strip elements
     if (fin) {
-#if DW2_MODEL_FENCES
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
-        if (a.model_fences) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
         // last arriver: the four slabs in split order (its own included: same bits whoever is last), all loads first
         f32x4 p[DW2_SPLITS], q[DW2_SPLITS];
 #pragma unroll
@@ -471,7 +403,6 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
 #pragma unroll
             for (int w = 0; w < 8; ++w) s += red[w];
             a.parts[gtile] = s;
-            if constexpr (ADAM) __hip_atomic_store(ad->ent + gtile, ((unsigned long long)epoch << 32) | __float_as_uint(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.counters + gtile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
         }
         __syncthreads();
@@ -512,109 +443,6 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& a, float* lds, const int
             }
         }
     }
-    if constexpr (ADAM) {
-        DW2_STAMP(8);
-        // Adam slots + weights of what this workgroup holds: on their way while the workgroups meet (the loss sums and the row count were written through
-        // and drained before the tile arrival above; the partials travel inside the words)
-        // Only the 64 finishers go on (the other 192 workgroups would only add pollers to the table's lines): a finisher also takes the slot-job elements
-        // of its tile's four workgroups (their results were written through and drained before their arrivals, as in the PEER form)
-        if (!fin) { DW2_STAMP(9); DW2_STAMP(10); DW2_STAMP(7); return; }
-        am = *reinterpret_cast<const float4*>(ad->m + moff); av = *reinterpret_cast<const float4*>(ad->v + moff); at = *reinterpret_cast<const float4*>(ad->theta + moff);
-        if (strip_thread) { sm = *reinterpret_cast<const float4*>(ad->m + soff); sv2 = *reinterpret_cast<const float4*>(ad->v + soff); st = *reinterpret_cast<const float4*>(ad->theta + soff); }
-        int job_dst = -1, job_par = 0; float job_g = 0.f, job_m = 0.f, job_v = 0.f, job_t = 0.f;
-        if (tid < DW2_SPLITS * a.jobs_per_wg) {
-            const int sp = tid / a.jobs_per_wg, jl2 = tid - sp * a.jobs_per_wg;
-            const int jb2 = ((tile << 3) | (sp << 1) | tower) * a.jobs_per_wg + jl2;
-            if (jb2 < a.n_jobs) {
-                const int4 jd = reinterpret_cast<const int4*>(a.jobs)[jb2];
-                if (jd.w != 0) {                                  // SlotJob::in_norm = 1 + the element's index in the small-parameter mirror (0: a loss sum)
-                    job_dst = jd.z; job_par = jd.w - 1;
-                    job_g = __hip_atomic_load(a.grad + job_dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    job_m = ad->m[job_dst]; job_v = ad->v[job_dst]; job_t = ad->theta[job_dst];
-                }
-            }
-        }
-        // ---- the meeting: thread t < 256 watches words t and t + 256 -- exactly the partials adam_kernel's thread t adds ----------------------------------
-        float s = 0.f;
-        unsigned polls = 0;
-        for (;;) {
-            bool ok = true;
-            if (tid < 256) {
-                const unsigned long long e0 = __hip_atomic_load(ad->ent + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (int)((unsigned)(e0 >> 32) - epoch) >= 0; s = __uint_as_float((unsigned)e0);
-                if (tid < DW2_TILES + DW2_GRID - 256) {
-                    const unsigned long long e1 = __hip_atomic_load(ad->ent + 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && (int)((unsigned)(e1 >> 32) - epoch) >= 0; s += __uint_as_float((unsigned)e1);
-                }
-            }
-            if (__syncthreads_and(ok ? 1 : 0)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++polls > (1u << 20)) { if (tid == 0) __hip_atomic_store(ad->ent + DW2_ENT_ERR, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-        DW2_STAMP(9);
-        // ---- the global norm: adam_kernel's tree (wave butterfly; the four waves pairwise) -------------------------------------------------------------
-        float* red = lds + DW2_NBUF * LD::BUF + 16;
-        s = wave_sum_lane0(s);
-        if (tid < 256 && lane == 0) red[wave] = s;
-        __syncthreads();
-        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-        float scale = ad->max_norm * tf_min(1.0f / norm, 1.0f / ad->max_norm);      // G:24289-24472
-        if (!isfinite(norm)) scale = __builtin_nanf("");                          // G:24493-24543
-        const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-        const float omb1 = 1.0f - ad->beta1, omb2 = 1.0f - ad->beta2;
-        DW2_STAMP(10);
-        {
-            // the tile: thread t = row t / 8, columns 4 (t % 8) .. + 3 of the [64 x 32] tile
-            float mo[4], vo[4], to[4];
-            const float mv[4] = {am.x, am.y, am.z, am.w}, vv[4] = {av.x, av.y, av.z, av.w}, tv[4] = {at.x, at.y, at.z, at.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) adam_element<false>(t4[k] * scale, mv[k], vv[k], tv[k], omb1, omb2, alpha, ad->eps, mo[k], vo[k], to[k]);
-            *reinterpret_cast<float4*>(ad->m + moff) = make_float4(mo[0], mo[1], mo[2], mo[3]);
-            *reinterpret_cast<float4*>(ad->v + moff) = make_float4(vo[0], vo[1], vo[2], vo[3]);
-            *reinterpret_cast<float4*>(ad->theta + moff) = make_float4(to[0], to[1], to[2], to[3]);
-            float* tt = lds;                                                      // [32][65]: the transposed tile (the partials parked there are spent)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tt[(4 * (tid & 7) + k) * 65 + (tid >> 3)] = to[k];
-            if (strip_thread) {
-                const float sm4[4] = {sm.x, sm.y, sm.z, sm.w}, sv4[4] = {sv2.x, sv2.y, sv2.z, sv2.w}, st4[4] = {st.x, st.y, st.z, st.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) adam_element<false>(u4[k] * scale, sm4[k], sv4[k], st4[k], omb1, omb2, alpha, ad->eps, mo[k], vo[k], to[k]);
-                *reinterpret_cast<float4*>(ad->m + soff) = make_float4(mo[0], mo[1], mo[2], mo[3]);
-                *reinterpret_cast<float4*>(ad->v + soff) = make_float4(vo[0], vo[1], vo[2], vo[3]);
-                *reinterpret_cast<float4*>(ad->theta + soff) = make_float4(to[0], to[1], to[2], to[3]);
-                if (kind == 1) {                                                  // W_mu^T [AP][256]: 16 consecutive floats per row of the transposed strip
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { const int e = 4 * tid + k; ad->thetaT[ad->wmuT_off + (e % AP) * 256 + 16 * sidx + e / AP] = to[k]; }
-                }
-            }
-            __syncthreads();
-            {   // W1^T: row j0 + rp of the transposed matrix, 64 consecutive floats starting at column i0
-                const int rp = tid >> 4, q4 = 4 * (tid & 15);
-                const float* r = tt + rp * 65 + q4;
-                *reinterpret_cast<float4*>(ad->thetaT + ad->w1T_off[tower] + (j0 + rp) * 256 + i0 + q4) = make_float4(r[0], r[1], r[2], r[3]);
-            }
-        }
-        if (job_dst >= 0) {
-            float mo, vo, to;
-            adam_element<false>(job_g * scale, job_m, job_v, job_t, omb1, omb2, alpha, ad->eps, mo, vo, to);
-            ad->m[job_dst] = mo; ad->v[job_dst] = vo; ad->theta[job_dst] = to;
-            ad->par[job_par] = to;
-        }
-        if (gtile == 0) {
-            if (tid == 0) {
-                ad->beta_pow[2] = b1p * ad->beta1;                                // G:31217-31342 (after the applies)
-                ad->beta_pow[3] = b2p * ad->beta2;
-                if (ad->norm_out) *ad->norm_out = norm;
-            }
-            if (ad->loss_row && tid < 5) {
-                const float n = __hip_atomic_load(a.grad + a.tail_off + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float sum = __hip_atomic_load(a.grad + a.tail_off + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                float r = sum / n;
-                if (tid == 1 || tid == 3) r = 0.5f * r;                           // vf_loss, approxkl carry the 0.5
-                ad->loss_row[tid] = r;
-            }
-        }
-    }
     DW2_STAMP(7);
 }
 
@@ -623,13 +451,6 @@ __global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_kernel(Dw2Ar
     extern __shared__ __attribute__((aligned(16))) float lds[];
     warm_kernargs<sizeof(Dw2Args)>();
     dw2_body<KP0, AP>(a, lds, (int)blockIdx.x);
-}
-
-template <int KP0, int AP>
-__global__ __launch_bounds__(DW2_THREADS) void weight_grad_assemble_adam_kernel(Dw2Args a, Dw2Adam ad) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    warm_kernargs<sizeof(Dw2Args) + sizeof(Dw2Adam)>();
-    dw2_body<KP0, AP, false, false, true>(a, lds, (int)blockIdx.x, nullptr, nullptr, &ad);
 }
 
 template <int KP0, int AP>

@@ -9,7 +9,6 @@
 #include "ppo_peer.hpp"
 #include "ppo_dw2.hpp"
 #include "ppo_train8.hpp"
-#include "ppo_fused_ab.hpp"
 #include "ppo_rollout1.hpp"
 
 #include <dlfcn.h>
@@ -51,11 +50,11 @@ const char* kProfNames[PK_COUNT] = {"policy_step", "train_fwd_bwd", "weight_grad
 
 // which kernel VARIANT a call took (ppo_kernel_counts): the fast paths are chosen by shape, and a test must be able to say which one ran
 enum KernelVariant { KV_TRAIN8 = 0, KV_TRAIN_FB, KV_DW2, KV_DW, KV_GRAD_REDUCE, KV_NARROW_TRAIN_STATIC, KV_NARROW_TRAIN, KV_NARROW_STEP_STATIC, KV_NARROW_STEP,
-                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_FUSED_AB, KV_DW2_ADAM, KV_BF16_REDUCE_ADAM, KV_NARROW_EPOCH, KV_COUNT };
+                     KV_POLICY_STEP, KV_ROLLOUT1, KV_ROLLOUT_PERSISTENT, KV_ROLLOUT_COOP, KV_COLLECT_FUSED, KV_BF16_TRAIN, KV_BF16_STEP, KV_BF16_REDUCE_ADAM, KV_NARROW_EPOCH, KV_COUNT };
 const char* kVariantNames[KV_COUNT] = {"train8_kernel", "train_fwd_bwd_kernel", "weight_grad_assemble_kernel", "weight_grad_kernel", "grad_reduce_kernel",
                                        "narrow_train_kernel<static>", "narrow_train_kernel<runtime>", "narrow_step_kernel<static>", "narrow_step_kernel<runtime>",
                                        "policy_step_kernel", "narrow_rollout1_kernel", "narrow_rollout_kernel", "narrow_rollout_coop_kernel", "narrow_collect_kernel",
-                                       "bf16_train_sequence", "bf16_step_sequence", "train8_dw2_fused_kernel", "weight_grad_assemble_adam", "bf16_reduce_adam_kernel", "narrow_epoch_kernel"};
+                                       "bf16_train_sequence", "bf16_step_sequence", "bf16_reduce_adam_kernel", "narrow_epoch_kernel"};
 
 // RCCL entry points resolved at run time (the single-GPU path must not depend on librccl being loadable)
 struct Rccl {
@@ -93,12 +92,6 @@ struct ppo_handle {
     int n_tiled = 0; AdamArgs::Tiled tiled[ADAM_MAX_TILED]{};   // matrices whose transposed copy adam_kernel writes tile by tile
     // train workspaces (sized for ws_rows minibatch rows)
     int ws_rows = 0;
-    // diagnostic (PPO_HIP_DEBUG_SNAPSHOT=<train step of an update>, read at ppo_create): ppo_update copies every buffer ppo_debug_buffer knows into an arena right behind that train
-    // step's launches (device-to-device copies in the stream / nodes of the update's graph), readable as "snap:<name>".  -1 = off: nothing is enqueued, nothing allocated.
-    int snap_step = -1;
-    float* snap_arena = nullptr; size_t snap_words = 0;
-    struct SnapEnt { std::string name; size_t off, words; };
-    std::vector<SnapEnt> snap_index;
     float* x0g = nullptr;
     float* hg[2][PPO_MAX_LAYERS]{};
     float* dyg[2][PPO_MAX_LAYERS]{};
@@ -113,14 +106,9 @@ struct ppo_handle {
     // weight gradients + gradient assembly in one launch (ppo_dw2.hpp; 18-obs / [256,256] shape)
     bool dw2 = false;
     bool t8 = false;                  // 8-wave train kernel with K-split wave pairs (ppo_train8.hpp; same shape as dw2)
-    bool fuse_ab = false;             // PPO_HIP_FUSE_AB=1: train8 + weight_grad_assemble as ONE launch around a grid-wide meeting (ppo_fused_ab.hpp; measured, not the default)
     // data-parallel adam_kernel<.., MEET>: the meeting's epoch words (+ error word) and the workgroups' partial sums of squares; PPO_HIP_NO_ADAM_MEET=1:
     // the round-4 sequence (all-reduce + grad_sumsq_kernel / push + sum kernels, then the plain adam_kernel)
     unsigned* adam_meet_words = nullptr; float* adam_meet_parts = nullptr; bool adam_meet = false;
-    // clip + Adam inside weight_grad_assemble_adam_kernel (single GPU, [256,256] pair; ppo_dw2.hpp): PPO_HIP_ADAM_IN_B=1 on a whole device; measured, breaks
-    // even with the adam_kernel launch, so not the default
-    bool dw2_adam = false; unsigned long long* dw2_meet = nullptr;     // [DW2_TILES + DW2_GRID] {epoch, partial} words, [DW2_ENT_ERR] raised when a wait timed out
-    unsigned* fab_meet = nullptr;     // the meeting's table: [FAB_GRID] per-workgroup epoch words, [FAB_GRID] raised when a wait timed out
     unsigned* dw2_counters = nullptr; float* dw2_parts = nullptr; SlotJob* dw2_jobs = nullptr; int dw2_n_jobs = 0, dw2_jpw = 0;
     // staging for host-pointer calls
     int st_rows = 0;
@@ -215,9 +203,8 @@ struct ppo_handle {
     bool nw_epoch = false; unsigned* nw_epoch_words = nullptr;
     bool nw_epoch_xl = false;         // ... its XCD-local form (workgroups 0, 8, 16, ... of the launch; ordinary stores / loads through one L2; a partial buffer per step)
     float* nw_epoch_partials = nullptr; size_t nw_epoch_cap = 0;
-    bool nw_epoch_dist = false; unsigned* nw_epochd_words = nullptr; int n_cu = 0;      // ... and its form for larger minibatches (narrow_epoch_dist_kernel: one workgroup per row group and tower)
-    bool adam_fast = false;           // adam_kernel uses the 1-ulp quotient of the deferred form (nw_lazy, or PPO_HIP_ADAM_FAST=1 for the bitwise test)
-    bool adam_exact = false;          // PPO_HIP_ADAM_EXACT=1: the deferred / resident forms with the correctly rounded quotient (no deviation from the reference's arithmetic)
+    bool adam_fast = false;           // PPO_HIP_ADAM_FAST=1: every Adam step of the handle uses the hardware's 1-ulp reciprocal / square root in the quotient (opt-in since round 6)
+    bool adam_exact = false;          // a deferred-Adam handle (nw_lazy) without that switch: its deferred / resident forms use the correctly rounded quotient (the default)
     int nw_cur = 0;                   // parameter set holding the current weights (0 outside ppo_update)
     bool nw_pending = false; float* nw_pending_loss = nullptr; int nw_pending_parts = 0;
     float* nw_coop = nullptr; int nw_coop_G = 0;      // cooperative persistent rollout: [2][G][NW_COOP_PW] chunk moments, then {arrive, err}
@@ -234,7 +221,7 @@ struct ppo_handle {
     struct Peer {
         bool on = false;                                // every collective that fits `cap` goes through the peer kernels
         bool usable = false;                            // the probe passed on every rank (ppo_dist_peer_enable may switch `on`)
-        bool coarse = false, coarse_requested = false;  // the region is plain hipMalloc memory (refused unless asked for: PPO_HIP_PEER_MEM=c)
+        bool coarse = false;                            // the region is plain hipMalloc memory: the peer path is refused
         void* region = nullptr;                         // mine: [flag block | slots[2][world][cap]] (exported over IPC)
         size_t cap = 0;                                 // floats per slot (multiple of PEER_CHUNK)
         int scap = 0;                                   // floats per slot of the statistics area behind the slots
@@ -280,6 +267,21 @@ int fail(ppo_handle* h, const char* fmt, ...) {
 // The update's executable graph AND the captured graph it came from go together.  (Rounds 1 - 5 destroyed the captured graph right after hipGraphInstantiate, which
 // is allowed; it is kept now because a runtime that held pointers into the captured graph's node parameters was one suspect for the open observation of DESIGN.md
 // section 9.  It was NOT the cause -- the observation is unchanged with the graph kept -- but a few hundred KB per handle cost nothing and rule that class out.)
+// Zero a few words from INSIDE the launch sequence: a kernel, not hipMemsetAsync.  The update's sequence is captured into a hipGraph and replayed, and a memset NODE in
+// that graph is not safe on this runtime (ROCm 7.0.2, gfx950): in a process that has lived for a while, a replay ran the node's fill in the MIDDLE of the kernels behind
+// it -- weight_grad_assemble_kernel's arrival counters were cleared while its workgroups were counting, no tile found its last arriver, and from then on every tile was
+// "finished" by whoever brought a half-counted word to 4 (found in round 6 through the oracle leg of tests/test_other_shapes.py's interleaved-handles test: both the
+// handle run beside others AND the handle run alone were wrong by 1e-2 after enough replays, with the counters non-zero behind the update; eager launches and a graph
+// without the node were right).  Rule: nothing but kernel nodes (and the collective library's own) in a captured sequence.  DESIGN.md section 9.
+__global__ void zero_words_kernel(unsigned* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+static int zero_words(ppo_handle* h, unsigned* p, int n) {
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, h->stream, p, n);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
 static void drop_graph(ppo_handle* h) {
     if (h->upd_graph) { (void)hipGraphExecDestroy(h->upd_graph); h->upd_graph = nullptr; }
     if (h->upd_graph_tmpl) { (void)hipGraphDestroy(h->upd_graph_tmpl); h->upd_graph_tmpl = nullptr; }
@@ -509,8 +511,7 @@ void build_narrow_layout(ppo_handle* h) {
     h->nw_stride = ru(h->P_pad + 8, 64);
     // compile-time shape of the reference's own network (18 obs / 18 act padded to 32, [64,64]); anything else runs the
     // runtime-shape instantiation
-    { const char* e = getenv("PPO_HIP_NO_NARROW_STATIC");     // (tests: the runtime-shape instantiation on the same shape)
-      h->nw_static = !(e && e[0] == '1') && n.L == 2 && (n.Kp0 == 32 || n.Kp0 == 64) && n.Ap == 32 && n.Hp[0] == 64 && n.Hp[1] == 64; }
+    h->nw_static = n.L == 2 && (n.Kp0 == 32 || n.Kp0 == 64) && n.Ap == 32 && n.Hp[0] == 64 && n.Hp[1] == 64;
     h->narrow = true;
 }
 
@@ -1037,35 +1038,10 @@ int peer_check(ppo_handle* h) {
     return 0;
 }
 
-// after a stream synchronisation: did the fused train kernel's grid-wide meeting time out (its workgroups were not all resident)?
-int fab_check(ppo_handle* h) {
-    if (!h->fab_meet || !h->fuse_ab) return 0;
-    unsigned e = 0;
-    HIP_OK(h, hipMemcpy(&e, h->fab_meet + FAB_GRID, sizeof e, hipMemcpyDeviceToHost));
-    if (e) {
-        (void)hipMemset(h->fab_meet, 0, (FAB_GRID + 32) * sizeof e);
-        h->fuse_ab = false;
-        drop_graph(h);
-        return fail(h, "train8_dw2_fused_kernel: its 256 workgroups were not resident together within 0.5 s (is another process using this GPU?); this "
-                       "step's results are invalid.  The handle now runs the two-launch form (the default without PPO_HIP_FUSE_AB=1)");
-    }
-    return 0;
-}
-
 // after a stream synchronisation: did a meeting of narrow_epoch_kernel time out?
 int nw_epoch_check(ppo_handle* h) {
     if (!h->nw_epoch || !h->nw_epoch_words) return 0;
     unsigned e = 0;
-    if (h->nw_epoch_dist && h->nw_epochd_words) {
-        HIP_OK(h, hipMemcpy(&e, h->nw_epochd_words + NW_EPOCHD_MAX_WG, sizeof e, hipMemcpyDeviceToHost));
-        if (e) {
-            (void)hipMemset(h->nw_epochd_words, 0, (NW_EPOCHD_MAX_WG + 64 + 5 * 128) * sizeof e);
-            h->nw_epoch_dist = false;
-            drop_graph(h);
-            return fail(h, "narrow_epoch_dist_kernel: its workgroups were not resident together (is another process using this GPU?); this update's results are invalid.  "
-                           "The handle now launches every train step (the default without PPO_HIP_NARROW_EPOCH_DIST=1)");
-        }
-    }
     HIP_OK(h, hipMemcpy(&e, h->nw_epoch_words + NW_EPOCH_WORDS - 1, sizeof e, hipMemcpyDeviceToHost));
     if (e == 2) {
         (void)hipMemset(h->nw_epoch_words, 0, NW_EPOCH_WORDS * sizeof e);
@@ -1080,21 +1056,6 @@ int nw_epoch_check(ppo_handle* h) {
         drop_graph(h);
         return fail(h, "narrow_epoch_kernel: its workgroups were not resident together (is another process using this GPU?); this update's results are invalid.  "
                        "The handle now launches every train step (PPO_HIP_NO_NARROW_EPOCH=1 selects that from the start)");
-    }
-    return 0;
-}
-
-// after a stream synchronisation: did weight_grad_assemble_adam_kernel's meeting time out?
-int dw2_adam_check(ppo_handle* h) {
-    if (!h->dw2_meet || !h->dw2_adam) return 0;
-    unsigned long long e = 0;
-    HIP_OK(h, hipMemcpy(&e, h->dw2_meet + DW2_ENT_ERR, sizeof e, hipMemcpyDeviceToHost));
-    if (e) {
-        (void)hipMemset(h->dw2_meet, 0, (DW2_ENT_ERR + 8) * sizeof e);
-        h->dw2_adam = false;
-        drop_graph(h);
-        return fail(h, "weight_grad_assemble_adam_kernel: its 256 workgroups were not resident together within ~0.5 s (is another process using this GPU?); this "
-                       "step's results are invalid.  The handle now launches adam_kernel separately (the default without PPO_HIP_ADAM_IN_B=1)");
     }
     return 0;
 }
@@ -1140,9 +1101,7 @@ int enqueue_adam(ppo_handle* h, float* loss_row, int n_sumsq = 0, const float* p
     AdamArgs aa{h->theta, h->adam_m, h->adam_v, h->grad, h->sumsq, h->n_blocks, h->thetaT, h->par, h->grad_src, h->hyper, h->beta_pow,
                 h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm, loss_row, h->norm_out, parts, n_parts,
                 0, {}, h->bf.on ? h->bf.theta_bf : nullptr, h->narrow ? h->nw_img : nullptr, nullptr, nullptr, nullptr};
-    { const char* e = getenv("PPO_HIP_ADAM_NO_TILES");           // (read per call: the test compares both forms in one process)
-      const bool no_tiles = e && e[0] == '1';
-      if (!no_tiles) { aa.n_tiled = h->n_tiled; for (int q = 0; q < h->n_tiled; ++q) aa.tiled[q] = h->tiled[q]; } }
+    aa.n_tiled = h->n_tiled; for (int q = 0; q < h->n_tiled; ++q) aa.tiled[q] = h->tiled[q];
 #ifdef PPO_STAMPS
     if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
     aa.stamps = g_stamps + 4096 * 40;
@@ -1176,25 +1135,13 @@ void launch_dw2(ppo_handle* h, const Dw2Args& da) {
     hipLaunchKernelGGL((weight_grad_assemble_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da);
 }
 template <int KP0, int AP>
-void launch_dw2_adam(ppo_handle* h, const Dw2Args& da, const Dw2Adam& ad) {
-    const size_t lds = sizeof(float) * Dw2L<KP0, AP>::LDS_FLOATS;
-    hipLaunchKernelGGL((weight_grad_assemble_adam_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da, ad);
-}
-template <int KP0, int AP>
 void launch_dw2_peer(ppo_handle* h, const Dw2Args& da) {
     const size_t lds = sizeof(float) * Dw2L<KP0, AP>::LDS_FLOATS;
     hipLaunchKernelGGL((weight_grad_assemble_peer_kernel<KP0, AP>), dim3(DW2_GRID), dim3(DW2_THREADS), lds, h->stream, da, h->peer.dev);
 }
 template <int KP0, int AP>
-void launch_fused_ab(ppo_handle* h, const TrainArgs& ta, const Dw2Args& da, int n_rb) {
-    const size_t lds = sizeof(float) * FabL<KP0, AP>::FLOATS;
-    hipLaunchKernelGGL((train8_dw2_fused_kernel<KP0, AP>), dim3(DW2_GRID), dim3(FAB_THREADS), lds, h->stream, h->net, ta, da, h->fab_meet, n_rb);
-}
-template <int KP0, int AP>
 bool set_lds_pair() {
     return hipFuncSetAttribute((const void*)weight_grad_assemble_peer_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess &&
-           hipFuncSetAttribute((const void*)weight_grad_assemble_adam_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess &&
-           hipFuncSetAttribute((const void*)train8_dw2_fused_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * FabL<KP0, AP>::FLOATS) == hipSuccess &&
            hipFuncSetAttribute((const void*)train8_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T8L<KP0, AP>::TOTAL) == hipSuccess &&
            hipFuncSetAttribute((const void*)weight_grad_assemble_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess;
 }
@@ -1314,20 +1261,6 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
         da.stamps = g_stamps + 4096 * 16;
 #endif
         da.n_rowblocks = n_rb; da.slot_w = n.slot_w; da.n_local = (float)ta.n; da.beta_pow = h->beta_pow; da.tail_off = h->P_pad;
-        { const char* e1 = getenv("PPO_HIP_DW2_OWN_LINES"); const char* e2 = getenv("PPO_HIP_DW2_FENCES");       // (read per call: a test compares the forms in one process; a graph keeps what it captured)
-          da.own_lines = (e1 && e1[0] == '1') ? 1 : 0; da.model_fences = (e2 && e2[0] == '1') ? 1 : 0; }
-    }
-    // one launch for both kernels when every workgroup of both phases is resident at once (<= 2048 rows: 2 n_rb <= 256 = one workgroup per CU)
-    if (use_dw2 && h->t8 && h->fuse_ab && 2 * n_rb <= DW2_GRID && n_rb % 4 == 0) {
-        ProfScope ps(h, PK_TRAIN_FB);
-        ++h->kv[KV_FUSED_AB];
-        if (n.Kp0 == 32 && n.Ap == 32) launch_fused_ab<32, 32>(h, ta, da, n_rb);
-        else if (n.Kp0 == 64 && n.Ap == 32) launch_fused_ab<64, 32>(h, ta, da, n_rb);
-        else if (n.Kp0 == 32 && n.Ap == 64) launch_fused_ab<32, 64>(h, ta, da, n_rb);
-        else launch_fused_ab<64, 64>(h, ta, da, n_rb);
-        HIP_OK(h, hipGetLastError());
-        if (h->comm) { if (enqueue_grad_allreduce(h)) return -1; return enqueue_adam(h, loss_row); }
-        return enqueue_adam(h, loss_row, DW2_TILES + DW2_GRID, h->dw2_parts);
     }
     {
         ProfScope ps(h, PK_TRAIN_FB);
@@ -1365,22 +1298,6 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
             HIP_OK(h, hipGetLastError());
         }
         return enqueue_adam(h, loss_row, 0, nullptr, 2);
-    }
-    if (use_dw2 && !h->comm && h->dw2_adam && !h->adam_fast) {
-        const char* e1 = getenv("PPO_HIP_ADAM_IN_B"); const char* e2 = getenv("PPO_HIP_ADAM_NO_TILES");     // (read per call: tests compare the forms in one process; a graph keeps what it captured)
-        if (e1 && e1[0] == '1' && !(e2 && e2[0] == '1')) {
-            // ... and clip + Adam in the same launch: its 256 workgroups meet once the partial sums of squares are out (ppo_dw2.hpp, Dw2Adam)
-            ProfScope ps(h, PK_DW);
-            ++h->kv[KV_DW2_ADAM];
-            Dw2Adam ad{h->theta, h->adam_m, h->adam_v, h->thetaT, h->par, h->hyper, h->beta_pow, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm,
-                       loss_row, h->norm_out, h->dw2_meet, {n.wT_off[0][1], n.wT_off[1][1]}, n.wmuT_off};
-            if (n.Kp0 == 32 && n.Ap == 32) launch_dw2_adam<32, 32>(h, da, ad);
-            else if (n.Kp0 == 64 && n.Ap == 32) launch_dw2_adam<64, 32>(h, da, ad);
-            else if (n.Kp0 == 32 && n.Ap == 64) launch_dw2_adam<32, 64>(h, da, ad);
-            else launch_dw2_adam<64, 64>(h, da, ad);
-            HIP_OK(h, hipGetLastError());
-            return 0;
-        }
     }
     if (use_dw2) {
         // weight gradients + slab / slot sums + partial sums of squares in ONE launch (ppo_dw2.hpp): no grad_reduce_kernel
@@ -1541,8 +1458,6 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { fail(h, "hipStreamCreate failed"); return bail(0); }
     const char* ng = getenv("PPO_HIP_NO_GRAPH");
     h->use_graph = !(ng && ng[0] == '1');
-    { const char* sn = getenv("PPO_HIP_DEBUG_SNAPSHOT");     // diagnostic: copy every buffer behind train step <n> of each update (ppo_debug_buffer "snap:<name>")
-      if (sn && sn[0] >= '0' && sn[0] <= '9') h->snap_step = atoi(sn); }
     if (cfg->compute_dtype != PPO_F32 && cfg->compute_dtype != PPO_BF16) { fail(h, "ppo_create: compute_dtype must be PPO_F32 or PPO_BF16"); return bail(0); }
     h->bf.on = cfg->compute_dtype == PPO_BF16;
     if (build_layout(h)) return bail(0);
@@ -1553,8 +1468,8 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
     auto set_lds = [&](const void* f) { attr_ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess; };
     set_lds((const void*)policy_step_kernel<4, 2, 2, false>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2, false>);
     set_lds((const void*)train_fwd_bwd_kernel<4, 2, 2, false, true>);
-    { const char* e = getenv("PPO_HIP_NO_EARLY"); const NetDev& nn = h->net;
-      h->early = !(e && e[0] == '1') && !nn.wide && h->CT == 4 && h->CTH == 2 && nn.L >= 2 && nn.Kp0 == 32 && nn.Ap == 32 && nn.Hp[0] == 256 && nn.Hp[nn.L - 1] == 256; }
+    { const NetDev& nn = h->net;
+      h->early = !nn.wide && h->CT == 4 && h->CTH == 2 && nn.L >= 2 && nn.Kp0 == 32 && nn.Ap == 32 && nn.Hp[0] == 256 && nn.Hp[nn.L - 1] == 256; }
     set_lds((const void*)policy_step_kernel<4, 2, 0, false>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0, false>);
     set_lds((const void*)policy_step_kernel<1, 1, 0, false>); set_lds((const void*)train_fwd_bwd_kernel<1, 1, 0, false>);
     set_lds((const void*)policy_step_kernel<4, 2, 0, true>); set_lds((const void*)train_fwd_bwd_kernel<4, 2, 0, true>);
@@ -1576,11 +1491,6 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
       h->t8 = !(e && e[0] == '1') && !nn.wide && h->CT == 4 && nn.L == 2 && nn.Hp[0] == 256 && nn.Hp[1] == 256 && nn.Kp0 <= 64 && nn.Ap <= 64;
       if ((h->t8 || h->dw2) && !(set_lds_pair<32, 32>() && set_lds_pair<64, 32>() && set_lds_pair<32, 64>() && set_lds_pair<64, 64>())) {
           fail(h, "hipFuncSetAttribute failed for train8_kernel / weight_grad_assemble_kernel"); return bail(0); } }
-    { const char* e = getenv("PPO_HIP_FUSE_AB");
-      // OPT-IN (measured slower than the two launches, profiles/r05_a_*: 40.3 vs 39.85 us per train step with the group-local meeting, 40.7 grid-wide).  The fused form's grid-wide meeting
-      // needs all DW2_GRID workgroups resident at once: one per CU (each takes > 80 KB of LDS)
-      h->fuse_ab = (e && e[0] == '1') && h->t8 && h->dw2 && prop.multiProcessorCount >= DW2_GRID;
-      if (h->fuse_ab && dev_alloc(h, &h->fab_meet, FAB_GRID + 32)) return bail(0); }
     if (h->dw2) {
         // slot jobs: every element the train kernel leaves as per-row-block partial sums (bias / logstd / value-head gradients), then the loss sums
         const NetDev& nn = h->net;
@@ -1606,9 +1516,6 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
             if (dev_alloc(h, &h->dw2_jobs, jobs.size()) || dev_alloc(h, &h->dw2_counters, (size_t)DW2_TILES) || dev_alloc(h, &h->dw2_parts, (size_t)DW2_TILES + DW2_GRID)) return bail(0);
             HIP_OK(h, hipMemcpyAsync(h->dw2_jobs, jobs.data(), jobs.size() * sizeof(SlotJob), hipMemcpyHostToDevice, h->stream));
             HIP_OK(h, hipStreamSynchronize(h->stream));
-            // clip + Adam in the same launch: its grid-wide meeting needs all DW2_GRID workgroups resident at once -- one per CU of a whole device
-            h->dw2_adam = h->t8 && prop.multiProcessorCount >= DW2_GRID;
-            if (h->dw2_adam && dev_alloc(h, &h->dw2_meet, DW2_ENT_ERR + 8)) return bail(0);
         }
     }
     if (h->bf.on && bf16_create(h)) return bail(0);
@@ -1626,8 +1533,6 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
         big_lds((const void*)narrow_epoch_kernel<32, true>); big_lds((const void*)narrow_epoch_kernel<64, true>);
         big_lds((const void*)narrow_epoch_kernel<32, false, true>); big_lds((const void*)narrow_epoch_kernel<64, false, true>);
         big_lds((const void*)narrow_epoch_kernel<32, true, true>); big_lds((const void*)narrow_epoch_kernel<64, true, true>);
-        big_lds((const void*)narrow_epoch_dist_kernel<32>); big_lds((const void*)narrow_epoch_dist_kernel<64>);
-        big_lds((const void*)narrow_epoch_dist_kernel<32, true>); big_lds((const void*)narrow_epoch_dist_kernel<64, true>);
         if (!attr_ok) { fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the narrow kernels"); return bail(0); }
         { const char* e1 = getenv("PPO_HIP_NO_HOST_FUSED"); const char* e2 = getenv("PPO_HIP_NO_HOST_RESIDENT");
           h->opt_no_host_fused = e1 && e1[0] == '1'; h->opt_no_host_resident = e2 && e2[0] == '1'; }
@@ -1636,19 +1541,17 @@ int ppo_create(const ppo_config* cfg, ppo_handle** out) {
             // second parameter / moment set of the deferred Adam (zero-filled: the padding elements are never written and must read 0)
             if (dev_alloc(h, &h->nw_theta1, P) || dev_alloc(h, &h->nw_m1, P) || dev_alloc(h, &h->nw_v1, P)) return bail(0);
             h->nw_lazy = true;
-            { const char* ex = getenv("PPO_HIP_ADAM_EXACT"); h->adam_exact = ex && ex[0] == '1'; }      // keep the deferred / resident forms, drop their 1-ulp quotient (~6 - 9 % of the train step)
-            h->adam_fast = !h->adam_exact;
+            // the deferred / resident forms compute TF's quotient with the correctly rounded square root and division by DEFAULT since round 6 (no deviation from the
+            // reference's arithmetic; 6 - 9 % of this shape's train step); PPO_HIP_ADAM_FAST=1 (below) opts into the hardware's 1-ulp reciprocal / square root
+            h->adam_exact = true; h->adam_fast = false;
             const char* ne = getenv("PPO_HIP_NO_NARROW_EPOCH");
             h->nw_epoch = !(ne && ne[0] == '1') && prop.multiProcessorCount >= 2 * 2 * NW_EPOCH_MAX_G;
             if (h->nw_epoch && dev_alloc(h, &h->nw_epoch_words, NW_EPOCH_WORDS)) return bail(0);
             { const char* nx = getenv("PPO_HIP_NO_NARROW_EPOCH_XL"); h->nw_epoch_xl = h->nw_epoch && !(nx && nx[0] == '1') && prop.multiProcessorCount >= 64; }
-            { const char* nd = getenv("PPO_HIP_NARROW_EPOCH_DIST"); h->n_cu = prop.multiProcessorCount;       // OPT-IN: measured slower than the launches (profiles/r05_i_*)
-              h->nw_epoch_dist = h->nw_epoch && nd && nd[0] == '1' && h->P_pad / 64 <= NW_THREADS;
-              if (h->nw_epoch_dist && dev_alloc(h, &h->nw_epochd_words, NW_EPOCHD_MAX_WG + 64 + 5 * 128)) return bail(0); }
         }
         if (dev_alloc(h, &h->nw_img, (size_t)2 * h->nw.w_total)) return bail(0);
     }
-    { const char* af = getenv("PPO_HIP_ADAM_FAST"); if (af && af[0] == '1') h->adam_fast = true; }
+    { const char* af = getenv("PPO_HIP_ADAM_FAST"); if (af && af[0] == '1') { h->adam_fast = true; h->adam_exact = false; } }      // every Adam step of the handle, so that its forms agree bit for bit
     const float pw[2] = {cfg->adam_beta1, cfg->adam_beta2};
     if (ppo_set_beta_powers(h, pw)) return bail(0);
     *out = h;
@@ -1666,11 +1569,9 @@ void ppo_destroy(ppo_handle* h) {
     if (h->peer.region) (void)hipFree(h->peer.region);
     if (h->peer.local) (void)hipFree(h->peer.local);
     for (float* p : {h->nw_theta1, h->nw_m1, h->nw_v1}) if (p) (void)hipFree(p);
-    if (h->snap_arena) (void)hipFree(h->snap_arena);
     if (h->nw_partials) (void)hipFree(h->nw_partials);
     if (h->nw_epoch_words) (void)hipFree(h->nw_epoch_words);
     if (h->nw_epoch_partials) (void)hipFree(h->nw_epoch_partials);
-    if (h->nw_epochd_words) (void)hipFree(h->nw_epochd_words);
     if (h->nw_img) (void)hipFree(h->nw_img);
     if (h->nw_alt) (void)hipFree(h->nw_alt);
     if (h->nw_coop) (void)hipFree(h->nw_coop);
@@ -1678,8 +1579,6 @@ void ppo_destroy(ppo_handle* h) {
     for (float* p : {h->gs_obs, h->gs_act, h->gs_ret, h->gs_val, h->gs_nlp}) if (p) (void)hipFree(p);
     if (h->dw2_jobs) (void)hipFree(h->dw2_jobs);
     if (h->dw2_counters) (void)hipFree(h->dw2_counters);
-    if (h->fab_meet) (void)hipFree(h->fab_meet);
-    if (h->dw2_meet) (void)hipFree(h->dw2_meet);
     for (int d = 0; d < 2; ++d) if (h->bf.chain_words[d]) (void)hipFree(h->bf.chain_words[d]);
     if (h->bf.chain_err_host) (void)hipHostFree(h->bf.chain_err_host);
     if (h->bf.ra_ent) (void)hipFree(h->bf.ra_ent);
@@ -1891,12 +1790,12 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
     ta.obs = h->st_obs; ta.actions = h->st_act; ta.advs = h->st_vec[2]; ta.returns = h->st_vec[3]; ta.old_neglogp = h->st_vec[4];
     ta.old_values = h->st_vec[5]; ta.adv_stats = nullptr; ta.n = n;
     ta.inv_n = 1.0f / (float)((int64_t)n * h->world);
-    if (h->dw2) HIP_OK(h, hipMemsetAsync(h->dw2_counters, 0, DW2_TILES * sizeof(unsigned), h->stream));
+    if (h->dw2 && zero_words(h, h->dw2_counters, DW2_TILES)) return -1;
     if (enqueue_train(h, ta, h->st_loss)) return -1;
     HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    return fab_check(h) || dw2_adam_check(h) || adam_meet_check(h) || bf16_chain_check(h) ? -1 : 0;
+    return adam_meet_check(h) || bf16_chain_check(h) ? -1 : 0;
 }
 
 int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm) {
@@ -2031,8 +1930,7 @@ static int enqueue_norm_batch(ppo_handle* h, const float* obs_dev, int rows, con
     NormBatchArgs a{};
     const int D = h->net.O;
     a.D = D; a.obs = obs_dev; a.rows = rows; a.obs_st = h->obs_rms;
-    static const bool no_strips = [] { const char* e = getenv("PPO_HIP_NO_OBS_STRIPS"); return e && e[0] == '1'; }();
-    if (obs_dev && !no_strips && D % 64 == 0 && D <= 64 * 254 && rows >= 256) {
+    if (obs_dev && D % 64 == 0 && D <= 64 * 254 && rows >= 256) {
         // wide observations: 64-column groups x row splits (obs_cgroup_job): splits of 128 rows (a thread's 8 rows stay in registers) where the table
         // of sets allows it (<= NB_CG_MAX_WG workgroups, <= 256 splits for the combine)
         a.n_strips = D / 64;
@@ -2533,15 +2431,14 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
         if (enqueue_norm_batch(h, h->raw_obs, E, nullptr, nullptr, 0, nullptr, nullptr)) return -1;
     }
     // small environment counts on the narrow path: one fused launch per env step (policy step + env + EnvNormalize bookkeeping)
-    static const bool no_fused = [] { const char* e = getenv("PPO_HIP_NO_FUSED_COLLECT"); return e && e[0] == '1'; }();
-    const bool fused = h->narrow && !h->comm && !no_fused && E <= NW_ROWS && n.O <= 64;
+    const bool fused = h->narrow && !h->comm && E <= NW_ROWS && n.O <= 64;
     // ... and on top of that the whole rollout in ONE launch of one persistent workgroup (narrow_rollout_kernel): state in LDS,
     // only stores leave the CU; the value tower runs afterwards, batched over the T x E normalised rows
     const char* npe = getenv("PPO_HIP_NO_PERSISTENT_COLLECT");
     const bool no_persist = npe && npe[0] == '1';
     // (up to NW_RO_MAX_E environments: the one workgroup walks them in groups of 32 rows)
     const size_t ro_lds = ((size_t)h->nw.lds_total + (E > NW_ROWS ? nw_ro_extra(E, n.O) : NW_RO_EXTRA)) * sizeof(float);
-    const bool persistent = h->narrow && !h->comm && !no_fused && !no_persist && E <= NW_RO_MAX_E && n.O <= 64 && n.A <= 64 && ro_lds <= 160 * 1024;
+    const bool persistent = h->narrow && !h->comm && !no_persist && E <= NW_RO_MAX_E && n.O <= 64 && n.A <= 64 && ro_lds <= 160 * 1024;
     if (persistent) {
         NwRolloutArgs q{};
         q.img = h->nw_img;
@@ -2564,7 +2461,7 @@ int ppo_collect_synthetic(ppo_handle* h, uint32_t seed, int32_t env0, uint32_t s
     }
     // 65..2048 environments: G = ceil(E / 32) resident workgroups, one per CU, meeting once per env step for the statistics
     const int coopG = (E + NW_ROWS - 1) / NW_ROWS;
-    const bool coop = !persistent && h->narrow && !h->comm && !no_fused && !no_persist && E > NW_RO_MAX_E && coopG <= NW_COOP_MAX_G && n.O <= 64 && n.A <= 64 &&
+    const bool coop = !persistent && h->narrow && !h->comm && !no_persist && E > NW_RO_MAX_E && coopG <= NW_COOP_MAX_G && n.O <= 64 && n.A <= 64 &&
                       ((size_t)h->nw.lds_total + NW_RO_EXTRA) * sizeof(float) <= 160 * 1024 &&
                       coopG * (2 * n.O + 3) <= h->nw.w_total - h->nw.w_fwd;             // the chunks of a step are staged in the image's unused backward half
     if (coop) {
@@ -2693,7 +2590,7 @@ int ppo_rollout_upload(ppo_handle* h, int field, const float* src, int64_t count
 }
 
 // ---- update -----------------------------------------------------------------------------------------------------------
-// every device buffer of a handle by name (ppo_debug_buffer; the diagnostic snapshot): pointer (null = this shape does not use it) and length in 4-byte words
+// every device buffer of a handle by name (ppo_debug_buffer): pointer (null = this shape does not use it) and length in 4-byte words
 struct DbgEnt { const char* name; const void* p; size_t words; };
 static std::vector<DbgEnt> debug_table(ppo_handle* h) {
     const NetDev& n = h->net;
@@ -2718,39 +2615,11 @@ static std::vector<DbgEnt> debug_table(ppo_handle* h) {
     };
 }
 
-// diagnostic snapshot (ppo_handle::snap_step): the arena is laid out -- and (re)allocated, which drops the update's graph -- outside any capture, from ppo_update
-static int snapshot_prepare(ppo_handle* h) {
-    std::vector<ppo_handle::SnapEnt> idx;
-    size_t total = 0;
-    for (const DbgEnt& e : debug_table(h)) {
-        if (!e.p || !e.words) continue;
-        idx.push_back({e.name, total, e.words});
-        total += (e.words + 63) / 64 * 64;
-    }
-    bool same = h->snap_arena && total == h->snap_words && idx.size() == h->snap_index.size();
-    for (size_t i = 0; same && i < idx.size(); ++i) same = idx[i].name == h->snap_index[i].name && idx[i].off == h->snap_index[i].off && idx[i].words == h->snap_index[i].words;
-    if (same) return 0;
-    HIP_OK(h, hipStreamSynchronize(h->stream));
-    drop_graph(h);
-    if (dev_alloc(h, &h->snap_arena, total)) return -1;
-    h->snap_words = total; h->snap_index = std::move(idx);
-    return 0;
-}
-static int enqueue_snapshot(ppo_handle* h) {
-    const std::vector<DbgEnt> tab = debug_table(h);
-    for (const ppo_handle::SnapEnt& s : h->snap_index)
-        for (const DbgEnt& e : tab)
-            if (s.name == e.name && e.p && e.words == s.words)
-                HIP_OK(h, hipMemcpyAsync(h->snap_arena + s.off, e.p, s.words * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    return 0;
-}
-
 static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perms) {
     const int B = h->E * h->T, M = B / nmb;
     // the per-tile arrival counters of weight_grad_assemble_kernel are reset by their last arriver; an update that was cut short
     // (a failed launch) must not leave them half-counted for the next one: zeroed here, a memset node of the replayed graph
-    { const char* nm = getenv("PPO_HIP_DW2_NO_MEMSET");           // (diagnostic, read when the update is captured: the counters are zero between launches anyway)
-      if (h->dw2 && !(nm && nm[0] == '1')) HIP_OK(h, hipMemsetAsync(h->dw2_counters, 0, DW2_TILES * sizeof(unsigned), h->stream)); }
+    if (h->dw2 && zero_words(h, h->dw2_counters, DW2_TILES)) return -1;
     h->nw_pending = false; h->nw_cur = 0;                      // outside an update the weights always live in set 0
     uint32_t bits = 1;
     while ((1u << bits) < (uint32_t)B) ++bits;
@@ -2778,9 +2647,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
                 HIP_OK(h, hipGetLastError());
             } else if (!h->comm) {
                 ea.phase = 0;
-                const char* em = getenv("PPO_HIP_NO_EPOCH_MERGE");       // (read when the update is captured: the test compares both forms)
-                const bool no_merge = em && em[0] == '1';
-                if (!h->bf.on && M <= EPG_MAX_M && !no_merge) {
+                if (!h->bf.on && M <= EPG_MAX_M) {
                     // index map, advantage statistics AND the gather of the epoch in one launch (fp32 paths; the bf16 path stages its epoch separately)
                     GatherArgs ga{h->d_gidx, h->d_advstats, B, M, h->net.O, h->net.A, h->ro_obs, h->ro_act, h->ro_ret, h->ro_val, h->ro_nlp,
                                   h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};
@@ -2811,8 +2678,7 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             GatherArgs ga{h->d_gidx, h->d_advstats, B, M, h->net.O, h->net.A, h->ro_obs, h->ro_act, h->ro_ret, h->ro_val, h->ro_nlp,
                           h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp};
             if (h->global_shuffle && h->comm && h->world > 1) { ga.obs = h->gs_obs; ga.act = h->gs_act; ga.ret = h->gs_ret; ga.val = h->gs_val; ga.nlp = h->gs_nlp; }
-            const char* ng = getenv("PPO_HIP_NO_GATHER4");         // (read when the update is captured: the test compares both forms)
-            const bool wide4 = h->net.O % 4 == 0 && h->net.A % 4 == 0 && !(ng && ng[0] == '1');
+            const bool wide4 = h->net.O % 4 == 0 && h->net.A % 4 == 0;
             // bf16 path: the epoch's observations become bf16 once; a minibatch is then a row slice.  With 16-byte rows the gather writes them itself
             const bool fuse_stage = wide4 && h->bf.on && M % GB_PAD == 0 && h->bf.xe_rows >= B && h->net.Kp0 % 4 == 0 && !(h->global_shuffle && h->comm && h->world > 1);
             if (wide4) {
@@ -2863,30 +2729,6 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             HIP_OK(h, hipGetLastError());
             continue;
         }
-        if (h->narrow && h->nw_lazy && h->nw_epoch && h->nw_epoch_dist && !h->comm && egroups > NW_EPOCH_MAX_G && egroups <= h->nw_groups_cap &&
-            2 * egroups <= std::min(NW_EPOCHD_MAX_WG, h->n_cu) && !(ne && ne[0] == '1')) {
-            // larger minibatches: the resident epoch with a distributed assembly (ppo_narrow.hpp, narrow_epoch_dist_kernel; one workgroup per row group and tower, all resident)
-            ProfScope ps(h, PK_TRAIN_FB);
-            const NetDev& n = h->net;
-            NwEpochDistArgs da{NwEpochArgs{h->mb_obs, h->mb_act, h->mb_adv, h->mb_ret, h->mb_val, h->mb_nlp, M, nmb, 1.0f / (float)M, h->nw_img, h->nw_partials, h->nw_stride,
-                                           h->theta, h->adam_m, h->adam_v, h->grad, h->hyper, h->beta_pow, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm,
-                                           h->d_loss_rows + (size_t)ep * nmb * 5, h->norm_out, h->nw_epochd_words, h->P_pad / 64, nullptr},
-                               h->grad_src, h->sumsq, reinterpret_cast<float*>(h->nw_epochd_words + NW_EPOCHD_MAX_WG + 64)};
-#ifdef PPO_STAMPS
-            if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
-            da.e.stamps = g_stamps;
-#endif
-            const size_t lds = (size_t)h->nw.lds_total * sizeof(float);
-            ++h->kv[KV_NARROW_EPOCH];
-            if (h->adam_exact) {
-                if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_dist_kernel<32, true>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
-                else hipLaunchKernelGGL((narrow_epoch_dist_kernel<64, true>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
-            }
-            else if (n.Kp0 == 32) hipLaunchKernelGGL((narrow_epoch_dist_kernel<32>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
-            else hipLaunchKernelGGL((narrow_epoch_dist_kernel<64>), dim3(egroups, 2), dim3(NW_THREADS), lds, h->stream, n, h->nw, da);
-            HIP_OK(h, hipGetLastError());
-            continue;
-        }
         for (int k = 0; k < nmb; ++k) {
             TrainArgs ta{};
             const size_t r0 = (size_t)k * M;
@@ -2894,7 +2736,6 @@ static int enqueue_update(ppo_handle* h, int epochs, int nmb, bool explicit_perm
             ta.old_neglogp = h->mb_nlp + r0; ta.advs = h->mb_adv + r0; ta.adv_stats = nullptr; ta.n = M;
             ta.inv_n = 1.0f / (float)((int64_t)M * h->world);
             if (enqueue_train(h, ta, h->d_loss_rows + (size_t)(ep * nmb + k) * 5, /*defer*/ true)) return -1;
-            if (h->snap_step == ep * nmb + k && h->snap_arena && enqueue_snapshot(h)) return -1;       // (diagnostic, off by default)
         }
     }
     if (flush_pending_adam(h)) return -1;
@@ -2948,7 +2789,6 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
             h->nw_epoch_cap = need;
         }
     }
-    if (h->snap_step >= 0 && snapshot_prepare(h)) return -1;
     if (set_hyper(h, lr, cliprange)) return -1;
     const bool explicit_perms = perms != nullptr;
     if (explicit_perms) {
@@ -3027,7 +2867,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
-    if (fab_check(h) || dw2_adam_check(h) || adam_meet_check(h) || bf16_chain_check(h) || nw_epoch_check(h)) return -1;
+    if (adam_meet_check(h) || bf16_chain_check(h) || nw_epoch_check(h)) return -1;
     return peer_check(h);
 }
 
@@ -3101,7 +2941,6 @@ int ppo_dist_init(ppo_handle* h, int32_t world, int32_t rank, const char uid[128
         }
         if (dt) (void)hipFree(dt);
         h->dev_shared = shared;
-        if (shared) h->fuse_ab = false;
     }
     // Collectives inside the update's hipGraph: with a communicator the eager sequence is 5-6 launches and up to three
     // collectives per train step issued from the host, which at narrow networks is slower than the GPU runs them.  Whether
@@ -3177,22 +3016,16 @@ int ppo_dist_peer_export(ppo_handle* h, char handle[64]) {
         P.cap = (size_t)ru(std::max(h->P_pad + 8, 4096), PEER_CHUNK_MAX);
         P.scap = ru(2 * h->net.O + 4, 64);                        // a rank's batch moments of an env step: (n, mean[O], M2[O]) + (n, mean, M2) of the returns
         const size_t bytes = kPeerFlagBytes + (size_t)2 * h->world * (P.cap + P.scap) * sizeof(float);
-        // memory kind of the region (other devices write into it): fine-grained = coherent at system scope with the kernels'
-        // fences, cached in L2; uncached = every access goes to memory (slowest, needs no fence to be seen); coarse = plain
-        // hipMalloc (fastest; coherent across devices only at kernel boundaries by the letter of the memory model)
-        const char* mk = getenv("PPO_HIP_PEER_MEM");
-        const int kind = !mk ? 0 : mk[0] == 'u' ? 1 : mk[0] == 'c' ? 2 : 0;
-        hipError_t e = hipErrorUnknown;
-        if (kind == 0) e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocFinegrained);
-        if (kind == 1 || (kind == 0 && e != hipSuccess)) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocUncached); }
+        // memory kind of the region (other devices write into it): fine-grained = coherent at system scope with the kernels' fences, cached in L2; failing that, uncached
+        // (every access goes to memory: slower, needs no fence to be seen).  Plain hipMalloc is NOT an option: a remote write may leave a stale line in this device's L2
+        // that even sc1 loads can hit -- then the region exists (so that the collective attach can still run and agree) but the peer path is refused.
+        hipError_t e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P.region, bytes, hipDeviceMallocUncached); }
         P.coarse = false;
         if (e != hipSuccess) {
-            // plain hipMalloc: a remote write may leave a stale line in this device's L2 that even sc1 loads can hit.  Only on
-            // explicit request (PPO_HIP_PEER_MEM=c, single-device experiments); otherwise the region exists (so that the
-            // collective attach can still run and agree) but the peer path is refused there.
             (void)hipGetLastError(); P.region = nullptr; HIP_OK(h, hipMalloc(&P.region, bytes));
-            P.coarse = true; P.coarse_requested = kind == 2;
-            if (kind != 2) fprintf(stderr, "libppo_hip: no fine-grained / uncached device memory for the peer region (rank %d): the peer all-reduce stays off, RCCL is used\n", h->rank);
+            P.coarse = true;
+            fprintf(stderr, "libppo_hip: no fine-grained / uncached device memory for the peer region (rank %d): the peer all-reduce stays off, RCCL is used\n", h->rank);
         }
         HIP_OK(h, hipMemset(P.region, 0, bytes));
         static_assert((PEER_SFLAG_OFF + 2 * 2 * PEER_MAX_WORLD * PEER_FLAG_STRIDE) * sizeof(unsigned) <= 4096, "statistics flags fit the flag block");
@@ -3282,7 +3115,7 @@ int ppo_dist_peer_attach(ppo_handle* h, const char* handles) {
     const char* en = getenv("PPO_HIP_PEER_REDUCE");
     const bool wanted = !(en && en[0] == '0');
     // the verdict must be COMMON: a rank that could not map a peer, or whose probe failed, takes everybody back to RCCL
-    bool ok = wanted && mapped && (!P.coarse || P.coarse_requested);
+    bool ok = wanted && mapped && !P.coarse;
     if (wanted) ok = peer_probe(h) && ok;
     // My slots go back to zero before I join the agreement below: the probe's patterns must not stay in elements that a later collective leaves
     // unwritten (the padding of the parameter vector, which weight_grad_assemble_kernel<.., PEER>'s tile pushes never touch and adam_kernel<.., 2>
@@ -3365,18 +3198,29 @@ int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_co
     ENTER_Q(h);
     HIP_OK(h, hipStreamSynchronize(h->stream));
     const void* p = nullptr; size_t words = 0; bool found = false;
-    if (!strncmp(name, "snap:", 5)) {
-        // the copy PPO_HIP_DEBUG_SNAPSHOT=<step> made right behind that train step of the last ppo_update (0 words: no snapshot, or the buffer is not used by this shape)
-        for (const DbgEnt& e : debug_table(h)) if (!strcmp(e.name, name + 5)) found = true;
-        for (const ppo_handle::SnapEnt& s : h->snap_index) if (s.name == name + 5) { p = h->snap_arena + s.off; words = s.words; }
-    } else {
-        for (const DbgEnt& e : debug_table(h)) if (!strcmp(e.name, name)) { found = true; p = e.p; words = e.words; }
-    }
+    for (const DbgEnt& e : debug_table(h)) if (!strcmp(e.name, name)) { found = true; p = e.p; words = e.words; }
     if (!found) return fail(h, "ppo_debug_buffer: no buffer named '%s'", name);
     if (!p || !words) { *count = 0; return 0; }               // this handle's shape does not use the buffer
     *count = (int64_t)words;
     const size_t c = std::min<size_t>(words, (size_t)std::max<int64_t>(max_count, 0));
     if (c) HIP_OK(h, hipMemcpy(dst, p, c * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// What the update's captured graph is made of: counts[0] kernel nodes, [1] memset nodes, [2] memcpy nodes, [3] anything else; returns -1 when no graph is held (eager
+// handles, or before the first ppo_update).  The rule since round 6 is "kernel nodes only" (zero_words above): tests/test_race_guards.py holds every shape to it.
+int ppo_debug_graph_nodes(ppo_handle* h, int32_t counts[4]) {
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    if (!h->upd_graph_tmpl) return -1;
+    size_t n = 0;
+    HIP_OK(h, hipGraphGetNodes(h->upd_graph_tmpl, nullptr, &n));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) HIP_OK(h, hipGraphGetNodes(h->upd_graph_tmpl, nodes.data(), &n));
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType ty;
+        HIP_OK(h, hipGraphNodeGetType(nodes[i], &ty));
+        ++counts[ty == hipGraphNodeTypeKernel ? 0 : ty == hipGraphNodeTypeMemset ? 1 : ty == hipGraphNodeTypeMemcpy ? 2 : 3];
+    }
     return 0;
 }
 

@@ -52,7 +52,6 @@ struct NwTrainArgs {
     float* partials;               // [2 towers][n_groups][part_stride]; a workgroup writes its tower's tensors + 8 tail floats
     int n_groups; int part_stride;
     unsigned long long* stamps;    // diagnostic builds only (-DPPO_STAMPS): [workgroups][32] cycle stamps
-    float* loss_compact;           // narrow_epoch_dist_kernel only (else null): the workgroup's loss sums ALSO as [5 quantities][128 row groups] (one coalesced load per quantity there)
 };
 #ifdef PPO_STAMPS
 #define NSTAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -274,7 +273,7 @@ __device__ __forceinline__ void nw_lazy_issue(const NetDev& net, const NwLazyArg
 // `red`: 4 floats of LDS scratch.  Ends with the image complete in LDS (caller synchronises).
 // RESIDENT (narrow_epoch_kernel): the moments and the weights stay in R from step to step (R.m / R.v / R.t receive the results), the pieces go back to
 // memory only when `write_back` says so (the epoch's last step), and the caller keeps the powers, the loss row and the norm.
-// EXACT (PPO_HIP_ADAM_EXACT=1): correctly rounded square root and division instead of the 1-ulp instructions -- a template parameter, not a run-time flag: with both
+// EXACT (the default since round 6; PPO_HIP_ADAM_FAST=1 selects the other instantiation): correctly rounded square root and division instead of the 1-ulp instructions -- a template parameter, not a run-time flag: with both
 // sequences in one kernel the default form lost 6 % (measured).
 template <int NP, bool RESIDENT = false, bool EXACT = false>
 __device__ __forceinline__ void nw_lazy_apply(const NetDev& net, const NwLayout& lay, const NwLazyArgs& z, int tower, int grp, int n_groups,
@@ -574,7 +573,6 @@ __device__ __forceinline__ void nw_train_body(const NetDev& net, const NwLayout&
         if (vec == L + 2 && lane < 4) {                               // pg, entropy, kl, clipfrac sums
             const float s4 = colsum(lay.misc, 4, lane);
             pst(out + (net.n_theta + lane), s4);
-            if (a.loss_compact) pst(a.loss_compact + (lane == 0 ? 0 : lane + 1) * 128 + grp, s4);
         }
     } else {
         if (vec == L && lane < HpL) {                                 // dW_v[k] = sum_rows h_L[row,k] * dv[row]
@@ -588,7 +586,6 @@ __device__ __forceinline__ void nw_train_body(const NetDev& net, const NwLayout&
 #pragma unroll
             for (int q = 0; q < NW_ROWS; ++q) s += PB[(q >> 4) * lay.pipe_total + lay.misc + 16 * lane + (q & 15)];
             pst(out + (lane == 0 ? net.bv_off : net.n_theta), s);
-            if (lane == 1 && a.loss_compact) pst(a.loss_compact + 128 + grp, s);
         }
     }
     NSTAMP(11);
@@ -923,230 +920,9 @@ __global__ __launch_bounds__(NW_THREADS) void narrow_epoch_kernel(NetDev net, Nw
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// The same resident epoch for LARGER minibatches (3 .. 64 row groups per tower: BASELINE configs[3]'s 2048-row minibatches are 64 groups x 2 towers = 128
-// workgroups, one per CU): reading every other workgroup's partial vector is out of the question (128 x 26 KB per workgroup and step), so the assembly is
-// DISTRIBUTED as narrow_reduce_kernel's is -- workgroup w adds up the 64-element chunks w, w + 2 G, ... over all row groups (that kernel's thread layout and
-// summation order: 4 lanes per element, each a quarter of the groups) and publishes the reduced elements and the chunk's sum of squares write-through -- and a step
-// has TWO meetings: partial vectors out | reduced gradient + sums of squares out.  Then every workgroup reads its tower's gradient (16-byte write-through loads)
-// and all chunk sums and applies clip + Adam to its LDS image as above.  Bit-identical to the launch per step; the workgroups span all XCDs, so everything
-// exchanged travels write-through.  What goes away per step: two launches, the deferred Adam's 160 KB prologue, the image reload.
-// OPT-IN (PPO_HIP_NARROW_EPOCH_DIST=1): at configs[3] (128 workgroups) a step is 22.2 us against 19.0 with the launches -- two meetings of 128 workgroups cost
-// 5.5 k + >= 4 k cycles even with one watcher and a GO word (10.8 k each with every workgroup polling the table), the chunk work 6.2 k (13 k in the workgroups
-// whose two chunks both belong to the policy tower, unexplained), gradient + sums 1.5 k, Adam 6 k: ~30 k cycles of overhead against the launch form's ~26 k
-// (profiles/r05_i_narrow_epoch_kernel.txt).
-// ------------------------------------------------------------------------------------------------------------------------
-#define NW_EPOCHD_MAX_WG 256
-struct NwEpochDistArgs {
-    NwEpochArgs e;               // (partials: ONE set [2 towers][G][part_stride]; words: [NW_EPOCHD_MAX_WG] counters + the error word behind them)
-    const GradSrc* src;          // narrow_reduce_kernel's table: which tower a 256-element block belongs to (kind 2: an alignment gap)
-    float* sumsq;                // [n_chunks] per-chunk sums of squares of the step
-    float* loss_compact;         // [5][128]: every row group's loss sums, compact (the partial vectors hold them 64 KB apart)
-};
-
-template <int KP0, bool EXACT = false>
-__global__ __launch_bounds__(NW_THREADS) void narrow_epoch_dist_kernel(NetDev net, NwLayout lay, NwEpochDistArgs d) {
-    constexpr int HP = 64, AP = 32, LL = 2, NP = NwLazyN<KP0>::N;
-    typedef NwShape<KP0, HP, AP, LL> S;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const NwEpochArgs& e = d.e;
-    const int G = (int)gridDim.x, nwg = 2 * G, tower = blockIdx.y, grp = blockIdx.x, wid = tower * G + grp;
-    const int tid0 = threadIdx.x;
-    const int row0 = grp * NW_ROWS;
-    const unsigned e0 = __hip_atomic_load(e.words + NW_EPOCHD_MAX_WG + 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // meetings completed by earlier launches (see narrow_epoch_kernel)
-    NwLazyRegs<NP> R;
-    R.b1p = e.beta_pow[2]; R.b2p = e.beta_pow[3]; R.lr = e.hyper[0];
-    int offs[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int off = offs[k] = nw_lazy_piece(net, tower, k, tid0).off;
-        R.g[k] = R.m[k] = R.v[k] = R.t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (off >= 0) { R.m[k] = *reinterpret_cast<const float4*>(e.m + off); R.v[k] = *reinterpret_cast<const float4*>(e.v + off); R.t[k] = *reinterpret_cast<const float4*>(e.theta + off); }
-    }
-    const float* v0 = tower == 0 ? e.advs : e.returns; const float* v1 = tower == 0 ? e.old_neglogp : e.old_values;
-    nw_stage<S>(net, lay, e.img + (size_t)tower * lay.w_total, lay.w_total, lds, e.obs, row0, e.M, ObsNorm{nullptr, nullptr, 0.f, 0.f, 0}, nullptr, tower,
-                e.actions, v0, v1, tower == 0 ? 1 : 2);
-    float* parts = lds + lay.w_total + lay.dy[0];            // [512] chunk sums of squares (over pipe 0's dY tile, dead between a step's last product and the next step)
-    float* red = lds + lay.w_total + lay.misc;               // 4 floats of pipe 0's loss scratch for nw_lazy_apply ...
-    float* red2 = lds + lay.w_total + lay.pipe_total + lay.misc;      // ... and pipe 1's: [2][4] for the two chunks a workgroup assembles at a time, [8..12] the loss sums
-    NwTrainArgs ta{};
-    ta.hyper = e.hyper; ta.n = e.M; ta.inv_n = e.inv_n; ta.n_groups = G; ta.part_stride = e.part_stride; ta.stamps = nullptr; ta.partials = e.partials;
-    ta.loss_compact = d.loss_compact;
-    NwLazyArgs z{};
-    z.n_parts = e.n_chunks; z.parts = parts; z.th_out = e.theta; z.m_out = e.m; z.v_out = e.v; z.beta1 = e.beta1; z.beta2 = e.beta2; z.eps = e.eps; z.max_norm = e.max_norm;
-    float norm = 0.f;
-    // meetings: a word per workgroup counts its arrivals; wave 0 watches all 2 G of them
-    // meetings: a word per workgroup counts its arrivals.  ONE workgroup (0) watches the 2 G words and raises a GO word on a line of its own, everybody else
-    // watches that: with every workgroup polling the table itself the lines the arrivals are stored to are hammered by 2 G pollers and the LAST arrival's store
-    // queues behind them (measured at 128 workgroups: 10.8 k cycles from the last arrival to the release; the stores now go to lines only one wave reads)
-    unsigned* go = e.words + NW_EPOCHD_MAX_WG + 32;
-    auto meet = [&](unsigned target, int tid, int lane) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores are complete
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(e.words + wid, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < 64) {
-            unsigned polls = 0;
-            if (wid == nwg - 1) {            // (a value-tower workgroup: that tower's matrix phases are 5 k cycles shorter)
-                for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int q = 0; q < NW_EPOCHD_MAX_WG / 64; ++q) {
-                        const int i = lane + 64 * q;
-                        if (i < nwg) ok = ok && (int)(__hip_atomic_load(e.words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
-                    }
-                    if (__all(ok)) break;
-                    if (++polls > (1u << 22)) { if (lane == 0) __hip_atomic_store(e.words + NW_EPOCHD_MAX_WG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-                if (lane == 0) __hip_atomic_store(go, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (lane == 0) {
-                while ((int)(__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++polls > (1u << 22)) { __hip_atomic_store(e.words + NW_EPOCHD_MAX_WG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-            }
-        }
-        __syncthreads();
-    };
-    for (int k = 0; k < e.nmb; ++k) {
-        int tid = tid0, lane = tid0 & 63;
-        asm volatile("" : "+v"(tid), "+v"(lane));             // (an opaque thread index per iteration: see narrow_epoch_kernel)
-        __syncthreads();
-        const bool last = k == e.nmb - 1;
-        constexpr int OVN = NW_ROWS * KP0 / NW_THREADS, AVN = NW_ROWS * AP / NW_THREADS;
-        float nxo[OVN], nxa[AVN], nx0 = 0.f, nx1 = 0.f;       // the next minibatch's rows wait in registers under this step
-        {
-            const size_t ro = (size_t)(k + 1) * e.M;
-#pragma unroll
-            for (int q = 0; q < OVN; ++q) {
-                const int i = tid + NW_THREADS * q, r = i / KP0, j = i - r * KP0, row = row0 + r;
-                nxo[q] = (!last && row < e.M && j < net.O) ? e.obs[(ro + row) * net.O + j] : 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < AVN; ++q) {
-                const int i = tid + NW_THREADS * q, r = i / AP, j = i - r * AP, row = row0 + r;
-                nxa[q] = (!last && tower == 0 && row < e.M && j < net.A) ? e.actions[(ro + row) * net.A + j] : 0.f;
-            }
-            if (!last && tid < NW_ROWS && row0 + tid < e.M) { nx0 = v0[ro + row0 + tid]; nx1 = v1[ro + row0 + tid]; }
-        }
-        ta.stamps = (k == e.nmb - 2) ? e.stamps : nullptr;
-        EPSTAMP(0);
-        nw_train_body<KP0, HP, AP, LL, true>(net, lay, ta, lds, tower, grp, tid);
-        EPSTAMP(16);
-        meet(e0 + 2u * (unsigned)k + 1u, tid, lane);
-        EPSTAMP(17);          // ---- every partial vector of the step is out ----------------------------------------------------
-        if (!last) {                                          // the next minibatch's rows: registers -> the tiles nw_stage fills
-#pragma unroll
-            for (int q = 0; q < OVN; ++q) {
-                const int i = tid + NW_THREADS * q, r = i / KP0, j = i - r * KP0;
-                lds[lay.w_total + (r >> 4) * lay.pipe_total + lay.x[0] + (r & 15) * lay.ldx[0] + j] = nxo[q];
-            }
-            if (tower == 0) {
-#pragma unroll
-                for (int q = 0; q < AVN; ++q) {
-                    const int i = tid + NW_THREADS * q, r = i / AP, j = i - r * AP;
-                    lds[lay.w_total + (r >> 4) * lay.pipe_total + lay.acts + (r & 15) * AP + j] = nxa[q];
-                }
-            }
-            if (tid < NW_ROWS) {
-                float* rv = lds + lay.w_total + (tid >> 4) * lay.pipe_total + lay.rowv;
-                rv[2 * (tid & 15)] = nx0; rv[2 * (tid & 15) + 1] = nx1;
-            }
-        }
-        // (the five loss sums {pg, vf, ent, kl, cf} over the row groups go to workgroups 0 .. 4, one each, requested first: each is 2 G four-byte loads from as many
-        // cache lines, and all five in ONE workgroup were 7 k cycles every other workgroup then waited for at the second meeting)
-        float tlv[NW_EPOCHD_MAX_WG / 2 / 32];
-        if (wid < 5 && tid < 32) {
-            const int q = wid, ln = tid;
-#pragma unroll
-            for (int j = 0; j < NW_EPOCHD_MAX_WG / 2 / 32; ++j) {
-                const int gi = ln + 32 * j;
-                tlv[j] = gi < G ? __hip_atomic_load(d.loss_compact + q * 128 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-            }
-        }
-        // ---- this workgroup's chunks: narrow_reduce_kernel's arithmetic, two chunks at a time (threads 0..255 | 256..511) -------------------------------------
-        {
-            const int half = uni(tid >> 8), t = tid & 255, el = t >> 2, sub = t & 3;
-            for (int c0 = wid; c0 < e.n_chunks; c0 += 2 * nwg) {
-                const int c = c0 + half * nwg;
-                const bool have = c < e.n_chunks;
-                const int idx = (have ? c : 0) * 64 + el;
-                float sum = 0.f;
-                if (have) {
-                    const GradSrc gs = d.src[idx >> 8];
-                    if (gs.kind != 2) {
-                        const float* p = e.partials + (size_t)gs.tower * G * e.part_stride + idx;
-                        const int per = (G + 3) / 4, g0 = sub * per, g1 = min(G, g0 + per);
-                        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                        int gi = g0;
-                        for (; gi + 4 <= g1; gi += 4) {
-                            const float a0 = __hip_atomic_load(p + (size_t)gi * e.part_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const float a1 = __hip_atomic_load(p + (size_t)(gi + 1) * e.part_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const float a2 = __hip_atomic_load(p + (size_t)(gi + 2) * e.part_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const float a3 = __hip_atomic_load(p + (size_t)(gi + 3) * e.part_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-                        }
-                        for (; gi < g1; ++gi) s0 += __hip_atomic_load(p + (size_t)gi * e.part_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sum = (s0 + s1) + (s2 + s3);
-                    }
-                }
-                sum += dpp_move<0xB1>(sum);                   // lane ^ 1, lane ^ 2: (x0 + x1) + (x2 + x3), identical in all four lanes
-                sum += dpp_move<0x4E>(sum);
-                if (have && sub == 0) __hip_atomic_store(e.grad + idx, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                float q = (sub == 0) ? sum * sum : 0.f;
-                q = wave_sum_lane0(q);
-                if ((t & 63) == 0) red2[4 * half + (t >> 6)] = q;
-                __syncthreads();
-                if (t == 0 && have) __hip_atomic_store(d.sumsq + c, (red2[4 * half] + red2[4 * half + 1]) + (red2[4 * half + 2] + red2[4 * half + 3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-            }
-        }
-        if (wid < 5 && tid < 64) {                            // narrow_reduce_kernel's tail: 32 lanes, each its groups in order, then the 32-lane tree
-            const int ln = tid;
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < NW_EPOCHD_MAX_WG / 2 / 32; ++j) if (ln < 32 && ln + 32 * j < G) s += tlv[j];
-            s = half_sum_lane0(s);
-            if (ln == 0) __hip_atomic_store(e.grad + net.n_theta + wid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        EPSTAMP(23);
-        meet(e0 + 2u * (unsigned)k + 2u, tid, lane);
-        float tailv = 0.f;
-        EPSTAMP(18);          // ---- the reduced gradient and every chunk's sum of squares are out --------------------------------
-        {
-            f32x4 g4[NP];
-#pragma unroll
-            for (int kk = 0; kk < NP; ++kk) g4[kk] = nb_ld4_sc1(e.grad + (offs[kk] >= 0 ? offs[kk] : 0));
-            const float pq = tid < e.n_chunks ? __hip_atomic_load(d.sumsq + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;      // (NW_THREADS = 512 >= n_chunks)
-            if (wid == 0 && tid < 5) tailv = __hip_atomic_load(e.grad + net.n_theta + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            parts[tid] = pq;
-            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0;
-            if constexpr (NP == 5) nb_wait8(g4[0], g4[1], g4[2], g4[3], g4[4], d0, d1, d2); else nb_wait8(g4[0], g4[1], g4[2], g4[3], g4[4], g4[5], d0, d1);
-#pragma unroll
-            for (int kk = 0; kk < NP; ++kk) R.g[kk] = offs[kk] >= 0 ? make_float4(g4[kk][0], g4[kk][1], g4[kk][2], g4[kk][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-        R.part = (tid < 256 && tid < e.n_chunks) ? parts[tid] : 0.f;
-        EPSTAMP(24);
-        nw_lazy_apply<NP, true, EXACT>(net, lay, z, tower, grp, G, R, lds, red, nullptr, last, &norm, tid);
-        EPSTAMP(19);
-        if (wid == 0 && tid < 5) e.loss_rows[(size_t)k * 5 + tid] = tailv / (float)e.M * ((tid == 1 || tid == 3) ? 0.5f : 1.0f);       // (vf_loss, approxkl carry the 0.5)
-        if (!last) { R.b1p = R.b1p * e.beta1; R.b2p = R.b2p * e.beta2; }
-    }
-    __syncthreads();
-    const int tid = tid0;
-    if (grp == 0) {
-        float* img = e.img + (size_t)tower * lay.w_total;
-        for (int i = tid; i < lay.w_total / 4; i += NW_THREADS) reinterpret_cast<float4*>(img)[i] = reinterpret_cast<const float4*>(lds)[i];
-    }
-    if (wid == 0 && tid == 0) {
-        __hip_atomic_store(e.words + NW_EPOCHD_MAX_WG + 48, e0 + 2u * (unsigned)e.nmb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        e.beta_pow[0] = R.b1p; e.beta_pow[1] = R.b2p;
-        e.beta_pow[2] = R.b1p * e.beta1; e.beta_pow[3] = R.b2p * e.beta2;
-        if (e.norm_out) *e.norm_out = norm;
-        e.grad[net.n_theta + 5] = (float)e.M;
-    }
-}
-
+// (Round 5 also had this resident epoch for LARGER minibatches -- narrow_epoch_dist_kernel, the assembly dealt over up to 128 workgroups with two meetings per
+// minibatch -- opt-in and measured slower than the launches at configs[3]: 22.2 vs 19.0 us per step, profiles/r05_i_narrow_epoch_kernel.txt.  Removed in round 6;
+// branch experiments-r05.)
 // ------------------------------------------------------------------------------------------------------------------------
 // Act model for narrow nets: the same forward on 32 rows per workgroup and tower, weights from the packed image.
 // `img` rides in StepArgs::theta (the narrow launch passes the image instead of the padded parameter vector).

@@ -38,10 +38,6 @@ struct T8L {
 #ifndef T8_W1T
 #define T8_W1T 0                  // where the backward product's first two W1^T stages are requested: 0 before the K-halves' exchange, 1 after it, 2 one after it + one behind the epilogue's barrier
 #endif
-#ifndef FAB_WT
-#define FAB_WT 1                  // 0 (with T8_WT 0): TIMING EXPERIMENT ONLY -- the fused launch's phase A stores plainly (write-back), so that phase B finds the lines in
-                                  // the writing XCD's L2; cross-XCD readers (the slot jobs) then see stale data: results are wrong
-#endif
 #ifndef T8_WT
 #define T8_WT 1                   // workspace stores write-through (sc1): drain while the kernel computes instead of at its end
 #endif
@@ -133,11 +129,10 @@ __device__ __forceinline__ void t8_exchange(const f32x4 (&acc)[4], float* xch, i
         for (int i = 0; i < 2; ++i) out[j][i] = kh ? th[i][j] + acc[j][keep + i] : acc[j][keep + i] + th[i][j];
 }
 
-// The kernel's body.  FUSED: called as the first phase of train8_dw2_fused_kernel (ppo_fused_ab.hpp), whose second phase reads the workspaces
-// AND the per-row-block slots in the same launch: every global store is then write-through (sc1), so that a reader on any XCD finds it at the
-// memory side once the storing wave has drained (the standalone kernel leaves the small outputs -- x0g, dmug, slots -- to the kernel boundary).
-// bx / by / gx: the standalone launch's block index (x, y) and grid width.
-template <int KP0, int AP, bool FUSED>
+// The kernel's body.  The big workspaces leave write-through (T8_WT: they drain while the kernel computes); the small outputs -- x0g, dmug, slots -- are plain
+// stores left to the kernel boundary.  (Round 5 also called this body as the first phase of a fused train + weight-gradient launch; measured slower twice and removed
+// in round 6: profiles/r05_a_*, branch experiments-r05.)  bx / by / gx: the launch's block index (x, y) and grid width.
+template <int KP0, int AP>
 __device__ __forceinline__ void train8_body(const NetDev& net, const TrainArgs& a, float* lds, const unsigned bx, const unsigned by, const unsigned gx) {
     typedef T8L<KP0, AP> L8;
     constexpr int KS0 = KP0 / 16, KSA = AP / 16;       // k-steps of 16 in the first layer / in the head's backward product
@@ -209,7 +204,7 @@ __device__ __forceinline__ void train8_body(const NetDev& net, const TrainArgs& 
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
         lds[L8::X0 + er * L8::LD0 + ej + 32 * q] = ov[q];
-        if (tower == 0) st_wt<FUSED && FAB_WT != 0>(a.x0g + (size_t)(row0 + er) * KP0 + ej + 32 * q, ov[q]);         // rows >= n and padding columns: zeros
+        if (tower == 0) st_wt<false>(a.x0g + (size_t)(row0 + er) * KP0 + ej + 32 * q, ov[q]);         // rows >= n and padding columns: zeros
     }
     if (tower == 0) {
 #pragma unroll
@@ -279,7 +274,7 @@ __device__ __forceinline__ void train8_body(const NetDev& net, const TrainArgs& 
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = (row0 + row < a.n) ? fast_tanh(out[j][i] + bb[j]) : 0.f;
             *reinterpret_cast<float4*>(lds + L8::H2 + row * T8_LD + col) = make_float4(y[0], y[1], y[2], y[3]);
-            if (tower == 0) st_wt4<T8_WT != 0 || (FUSED && FAB_WT != 0)>(a.hg[0][1] + (size_t)(row0 + row) * 256 + col, make_float4(y[0], y[1], y[2], y[3]));   // (the value head's weight gradient is formed here: nobody reads a copy of its input)
+            if (tower == 0) st_wt4<T8_WT != 0>(a.hg[0][1] + (size_t)(row0 + row) * 256 + col, make_float4(y[0], y[1], y[2], y[3]));   // (the value head's weight gradient is formed here: nobody reads a copy of its input)
         }
     }
     lds_barrier();
@@ -362,20 +357,20 @@ __device__ __forceinline__ void train8_body(const NetDev& net, const TrainArgs& 
             }
             lds[L8::MU + er * L8::LDM + ej + 32 * q] = dmu;                            // the d mu tile: A operand of the head's backward product
             lds[L8::DLS + er * AP + ej + 32 * q] = dl;
-            st_wt<FUSED && FAB_WT != 0>(a.dmug + (size_t)(row0 + er) * AP + ej + 32 * q, dmu);                      // dead rows / padding columns: zeros
+            st_wt<false>(a.dmug + (size_t)(row0 + er) * AP + ej + 32 * q, dmu);                      // dead rows / padding columns: zeros
         }
         lds_barrier();
         if (tid < AP) {
             float sb = 0.f, sl = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) { sb += lds[L8::MU + q * L8::LDM + tid]; sl += lds[L8::DLS + q * AP + tid]; }
-            st_wt<FUSED && FAB_WT != 0>(slot + net.slot_head + tid, sb);
-            st_wt<FUSED && FAB_WT != 0>(slot + net.slot_aux + tid, sl);
+            st_wt<false>(slot + net.slot_head + tid, sb);
+            st_wt<false>(slot + net.slot_aux + tid, sl);
         } else if (tid < AP + 4) {
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) s += misc[q * 4 + (tid - AP)];
-            st_wt<FUSED && FAB_WT != 0>(slot + net.slot_loss + (tid - AP), s);
+            st_wt<false>(slot + net.slot_loss + (tid - AP), s);
         }
         STAMP(7);
         // ---- dY1 = (d mu W_mu^T) .* (1 - h2^2), 32 columns per wave -----------------------------------------------------------------
@@ -420,8 +415,8 @@ __device__ __forceinline__ void train8_body(const NetDev& net, const TrainArgs& 
             float sb = 0.f, sl = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) { sb += misc[q]; sl += misc[16 + q]; }
-            st_wt<FUSED && FAB_WT != 0>(slot + net.slot_aux, sb);            // db_v
-            st_wt<FUSED && FAB_WT != 0>(slot + net.slot_loss, sl);           // sum of max((v-R)^2, (vclip-R)^2)
+            st_wt<false>(slot + net.slot_aux, sb);            // db_v
+            st_wt<false>(slot + net.slot_loss, sl);           // sum of max((v-R)^2, (vclip-R)^2)
         }
         // dW_v[k] = sum_rows h2[row,k] dv[row] ; dY1 = dv (x) w_v .* (1 - h2^2): thread (k = tid & 255, rows 8 (tid >> 8) .. + 7)
         {
@@ -431,14 +426,14 @@ __device__ __forceinline__ void train8_body(const NetDev& net, const TrainArgs& 
                 float sw = 0.f;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sw = fmaf(h2[q * T8_LD + k], misc[q], sw);
-                st_wt<FUSED && FAB_WT != 0>(slot + net.slot_head + k, sw);
+                st_wt<false>(slot + net.slot_head + k, sw);
             }
 #pragma unroll
             for (int q = q0; q < q0 + 8; ++q) {
                 const float h = h2[q * T8_LD + k];
                 const float d = (misc[q] * w) * (1.0f - h * h);
                 d2[q * T8_LD + k] = d;
-                st_wt<T8_WT != 0 || (FUSED && FAB_WT != 0)>(a.dyg[1][1] + (size_t)(row0 + q) * 256 + k, d);             // dead rows: d == 0
+                st_wt<T8_WT != 0>(a.dyg[1][1] + (size_t)(row0 + q) * 256 + k, d);             // dead rows: d == 0
             }
         }
     }
@@ -459,7 +454,7 @@ __device__ __forceinline__ void train8_body(const NetDev& net, const TrainArgs& 
             const float4 hh = *reinterpret_cast<const float4*>(lds + L8::H1 + row * T8_LD + col);
             const float4 y = make_float4(out[0][i] * (1.0f - hh.x * hh.x), out[1][i] * (1.0f - hh.y * hh.y), out[2][i] * (1.0f - hh.z * hh.z), out[3][i] * (1.0f - hh.w * hh.w));
             *reinterpret_cast<float4*>(lds + L8::D1 + row * T8_LD + col) = y;
-            st_wt4<T8_WT != 0 || (FUSED && FAB_WT != 0)>(a.dyg[tower][0] + (size_t)(row0 + row) * 256 + col, y);
+            st_wt4<T8_WT != 0>(a.dyg[tower][0] + (size_t)(row0 + row) * 256 + col, y);
         }
     }
     lds_barrier();
@@ -471,7 +466,7 @@ __device__ __forceinline__ void train8_body(const NetDev& net, const TrainArgs& 
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += src[q * T8_LD + k];
-        st_wt<FUSED && FAB_WT != 0>(slot + net.slot_db[tid < 256 ? 1 : 0] + k, s);
+        st_wt<false>(slot + net.slot_db[tid < 256 ? 1 : 0] + k, s);
     }
     STAMP(10);
 }
@@ -480,5 +475,5 @@ template <int KP0, int AP>
 __global__ __launch_bounds__(T8_THREADS) void train8_kernel(NetDev net, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     warm_kernargs<sizeof(NetDev) + sizeof(TrainArgs)>();
-    train8_body<KP0, AP, false>(net, a, lds, blockIdx.x, blockIdx.y, gridDim.x);
+    train8_body<KP0, AP>(net, a, lds, blockIdx.x, blockIdx.y, gridDim.x);
 }

@@ -38,9 +38,12 @@ def main():
                     raise RuntimeError("no IPC handle from rank %d" % r)
                 time.sleep(0.01)
             handles.append(open(fn, "rb").read())
-        if not g.dist_peer_attach(handles):
-            raise RuntimeError("peer all-reduce probe failed (rank %d)" % rank)
-        assert g.dist_graph_collectives()
+        if os.environ.get("PPO_HIP_PEER_REDUCE") == "0":                    # the switch: regions exported and attached, the exchange stays on the collective library
+            assert not g.dist_peer_attach(handles) and not g.dist_peer_active()
+        else:
+            if not g.dist_peer_attach(handles):
+                raise RuntimeError("peer all-reduce probe failed (rank %d)" % rank)
+            assert g.dist_graph_collectives()
     g.norm_init(El, float(d["gamma"]))
     g.rollout_alloc(El, T)
     if os.environ.get("PPO_TEST_DRILL") == "1" and rank == world - 1:

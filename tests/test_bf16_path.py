@@ -76,11 +76,13 @@ def test_bf16_step_and_train_step_against_fp32_oracle(hidden, O, A, n):
     np.testing.assert_allclose(g.beta_powers(), orc.pow, rtol=1e-6)
 
 
-def test_bf16_matches_the_fp32_hip_path_over_an_update():
+@pytest.mark.parametrize("E,T,nmb", [(64, 8, 4), (100, 10, 5)])
+def test_bf16_matches_the_fp32_hip_path_over_an_update(E, T, nmb):
     """Same rollout inputs, same permutations: loss rows of the bf16 path track the library's exact-fp32 path within 1e-2
-    (relative on vf_loss / entropy, absolute on the near-zero terms) over 2 epochs x 4 minibatches at 256/64/[1024]^3."""
+    (relative on vf_loss / entropy, absolute on the near-zero terms) over 2 epochs at 256/64/[1024]^3: 128-row minibatches (the epoch's observations
+    are written once, as bf16 operand rows, by epoch_gather4_kernel) and 200-row ones (not a multiple of the GEMM's row padding: every minibatch is staged by itself)."""
     import ppo_cpp_amd
-    hidden, O, A, E, T, nmb, epochs = (1024, 1024, 1024), 256, 64, 64, 8, 4, 2
+    hidden, O, A, epochs = (1024, 1024, 1024), 256, 64, 2
     orc, gb = pair_bf16(hidden, O, A)
     gf = ppo_cpp_amd.PPOHip(O, A, list(hidden)); gf.set_flat(orc.theta)
     rng = np.random.RandomState(9)
@@ -236,30 +238,3 @@ def test_bf16_train_steps_of_changing_row_counts_on_one_handle():
             if np.linalg.norm(rt) > 1e-3 * ref_norm:
                 assert cosine(gt, rt) > 0.995, (name, it, n, cosine(gt, rt))
     g.close()
-
-
-@pytest.mark.parametrize("hidden,O,A,E,T,nmb,explicit", [((1024, 1024, 1024), 256, 64, 256, 16, 4, True), ((512, 512), 64, 20, 64, 16, 2, False), ((1024, 1024, 1024), 256, 64, 100, 10, 5, False)])
-def test_vectorised_epoch_gather_with_bf16_rows_is_bitwise_the_gather_plus_staging(hidden, O, A, E, T, nmb, explicit, monkeypatch):
-    """bf16 path, observation / action widths that are multiples of 4: epoch_gather4_kernel moves 16 bytes per access and writes the epoch's observations ONCE, as the
-    bf16 operand rows (no fp32 copy of the epoch, no staging launch); PPO_HIP_NO_GATHER4=1 keeps epoch_gather_kernel + bf16_stage4_kernel.  Same values either way:
-    loss rows, weights and moments of two two-epoch updates must be the same BITS -- 1024-row minibatches (staged epoch), 512-row ones on a smaller net, and
-    200-row minibatches (not a multiple of the GEMM's row padding: the epoch is not staged, the vectorised gather still runs)."""
-    rng = np.random.RandomState(3)
-    noise = rng.normal(size=(T, E, A)).astype(np.float32)
-    perms = [np.stack([rng.permutation(E * T) for _ in range(2)]).astype(np.int32) if explicit else None for _ in range(2)]
-    outs = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("PPO_HIP_NO_GATHER4", mode)
-        orc, g = pair_bf16(hidden, O, A)
-        g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
-        g.collect_synthetic(1234, GAMMA, LAM, noise)
-        acc = []
-        for u in range(2):
-            rows, mean = g.update(LR, CR, 2, nmb, perms[u], seed=4 + u)
-            acc += [rows.copy(), g.get_flat(0), g.get_flat(1), g.get_flat(2)]
-        outs.append(acc)
-        g.close()
-    monkeypatch.delenv("PPO_HIP_NO_GATHER4", raising=False)
-    assert np.isfinite(outs[0][0]).all()
-    for a, b in zip(*outs):
-        np.testing.assert_array_equal(a, b)

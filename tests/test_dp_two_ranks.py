@@ -65,6 +65,20 @@ def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, world,
     peer = True: every collective goes through the one-shot peer all-reduce (ppo_peer.hpp) -- the processes map each
     other's gather region over hipIpc (same mechanism as the GPUs of a node; here all regions live on the one test GPU) and
     the whole update, collectives included, replays from the hipGraph."""
+    _union_against_the_oracle(tmp_path, world, hidden, E, T, nmb, epochs, peer)
+
+
+# every data-parallel run-time switch of the library (INTEGRATION.md, "Run-time switches") against the ORACLE over the union, not only against its sibling form
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,E,T,nmb", [((256, 256), 64, 8, 4), ((64, 64), 16, 16, 4)])
+@pytest.mark.parametrize("peer,switch", [(True, "PPO_HIP_NO_ADAM_MEET=1"), (True, "PPO_HIP_NO_PEER_TILES=1"), (True, "PPO_HIP_PEER_STATS=0"), (True, "PPO_HIP_PEER_TIMEOUT_MS=20000"),
+                                         (True, "PPO_HIP_PEER_REDUCE=0"), (False, "PPO_HIP_GRAPH_RCCL=1"), (False, "PPO_HIP_GRAPH_RCCL=0")])
+def test_data_parallel_switches_against_the_oracle(tmp_path, hidden, E, T, nmb, peer, switch):
+    k, v = switch.split("=")
+    _union_against_the_oracle(tmp_path, 2, hidden, E, T, nmb, 1, peer, {k: v})
+
+
+def _union_against_the_oracle(tmp_path, world, hidden, E, T, nmb, epochs, peer, extra_env=None):
     tmp = str(tmp_path)
     fake = build_fake_rccl(tmp)
     orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(11)
@@ -88,6 +102,7 @@ def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, world,
     np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
              noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
     env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="1" if peer else "0")
+    env.update(extra_env or {})
     outs = run_workers(tmp, world, fin, env)
     for out in outs:                                                           # the communicator itself reports `world` ranks
         assert int(out["comm_nranks"]) == world

@@ -26,6 +26,22 @@ def test_host_utilities():
                                                        # env/hexapod_closed_loop_env.hpp:20,61-72), with ONE environment like its shipped command line and with 8
                                                        ((64, 64), 1, 64, 4, 2, 36, 18), ((256, 256), 8, 16, 4, 2, 36, 18)])
 def test_learn_matches_the_oracle_update_by_update(hidden, E, T, nmb, epochs, O, A, reference_loop):
+    _learn_against_the_oracle(hidden, E, T, nmb, epochs, O, A, reference_loop)
+
+
+# every host-Env run-time switch of the library ("Run-time switches") against the ORACLE, on a shape that reaches the form it replaces:
+# <= 32 environments of the narrow net (resident / fused host kernels), ONE environment (the transition also through the BAR; a resident kernel that parks itself
+# after 50 polls), a net wider than 64 (the policy kernel publishing the actions itself: off, and forced up to 16 blocks of 16 rows)
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch,hidden,E,T", [("PPO_HIP_NO_HOST_RESIDENT=1", (64, 64), 8, 32), ("PPO_HIP_NO_HOST_FUSED=1", (64, 64), 8, 32), ("PPO_HIP_NO_VRAM_INBOX=1", (64, 64), 1, 64),
+                                               ("PPO_HIP_HOST_POLLS=50", (64, 64), 1, 64), ("PPO_HIP_NO_DIRECT_ACT=1", (256, 256), 8, 16), ("PPO_HIP_DIRECT_ACT_MAX_BLOCKS=16", (256, 256), 128, 4)])
+def test_host_env_switches_against_the_oracle(switch, hidden, E, T, monkeypatch):
+    k, v = switch.split("=")
+    monkeypatch.setenv(k, v)
+    _learn_against_the_oracle(hidden, E, T, 4, 2, 18, 18, False)
+
+
+def _learn_against_the_oracle(hidden, E, T, nmb, epochs, O, A, reference_loop):
     """PPO2::learn end to end against the oracle (reference ppo2/ppo2.hpp:264-349 driving ppo2/runner.hpp:56-191): SeededEnvMock x 8
     behind VecEnv + EnvNormalize, two updates with EXPLICIT exploration noise and epoch permutations, through the HBM-resident
     loop and through the literal reference loop (Runner::run, host-side row permutation and slicing, _train_step per minibatch).

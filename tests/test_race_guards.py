@@ -197,3 +197,51 @@ def test_actions_published_by_the_policy_kernel_are_the_rollout_rows(monkeypatch
     for a, b in zip(outs["direct"], outs["copy"]):
         for f in a:
             np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+
+
+_GRAPH_SHAPES = [((64, 64), 18, 18, 1, 512, 8, False), ((64, 64), 18, 18, 64, 64, 4, False), ((256, 256), 18, 18, 64, 16, 4, False), ((256, 256), 36, 18, 512, 16, 4, False),
+                 ((512, 256, 256), 18, 18, 32, 16, 4, False), ((1024, 1024, 1024), 256, 64, 256, 16, 4, True)]
+
+
+@pytest.mark.parametrize("hidden,O,A,E,T,nmb,bf16", _GRAPH_SHAPES)
+def test_update_graph_holds_kernel_nodes_only(hidden, O, A, E, T, nmb, bf16):
+    """The rule behind round 6's finding (ppo_hip.hip, zero_words): the launch sequence ppo_update captures and replays holds KERNEL nodes only.  A hipMemsetAsync node at its
+    head (weight_grad_assemble_kernel's arrival counters) replayed out of order on ROCm 7.0.2 in a long-lived process and left every [256,256] update wrong by 1e-2 from then
+    on; memset / memcpy nodes are therefore not allowed in the graph at all.  Every kernel family's update (resident epoch kernel, narrow launches, the [256,256] pair, the
+    round-2 kernels behind three hidden layers, the bf16 path) with the on-device shuffle and with explicit permutations."""
+    g = ppo_cpp_amd.PPOHip(O, A, list(hidden), compute_dtype=1 if bf16 else 0)
+    g.init_orthogonal(0); g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+    g.collect_synthetic(7, GAMMA, LAM, None, env0=0, step0=0, first=True)
+    for explicit in (False, True):
+        perms = np.stack([np.random.RandomState(e).permutation(E * T).astype(np.int32) for e in range(2)]) if explicit else None
+        g.update(LR, CR, 2, nmb, perms, seed=1, want_rows=False)
+        nodes = g.debug_graph_nodes()
+        assert nodes is not None and nodes["kernel"] >= 2 * nmb // 8 + 1, nodes
+        assert nodes["memset"] == 0 and nodes["memcpy"] == 0 and nodes["other"] == 0, "the update's graph must hold kernel nodes only: %s" % nodes
+    g.close()
+
+
+@pytest.mark.parametrize("hidden,O,A,E,T,nmb,bf16", _GRAPH_SHAPES)
+def test_results_do_not_depend_on_what_the_lds_held(hidden, O, A, E, T, nmb, bf16):
+    """Every kernel must write the LDS it reads: two collect + update iterations with a NaN pattern left in every LDS word of every CU in front of each call
+    (ppo_debug_poison_lds) against the same run without -- same bits.  (A workgroup that reads LDS it never wrote sees what the previous workgroup on its CU left there: a
+    result that depends on which kernels ran before, which is what round 5's open finding looked like before its cause was known.)"""
+    outs = []
+    for poison in (False, True):
+        g = ppo_cpp_amd.PPOHip(O, A, list(hidden), compute_dtype=1 if bf16 else 0)
+        g.init_orthogonal(0); g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+        acc = []
+        for it in range(2):
+            if poison:
+                g.debug_poison_lds()
+            g.collect_synthetic(7, GAMMA, LAM, None, env0=0, step0=it * T, first=(it == 0))
+            acc += [g.rollout_get(f) for f in ("actions", "values", "neglogp", "returns")]
+            if poison:
+                g.debug_poison_lds()
+            rows, mean = g.update(LR, CR, 2, nmb, None, seed=3 + it)
+            acc += [rows.copy(), g.get_flat(0), g.get_flat(1), g.get_flat(2)]
+        assert np.isfinite(acc[-3]).all()
+        outs.append(acc)
+        g.close()
+    for k, (a, b) in enumerate(zip(*outs)):
+        np.testing.assert_array_equal(a, b, err_msg="output %d differs once the LDS holds NaNs in front of every call" % k)

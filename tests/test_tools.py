@@ -22,3 +22,24 @@ def test_tools_named_in_the_documents_exist():
     text = open(os.path.join(ROOT, "DESIGN.md")).read() + open(os.path.join(ROOT, "tools", "README.md")).read()
     for name in set(re.findall(r"tools/([A-Za-z0-9_]+\.(?:py|sh))", text)):
         assert os.path.exists(os.path.join(ROOT, "tools", name)), name
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_first_multi_device_command_dry_run_on_one_gpu(tmp_path):
+    """tools/first_8gpu.sh, the ONE command for the first run on more than one device, as a dry run on the one test GPU (--stand-in: every rank on device 0, the
+    shared-memory stand-in behind the nccl* calls; --quick: cfg4 only, 2 steps): both exchange paths at world 4, the curve's bench lines, `ppo_cpp_hip --ranks 4`, and
+    the one JSON it writes -- so that the day a node exists the command is known to run."""
+    import json
+    from tests.test_dp_two_ranks import build_fake_rccl
+    fake = build_fake_rccl(str(tmp_path))
+    out = os.path.join(str(tmp_path), "first.json")
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "first_8gpu.sh"), "--out", out, "--max-gpus", "4", "--quick", "--stand-in", fake],
+                       capture_output=True, text=True, timeout=1500)
+    rep = json.load(open(out))
+    assert p.returncode == 0, json.dumps([{k: s[k] for k in ("what", "rc", "stderr_tail")} for s in rep["steps"] if s["rc"] != 0])[:3000]
+    assert rep["rccl_nranks"] == 4 and rep["distinct_devices"] == 1 and rep["replicas_bit_identical"] is True and rep["cpp_driver_replicas_byte_identical"] is True
+    assert rep["peer_path_used"] is True
+    assert set(rep["values"]["cfg4/rccl"]) == {"2", "4"} and set(rep["values"]["cfg4/single"]) == {"1"} and all(v > 0 for v in rep["values"]["cfg4/auto"].values())
