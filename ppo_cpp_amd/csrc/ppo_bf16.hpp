@@ -100,22 +100,24 @@ __device__ __forceinline__ bf16x8 gt_frag(const char* sub, int f0, int ks) {
 // BT: the B operand is stored [K][J] (reduction index = row, e.g. a weight matrix as it lies): its 16 pieces are 4 k-rows x 256 B
 // of a [64][128] image read back with transposed reads (gt_frag) instead of [128][64] rows read with ds_read_b128.
 template <int WM, bool BT = false>
-__device__ __forceinline__ void gb_stage(const bf16_t* __restrict__ A, int lda, int i0, const bf16_t* __restrict__ B, int ldb, int j0, int k0, char* st) {
+__device__ __forceinline__ void gb_stage_piece(const bf16_t* __restrict__ A, int lda, int i0, const bf16_t* __restrict__ B, int ldb, int j0, int k0, char* st, const int q) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int PA = GB_BM(WM) / 8;
+    const int piece = wave + 2 * WM * q;                     // wave-uniform
+    const bool isA = piece < PA;
+    const int r = (isA ? piece : piece - PA) * 8 + (lane >> 3), c = lane & 7;
+    const int rt = 4 * (piece - PA) + (lane >> 4), cht = (lane & 15) ^ gt_swz(rt);
+    const bf16_t* src = isA ? A + (size_t)(i0 + r) * lda + k0 + gb_swz(r, c) * 8
+                      : BT  ? B + (size_t)(k0 + rt) * ldb + j0 + 8 * cht
+                            : B + (size_t)(j0 + r) * ldb + k0 + gb_swz(r, c) * 8;
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(st + piece * 1024), 16, 0, 0);
+}
+template <int WM, bool BT = false>
+__device__ __forceinline__ void gb_stage(const bf16_t* __restrict__ A, int lda, int i0, const bf16_t* __restrict__ B, int ldb, int j0, int k0, char* st) {
 #pragma unroll
-    for (int q = 0; q < GB_PIECES(WM); ++q) {
-        const int piece = wave + 2 * WM * q;                 // wave-uniform
-        const bool isA = piece < PA;
-        const int r = (isA ? piece : piece - PA) * 8 + (lane >> 3), c = lane & 7;
-        const int rt = 4 * (piece - PA) + (lane >> 4), cht = (lane & 15) ^ gt_swz(rt);
-        const bf16_t* src = isA ? A + (size_t)(i0 + r) * lda + k0 + gb_swz(r, c) * 8
-                          : BT  ? B + (size_t)(k0 + rt) * ldb + j0 + 8 * cht
-                                : B + (size_t)(j0 + r) * ldb + k0 + gb_swz(r, c) * 8;
-        typedef const __attribute__((address_space(1))) void* gptr;
-        typedef __attribute__((address_space(3))) void* lptr;
-        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(st + piece * 1024), 16, 0, 0);
-    }
+    for (int q = 0; q < GB_PIECES(WM); ++q) gb_stage_piece<WM, BT>(A, lda, i0, B, ldb, j0, k0, st, q);
 }
 
 // fragment of MFMA k-step ks (0/1) for the 16 rows starting at r0: lane (r = lane & 15, g = lane >> 4) holds
@@ -187,11 +189,10 @@ __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restri
         else gb_wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-#ifndef GB_NOLOAD
-        if (t + 2 < nt) {
-            int nb = cur + 2; if (nb >= GB_STAGES) nb -= GB_STAGES;
-            gb_stage<WM, BT>(A, lda, i0, B, ldb, j0, kbeg + (t + 2) * GB_K, lds + nb * SB);
-        }
+        int nb = cur + 2; if (nb >= GB_STAGES) nb -= GB_STAGES;
+        const bool more = t + 2 < nt;
+#if !defined(GB_NOLOAD) && !defined(GB_DMA_INTERLEAVE)
+        if (more) gb_stage<WM, BT>(A, lda, i0, B, ldb, j0, kbeg + (t + 2) * GB_K, lds + nb * SB);
 #endif
         if constexpr (IMG) {
             if (t == (nt > 1 ? nt - 2 : 0)) gb_stage_image<WM, GB_IMG_P1(WM)>(H, ldh, i0, j0, lds, 0);                                   // buffer 0 is free
@@ -212,13 +213,23 @@ __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restri
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a) {
 #pragma unroll
 #ifndef GB_NOMFMA
                 for (int b = 0; b < 4; ++b) acc.v[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][b], af[ks][a], acc.v[a][b], 0, 0, 0);
 #else
                 for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(af[ks][a]), "v"(bfr[ks][b]));
 #endif
+#ifdef GB_DMA_INTERLEAVE
+                // EXPERIMENT (round 6): stage t+2's requests from INSIDE the matrix block, one 1-KB piece behind every four matrix instructions,
+                // instead of all NP at the stage's head beside the fragment reads
+                if (4 * ks + a < NP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) gb_stage_piece<WM, BT>(A, lda, i0, B, ldb, j0, kbeg + (t + 2) * GB_K, lds + nb * SB, 4 * ks + a);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
+            }
         __builtin_amdgcn_s_setprio(0);
         if (++cur == GB_STAGES) cur = 0;
     }

@@ -72,7 +72,9 @@ def test_two_ranks_equal_the_single_process_oracle_on_the_union(tmp_path, world,
 @pytest.mark.gpu
 @pytest.mark.parametrize("hidden,E,T,nmb", [((256, 256), 64, 8, 4), ((64, 64), 16, 16, 4)])
 @pytest.mark.parametrize("peer,switch", [(True, "PPO_HIP_NO_ADAM_MEET=1"), (True, "PPO_HIP_NO_PEER_TILES=1"), (True, "PPO_HIP_PEER_STATS=0"), (True, "PPO_HIP_PEER_TIMEOUT_MS=20000"),
-                                         (True, "PPO_HIP_PEER_REDUCE=0"), (False, "PPO_HIP_GRAPH_RCCL=1"), (False, "PPO_HIP_GRAPH_RCCL=0")])
+                                         # (PPO_HIP_GRAPH_RCCL=1 FORCES the capture: the shared-memory stand-in cannot be captured, so that value has its case with the
+                                         #  real library at world 1, tests/test_hip_parity.py::test_rccl_plumbing_single_rank_communicator)
+                                         (True, "PPO_HIP_PEER_REDUCE=0"), (False, "PPO_HIP_GRAPH_RCCL=0")])
 def test_data_parallel_switches_against_the_oracle(tmp_path, hidden, E, T, nmb, peer, switch):
     k, v = switch.split("=")
     _union_against_the_oracle(tmp_path, 2, hidden, E, T, nmb, 1, peer, {k: v})

@@ -523,10 +523,19 @@ def test_full_size_config3_properties():
     assert (rows[1:, 3] > 0).all()
 
 
-def test_rccl_plumbing_single_rank_communicator():
+@pytest.mark.parametrize("graph_rccl", [None, "0", "1"])
+def test_rccl_plumbing_single_rank_communicator(graph_rccl, monkeypatch):
     """ppo_dist_init with world_size 1 exercises the run-time RCCL loading, the communicator and the in-stream
-    ncclAllReduce of the gradient buffer (the N-rank code path); results must still match the oracle."""
+    ncclAllReduce of the gradient buffer (the N-rank code path); results must still match the oracle -- with the capture probe deciding whether the collectives ride in the
+    update's graph (None), with the eager sequence forced (PPO_HIP_GRAPH_RCCL=0) and with the capture forced (=1; skipped where the probe says this RCCL cannot be captured)."""
     import ppo_cpp_amd
+    if graph_rccl == "1":
+        probe = ppo_cpp_amd.PPOHip(18, 18, [64, 64]); probe.dist_init(1, 0, ppo_cpp_amd.PPOHip.dist_unique_id())
+        capturable = probe.dist_graph_collectives(); probe.close()
+        if not capturable:
+            pytest.skip("this collective library cannot be stream-captured (the probe of ppo_dist_init): forcing it is an error by design")
+    if graph_rccl is not None:
+        monkeypatch.setenv("PPO_HIP_GRAPH_RCCL", graph_rccl)
     orc, g = pair((64, 64))
     g.dist_init(1, 0, ppo_cpp_amd.PPOHip.dist_unique_id())
     for it in range(2):
@@ -559,6 +568,9 @@ def test_rccl_plumbing_single_rank_communicator():
     rows, _ = g2.update(LR, CR, epochs, nmb, perms)             # the collectives ride in the graph when the probe of ppo_dist_init passed, eagerly otherwise
     close(rows, ref_rows, rtol=2e-4, atol=2e-6, msg="loss rows under a communicator")
     close(g2.get_flat(0), orc2.theta, rtol=2e-4, atol=5e-6)
+    if graph_rccl is not None:
+        assert bool(g2.dist_graph_collectives()) == (graph_rccl == "1")
+    g.close(); g2.close()
 
 
 @pytest.mark.parametrize("hidden", [(64, 64), (256, 256)])
