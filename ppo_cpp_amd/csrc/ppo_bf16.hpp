@@ -191,7 +191,8 @@ __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restri
         __builtin_amdgcn_sched_barrier(0);
         int nb = cur + 2; if (nb >= GB_STAGES) nb -= GB_STAGES;
         const bool more = t + 2 < nt;
-#if !defined(GB_NOLOAD) && !defined(GB_DMA_INTERLEAVE)
+#ifndef GB_NOLOAD
+        // (round 6: the same requests issued from inside the matrix block, one piece behind every four matrix instructions, measured 1 %: profiles/r06_d_*; not kept)
         if (more) gb_stage<WM, BT>(A, lda, i0, B, ldb, j0, kbeg + (t + 2) * GB_K, lds + nb * SB);
 #endif
         if constexpr (IMG) {
@@ -219,15 +220,6 @@ __device__ __forceinline__ void gb_mainloop(GemmAcc& acc, const bf16_t* __restri
                 for (int b = 0; b < 4; ++b) acc.v[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][b], af[ks][a], acc.v[a][b], 0, 0, 0);
 #else
                 for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(af[ks][a]), "v"(bfr[ks][b]));
-#endif
-#ifdef GB_DMA_INTERLEAVE
-                // EXPERIMENT (round 6): stage t+2's requests from INSIDE the matrix block, one 1-KB piece behind every four matrix instructions,
-                // instead of all NP at the stage's head beside the fragment reads
-                if (4 * ks + a < NP) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) gb_stage_piece<WM, BT>(A, lda, i0, B, ldb, j0, kbeg + (t + 2) * GB_K, lds + nb * SB, 4 * ks + a);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
 #endif
             }
         __builtin_amdgcn_s_setprio(0);

@@ -2353,7 +2353,10 @@ int ppo_rollout_act(ppo_handle* h, int32_t t, const float* noise, float* actions
         return 0;
     }
     // one D2H into the handle's pinned landing buffer and the ONLY stream synchronisation of an env step: the statistics
-    // kernel of the previous ppo_rollout_observe, this policy step and the copy drain together
+    // kernel of the previous ppo_rollout_observe, this policy step and the copy drain together.  (Round 6 tried a copy-out KERNEL in its place -- 32 workgroups storing
+    // 16 bytes per lane into the pinned buffer, a pinned word per slice, the host polling the words instead of the stream: no gain at 4096 environments, 1.25 vs 1.17 ms
+    // per 16 env steps on one box, profiles/r06_c_*: this phase is the H2D copy of the last transition + the statistics kernel + the policy kernel in front of the copy,
+    // not the copy command.)
     HIP_OK(h, hipMemcpyAsync(h->pin_out, h->ro_act + (size_t)t * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (bf16_chain_err_async(h)) return -1;
     // busy-wait on the stream: the blocking synchronise parks the thread on an interrupt and wakes it ~100-200 us late,
