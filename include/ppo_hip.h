@@ -216,6 +216,11 @@ int ppo_dist_peer_enable(ppo_handle* h, int on);
  * rows (ncclAllGather, once per ppo_update); rank r trains rows [r M, (r + 1) M) of every global minibatch of M * world rows.
  * A row index is e_global * T + t with e_global = rank * n_envs + e (runner.hpp:136-152 over the environments of all ranks). */
 int ppo_dist_global_shuffle(ppo_handle* h, int on);
+/* bf16 path under a communicator of more than one rank (collective library, not the peer regions): the gradient of a train step leaves in BUCKETS -- last layer + heads
+ * first -- each bucket's ncclAllReduce on a second stream under the remaining backward and weight-gradient launches (default on; 0 = one all-reduce of the whole vector behind
+ * them; 2 = also under a one-rank communicator, for measuring what the per-layer launches cost a rank).  Collective: call it at the same point on every rank.
+ * No reference counterpart (its job is one process); DESIGN.md section 6. */
+int ppo_dist_bucketed(ppo_handle* h, int on);
 
 /* ---- measurement hooks ----------------------------------------------------------------------------------
  * per-kernel device time (ms) accumulated with hipEvents on the handle's stream since the last reset;

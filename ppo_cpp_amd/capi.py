@@ -306,6 +306,10 @@ class PPOHip:
         self._ck(self.lib.ppo_dist_global_shuffle(self.h, int(on)))
         self._global_shuffle = bool(on) and self.world > 1
 
+    def dist_bucketed(self, on=True):
+        """bf16 path under a communicator: gradient buckets on a second stream (True, the default) / one all-reduce (False) / 2: buckets also at world 1 (measurement)"""
+        self._ck(self.lib.ppo_dist_bucketed(self.h, int(on)))
+
     def dist_peer_enable(self, on=True):
         self._ck(self.lib.ppo_dist_peer_enable(self.h, int(on)))
 

@@ -861,7 +861,7 @@ __device__ __forceinline__ void bgr_chunk(const ReduceArgs& a, int chunk, int la
     if (s.kind == 0) {
         // the lane's 4 elements lie in one tile of the weight-gradient GEMM: as many partial sums as workgroups touched that tile
         const int e = (int)(idx - (size_t)s.base), row = e / s.pcol, col = e - row * s.pcol;
-        const int tile = s.tile0 + (row / a.sk_bm) * (s.pcol / GB_N) + col / GB_N;
+        const int tile = s.tile0 + (row / a.sk_bm) * (s.pcol / GB_N) + col / GB_N - a.sk_tile_base;
         const int cnt = (tile * a.sk_nst + a.sk_nst - 1) / a.sk_per - (tile * a.sk_nst) / a.sk_per + 1;
         for (int k = 0; k < cnt; ++k) {
             const float4 v = *reinterpret_cast<const float4*>(a.slabs + (size_t)k * a.slab_stride + idx);
@@ -902,10 +902,13 @@ __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_grad_reduce_kernel(Reduce
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // highest chunks first: the slot-summed vectors (head bias, logstd: many dependent-free but latency-bound loads per lane) sit at
     // the END of the parameter vector and must not be the launch's tail
-    const int chunk = a.n_blocks - (int)(blockIdx.x * BGR_WAVES + wave);
+    // (a bucket: chunks [chunk_lo, chunk_hi), highest first, the tail block with the bucket that reaches the vector's end)
+    const bool whole = a.chunk_hi == 0;
+    const int top = whole || a.chunk_hi == a.n_blocks ? a.n_blocks : a.chunk_hi - 1, lo = whole ? 0 : a.chunk_lo;
+    const int chunk = top - (int)(blockIdx.x * BGR_WAVES + wave);
     float q = 0.f;
     if (chunk == a.n_blocks) { float tl[5]; bgr_tail(a, lane, tl); }
-    else if (chunk >= 0) {
+    else if (chunk >= lo) {
         float g[4];
         bgr_chunk(a, chunk, lane, g);
         *reinterpret_cast<float4*>(a.grad + (size_t)chunk * 256 + 4 * lane) = make_float4(g[0], g[1], g[2], g[3]);

@@ -183,6 +183,9 @@ struct ppo_handle {
         float* dbias = nullptr; int db_off[2][PPO_MAX_LAYERS]{}; int n_dbias = 0;
         DwTileB* dw_tiles = nullptr; int n_dw_tiles = 0; int dw_wm = 4;
         int tile0[2][PPO_MAX_LAYERS + 1]{};             // first weight-gradient tile of every matrix ([L] = the head), in the order of the tile table
+        int layer_tile0[PPO_MAX_LAYERS + 2]{};          // ... and of every layer's pair of matrices ([L] = the heads, [L + 1] = the table's end): the table is layer-major
+        // data parallel over the collective library: gradient buckets (last layer + heads first) all-reduced on a second stream under the remaining backward / weight-gradient launches
+        bool bucketed = true, bucketed_any_world = false; hipStream_t comm_stream = nullptr; hipEvent_t bk_ev[PPO_MAX_LAYERS + 1]{}; hipEvent_t bk_join = nullptr;
         // the hidden layers of a pass as ONE launch (gemm_chain_bf16_kernel): its word tables (forward, backward); PPO_HIP_NO_BF16_CHAIN=1: a launch per layer
         bool chain = false; unsigned* chain_words[2]{}; int n_cu = 0;
         bool chain_used = false; unsigned* chain_err_host = nullptr;     // a chained launch since the last check; pinned landing words of its two error words (act paths)
@@ -450,11 +453,17 @@ int build_layout(ppo_handle* h) {
         b.dw_wm = 4;
         if (n.Kp0 % 256) b.dw_wm = 2;
         for (int l = 0; l < n.L; ++l) if (n.Hp[l] % 256) b.dw_wm = 2;
+        // LAYER-major since round 6 (rounds 2 - 5: tower-major): layer l's matrices of both towers, then layer l + 1's, the heads last -- the tiles of a layer (and of
+        // "last layer + heads") are then one contiguous range of the table, which is what the bucketed data-parallel step launches by itself (bf16_train_bucketed)
         int t0 = 0;
-        for (int t = 0; t < 2; ++t) {
-            for (int l = 0; l < n.L; ++l) { b.tile0[t][l] = t0; t0 += ((l ? n.Hp[l - 1] : n.Kp0) / GB_BM(b.dw_wm)) * (n.Hp[l] / GB_N); }
-            b.tile0[t][n.L] = t0; t0 += (n.Hp[n.L - 1] / GB_BM(b.dw_wm)) * (n.Ap / GB_N);
+        for (int l = 0; l <= n.L; ++l) {
+            b.layer_tile0[l] = t0;
+            for (int t = 0; t < 2; ++t) {
+                b.tile0[t][l] = t0;
+                t0 += l < n.L ? ((l ? n.Hp[l - 1] : n.Kp0) / GB_BM(b.dw_wm)) * (n.Hp[l] / GB_N) : (n.Hp[n.L - 1] / GB_BM(b.dw_wm)) * (n.Ap / GB_N);
+            }
         }
+        b.layer_tile0[n.L + 1] = t0;
         n.lds_total = 0; h->lds_step_total = 0; h->CTH = 0;
         n.slot_head = 0; n.slot_aux = n.Ap; n.slot_loss = 2 * n.Ap; n.slot_w = 2 * n.Ap + 8;
         return 0;
@@ -782,10 +791,11 @@ int bf16_ensure_ws(ppo_handle* h, int rows) {
     auto add = [&](const bf16_t* A, const bf16_t* B, int Kp, int Np, int out_off) {
         for (int i = 0; i < Kp; i += GB_BM(b.dw_wm)) for (int j = 0; j < Np; j += GB_N) tiles.push_back(DwTileB{A, B, Kp, Np, i, j, out_off, Np, A == b.x0 ? 1 : 0});
     };
-    for (int t = 0; t < 2; ++t) {
-        for (int l = 0; l < n.L; ++l) add(l ? b.hb[t][l - 1] : b.x0, b.dy[t][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l], n.w_off[t][l]);
-        add(b.hb[t][n.L - 1], b.dhead[t], n.Hp[n.L - 1], n.Ap, t ? n.wv_off : n.wmu_off);
-    }
+    for (int l = 0; l <= n.L; ++l)                             // layer-major (tile0 / layer_tile0 above): both towers' matrices of a layer side by side, the heads last
+        for (int t = 0; t < 2; ++t) {
+            if (l < n.L) add(l ? b.hb[t][l - 1] : b.x0, b.dy[t][l], l ? n.Hp[l - 1] : n.Kp0, n.Hp[l], n.w_off[t][l]);
+            else add(b.hb[t][n.L - 1], b.dhead[t], n.Hp[n.L - 1], n.Ap, t ? n.wv_off : n.wmu_off);
+        }
     b.n_dw_tiles = (int)tiles.size();
     if (dev_alloc(h, &b.dw_tiles, tiles.size())) return -1;
     HIP_OK(h, hipMemcpyAsync(b.dw_tiles, tiles.data(), tiles.size() * sizeof(DwTileB), hipMemcpyHostToDevice, h->stream));
@@ -886,7 +896,9 @@ long bf16_epoch_row(ppo_handle* h, const TrainArgs& ta, int Rp) {
     return (r0 + ta.n <= b.xe_rows) ? r0 : -1;
 }
 
-int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
+bool bf16_backward_links(ppo_handle* h, GemmArgs (&bl)[PPO_MAX_LAYERS], int (&outw)[PPO_MAX_LAYERS]);
+// links_only: forward + heads + loss only (the bucketed data-parallel step runs the backward links itself)
+int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp, bool links_only = false) {
     ppo_handle::Bf16& b = h->bf;
     const NetDev& n = h->net;
     const long er = bf16_epoch_row(h, ta, Rp);
@@ -900,10 +912,21 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
     if (n.A > 64 * BL_EPT) return fail(h, "bf16 path: more than %d actions", 64 * BL_EPT);
     hipLaunchKernelGGL(bf16_loss_kernel, dim3(Rp / BL_ROWS), dim3(64 * BL_ROWS), (size_t)(2 * BL_ROWS * n.Ap + 6 * BL_ROWS) * sizeof(float), h->stream, la);
     HIP_OK(h, hipGetLastError());
-    // dY_{L-1} = (d head * W_head^T) .* (1 - h_L^2), then down the hidden layers
-    const int HpL = n.Hp[n.L - 1];
+    if (links_only) return 0;
     GemmArgs bl[PPO_MAX_LAYERS];
     int outw[PPO_MAX_LAYERS];
+    const bool same_j = bf16_backward_links(h, bl, outw);
+    const int HpL = n.Hp[n.L - 1];
+    if (!(same_j && n.L <= GB_CHAIN_MAX && bf16_chain<GEPI_TANHGRAD>(h, bl, n.L, Rp, HpL, 1)))
+        for (int k = 0; k < n.L; ++k) if (bf16_gemm<GEPI_TANHGRAD>(h, bl[k], Rp, outw[k])) return -1;
+    return 0;
+}
+
+// the backward pass as L links: link 0 = dY_{L-1} = (d head * W_head^T) .* (1 - h_L^2), link k = down one hidden layer; returns whether all outputs have one width
+bool bf16_backward_links(ppo_handle* h, GemmArgs (&bl)[PPO_MAX_LAYERS], int (&outw)[PPO_MAX_LAYERS]) {
+    ppo_handle::Bf16& b = h->bf;
+    const NetDev& n = h->net;
+    const int HpL = n.Hp[n.L - 1];
     bool same_j = true;
     {
         GemmArgs a{};
@@ -926,9 +949,7 @@ int bf16_train_fwd_bwd(ppo_handle* h, const TrainArgs& ta, int Rp) {
         bl[n.L - l] = a; outw[n.L - l] = n.Hp[l - 1];
         same_j = same_j && n.Hp[l - 1] == HpL;
     }
-    if (!(same_j && n.L <= GB_CHAIN_MAX && bf16_chain<GEPI_TANHGRAD>(h, bl, n.L, Rp, HpL, 1)))
-        for (int k = 0; k < n.L; ++k) if (bf16_gemm<GEPI_TANHGRAD>(h, bl[k], Rp, outw[k])) return -1;
-    return 0;
+    return same_j;
 }
 
 // work split of the weight-gradient GEMM for `Rp` rows: stages per workgroup (see DwArgsB).  One round on the 256 CUs when there is
@@ -941,12 +962,22 @@ void bf16_dw_split(ppo_handle* h, int Rp, int& nst, int& per, int& groups) {
     groups = (total + per - 1) / per;
 }
 
-int bf16_weight_grads(ppo_handle* h, const TrainArgs& ta, int Rp) {
+// tile0 / ntiles: a contiguous range of the (layer-major) tile table walked as a launch of its own (-1: the whole table); per_out: the split the assembly needs
+int bf16_weight_grads(ppo_handle* h, const TrainArgs& ta, int Rp, int tile0 = -1, int ntiles = 0, int* per_out = nullptr) {
     ppo_handle::Bf16& b = h->bf;
     const long er = bf16_epoch_row(h, ta, Rp);
     int nst, per, groups;
     bf16_dw_split(h, Rp, nst, per, groups);
-    DwArgsB da{b.dw_tiles, nst, per, b.n_dw_tiles * nst, h->slabs, (size_t)h->P_pad, er >= 0 ? b.xe + (size_t)er * h->net.Kp0 : nullptr, h->net.Kp0};
+    const DwTileB* tiles = b.dw_tiles; int nt = b.n_dw_tiles;
+    if (tile0 >= 0) {
+        tiles += tile0; nt = ntiles;
+        const int total = nt * nst;
+        per = std::max((total + 255) / 256, (nst + h->max_split - 3) / (h->max_split - 2));
+        per = std::min(std::max(per, 1), nst);
+        groups = (total + per - 1) / per;
+    }
+    if (per_out) *per_out = per;
+    DwArgsB da{tiles, nst, per, nt * nst, h->slabs, (size_t)h->P_pad, er >= 0 ? b.xe + (size_t)er * h->net.Kp0 : nullptr, h->net.Kp0};
 #ifdef PPO_STAMPS
     if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
     da.stamps = groups <= 512 ? g_stamps + 4096 * 16 : nullptr;
@@ -1146,6 +1177,63 @@ bool set_lds_pair() {
            hipFuncSetAttribute((const void*)weight_grad_assemble_kernel<KP0, AP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * Dw2L<KP0, AP>::LDS_FLOATS) == hipSuccess;
 }
 
+// Data parallel over the collective library, bf16 path (BASELINE configs[4]: 19 MB of gradient per train step): the gradient leaves in BUCKETS, last layer + heads first.
+// Backward link k (a launch of its own here; the single-rank step chains them) is followed by the weight-gradient GEMM of exactly the matrices it completed (a contiguous
+// range of the layer-major tile table, work-balanced over the chip by itself) and their assembly, and that bucket's ncclAllReduce goes to a SECOND stream, where it runs
+// under link k + 1 and its weight gradients; the streams join in front of the sums of squares + clip + Adam.  With one exposed all-reduce of the whole vector behind a
+// ~230 us step, an 8-GPU job would spend ~40 % of its time in it; whether the overlap delivers cannot be measured on one device -- what CAN be
+// measured is what the per-layer launches cost one rank (profiles/r06_f_*), and that the result is the oracle's over the union at world 2 and 8
+// (tests/test_dp_two_ranks.py::test_two_ranks_bf16_path).  ppo_dist_bucketed(h, 0) keeps the single all-reduce.  No reference counterpart.
+int bf16_train_bucketed(ppo_handle* h, const TrainArgs& ta, int Rp, float* loss_row) {
+    ppo_handle::Bf16& b = h->bf;
+    const NetDev& n = h->net;
+    if (!b.comm_stream) {
+        HIP_OK(h, hipStreamCreateWithFlags(&b.comm_stream, hipStreamNonBlocking));
+        for (int k = 0; k <= PPO_MAX_LAYERS; ++k) HIP_OK(h, hipEventCreateWithFlags(&b.bk_ev[k], hipEventDisableTiming));
+        HIP_OK(h, hipEventCreateWithFlags(&b.bk_join, hipEventDisableTiming));
+    }
+    { ProfScope ps(h, PK_TRAIN_FB); if (bf16_train_fwd_bwd(h, ta, Rp, /*links_only*/ true)) return -1; }
+    GemmArgs bl[PPO_MAX_LAYERS];
+    int outw[PPO_MAX_LAYERS];
+    (void)bf16_backward_links(h, bl, outw);
+    int nst, per_all, groups_all;
+    bf16_dw_split(h, Rp, nst, per_all, groups_all);
+    for (int k = 0; k < n.L; ++k) {
+        const int l = n.L - 1 - k;                           // the layer whose pre-activation gradient this link completes
+        { ProfScope ps(h, PK_TRAIN_FB); if (bf16_gemm<GEPI_TANHGRAD>(h, bl[k], Rp, outw[k])) return -1; }
+        const int t0 = b.layer_tile0[l], t1 = k == 0 ? b.layer_tile0[n.L + 1] : b.layer_tile0[l + 1];
+        int per = 0;
+        { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, ta, Rp, t0, t1 - t0, &per)) return -1; }
+        const int c0 = n.w_off[0][l] / 256, c1 = k == 0 ? h->n_blocks : n.w_off[0][l + 1] / 256;
+        {
+            ProfScope ps(h, PK_REDUCE);
+            ReduceArgs ra{};
+            ra.sk_nst = nst; ra.sk_per = per; ra.sk_bm = GB_BM(b.dw_wm); ra.sk_tile_base = t0; ra.chunk_lo = c0; ra.chunk_hi = c1;
+            ra.src = h->grad_src; ra.n_blocks = h->n_blocks; ra.slabs = h->slabs; ra.slab_stride = (size_t)h->P_pad; ra.nsplit = 0;
+            ra.slots[0] = h->slots[0]; ra.slots[1] = h->slots[1]; ra.n_rowblocks = Rp / BL_ROWS; ra.slot_w = n.slot_w; ra.slot_loss = n.slot_loss;
+            ra.grad = h->grad; ra.sumsq = h->sumsq; ra.n_local = (float)ta.n; ra.beta_pow = h->beta_pow; ra.direct = b.dbias;
+            ra.n_direct = Rp / (Rp % 256 == 0 ? 256 : 128); ra.direct_stride = b.n_dbias;
+            const int chunks = c1 - c0 + (k == 0 ? 1 : 0);     // (+ the tail block: loss sums, row count, the powers' cur <- next, with the bucket at the vector's end)
+            hipLaunchKernelGGL(bf16_grad_reduce_kernel, dim3((chunks + BGR_WAVES - 1) / BGR_WAVES), dim3(64 * BGR_WAVES), 0, h->stream, ra);
+            HIP_OK(h, hipGetLastError());
+        }
+        {
+            ProfScope ps(h, PK_COMM);
+            HIP_OK(h, hipEventRecord(b.bk_ev[k], h->stream));
+            HIP_OK(h, hipStreamWaitEvent(b.comm_stream, b.bk_ev[k], 0));
+            float* buf = h->grad + (size_t)c0 * 256;
+            const size_t count = (size_t)(c1 - c0) * 256 + (k == 0 ? 8 : 0);
+            const int rc = h->rccl.AllReduce(buf, buf, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, b.comm_stream);
+            if (rc != 0) return fail(h, "ncclAllReduce (bucket %d) failed: %s", k, h->rccl.GetErrorString ? h->rccl.GetErrorString(rc) : "?");
+        }
+    }
+    HIP_OK(h, hipEventRecord(b.bk_join, b.comm_stream));
+    HIP_OK(h, hipStreamWaitEvent(h->stream, b.bk_join, 0));
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(h->n_blocks), dim3(256), 0, h->stream, h->grad, h->sumsq);
+    HIP_OK(h, hipGetLastError());
+    return enqueue_adam(h, loss_row);
+}
+
 // the per-minibatch launch sequence: fwd+loss+bwd -> weight grads -> reduce [-> all-reduce] -> clip+Adam
 // defer (narrow reference shape, inside ppo_update only): leave this step's clip + Adam to the next train kernel's prologue
 // (flush_pending_adam after the last step)
@@ -1210,6 +1298,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
     if (h->bf.on) {
         const int Rp = ru(ta.n, GB_PAD);
         ++h->kv[KV_BF16_TRAIN];
+        if (h->comm && !h->peer.on && h->net.L >= 2 && (h->bf.bucketed_any_world || (h->world > 1 && h->bf.bucketed))) return bf16_train_bucketed(h, ta, Rp, loss_row);
         { ProfScope ps(h, PK_TRAIN_FB); if (bf16_train_fwd_bwd(h, ta, Rp)) return -1; }
         { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, ta, Rp)) return -1; }
         {
@@ -1581,6 +1670,7 @@ void ppo_destroy(ppo_handle* h) {
     if (h->dw2_counters) (void)hipFree(h->dw2_counters);
     for (int d = 0; d < 2; ++d) if (h->bf.chain_words[d]) (void)hipFree(h->bf.chain_words[d]);
     if (h->bf.chain_err_host) (void)hipHostFree(h->bf.chain_err_host);
+    if (h->bf.comm_stream) { (void)hipStreamDestroy(h->bf.comm_stream); for (auto& e : h->bf.bk_ev) if (e) (void)hipEventDestroy(e); if (h->bf.bk_join) (void)hipEventDestroy(h->bf.bk_join); }
     if (h->bf.ra_ent) (void)hipFree(h->bf.ra_ent);
     if (h->adam_meet_words) (void)hipFree(h->adam_meet_words);
     if (h->adam_meet_parts) (void)hipFree(h->adam_meet_parts);
@@ -3154,6 +3244,15 @@ int ppo_dist_global_shuffle(ppo_handle* h, int on) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
     drop_graph(h);
     h->global_shuffle = on != 0;
+    return 0;
+}
+
+int ppo_dist_bucketed(ppo_handle* h, int on) {
+    ENTER(h);
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    h->bf.bucketed = on != 0;
+    h->bf.bucketed_any_world = on == 2;                         // (2: also under a ONE-rank communicator -- tools/peer_overhead.py measures what the per-layer launches cost one rank)
     return 0;
 }
 

@@ -1481,6 +1481,8 @@ struct ReduceArgs {
     const float* slabs; size_t slab_stride; int nsplit;
     int sk_nst, sk_per, sk_bm;   // bf16 path (work-balanced weight-gradient GEMM): stages per tile, stages per workgroup, tile rows; a tile's
                                  // partial sums are slabs 0 .. (last - first) of the workgroups first = t*nst/per .. last = (t*nst+nst-1)/per
+    int sk_tile_base;            // ... t = the tile's index in the launch's OWN sequence: its index in the table minus this (0: the launch walked the whole table)
+    int chunk_lo, chunk_hi;      // bf16_grad_reduce_kernel on a BUCKET (bucketed data-parallel step): chunks [chunk_lo, chunk_hi) only; 0, 0 = the whole vector + the tail block
     const float* slots[2]; int n_rowblocks; int slot_w;
     int slot_loss;
     const float* direct;         // kind 3: per-row-tile sums (bias gradients from the bf16 path's TanhGrad epilogues), [n_direct][direct_stride], indexed slot_off + e

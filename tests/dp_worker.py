@@ -44,6 +44,8 @@ def main():
             if not g.dist_peer_attach(handles):
                 raise RuntimeError("peer all-reduce probe failed (rank %d)" % rank)
             assert g.dist_graph_collectives()
+    if os.environ.get("PPO_TEST_BUCKETED") == "0":
+        g.dist_bucketed(False)                                          # (bf16 path: one all-reduce of the whole gradient instead of the layer buckets)
     g.norm_init(El, float(d["gamma"]))
     g.rollout_alloc(El, T)
     if os.environ.get("PPO_TEST_DRILL") == "1" and rank == world - 1:

@@ -169,11 +169,15 @@ def test_two_ranks_literal_global_shuffle(tmp_path, world, hidden, E, T, nmb, ep
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,hidden,E,T,nmb,epochs", [(2, (256, 256), 64, 8, 4, 1), (2, (384, 256), 128, 16, 4, 2), (8, (256, 256), 128, 8, 4, 1)])
-def test_two_ranks_bf16_path(tmp_path, world, hidden, E, T, nmb, epochs):
+@pytest.mark.parametrize("world,hidden,E,T,nmb,epochs", [(2, (256, 256), 64, 8, 4, 1), (2, (384, 256), 128, 16, 4, 2), (8, (256, 256), 128, 8, 4, 1), (2, (256, 256, 256), 64, 8, 4, 1),
+                                                         (8, (256, 128, 256), 128, 8, 4, 1)])
+@pytest.mark.parametrize("bucketed", [True, False])
+def test_two_ranks_bf16_path(tmp_path, world, hidden, E, T, nmb, epochs, bucketed):
     """The bf16 matrix-core path under data parallelism (the configuration SURVEY 8e expects DP to pay for): gradient assembly per rank,
     all-reduce, recomputed sums of squares, fold, clip + Adam.  Against the fp32 oracle over the union at the bf16 path's stated
-    tolerances (tests/test_bf16_path.py); the replicas must stay bit-identical."""
+    tolerances (tests/test_bf16_path.py); the replicas must stay bit-identical.  bucketed (the default, ppo_dist_bucketed): the gradient leaves layer by layer,
+    last layer + heads first, each bucket's all-reduce on a second stream under the remaining backward / weight-gradient launches (2 and 3 buckets here);
+    False: one all-reduce of the whole vector behind them."""
     tmp = str(tmp_path)
     fake = build_fake_rccl(tmp)
     orc = o.Oracle(18, 18, list(hidden)); orc.init_orthogonal(13)
@@ -195,7 +199,7 @@ def test_two_ranks_bf16_path(tmp_path, world, hidden, E, T, nmb, epochs):
     fin = os.path.join(tmp, "in.npz")
     np.savez(fin, hidden=np.array(hidden), E=E, T=T, nmb=nmb, epochs=epochs, theta=theta0, uid=uid, gamma=GAMMA, lam=LAM, seed=1234,
              noise=noise, perms=perms, lr=LR, cr=CR, **{"ref_" + k: ro[k] for k in ("obs", "actions", "values", "neglogp", "returns")})
-    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="0", PPO_TEST_BF16="1")
+    env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", PPO_TEST_PEER="0", PPO_TEST_BF16="1", PPO_TEST_BUCKETED="1" if bucketed else "0")
     outs = run_workers(tmp, world, fin, env)
     ref_rows, _ = orc.update(ro, gperms, nmb, LR, CR)
     for out in outs:
