@@ -397,12 +397,21 @@ def main():
             dist.barrier()
 
     probe = None
-    if dist is not None and args.collective == "auto" and g.dist_peer_active():
-        # both exchange paths over a few steps each (first one warm / captured), the faster one runs the timed region
+    peer_attached = dist is not None and g.dist_peer_active()
+    if dist is not None and args.collective == "auto" and (peer_attached or bf16):
+        # every exchange form over a few steps each (first one warm / captured), the fastest one runs the timed region: the peer regions (when they attached),
+        # ncclAllReduce, and -- bf16 path -- ncclAllReduce of the gradient in layer BUCKETS on a second stream (the library's default there, ppo_dist_bucketed)
         probe = {}
         one_step(0, first=True)
-        for mode in ("peer", "rccl"):
-            g.dist_peer_enable(mode == "peer")
+        modes = (("peer",) if peer_attached else ()) + (("rccl", "rccl+buckets") if bf16 else ("rccl",))
+
+        def select(mode):
+            if peer_attached:
+                g.dist_peer_enable(mode == "peer")
+            if bf16:
+                g.dist_bucketed(mode == "rccl+buckets")
+        for mode in modes:
+            select(mode)
             one_step(1)
             barrier()
             t1 = time.perf_counter()
@@ -411,7 +420,7 @@ def main():
             g.sync()
             probe[mode] = 1e3 * ppodist.allreduce_max(dist, time.perf_counter() - t1) / 2
             barrier()
-        g.dist_peer_enable(probe["peer"] < probe["rccl"])
+        select(min(probe, key=probe.get))
     for i in range(max(args.warmup, 1)):
         losses = one_step(i, first=(i == 0 and probe is None))
     barrier()
@@ -427,7 +436,7 @@ def main():
     if dist is not None:
         # the replicas must have stayed bit-identical (same reduced gradient in the same order on every rank): checked, and fatal
         import hashlib
-        used = "peer" if g.dist_peer_active() else "rccl"
+        used = "peer" if g.dist_peer_active() else ("rccl+buckets" if (bf16 and (probe is None or min(probe, key=probe.get) == "rccl+buckets")) else "rccl")
         digests = ppodist.allgather_bytes(dist, hashlib.sha256(g.get_flat(0).tobytes()).digest(), 32)
         info = g.dist_info()
         mine = json.dumps({"rank": rank, "local_rank": local_rank, "device": info["device"], "pci_bus_id": info["pci_bus_id"], "pid": os.getpid()}).encode()

@@ -20,11 +20,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("collective,scaling,config", [("rccl", "weak", "cfg4"), ("peer", "weak", "cfg4"), ("auto", "weak", "cfg4"),
-                                                       ("rccl", "strong", "cfg4"), ("peer", "strong", "cfg3")])
+                                                       ("rccl", "strong", "cfg4"), ("peer", "strong", "cfg3"),
+                                                       # BASELINE configs[4] (bf16): auto also times the gradient-bucket form of the exchange (ppo_dist_bucketed)
+                                                       ("auto", "strong", "cfg5")])
 def test_two_rank_bench_flow(tmp_path, collective, scaling, config):
     fake = build_fake_rccl(str(tmp_path))
     port = 29500 + (os.getpid() + hash((collective, scaling)) % 97) % 400
     env = dict(os.environ, PPO_RCCL_LIBRARY=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", TMPDIR="/tmp")
+    if config == "cfg5":
+        env["PPO_HIP_PEER_REDUCE"] = "0"       # (two ranks of this shape on ONE device: the peer path's 19 MB pushes of both ranks wait on each other's workgroups -- a shared-device artefact)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", config, "--collective", collective, "--scaling", scaling]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -38,7 +42,8 @@ def test_two_rank_bench_flow(tmp_path, collective, scaling, config):
     if collective in ("rccl", "peer"):
         assert c["used"] == collective
     else:
-        assert set(c["auto_probe_ms_per_step"]) == {"peer", "rccl"} and c["used"] == min(c["auto_probe_ms_per_step"], key=c["auto_probe_ms_per_step"].get)
+        assert set(c["auto_probe_ms_per_step"]) == ({"rccl", "rccl+buckets"} if config == "cfg5" else {"peer", "rccl"})
+        assert c["used"] == min(c["auto_probe_ms_per_step"], key=c["auto_probe_ms_per_step"].get)
     assert "cpu_baseline" not in d                                # rank 0 at N = 1 only
 
 
