@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box, via gpurun): tools/final_profiles.sh <tag>  -> bench lines, rocprofv3 kernel stats and PMC passes of the
 # configurations quoted in DESIGN.md, under gpurun_out/<tag>/
-tag=${1:-r05_final}; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
+tag=${1:-r06_final}; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 python bench.py --steps 5 --warmup 2 > $out/bench_cfg3.json 2> $out/bench_cfg3.err || tail -3 $out/bench_cfg3.err
 for cfg in cfg2o36 cfg4o36; do python bench.py --config $cfg --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $out/bench_$cfg.json 2> $out/bench_$cfg.err; done
 for cfg in cfg3 cfg3o36 cfg2 cfg4 cfg5; do
