@@ -245,6 +245,9 @@ int ppo_debug_poison_lds(ppo_handle* h, uint32_t word);
 /* debug: the node types of the hipGraph the last ppo_update captured: counts = {kernel, memset, memcpy, other}; -1 when the handle holds no graph.  The library's rule is
  * kernel nodes only (a memset node replayed out of order on ROCm 7.0.2: DESIGN.md section 9). */
 int ppo_debug_graph_nodes(ppo_handle* h, int32_t counts[4]);
+/* debug: raise the error word of the bf16 path's chained launch as a failed hand-off would; the next call that chains its layers must report it (ppo_step / ppo_value /
+ * ppo_act_deterministic repeat their pass layer by layer; the rollout calls and ppo_update return the error) and the handle launches layer by layer from then on. */
+int ppo_debug_raise_chain_error(ppo_handle* h);
 
 #ifdef __cplusplus
 }

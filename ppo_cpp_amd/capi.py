@@ -343,6 +343,9 @@ class PPOHip:
             return None
         return dict(zip(("kernel", "memset", "memcpy", "other"), [int(x) for x in c]))
 
+    def debug_raise_chain_error(self):
+        self._ck(self.lib.ppo_debug_raise_chain_error(self.h))
+
     def debug_poison_lds(self, word=0x7FC0DEAD):
         """leave `word` (default: a NaN pattern) in every LDS word of every CU (include/ppo_hip.h, ppo_debug_poison_lds)"""
         self._ck(self.lib.ppo_debug_poison_lds(self.h, C.c_uint32(word)))

@@ -3309,6 +3309,19 @@ int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_co
     return 0;
 }
 
+// Raise the error word of the bf16 path's chained launch as a failed hand-off would (a row group spread over two XCDs, or a time-out): the NEXT call that chains its
+// layers must report it -- ppo_step / ppo_value / ppo_act_deterministic repeat their pass with a launch per layer, the rollout calls and ppo_update return the error --
+// and the handle launches layer by layer from then on (tests/test_bf16_path.py).  Returns -1 when the handle has no chained launch to fail.
+int ppo_debug_raise_chain_error(ppo_handle* h) {
+    ENTER(h);
+    ppo_handle::Bf16& b = h->bf;
+    if (!b.on || !b.chain || !b.chain_words[0]) return fail(h, "ppo_debug_raise_chain_error: this handle does not chain its layers");
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    const unsigned one = 1u;
+    HIP_OK(h, hipMemcpy(b.chain_words[0] + (size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS, &one, sizeof one, hipMemcpyHostToDevice));
+    return 0;
+}
+
 // What the update's captured graph is made of: counts[0] kernel nodes, [1] memset nodes, [2] memcpy nodes, [3] anything else; returns -1 when no graph is held (eager
 // handles, or before the first ppo_update).  The rule since round 6 is "kernel nodes only" (zero_words above): tests/test_race_guards.py holds every shape to it.
 int ppo_debug_graph_nodes(ppo_handle* h, int32_t counts[4]) {

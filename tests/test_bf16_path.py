@@ -243,3 +243,37 @@ def test_bf16_train_steps_of_changing_row_counts_on_one_handle(hidden):
             if np.linalg.norm(rt) > 1e-3 * ref_norm:
                 assert cosine(gt, rt) > 0.995, (name, it, n, cosine(gt, rt))
     g.close()
+
+
+def test_a_failed_chained_launch_is_reported_by_the_call_that_produced_the_garbage(capfd):
+    """the chained launch's error words (a row group spread over two XCDs, a time-out) used to be read by ppo_update / ppo_train_step only, so inference and
+    rollout calls returned garbage as success.  Now every call that chains its layers looks at them: ppo_step repeats its pass with a launch per layer and returns the
+    values a handle that never chained returns (same bits: the chained launch is bitwise the per-layer form), the rollout on the device env returns the error; afterwards
+    the handle launches layer by layer.  The failure is injected through ppo_debug_raise_chain_error."""
+    from ppo_cpp_amd.capi import PPOHipError
+    hidden, O, A, n = (1024, 1024, 1024), 256, 64, 4096
+    orc, g = pair_bf16(hidden, O, A)
+    rng = np.random.RandomState(2)
+    obs = rng.uniform(-1, 1, (n, O)).astype(np.float32); noise = rng.normal(size=(n, A)).astype(np.float32)
+    a0, v0, nlp0 = g.step(obs, noise)                                # chained, no error
+    g.debug_raise_chain_error()
+    a1, v1, nlp1 = g.step(obs, noise)                                # reports on stderr, repeats layer by layer
+    assert "repeated with a launch per layer" in capfd.readouterr().err
+    for x, y in ((a0, a1), (v0, v1), (nlp0, nlp1)):
+        np.testing.assert_array_equal(x, y)
+    a2, v2, _ = g.step(obs, noise)                                   # the handle stays on the per-layer form: no further report
+    assert capfd.readouterr().err == "" and np.array_equal(a2, a0) and np.array_equal(v2, v0)
+    with pytest.raises(PPOHipError, match="does not chain"):
+        g.debug_raise_chain_error()
+    g.close()
+    # the rollout path: the error surfaces from ppo_collect_synthetic itself
+    orc, g = pair_bf16(hidden, O, A)
+    E, T = 4096, 2
+    g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+    g.collect_synthetic(1234, GAMMA, LAM, None)
+    g.debug_raise_chain_error()
+    with pytest.raises(PPOHipError, match="gemm_chain_bf16_kernel"):
+        g.collect_synthetic(1234, GAMMA, LAM, None, step0=T, first=False)
+    g.collect_synthetic(1234, GAMMA, LAM, None, step0=T, first=False)      # layer by layer from now on
+    assert np.isfinite(g.rollout_get("values")).all()
+    g.close()
