@@ -43,3 +43,24 @@ def test_first_multi_device_command_dry_run_on_one_gpu(tmp_path):
     assert rep["rccl_nranks"] == 4 and rep["distinct_devices"] == 1 and rep["replicas_bit_identical"] is True and rep["cpp_driver_replicas_byte_identical"] is True
     assert rep["peer_path_used"] is True
     assert set(rep["values"]["cfg4/rccl"]) == {"2", "4"} and set(rep["values"]["cfg4/single"]) == {"1"} and all(v > 0 for v in rep["values"]["cfg4/auto"].values())
+
+
+def test_the_pytest_tail_carries_the_finding_of_a_failed_and_an_xfailed_test(tmp_path):
+    """tests/conftest.py's terminal summary: one line per failed / xfailed test with the head of its assertion message, at the very END of the output (`pytest -q` prints nothing
+    for an xfail, and round 5's finding was lost in exactly that way).  A throw-away test file run under this repository's conftest."""
+    import sys
+    import shutil
+    d = tmp_path / "tests"
+    d.mkdir()
+    shutil.copy(os.path.join(ROOT, "tests", "conftest.py"), str(d / "conftest.py"))
+    (d / "test_x.py").write_text(
+        "import pytest\n"
+        "def test_plain():\n    assert 1 + 1 == 3, 'first differing buffer: thetaT'\n"
+        "@pytest.mark.xfail(strict=False, reason='open')\n"
+        "def test_expected():\n    raise AssertionError('handle 1 differs first at iteration 1: loss rows')\n")
+    p = subprocess.run([sys.executable, "-m", "pytest", str(d), "-q", "-p", "no:cacheprovider"], capture_output=True, text=True, cwd=str(tmp_path))
+    tail = p.stdout.strip().splitlines()[-12:]
+    text = "\n".join(tail)
+    assert "findings (tests/conftest.py)" in text
+    assert any(l.startswith("FAILED") and "first differing buffer: thetaT" in l for l in tail), text
+    assert any(l.startswith("XFAILED") and "handle 1 differs first at iteration 1: loss rows" in l for l in tail), text
