@@ -102,3 +102,19 @@ def test_hip_path_learns_like_the_oracle(reference_loop):
     assert abs(first_h - first_r) < 0.08, msg                   # the same task and the same initial policy
     assert last_h - first_h > RISE and last_r - first_r > RISE, msg
     assert abs(last_h - last_r) < BAND, msg
+
+
+@pytest.mark.gpu
+def test_the_256x256_kernel_pair_learns_the_task_too():
+    """The same task through train8_kernel / weight_grad_assemble_kernel ([256,256], the headline's kernels; 64-row minibatches padded to whole chunks, 150 updates = 149 replays
+    of the update's graph): no oracle leg (the scalar oracle would need minutes at this width), but the curve must start where the task starts and rise like the [64,64] runs do --
+    a kernel pair that trained on stale or half-assembled gradients (round 5's open finding did exactly that after enough replays) flattens it."""
+    from ppo_cpp_amd import hostapi
+    # (learning rate 3e-4: at 1e-3 this width over-steps on every implementation alike -- approxkl 0.05, clipfrac 0.45, a flat curve from the default kernels, the round-2 kernels,
+    #  eager launches and the literal reference loop, measured in round 6 -- a property of the hyper-parameters, not of a kernel)
+    got = hostapi.learn_curve(E, T, [256, 256], UPDATES, NMB, EPOCHS, 3e-4, CR, gamma=GAMMA, lam=LAM, seed=11)
+    c = got["reward_curve"]
+    assert np.isfinite(c).all() and np.isfinite(got["losses"]).all()
+    first, last = c[:15].mean(), c[-15:].mean()
+    assert -1.6 < first < -1.35, first                          # sigma = 1, mu ~ 0: -(1 + |W obs|^2 / A) ~ -1.47
+    assert last - first > 0.12, "reward %.3f -> %.3f" % (first, last)      # (-1.46 -> -1.24 measured)
