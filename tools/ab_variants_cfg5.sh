@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of prebuilt library variants at configs[4] (cfg5): variants/ab_cfg5.sh <tag> <lib or "default"> ...   three alternating rounds
+# A/B of prebuilt library variants at configs[4] (cfg5): tools/ab_variants_cfg5.sh <tag> <lib or "default"> ...   three alternating rounds
 tag=$1; shift
 mkdir -p gpurun_out/abv
 for r in 1 2 3; do
