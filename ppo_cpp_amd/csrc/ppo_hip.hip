@@ -271,7 +271,8 @@ int fail(ppo_handle* h, const char* fmt, ...) {
 // is allowed; it is kept now because a runtime that held pointers into the captured graph's node parameters was one suspect for the open observation of DESIGN.md
 // section 9.  It was NOT the cause -- the observation is unchanged with the graph kept -- but a few hundred KB per handle cost nothing and rule that class out.)
 // Zero a few words from INSIDE the launch sequence: a kernel, not hipMemsetAsync.  The update's sequence is captured into a hipGraph and replayed, and a memset NODE in
-// that graph is not safe on this runtime (ROCm 7.0.2, gfx950): in a process that has lived for a while, a replay ran the node's fill in the MIDDLE of the kernels behind
+// that graph is not safe on the HIP runtime the PyTorch wheel bundles (HIP 7.0.51831; it serves any process that imports torch before loading this library -- every full
+// pytest run, every rank of bench.py -- while the system's 7.2 runtime replays the node correctly): a replay ran the node's fill in the MIDDLE of the kernels behind
 // it -- weight_grad_assemble_kernel's arrival counters were cleared while its workgroups were counting, no tile found its last arriver, and from then on every tile was
 // "finished" by whoever brought a half-counted word to 4 (found in round 6 through the oracle leg of tests/test_other_shapes.py's interleaved-handles test: both the
 // handle run beside others AND the handle run alone were wrong by 1e-2 after enough replays, with the counters non-zero behind the update; eager launches and a graph
