@@ -262,4 +262,6 @@ def test_graph_replays_under_the_hip_runtime_bundled_with_torch(tmp_path):
     for name in ("beside the narrow handle", "alone"):
         assert res[name]["nonzero_counters"] == [0] * 6, (name, res)
         assert max(res[name]["weight_err"]) < 5e-6, (name, res)
-    print("HIP runtime in the worker:", res["hip_runtimes"])
+    # ... and the bf16 path's event fork / join inside the captured graph (bucketed exchange, one-rank communicator over the real collective library) on the same runtime
+    assert res["bucketed_vs_single_theta_maxdiff"] < 1e-4 and res["bucketed_vs_single_rows_maxdiff"] < 5e-2, res
+    print("HIP runtime in the worker:", res["hip_runtimes"], "| collectives captured:", res["bucketed 2 graph collectives"])
