@@ -51,3 +51,11 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         terminalreporter.write_sep("=", "findings (tests/conftest.py)")
         for l in lines:
             terminalreporter.write_line(l)
+    # which HIP runtime served this process (the torch wheel bundles one of its own under the system's soname; whichever is loaded first serves everything)
+    try:
+        with open("/proc/self/maps") as f:
+            rt = sorted({l.split()[-1] for l in f if "libamdhip64" in l})
+        if rt:
+            terminalreporter.write_line("HIP runtime serving this process: " + ", ".join(rt))
+    except OSError:
+        pass
