@@ -504,10 +504,10 @@ def main():
     if bf16:
         # (round 5: the hidden layers of a pass are ONE chained launch at this minibatch size; a profile taken with PPO_HIP_NO_BF16_CHAIN=1 holds the
         # launch-per-layer names instead -- `alt_members` below)
-        alt_members = [("gemm_nt_bf16_kernel<4, 0>", L), ("gemm_nt_bf16_kernel<4, 2>", 1), ("bf16_loss_kernel", 1), ("gemm_nt_bf16_kernel<4, 1>", L)]
-        members = {"train_fwd_bwd": [("gemm_chain_bf16_kernel<0>", 1), ("gemm_nt_bf16_kernel<4, 2>", 1), ("bf16_loss_kernel", 1), ("gemm_chain_bf16_kernel<1>", 1)],
+        alt_members = [("gemm_nt_bf16_kernel<4, 0>", L), ("bf16_heads_kernel", 1), ("bf16_loss_kernel", 1), ("gemm_nt_bf16_kernel<4, 1>", L)]
+        members = {"train_fwd_bwd": [("gemm_chain_bf16_kernel<0>", 1), ("bf16_heads_kernel", 1), ("bf16_loss_kernel", 1), ("gemm_chain_bf16_kernel<1>", 1)],
                    "weight_grad": [("gemm_dw_bf16_kernel", 1)],
-                   "policy_step": [("bf16_stage_kernel", 1), ("gemm_nt_bf16_kernel<4, 0>", L), ("gemm_nt_bf16_kernel<4, 2>", 1), ("bf16_sample_kernel", 1)]}[dom]
+                   "policy_step": [("bf16_stage_kernel", 1), ("gemm_nt_bf16_kernel<4, 0>", L), ("bf16_heads_kernel", 1), ("bf16_sample_kernel", 1)]}[dom]
     else:
         first = {"train_fwd_bwd": ["train8_kernel", "train_fwd_bwd_kernel", "narrow_epoch_kernel", "narrow_train_kernel"],
                  "weight_grad": ["weight_grad_assemble_kernel", "weight_grad_kernel"],

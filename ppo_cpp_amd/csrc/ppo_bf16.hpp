@@ -33,7 +33,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define GB_K 64                    // reduction depth per LDS stage: 128-byte rows
 #define GB_STAGES 3                // LDS ring: stage t+2 is in flight while stage t is multiplied
 #define GB_PAD 128                 // every dimension of the bf16 path is padded to this
-#define GB_HEAD_SPLIT 4             // most reduction ranges of the head GEMM (GemmArgs::ksplit)
+#define GB_HEAD_SPLIT 4             // reduction ranges of the head kernel (HeadArgsB::ksplit)
 // WM = waves along i (2 or 4): tile rows BM = 64 WM, 2 WM waves (WM x 2), each a 64 x 64 accumulator block (4 x 4 MFMA tiles)
 #define GB_BM(WM) (64 * (WM))
 #define GB_THREADS(WM) (128 * (WM))
@@ -41,19 +41,16 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define GB_LDS_BYTES(WM) (GB_STAGES * GB_STAGE_BYTES(WM))          // 144 KB / 96 KB: one workgroup per CU
 #define GB_PIECES(WM) ((GB_BM(WM) + GB_N) / 8 / (2 * (WM)))        // 1-KB LDS-DMA pieces per wave and stage: 6 / 8
 
-enum { GEPI_TANH = 0, GEPI_TANHGRAD = 1, GEPI_F32 = 2, GEPI_DW = 3 };
+enum { GEPI_TANH = 0, GEPI_TANHGRAD = 1 };
 
 struct GemmArgs {
-    const bf16_t* A[2]; const bf16_t* B[2];   // per tower; row-major: A [I][K]; B [J][K] (TANHGRAD) or [K][J] (TANH, F32: the weights as they lie)
+    const bf16_t* A[2]; const bf16_t* B[2];   // per tower; row-major: A [I][K]; B [J][K] (TANHGRAD) or [K][J] (TANH: the weights as they lie)
     int lda, ldb;
     int K;                                    // reduction length
     int tiles_i;                              // tiles along i (block id -> (ti, tj) = (id % tiles_i, id / tiles_i))
-    const float* bias[2];                     // [J] fp32 (TANH, F32) or null
+    const float* bias[2];                     // [J] fp32 (TANH) or null
     const bf16_t* H[2]; int ldh;              // TANHGRAD: tanh outputs of this layer, [I][J]
     bf16_t* C[2]; int ldc;                    // out [I][J] bf16
-    float* F[2]; int ldf;                     // F32: out [I][J] fp32
-    int tiles_ij, ksplit; size_t f_split;     // F32 only: the reduction is cut into ksplit ranges, blocks [ks * tiles_ij, (ks+1) * tiles_ij) write the partial
-                                              // products of range ks to F + ks * f_split (bias in range 0); the consumers add the partials in range order
     float* bsum[2]; int bsum_ld;              // TANHGRAD: per row-tile column sums of the fp32 outputs, [tiles_i][bsum_ld] (bias gradients; may be null)
 #ifdef PPO_STAMPS
     unsigned long long* stamps;               // diagnostic builds only: [EPI][tower][block][8] cycle stamps of wave 0
@@ -337,9 +334,9 @@ __device__ __forceinline__ void gb_epilogue_bf16(GemmAcc& acc, const GemmArgs& a
 #endif
 }
 
-// one output tile of C = epilogue(A B): tower tw, rows i0 .., columns j0 .., reduction range ks (F32 only)
+// one output tile of C = epilogue(A B): tower tw, rows i0 .., columns j0 ..
 template <int WM, int EPI>
-__device__ __forceinline__ void gemm_nt_tile(const GemmArgs& a, int tw, int i0, int j0, int ks, char* gb_lds, unsigned long long* gst) {
+__device__ __forceinline__ void gemm_nt_tile(const GemmArgs& a, int tw, int i0, int j0, char* gb_lds, unsigned long long* gst) {
     GemmAcc acc;
     GSTAMP(0);
     float4 bias4[4];                                         // this lane's 16 bias values: requested before the loop, used after it
@@ -351,22 +348,8 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& a, int tw, int i0, 
         for (int nb = 0; nb < 4; ++nb) bias4[nb] = *reinterpret_cast<const float4*>(a.bias[tw] + j0 + (wave & 1) * 64 + 16 * nb + 4 * (lane >> 4));
     }
     if constexpr (EPI == GEPI_TANHGRAD) gb_mainloop<WM, true>(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, 0, a.K, gb_lds, a.H[tw], a.ldh, gst);
-    else if constexpr (EPI == GEPI_F32) gb_mainloop<WM, false, true>(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, ks * (a.K / a.ksplit), a.K / a.ksplit, gb_lds, nullptr, 0, gst);
     else gb_mainloop<WM, false, true>(acc, a.A[tw], a.lda, i0, a.B[tw], a.ldb, j0, 0, a.K, gb_lds, nullptr, 0, gst);
-    if constexpr (EPI == GEPI_F32) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, g = lane >> 4, c = lane & 15;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int j = j0 + wn + 16 * nb + 4 * g;
-            float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias[tw] && ks == 0) bj = *reinterpret_cast<const float4*>(a.bias[tw] + j);
-#pragma unroll
-            for (int ma = 0; ma < 4; ++ma)
-                *reinterpret_cast<float4*>(a.F[tw] + (size_t)ks * a.f_split + (size_t)(i0 + wm + 16 * ma + c) * a.ldf + j) =
-                    make_float4(acc.v[ma][nb][0] + bj.x, acc.v[ma][nb][1] + bj.y, acc.v[ma][nb][2] + bj.z, acc.v[ma][nb][3] + bj.w);
-        }
-    } else {
+    {
 #ifndef GB_NOEPI
         gb_epilogue_bf16<WM, EPI>(acc, a, tw, i0, j0, gb_lds, bias4, gst);
 #else
@@ -379,14 +362,13 @@ template <int WM, int EPI>
 __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_nt_bf16_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char gb_lds[];
     const int tw = blockIdx.y;
-    const int ks = EPI == GEPI_F32 ? blockIdx.x / a.tiles_ij : 0, bt = EPI == GEPI_F32 ? blockIdx.x % a.tiles_ij : blockIdx.x;
-    const int ti = bt % a.tiles_i, tj = bt / a.tiles_i;
+    const int ti = blockIdx.x % a.tiles_i, tj = blockIdx.x / a.tiles_i;
 #ifdef PPO_STAMPS
     unsigned long long* gst = a.stamps ? a.stamps + ((size_t)(EPI * 2 + tw) * 256 + blockIdx.x) * 8 : nullptr;
 #else
     unsigned long long* gst = nullptr;
 #endif
-    gemm_nt_tile<WM, EPI>(a, tw, ti * GB_BM(WM), tj * GB_N, ks, gb_lds, gst);
+    gemm_nt_tile<WM, EPI>(a, tw, ti * GB_BM(WM), tj * GB_N, gb_lds, gst);
 }
 
 // ---- a CHAIN of layers in one launch ---------------------------------------------------------------------------------------------------
@@ -442,7 +424,7 @@ __global__ __launch_bounds__(GB_THREADS(4)) void gemm_chain_bf16_kernel(ChainArg
             }
             __syncthreads();
         }
-        gemm_nt_tile<4, EPI>(ca.link[l], tw, ti * GB_BM(4), tj * GB_N, 0, gb_lds, nullptr);
+        gemm_nt_tile<4, EPI>(ca.link[l], tw, ti * GB_BM(4), tj * GB_N, gb_lds, nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's stores of the output tile are acknowledged by the L2
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(mine + (size_t)l * G * 16, (epoch << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -649,8 +631,126 @@ inline unsigned bf16_stage4_grid(int Kp0, size_t quads, unsigned want = 512) {
     return grid;
 }
 
+// ---- the two heads (G:5766-5893 act, G:9188-9427 train): mu = H_L W_mu + b_mu (A columns), v = H_L^v w_v + b_v (one column) -------------
+// A launch of their own since round 6.  Until then they were tiles of the big GEMM: 32 tiles of 256 x 128 with the reduction cut in four to
+// cover the chip, i.e. 128 workgroups that pulled 48 KB per 64-deep stage for a product of which half the policy columns and 127 of 128 value
+// columns are padding, and wrote 16.8 MB of fp32 partial products for the consumers to read back: 12.8 us of a 229 us train step.
+// Here a workgroup owns 64 ROWS of one tower and one of `ksplit` reduction ranges (the cut stays: it is what covers the chip, two workgroups
+// per CU); a wave owns 16 of the rows.  A row of H is read once, 16-byte loads straight into the matrix instruction's operand map (the
+// reduction index is contiguous).  W lies [K][Ap], reduction index = row: the range's rows come in by LDS-DMA as ONE [k][128] image (64 KB at
+// K = 1024, gt_swz on the source side, only the 16-byte chunks of columns that exist when TRIM) and out through the transposed reads of
+// gt_frag, for the 16-column blocks that exist (A / 16 for the policy, one for the value).  One barrier, no ring.  The fp32 partial products
+// of range ks go to F + ks * f_split (bias in range 0) and the consumers add them in range order, as before: a row's result does not depend
+// on the workgroup or slot that computed it (act and train model: same bits on the same weights).
+// (First form, measured and replaced: 32 rows and the WHOLE reduction per workgroup, wave w on the w-th quarter of K behind a wave-private ring
+// of four 32-row images: 10.6 us -- every workgroup pulls all of W, 256 KB, at the ~20 B/clk a CU gets from L2 into LDS; profiles/r06_j_*.)
+struct HeadArgsB {
+    const bf16_t* H[2]; int ldh;              // last hidden layer's outputs, [rows_pad][K]
+    const bf16_t* W[2]; int ldw;              // head weights as they lie, [K][Ap], Ap == 128
+    const float* bias[2];                     // [Ap] fp32
+    float* F[2]; int ldf; size_t f_split;     // out [ksplit][rows_pad][Ap] fp32: the columns of the tower's 16-column blocks are written
+    int K, ksplit;                            // K / ksplit a multiple of 32
+#ifdef PPO_STAMPS
+    unsigned long long* stamps;               // diagnostic builds only: [tower][block][8] cycle stamps of wave 0
+#endif
+};
+#define BH_ROWS 64
+#define BH_KPASS 256                          // rows of W in LDS at a time
+#define BH_LDS_BYTES (BH_KPASS * 256)         // 64 KB: two workgroups per CU
+
+// one pass: the image of rows k .. k + 32 nst of W, this wave's H fragments, nst k-steps.  FULL: nst == 8 is known at compile time -- the H loads are
+// unconditional, requested BEHIND the image (which comes from L2 and is needed by everybody) and waited for one k-step at a time by the compiler's own counts
+template <bool TRIM, bool FULL, int NCB>
+__device__ __forceinline__ void bh_pass(f32x4 (&acc)[NCB], const bf16_t* __restrict__ hrow, const bf16_t* __restrict__ W, int ldw, int k, int nst, char* img,
+                                        unsigned long long* gst) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+#pragma unroll
+    for (int q = 0; q < BH_KPASS / 16; ++q) {                // pieces of 4 rows x 256 B, dealt to the waves round robin
+        const int p = wave + 4 * q;
+        if (FULL || p < 8 * nst) {
+            const int rt = 4 * p + (lane >> 4), cht = (lane & 15) ^ gt_swz(rt);
+            if (!TRIM || cht < 2 * NCB) __builtin_amdgcn_global_load_lds((gptr)(W + (size_t)(k + rt) * ldw + 8 * cht), (lptr)(img + p * 1024), 16, 0, 0);
+        }
+    }
+    bf16x8 hf[BH_KPASS / 32];
+#pragma unroll
+    for (int s = 0; s < BH_KPASS / 32; ++s) {
+        if constexpr (FULL) hf[s] = *reinterpret_cast<const bf16x8*>(hrow + k + 32 * s);
+        else hf[s] = s < nst ? *reinterpret_cast<const bf16x8*>(hrow + k + 32 * s) : bf16x8{};
+    }
+    GSTAMP(1);
+    if constexpr (FULL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BH_KPASS / 32) : "memory");     // this wave's pieces of the image have landed (the H loads may be out)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSTAMP(2);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    GSTAMP(3);
+    // k-step s + 1's fragments are read under k-step s's matrix instructions (two sets); the scheduling barriers keep the compiler from hoisting all 64 reads
+    bf16x8 wf[2][NCB];
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb) wf[0][nb] = gt_frag(img, 16 * nb, 0);
+#pragma unroll
+    for (int s = 0; s < BH_KPASS / 32; ++s) {
+        if (FULL || s < nst) {
+            if (s + 1 < BH_KPASS / 32 && (FULL || s + 1 < nst)) {
+#pragma unroll
+                for (int nb = 0; nb < NCB; ++nb) wf[(s + 1) & 1][nb] = gt_frag(img, 16 * nb, s + 1);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NCB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s & 1][nb], hf[s], acc[nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// tower t with NCB 16-column blocks
+template <bool TRIM, int NCB>
+__device__ __forceinline__ void bh_tower(const HeadArgsB& a, int t, char* bh_lds) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int rg = blockIdx.x / a.ksplit, ks = blockIdx.x - rg * a.ksplit;
+    const int row = rg * BH_ROWS + wave * 16 + r;
+    const int kr = a.K / a.ksplit, k0 = ks * kr;
+    const bf16_t* __restrict__ hrow = a.H[t] + (size_t)row * a.ldh + 8 * g;
+#ifdef PPO_STAMPS
+    unsigned long long* gst = a.stamps ? a.stamps + ((size_t)t * gridDim.x + blockIdx.x) * 8 : nullptr;
+#else
+    unsigned long long* gst = nullptr;
+#endif
+    GSTAMP(0);
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kp = 0; kp < kr; kp += BH_KPASS) {
+        if (kp) __syncthreads();                             // the previous image is spent
+        if (kr - kp >= BH_KPASS) bh_pass<TRIM, true, NCB>(acc, hrow, a.W[t], a.ldw, k0 + kp, BH_KPASS / 32, bh_lds, gst);
+        else bh_pass<TRIM, false, NCB>(acc, hrow, a.W[t], a.ldw, k0 + kp, (kr - kp) / 32, bh_lds, gst);
+    }
+    GSTAMP(4);
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb) {
+        const int j = 16 * nb + 4 * g;
+        float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ks == 0) bj = *reinterpret_cast<const float4*>(a.bias[t] + j);
+        *reinterpret_cast<float4*>(a.F[t] + (size_t)ks * a.f_split + (size_t)row * a.ldf + j) = make_float4(acc[nb][0] + bj.x, acc[nb][1] + bj.y, acc[nb][2] + bj.z, acc[nb][3] + bj.w);
+    }
+#ifdef PPO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GSTAMP(5);
+}
+
+// NCBP: 16-column blocks of the policy head (A / 16 rounded up to 1, 2, 4 or 8); the value head has one
+template <bool TRIM, int NCBP>
+__global__ __launch_bounds__(256) void bf16_heads_kernel(HeadArgsB a) {
+    extern __shared__ __attribute__((aligned(16))) char bh_lds[];
+    if (blockIdx.y == 0) bh_tower<TRIM, NCBP>(a, 0, bh_lds);
+    else bh_tower<TRIM, 1>(a, 1, bh_lds);
+}
+
 // ---- act epilogue: sampling + neglogp (G:5894-6672) from the head GEMM's fp32 outputs ---------------------------------
-// head outputs arrive as `hsplit` partial products hstride floats apart (GemmArgs::ksplit), added here in range order
+// head outputs arrive as `hsplit` partial products hstride floats apart (HeadArgsB::ksplit), added here in range order
 __device__ __forceinline__ float head_sum(const float* p, size_t idx, int hsplit, size_t hstride) {
     float s = p[idx];
     for (int k = 1; k < hsplit; ++k) s += p[idx + (size_t)k * hstride];
@@ -927,12 +1027,13 @@ __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_grad_reduce_kernel(Reduce
 
 // ---- gradient assembly + clip + Adam in ONE launch (single GPU): bf16_grad_reduce_kernel's chunks and adam_kernel's elements are the same 256-element
 // chunks, so a persistent launch -- BRA_GRID workgroups of 16 waves, one per CU, each wave up to NR chunks -- keeps the assembled gradient (and the Adam
-// slots and weights it requested meanwhile) in REGISTERS across the one thing in between, the global norm.  Workgroup b plays the workgroups
+// slots and weights it requested meanwhile) in REGISTERS across the one thing in between, the global norm.  (store_grad == 0: the assembled gradient is
+// not written at all -- 4 of the launch's 41 bytes per parameter; ppo_get_last_grad rebuilds it from the slabs with bf16_grad_reduce_kernel when somebody asks.)  Workgroup b plays the workgroups
 // j = r BRA_GRID + b, r = 0 .. NR - 1, of the bf16_grad_reduce_kernel launch it replaces: partial j is formed exactly as there, and the sum over r is
 // exactly what adam_kernel's thread b adds up from the partials (it strides them by 256), so the table the workgroups meet on has ONE {epoch, sum} word
 // per workgroup and the norm, the clip factor and every element come out with the bits of the two launches (tests/test_bf16_path.py).  What goes away:
 // adam_kernel's read of the gradient (4 bytes per parameter), a launch boundary, and the wait for the Adam slots (they arrive while the slabs are
-// summed).  The gradient is still written (ppo_get_last_grad).  Bounded wait; PPO_HIP_NO_REDUCE_ADAM=1 keeps the two launches.
+// summed).  Bounded wait; PPO_HIP_NO_REDUCE_ADAM=1 keeps the two launches.
 #define BRA_GRID 256
 struct ReduceAdamArgs {
     ReduceArgs r;
@@ -941,6 +1042,7 @@ struct ReduceAdamArgs {
     float* loss_row; float* norm_out;
     unsigned long long* ent;     // [BRA_GRID] {epoch << 32 | sum of this workgroup's partials}, [BRA_GRID] raised when a wait timed out
     int n_old;                   // workgroups of the bf16_grad_reduce_kernel launch this one replaces
+    int store_grad;              // 0: only the loss tail of r.grad is written
 };
 template <int NR>
 __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_reduce_adam_kernel(ReduceAdamArgs a) {
@@ -968,7 +1070,7 @@ __global__ __launch_bounds__(64 * BGR_WAVES) void bf16_reduce_adam_kernel(Reduce
                 const size_t idx = (size_t)chunk * 256 + 4 * lane;
                 if constexpr (PREF) { M[r] = *reinterpret_cast<const float4*>(a.m + idx); V[r] = *reinterpret_cast<const float4*>(a.v + idx); T[r] = *reinterpret_cast<const float4*>(a.theta + idx); }
                 bgr_chunk(a.r, chunk, lane, G[r]);
-                *reinterpret_cast<float4*>(a.r.grad + idx) = make_float4(G[r][0], G[r][1], G[r][2], G[r][3]);
+                if (a.store_grad) *reinterpret_cast<float4*>(a.r.grad + idx) = make_float4(G[r][0], G[r][1], G[r][2], G[r][3]);
                 q = (G[r][0] * G[r][0] + G[r][1] * G[r][1]) + (G[r][2] * G[r][2] + G[r][3] * G[r][3]);
                 q = wave_sum_lane0(q);
             }

@@ -179,6 +179,11 @@ struct ppo_handle {
         bf16_t *hb[2][PPO_MAX_LAYERS]{}, *dy[2][PPO_MAX_LAYERS]{};     // [Rcap][Hp_l]: tanh outputs and the gradients w.r.t. the pre-activations
         float* head_out[2]{};                           // [GB_HEAD_SPLIT][Rcap][Ap] fp32 partial products of the head GEMM's reduction ranges
         int head_split = 1;                             // ranges the last bf16_forward used
+        // the fused assembly + Adam launch does not write the assembled gradient: whoever asks for it (ppo_get_last_grad, ppo_debug_buffer) has it rebuilt
+        // from the last train step's slabs first (bf16_materialize_grad).  lazy_last: the last train step ENQUEUED was of that kind (a replayed graph keeps
+        // what it captured: g_lazy); grad_lazy: h->grad is behind the last train step that RAN
+        bool lazy_last = false, g_lazy = false, grad_lazy = false;
+        ReduceArgs lazy_ra{}; int lazy_n_old = 0;
         bf16_t *dhead[2]{};
         float* dbias = nullptr; int db_off[2][PPO_MAX_LAYERS]{}; int n_dbias = 0;
         DwTileB* dw_tiles = nullptr; int n_dw_tiles = 0; int dw_wm = 4;
@@ -682,7 +687,8 @@ int bf16_create(ppo_handle* h) {
     auto lds_attr = [&](const void* f, int bytes) { ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
     lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_TANH>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_TANH>, GB_LDS_BYTES(2));
     lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_TANHGRAD>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_TANHGRAD>, GB_LDS_BYTES(2));
-    lds_attr((const void*)gemm_nt_bf16_kernel<4, GEPI_F32>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_nt_bf16_kernel<2, GEPI_F32>, GB_LDS_BYTES(2));
+    lds_attr((const void*)bf16_heads_kernel<true, 1>, BH_LDS_BYTES); lds_attr((const void*)bf16_heads_kernel<true, 2>, BH_LDS_BYTES);
+    lds_attr((const void*)bf16_heads_kernel<true, 4>, BH_LDS_BYTES); lds_attr((const void*)bf16_heads_kernel<true, 8>, BH_LDS_BYTES);
     lds_attr((const void*)gemm_dw_bf16_kernel<4>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_dw_bf16_kernel<2>, GB_LDS_BYTES(2));
     lds_attr((const void*)gemm_chain_bf16_kernel<GEPI_TANH>, GB_LDS_BYTES(4)); lds_attr((const void*)gemm_chain_bf16_kernel<GEPI_TANHGRAD>, GB_LDS_BYTES(4));
     if (!ok) return fail(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 GEMM kernels");
@@ -709,7 +715,7 @@ bool bf16_chain(ppo_handle* h, const GemmArgs* links, int n, int I, int J, int w
     ca.n = n; ca.tiles_i = tiles_i; ca.tiles_j = tiles_j;
     ca.words = b.chain_words[which] + (size_t)(G / 8 - 1) * GB_CHAIN_WORDS;      // a table per number of row groups (ChainArgs::words)
     ca.err = b.chain_words[which] + (size_t)GB_CHAIN_SHAPES * GB_CHAIN_WORDS;
-    for (int l = 0; l < n; ++l) { ca.link[l] = links[l]; ca.link[l].ksplit = 1; ca.link[l].tiles_i = tiles_i; ca.link[l].tiles_ij = tiles_i * tiles_j; }
+    for (int l = 0; l < n; ++l) { ca.link[l] = links[l]; ca.link[l].tiles_i = tiles_i; }
     hipLaunchKernelGGL((gemm_chain_bf16_kernel<EPI>), dim3(G * tiles_j), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, ca);
     b.chain_used = true;
     return hipGetLastError() == hipSuccess;
@@ -768,10 +774,22 @@ int bf16_chain_err_test(ppo_handle* h) {                        // (after the st
     return bf16_chain_check(h) ? 1 : 0;                         // (reads the words again, resets them, switches the chain off, sets the message)
 }
 
+// the assembled gradient of the last train step, when the launch that applied it did not write it (bf16_reduce_adam_kernel): the slabs, slot rows and bias-gradient
+// rows it was summed from are still the last step's, and bf16_grad_reduce_kernel adds them exactly as the fused launch did (same bits)
+int bf16_materialize_grad(ppo_handle* h) {
+    ppo_handle::Bf16& b = h->bf;
+    if (!b.grad_lazy) return 0;
+    hipLaunchKernelGGL(bf16_grad_reduce_kernel, dim3(b.lazy_n_old), dim3(64 * BGR_WAVES), 0, h->stream, b.lazy_ra);
+    HIP_OK(h, hipGetLastError());
+    b.grad_lazy = false;
+    return 0;
+}
+
 int bf16_ensure_ws(ppo_handle* h, int rows) {
     ppo_handle::Bf16& b = h->bf;
     const int R = ru(rows, GB_PAD);
     if (R <= b.Rcap) return 0;
+    if (bf16_materialize_grad(h)) return -1;                 // (the slot rows and bias-gradient rows it would be rebuilt from are about to be reallocated)
     drop_graph(h);
     HIP_OK(h, hipStreamSynchronize(h->stream));
     const NetDev& n = h->net;
@@ -808,18 +826,16 @@ int bf16_ensure_ws(ppo_handle* h, int rows) {
 template <int EPI>
 int bf16_gemm(ppo_handle* h, const GemmArgs& a, int I, int J) {
     GemmArgs g = a;
-    if (EPI != GEPI_F32) g.ksplit = 1;
-    const unsigned ks = (unsigned)g.ksplit;
 #ifdef PPO_STAMPS
     if (!g_stamps) (void)hipMalloc((void**)&g_stamps, 4096 * 48 * sizeof(unsigned long long));
     g.stamps = (I / 256) * (J / GB_N) <= 256 ? g_stamps : nullptr;
 #endif
     if (I % 256 == 0) {                                      // 256 x 128 tiles, 8 waves
-        g.tiles_i = I / 256; g.tiles_ij = (I / 256) * (J / GB_N);
-        hipLaunchKernelGGL((gemm_nt_bf16_kernel<4, EPI>), dim3(g.tiles_ij * ks, 2), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, g);
+        g.tiles_i = I / 256;
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<4, EPI>), dim3((I / 256) * (J / GB_N), 2), dim3(GB_THREADS(4)), GB_LDS_BYTES(4), h->stream, g);
     } else {
-        g.tiles_i = I / 128; g.tiles_ij = (I / 128) * (J / GB_N);
-        hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, EPI>), dim3(g.tiles_ij * ks, 2), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, g);
+        g.tiles_i = I / 128;
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, EPI>), dim3((I / 128) * (J / GB_N), 2), dim3(GB_THREADS(2)), GB_LDS_BYTES(2), h->stream, g);
     }
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -842,24 +858,31 @@ int bf16_forward(ppo_handle* h, int Rp, const bf16_t* x0_override = nullptr) {
         fl[l] = a;
         same_j = same_j && n.Hp[l] == n.Hp[0];
     }
-    GemmArgs a{};
-    const int HpL = n.Hp[n.L - 1];
-    for (int t = 0; t < 2; ++t) {
-        a.A[t] = b.hb[t][n.L - 1]; a.B[t] = b.theta_bf + (t ? n.wv_off : n.wmu_off); a.bias[t] = h->theta + (t ? n.bv_off : n.bmu_off); a.F[t] = b.head_out[t];
-    }
-    a.lda = HpL; a.ldb = n.Ap; a.K = HpL; a.ldf = n.Ap;
     // every hidden layer in ONE launch when the shape qualifies, else a launch per layer.  (The heads riding behind the last layer of the chained launch --
     // a workgroup's own column tile is one 128-deep reduction range -- was measured: -4.2 us on the pass, +1.8 us in the loss kernel for twice the
     // partial products, and +16 us per env step on the act path, which has to cut its heads the same way to give the same bits; not kept.)
     if (!(same_j && n.L <= GB_CHAIN_MAX && bf16_chain<GEPI_TANH>(h, fl, n.L, Rp, n.Hp[0], 0)))
         for (int l = 0; l < n.L; ++l) if (bf16_gemm<GEPI_TANH>(h, fl[l], Rp, n.Hp[l])) return -1;
-    // the heads are few tiles (Ap = 128 columns): cut the reduction so that the launch covers the chip; the partial products are
-    // added by the consumers (bf16_sample_kernel / bf16_loss_kernel) in range order
-    const int tiles = 2 * (Rp / (Rp % 256 == 0 ? 256 : 128)) * (n.Ap / GB_N);
-    int ks = 1;
-    while (ks < GB_HEAD_SPLIT && tiles * ks < 256 && (HpL / (2 * ks)) % GB_K == 0 && HpL / (2 * ks) >= 2 * GB_K) ks *= 2;
-    a.ksplit = ks; a.f_split = (size_t)b.Rcap * n.Ap; b.head_split = ks;
-    return bf16_gemm<GEPI_F32>(h, a, Rp, n.Ap);
+    // the heads: 64 rows of one tower and one reduction range per workgroup (bf16_heads_kernel)
+    const int HpL = n.Hp[n.L - 1];
+    if (n.Ap != GB_N) return fail(h, "bf16 path: the head kernel's images are 128 columns wide (Ap = %d)", n.Ap);
+    HeadArgsB ha{};
+    for (int t = 0; t < 2; ++t) {
+        ha.H[t] = b.hb[t][n.L - 1]; ha.W[t] = b.theta_bf + (t ? n.wv_off : n.wmu_off); ha.bias[t] = h->theta + (t ? n.bv_off : n.bmu_off); ha.F[t] = b.head_out[t];
+    }
+    ha.ldh = HpL; ha.ldw = n.Ap; ha.ldf = n.Ap; ha.K = HpL;
+    // the reduction in GB_HEAD_SPLIT ranges whatever the row count (the act model and the train model cut it alike: same bits per row)
+    int ks = GB_HEAD_SPLIT;
+    while (ks > 1 && (HpL / ks) % 32) ks /= 2;
+    ha.ksplit = ks; ha.f_split = (size_t)b.Rcap * n.Ap; b.head_split = ks;
+    const dim3 grid((Rp / BH_ROWS) * ks, 2);
+    const int ncb = (n.A + 15) / 16;
+    if (ncb <= 1) hipLaunchKernelGGL((bf16_heads_kernel<true, 1>), grid, dim3(256), BH_LDS_BYTES, h->stream, ha);
+    else if (ncb <= 2) hipLaunchKernelGGL((bf16_heads_kernel<true, 2>), grid, dim3(256), BH_LDS_BYTES, h->stream, ha);
+    else if (ncb <= 4) hipLaunchKernelGGL((bf16_heads_kernel<true, 4>), grid, dim3(256), BH_LDS_BYTES, h->stream, ha);
+    else hipLaunchKernelGGL((bf16_heads_kernel<true, 8>), grid, dim3(256), BH_LDS_BYTES, h->stream, ha);
+    HIP_OK(h, hipGetLastError());
+    return 0;
 }
 
 int bf16_stage(ppo_handle* h, const float* obs, int nrows, int Rp, ObsNorm nz, float* obs_out) {
@@ -1299,6 +1322,7 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
     if (h->bf.on) {
         const int Rp = ru(ta.n, GB_PAD);
         ++h->kv[KV_BF16_TRAIN];
+        h->bf.lazy_last = false;
         if (h->comm && !h->peer.on && h->net.L >= 2 && (h->bf.bucketed_any_world || (h->world > 1 && h->bf.bucketed))) return bf16_train_bucketed(h, ta, Rp, loss_row);
         { ProfScope ps(h, PK_TRAIN_FB); if (bf16_train_fwd_bwd(h, ta, Rp)) return -1; }
         { ProfScope ps(h, PK_DW); if (bf16_weight_grads(h, ta, Rp)) return -1; }
@@ -1315,8 +1339,9 @@ int enqueue_train(ppo_handle* h, TrainArgs ta, float* loss_row, bool defer = fal
             const char* e1 = getenv("PPO_HIP_NO_REDUCE_ADAM");                  // (read per call: a test compares the forms in one process; a graph keeps what it captured)
             if (!h->comm && h->bf.fuse_ra && !h->adam_fast && !(e1 && e1[0] == '1')) {
                 // ... and clip + Adam in the same persistent launch (ppo_bf16.hpp, bf16_reduce_adam_kernel)
+                h->bf.lazy_ra = ra; h->bf.lazy_n_old = n_old; h->bf.lazy_last = true;
                 ReduceAdamArgs fa{ra, h->theta, h->adam_m, h->adam_v, h->bf.theta_bf, h->hyper, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->cfg.max_grad_norm,
-                                  loss_row, h->norm_out, h->bf.ra_ent, n_old};
+                                  loss_row, h->norm_out, h->bf.ra_ent, n_old, /*store_grad*/ 0};
                 const int rounds = (n_old + BRA_GRID - 1) / BRA_GRID;
                 const dim3 g(BRA_GRID), blk(64 * BGR_WAVES);
                 ++h->kv[KV_BF16_REDUCE_ADAM];
@@ -1883,6 +1908,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
     ta.inv_n = 1.0f / (float)((int64_t)n * h->world);
     if (h->dw2 && zero_words(h, h->dw2_counters, DW2_TILES)) return -1;
     if (enqueue_train(h, ta, h->st_loss)) return -1;
+    h->bf.grad_lazy = h->bf.lazy_last;
     HIP_OK(h, hipMemcpyAsync(losses, h->st_loss, 5 * fb, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     prof_collect(h);
@@ -1892,6 +1918,7 @@ int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, c
 int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm) {
     ENTER(h);
     if (count != h->P_dense) return fail(h, "ppo_get_last_grad: count %lld != %d", (long long)count, h->P_dense);
+    if (bf16_materialize_grad(h)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     for (const Tensor& t : h->tensors) if (copy_tensor(h, h->grad, t, dst + t.off_dense, false)) return -1;
     if (global_norm) HIP_OK(h, hipMemcpy(global_norm, h->norm_out, sizeof(float), hipMemcpyDeviceToHost));
@@ -2942,7 +2969,7 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
                 const int rc = enqueue_update(h, epochs, nmb, explicit_perms);
                 const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
                 ok = rc == 0 && ce == hipSuccess && graph != nullptr && hipGraphInstantiate(&h->upd_graph, graph, nullptr, nullptr, 0) == hipSuccess;
-                if (ok) h->upd_graph_tmpl = graph;            // (kept alive beside the executable graph: drop_graph)
+                if (ok) { h->upd_graph_tmpl = graph; h->bf.g_lazy = h->bf.lazy_last; }            // (kept alive beside the executable graph: drop_graph)
                 else if (graph) (void)hipGraphDestroy(graph);
             }
             if (!ok) {
@@ -2954,9 +2981,10 @@ int ppo_update(ppo_handle* h, float lr, float cliprange, int32_t epochs, int32_t
                 h->g_epochs = epochs; h->g_nmb = nmb; h->g_E = h->E; h->g_T = h->T; h->g_explicit = (int)explicit_perms; h->g_world = gs ? -h->world : h->world;
             }
         }
-        if (h->upd_graph) HIP_OK(h, hipGraphLaunch(h->upd_graph, h->stream));
+        if (h->upd_graph) { HIP_OK(h, hipGraphLaunch(h->upd_graph, h->stream)); h->bf.lazy_last = h->bf.g_lazy; }
         else if (enqueue_update(h, epochs, nmb, explicit_perms)) return -1;
     } else if (enqueue_update(h, epochs, nmb, explicit_perms)) return -1;
+    h->bf.grad_lazy = h->bf.lazy_last;
     if (loss_rows) HIP_OK(h, hipMemcpyAsync(loss_rows, h->d_loss_rows, (size_t)steps * 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipMemcpyAsync(mean_losses, h->d_loss_mean, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -3299,6 +3327,7 @@ int ppo_kernel_counts(ppo_handle* h, int max, char names[][32], int64_t* enqueue
 // the interleaved-handles test's report); not part of the reference's interface.  *count = the buffer's length in 4-byte words; at most max_count are copied.
 int ppo_debug_buffer(ppo_handle* h, const char* name, float* dst, int64_t max_count, int64_t* count) {
     ENTER_Q(h);
+    if (bf16_materialize_grad(h)) return -1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     const void* p = nullptr; size_t words = 0; bool found = false;
     for (const DbgEnt& e : debug_table(h)) if (!strcmp(e.name, name)) { found = true; p = e.p; words = e.words; }

@@ -196,6 +196,40 @@ def test_assembly_clip_and_adam_in_one_launch_are_bitwise_the_two_launches(hidde
         np.testing.assert_array_equal(a, b)
 
 
+def test_gradient_behind_an_update_is_rebuilt_on_demand(monkeypatch):
+    """The fused assembly + Adam launch does not write the assembled gradient (4 of its 41 bytes per parameter); ppo_get_last_grad rebuilds it from the last train
+    step's slabs, slot rows and bias rows with bf16_grad_reduce_kernel.  Behind a captured update, a replayed one and a third (the host code of a train step does
+    not run on a replay), asked twice, and once with an act call of MORE rows in between (which reallocates the slot rows: the gradient has to be rebuilt before
+    that): the same BITS as a handle whose every step wrote its gradient (PPO_HIP_NO_REDUCE_ADAM=1), and a norm that is the gradient's."""
+    hidden, O, A, E, T, nmb, epochs = (512, 512), 64, 18, 64, 8, 4, 2
+    rng = np.random.RandomState(3)
+    noise = rng.normal(size=(T, E, A)).astype(np.float32)
+    perms = np.stack([rng.permutation(E * T) for _ in range(epochs)]).astype(np.int32)
+    big_obs = rng.normal(size=(1024, O)).astype(np.float32)
+    outs = []
+    for two in ("0", "1"):
+        monkeypatch.setenv("PPO_HIP_NO_REDUCE_ADAM", two)
+        orc, g = pair_bf16(hidden, O, A)
+        g.norm_init(E, GAMMA); g.rollout_alloc(E, T)
+        acc = []
+        for it in range(3):
+            g.collect_synthetic(100 + it, GAMMA, LAM, noise)
+            acc.append(g.update(LR, CR, epochs, nmb, perms)[0].copy())
+            if it == 2: g.value(big_obs)                    # 1024 rows > the 512 the workspaces were sized for
+            gr, nrm = g.last_grad()
+            gr2, nrm2 = g.last_grad()
+            np.testing.assert_array_equal(gr, gr2); assert nrm == nrm2
+            assert np.sqrt(np.sum(gr.astype(np.float64) ** 2)) == pytest.approx(nrm, rel=1e-5)
+            acc += [gr.copy(), np.float32(nrm)]
+        acc.append(g.get_flat(0))
+        g.close()
+        outs.append(acc)
+    monkeypatch.delenv("PPO_HIP_NO_REDUCE_ADAM", raising=False)
+    assert np.abs(outs[0][1]).max() > 0
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_chained_launches_of_two_row_counts_on_one_handle(monkeypatch):
     """One handle alternating between 4096-row and 2048-row train steps (32 and 16 row groups per chained launch -- as the act path's row count and the minibatch's
     do in a rollout + update): every shape has its own table of workgroup words (a shared table means a slot is different (link, row group) pairs under different
