@@ -110,7 +110,8 @@ int ppo_act_deterministic(ppo_handle* h, const float* obs, int32_t n, float* act
 int ppo_train_step(ppo_handle* h, float lr, float cliprange, const float* obs, const float* actions,
                    const float* advs, const float* returns, const float* old_neglogp, const float* old_values,
                    int32_t n, float losses[5]);
-/* gradient of the last ppo_train_step BEFORE clipping (debug/parity), dense flat order */
+/* gradient of the last train step (of ppo_train_step, or the last one of ppo_update) BEFORE clipping (debug/parity), dense flat order.
+ * PPO_BF16 handles on one GPU do not keep it: it is rebuilt here from the step's partial sums (same bits), which stay valid until the next train step. */
 int ppo_get_last_grad(ppo_handle* h, float* dst, int64_t count, float* global_norm);
 
 /* ---- fused host-loop numerics the north star moves onto the device ----------------------------------------
