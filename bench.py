@@ -496,7 +496,7 @@ def main():
     traffic = traffic_source = rocprof_avg_us = rocprof_source = None
     # kernel names of the dominant class, most specific first (the class "train_fwd_bwd" is train8_kernel on the 18-obs / [256,256] shape,
     # train_fwd_bwd_kernel on other wide fp32 shapes, narrow_train_kernel for nets <= 64 wide, the tanh GEMM on the bf16 path)
-    # The timed class may be ONE kernel (fp32 paths) or a SEQUENCE of launches per train step (bf16 path: L tanh GEMMs, the head GEMM, the loss
+    # The timed class may be ONE kernel (fp32 paths) or a SEQUENCE of launches per train step (bf16 path: L tanh GEMMs, the head kernel, the loss
     # kernel, L TanhGrad GEMMs).  `members` = (kernel-name pattern, launches of it per launch of the class); the profile numbers of a
     # class are the sums over its members x their launches per step, so that traffic / rocprof_avg_us describe the same thing as
     # flop_per_launch and avg_us.  (For a single-kernel class that is just that kernel's row.)
