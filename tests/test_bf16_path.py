@@ -34,6 +34,7 @@ def cosine(a, b):
 @pytest.mark.parametrize("hidden,O,A,n", [((1024, 1024, 1024), 256, 64, 256), ((256, 256), 18, 18, 200), ((300, 200), 40, 7, 130),
                                           ((300, 200), 40, 7, 100), ((256, 128), 18, 18, 384),            # 128-row tiles (rows % 256 != 0)
                                           ((1024, 1024, 1024), 256, 64, 1024), ((1024, 512), 300, 100, 1000), ((384,), 18, 18, 640),      # 16 stages per weight-gradient tile: the work-balanced split
+                                          ((128, 2048), 18, 18, 256), ((1280,), 18, 70, 128),     # the head kernel's reduction ranges longer than one LDS image: 512 = 2 images; 320 = one and a quarter (8 column blocks)
                                           # configs[4]'s own minibatch (64 stages per tile): ~55 s of scalar fp32 oracle, a soak case (tools/soak_suite.sh); the 4096-row
                                           # properties, chain and assembly cases below keep that size in -m gpu without the oracle
                                           pytest.param((1024, 1024, 1024), 256, 64, 4096, marks=pytest.mark.slow)])
