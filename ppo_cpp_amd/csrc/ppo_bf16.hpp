@@ -533,7 +533,12 @@ __global__ __launch_bounds__(GB_THREADS(WM)) void gemm_dw_bf16_kernel(DwArgsB a)
     while (s0 < end) {
         const int tile = s0 / a.nst;
         const int s1 = min(end, (tile + 1) * a.nst);
+#ifdef GT_SAME_PANEL
+        DwTileB t = a.tiles[tile];                          // timing diagnostic only: every tile reads tile 0's operand panels (3 MB: resident in every L2); results are wrong
+        { const DwTileB t0 = a.tiles[GT_SAME_PANEL]; t.A = t0.A; t.B = t0.B; t.lda = t0.lda; t.ldb = t0.ldb; t.i0 = t0.i0; t.j0 = t0.j0; t.is_x0 = t0.is_x0; }
+#else
         const DwTileB t = a.tiles[tile];
+#endif
         const int slab = w - (tile * a.nst) / a.per;           // this workgroup's rank among the tile's contributors
         const bool ov = t.is_x0 && a.x0;
         GemmAcc acc;
